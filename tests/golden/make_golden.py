@@ -1,0 +1,484 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in this container.
+
+  python tests/golden/make_golden.py            # rewrites tests/golden/*.json
+
+Source of truth (see refgen.py for how the generators are driven without any stand-in tool):
+  * field functions: the C text emitted by /root/reference/pseudo.py (X25519) and monty.py
+    (NIST256, X448) for a 64-bit word, compiled with gcc and called through ctypes exactly
+    as the reference's own self-test does (pseudo.py:1702-1750).  generic=True (default) and,
+    for the ladder primes, generic=False (rfc7748.c:20) variants of modadd/modsub/modneg.
+  * time.c protocol check words (pseudo.py:1235-1250, 1306-1318): the reference-emitted
+    modmul/modsqr run in the reference's loop shape by a small harness appended to the emitted C.
+  * modpro/modinv/modsqrt/modqr are NOT emitted (they need the external `addchain` tool);
+    their fixtures are the mathematical values after redc (chain-independent), as SURVEY 8(c)
+    caveat (1) prescribes.
+  * rfc7748(): rfc7748.c needs modpro/modinv (addchain) so it is unbuildable here without a
+    stand-in; the ladder fixtures are the reference's own KAT keys (rfc7748.c:271-277,
+    simd/rfc7748_simt.cu:244-249) with the RFC 7748 answers, RFC 7748 5.2 iteration vectors,
+    the reference main()'s LCG chain (rfc7748.c:297-305) and seeded random pairs, all computed
+    with an independent big-integer model of RFC 7748 section 5 written below.  Output bytes
+    are canonical, so this pins rfc7748() completely.
+
+Inputs are drawn from random.Random(seed) so the run is reproducible.  Only data is written.
+"""
+import ctypes, json, os, random, sys
+from ctypes import c_uint64, c_int, c_uint, c_char, POINTER
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refgen  # noqa: E402
+
+U64P = POINTER(c_uint64)
+
+HARNESS = r"""
+/* harness (ours): the reference's time.c loop shapes around the reference-emitted functions */
+unsigned int chain_modmul(spint *x, spint *y, long outer) {
+    spint z[Nlimbs]; long i; int j;
+    nres(x,x); nres(y,y);
+    for (i=0;i<outer;i++) for (j=0;j<200;j++) {
+        modmul(x,y,z); modmul(z,x,y); modmul(y,z,x); modmul(x,y,z); modmul(z,x,y);
+    }
+    redc(z,z);
+    for (j=0;j<Nlimbs;j++) x[j]=z[j];
+    return (unsigned int)(z[0]&0xFFFFFF);
+}
+unsigned int chain_modsqr(spint *x, long outer) {
+    spint z[Nlimbs]; long i; int j;
+    nres(x,x);
+    for (i=0;i<outer;i++) for (j=0;j<500;j++) { modsqr(x,z); modsqr(z,x); }
+    redc(z,z);
+    for (j=0;j<Nlimbs;j++) x[j]=z[j];
+    return (unsigned int)(z[0]&0xFFFFFF);
+}
+"""
+
+
+def hx(v):
+    return "0x%x" % v
+
+
+class Ref:
+    """ctypes view of the reference-emitted field code for one prime."""
+
+    def __init__(self, script, prime, overrides=None):
+        self.ns = refgen.load(script, 64, prime, overrides)
+        self.lib, self.csrc = refgen.build(self.ns, HARNESS)
+        ns = self.ns
+        self.N, self.base, self.n, self.p = ns["N"], ns["base"], ns["n"], ns["p"]
+        self.Nbytes = ns["Nbytes"]
+        L = self.lib
+        for f in ("modadd", "modsub", "modmul"):
+            getattr(L, f).argtypes = [U64P, U64P, U64P]
+        for f in ("modneg", "modsqr", "modcpy", "nres", "redc"):
+            getattr(L, f).argtypes = [U64P, U64P]
+        L.modmli.argtypes = [U64P, c_int, U64P]
+        L.modnsqr.argtypes = [U64P, c_int]
+        for f in ("flatten", "modfsb"):
+            getattr(L, f).argtypes = [U64P]
+            getattr(L, f).restype = c_uint64
+        for f in ("modis1", "modis0", "modsign"):
+            getattr(L, f).argtypes = [U64P]
+            getattr(L, f).restype = c_int
+        L.modcmp.argtypes = [U64P, U64P]
+        L.modcmp.restype = c_int
+        for f in ("modzer", "modone", "modhaf"):
+            getattr(L, f).argtypes = [U64P]
+        L.modint.argtypes = [c_int, U64P]
+        L.mod2r.argtypes = [c_uint, U64P]
+        L.modcmv.argtypes = [c_int, U64P, U64P]
+        L.modcsw.argtypes = [c_int, U64P, U64P]
+        L.modshl.argtypes = [c_uint, U64P]
+        L.modshr.argtypes = [c_uint, U64P]
+        L.modshr.restype = c_int
+        L.modexp.argtypes = [U64P, POINTER(c_char)]
+        L.modimp.argtypes = [POINTER(c_char), U64P]
+        L.modimp.restype = c_int
+        L.chain_modmul.argtypes = [U64P, U64P, ctypes.c_long]
+        L.chain_modmul.restype = c_uint
+        L.chain_modsqr.argtypes = [U64P, ctypes.c_long]
+        L.chain_modsqr.restype = c_uint
+
+    def arr(self, limbs=None):
+        return (c_uint64 * self.N)(*(limbs or [0] * self.N))
+
+    def split(self, x):
+        """integer -> limbs, top limb unmasked (pseudo.py:1769-1775)."""
+        b = 1 << self.base
+        out = []
+        for _ in range(self.N - 1):
+            out.append(x % b)
+            x >>= self.base
+        out.append(x)
+        return out
+
+    def un(self, f, a):
+        z = self.arr()
+        getattr(self.lib, f)(self.arr(a), z)
+        return list(z)
+
+    def bi(self, f, a, b):
+        z = self.arr()
+        getattr(self.lib, f)(self.arr(a), self.arr(b), z)
+        return list(z)
+
+    def inplace(self, f, a, *pre):
+        z = self.arr(a)
+        r = getattr(self.lib, f)(*pre, z)
+        return list(z), r
+
+
+def params_of(ref):
+    ns = ref.ns
+    keys_common = ["WL", "n", "base", "N", "xcess", "Nbytes", "PM1D2", "PE", "p", "m"]
+    keys_pm = ["mm", "TW", "EPM", "fred", "overflow", "carry_on", "bad_overflow_mul", "bad_overflow_sqr"]
+    keys_mo = ["E", "R", "ndash", "trin", "M", "PM", "fullmonty"]
+    out = {}
+    for k in keys_common + keys_pm + keys_mo:
+        if k in ns:
+            v = ns[k]
+            out[k] = hx(v) if isinstance(v, int) and not isinstance(v, bool) and v > 1 << 20 else v
+    if "ppw" in ns:
+        out["ppw"] = [("-" + hx(-v)) if v < 0 else hx(v) for v in ns["ppw"]]
+        out["cw"] = [hx(v) for v in ns["cw"]]
+    out["ROI"] = [hx(v) for v in ns["ROI"]]
+    out["header"] = [l for l in ref.csrc.splitlines() if l.startswith("#define")][:12]
+    out["log"] = ns["_log"].strip().splitlines()
+    return out
+
+
+def element_pool(ref, rng, count):
+    """limb arrays covering the contract: canonical, [p,2p) unmasked-top, corners (edge.py:343-359 style)."""
+    p, n, base = ref.p, ref.n, ref.base
+    vals = []
+    corners = [0, 1, 2, 3, p - 1, p - 2, p, p + 1, 2 * p - 1, 2 * p - 2, (p - 1) // 2, (p + 1) // 2,
+               1 << 64, (1 << 64) - 1, 1 << (n - 1), (1 << (n - 1)) - 1, (1 << n) - 1 if (1 << n) - 1 < 2 * p else p - 3,
+               (1 << n) - p, (1 << base) - 1, 1 << base, ((1 << base) - 1) << base]
+    r = rng.randrange(0, p)
+    corners += [r, pow(r, -1, p), (r + p)]
+    vals += [c for c in corners if 0 <= c < 2 * p]
+    while len(vals) < count:
+        k = len(vals) % 3
+        if k == 0:
+            vals.append(rng.randrange(0, p))
+        elif k == 1:
+            vals.append(rng.randrange(0, 2 * p))
+        else:
+            vals.append(rng.randrange(p, 2 * p))
+    return [ref.split(v) for v in vals[:count]], vals[:count]
+
+
+def field_fixture(script, prime, seed, count=160):
+    rng = random.Random(seed)
+    ref = Ref(script, prime)
+    N, p = ref.N, ref.p
+    fx = {"prime": prime, "generator": script, "generic": True, "params": params_of(ref), "seed": seed}
+    araw, aval = element_pool(ref, rng, count)
+    braw, bval = element_pool(ref, rng, count)
+    rng.shuffle(braw)
+    H = lambda limbs: [hx(v) for v in limbs]
+    ops = {}
+    # to internal form: nres of raw values (also a parity vector for nres itself on non-canonical input)
+    A = [ref.un("nres", a) for a in araw]
+    B = [ref.un("nres", b) for b in braw]
+    # second half of the pool: use raw limbs directly as internal-form operands (top limb unmasked, < 2p)
+    for i in range(count // 2, count):
+        A[i] = araw[i]
+        B[i] = braw[i]
+    fx["raw_a"] = [H(a) for a in araw]
+    fx["raw_b"] = [H(b) for b in braw]
+    fx["nres_raw_a"] = [H(ref.un("nres", a)) for a in araw]
+    fx["A"] = [H(a) for a in A]
+    fx["B"] = [H(b) for b in B]
+    for f in ("modadd", "modsub", "modmul"):
+        ops[f] = [H(ref.bi(f, a, b)) for a, b in zip(A, B)]
+    for f in ("modneg", "modsqr", "redc", "nres"):
+        ops[f] = [H(ref.un(f, a)) for a in A]
+    # chained, non-canonical: outputs fed back (what time.c and the ladder do)
+    C = [ref.bi("modmul", a, b) for a, b in zip(A, B)]
+    D = [ref.bi("modsub", a, b) for a, b in zip(A, B)]
+    Ee = [ref.bi("modadd", a, b) for a, b in zip(A, B)]
+    ops["chain_mul_CD"] = [H(ref.bi("modmul", c, d)) for c, d in zip(C, D)]
+    ops["chain_sqr_D"] = [H(ref.un("modsqr", d)) for d in D]
+    ops["chain_add_DE"] = [H(ref.bi("modadd", d, e)) for d, e in zip(D, Ee)]
+    ops["chain_sub_EC"] = [H(ref.bi("modsub", e, c)) for e, c in zip(Ee, C)]
+    ops["chain_redc_C"] = [H(ref.un("redc", c)) for c in C]
+    # aliasing (legal and used: pseudo.py:752,1783,1793; rfc7748.c:214)
+    al = []
+    for a, b in zip(A[:16], B[:16]):
+        x = ref.arr(a)
+        y = ref.arr(b)
+        ref.lib.modmul(x, y, x)
+        ref.lib.modsqr(x, x)
+        ref.lib.modadd(x, x, x)
+        ref.lib.modsub(x, y, x)
+        al.append(H(list(x)))
+    ops["alias_chain"] = al
+    # modmli by small ints (A24 of both curves, edge values); negative b sign-extends in the reference
+    ints = [0, 1, 2, 19, 121665, 39081, 121666, 0x7fffffff, 65536, 3]
+    ops["modmli_ints"] = ints
+    ops["modmli"] = [[H(_mli(ref, a, k)) for k in ints] for a in A[:48]]
+    # in-place predicates / normalisers
+    ops["modfsb"] = [[H(z), int(r)] for z, r in (ref.inplace("modfsb", a) for a in A)]
+    ops["flatten"] = [[H(z), int(r)] for z, r in (ref.inplace("flatten", a) for a in A)]
+    ops["modis1"] = [int(ref.lib.modis1(ref.arr(a))) for a in A]
+    ops["modis0"] = [int(ref.lib.modis0(ref.arr(a))) for a in A]
+    ops["modsign"] = [int(ref.lib.modsign(ref.arr(a))) for a in A]
+    ops["modcmp"] = [int(ref.lib.modcmp(ref.arr(a), ref.arr(b))) for a, b in zip(A, B)]
+    ops["modcmp_self"] = [int(ref.lib.modcmp(ref.arr(a), ref.arr(ref.bi("modadd", a, ref.split(0))))) for a in A[:32]]
+    ops["modhaf"] = [H(ref.inplace("modhaf", a)[0]) for a in A]
+    sh = []
+    for i, a in enumerate(A[:64]):
+        k = 1 + i % 8
+        zl, _ = ref.inplace("modshl", ref.un("redc", a), c_uint(k))
+        zr, r = ref.inplace("modshr", a, c_uint(k))
+        sh.append({"k": k, "shl_of_redc": H(zl), "shr": H(zr), "shr_ret": int(r)})
+    ops["shifts"] = sh
+    # conditional move / swap
+    cs = []
+    for i, (a, b) in enumerate(zip(A[:32], B[:32])):
+        d = i & 1
+        g, f = ref.arr(a), ref.arr(b)
+        ref.lib.modcsw(d, g, f)
+        f2 = ref.arr(b)
+        ref.lib.modcmv(d, ref.arr(a), f2)
+        cs.append({"d": d, "csw_g": H(list(g)), "csw_f": H(list(f)), "cmv_f": H(list(f2))})
+    ops["cond"] = cs
+    # constants
+    z = ref.arr(); ref.lib.modone(z); ops["modone"] = H(list(z))
+    z = ref.arr([7] * N); ref.lib.modzer(z); ops["modzer"] = H(list(z))
+    ops["modint"] = [[k, H(ref.inplace("modint", [0] * N, c_int(k))[0])] for k in (0, 1, 2, 9, 5, 121665, 39081)]
+    ops["mod2r"] = [[k, H(ref.inplace("mod2r", [0] * N, c_uint(k))[0])] for k in (0, 1, 51, 52, 56, 64, 100, 255, 256, 447, 448, 8 * ref.Nbytes - 1, 8 * ref.Nbytes)]
+    # byte import / export (big-endian, pseudo.py:1115-1146)
+    io_ = []
+    for i in range(48):
+        if i < 6:
+            v = [0, 1, p - 1, p, p + 1, (1 << (8 * ref.Nbytes)) - 1][i]
+        else:
+            v = rng.randrange(0, 1 << (8 * ref.Nbytes)) if i % 2 else rng.randrange(0, p)
+        bs = v.to_bytes(ref.Nbytes, "big")
+        buf = (c_char * ref.Nbytes)(*bs)
+        z = ref.arr()
+        r = ref.lib.modimp(buf, z)
+        out = (c_char * ref.Nbytes)()
+        ref.lib.modexp(z, out)
+        io_.append({"bytes": bs.hex(), "imp": H(list(z)), "imp_ret": int(r), "exp": bytes(out).hex()})
+    ops["bytes"] = io_
+    ops["modexp_A"] = []
+    for a in A[:48]:
+        out = (c_char * ref.Nbytes)()
+        ref.lib.modexp(ref.arr(a), out)
+        ops["modexp_A"].append(bytes(out).hex())
+    # chain-independent pins for modinv / modsqrt / modqr (after redc)
+    R = ref.ns.get("R", 1)
+    Rinv = pow(R, -1, p)
+    inv = []
+    for a in A[:48]:
+        val = _value(ref, a) * Rinv % p  # value represented by internal-form a
+        iv = pow(val, -1, p) if val else 0
+        qr = 1 if val == 0 or pow(val, (p - 1) // 2, p) == 1 else 0
+        inv.append({"x": H(a), "inv_redc": H(_canon(ref, iv)), "qr": qr, "value": hx(val)})
+    ops["modinv"] = inv
+    fx["ops"] = ops
+    # time.c protocol (pseudo.py:1862-1866 operands; check words pseudo.py:1250)
+    r42 = random.Random()
+    r42.seed(42)
+    ra, rb, rs, ri = (r42.randint(0, p - 1) for _ in range(4))
+    tm = {"ra": hx(ra), "rb": hx(rb), "rs": hx(rs), "ri": hx(ri)}
+    b = 1 << ref.base
+    mk = lambda v: [(v >> (ref.base * i)) % b for i in range(N)]  # makebig (pseudo.py:190-199)
+    for outer, tag in ((1, "1k"), (100, "100k"), (100000, "full")):
+        x, y = ref.arr(mk(ra)), ref.arr(mk(rb))
+        tm["modmul_check_" + tag] = hx(ref.lib.chain_modmul(x, y, outer))
+        tm["modmul_z_" + tag] = H(list(x))
+        x = ref.arr(mk(rs))
+        tm["modsqr_check_" + tag] = hx(ref.lib.chain_modsqr(x, outer))
+        tm["modsqr_z_" + tag] = H(list(x))
+    tm["modinv_check_full"] = hx(pow(ri, -1, p) & 0xFFFFFF)  # z = 1/ri after an even number of inversions
+    tm["modinv_z_full"] = H(_canon(ref, pow(ri, -1, p)))
+    fx["time"] = tm
+    return fx, ref
+
+
+def _mli(ref, a, k):
+    z = ref.arr()
+    ref.lib.modmli(ref.arr(a), c_int(k), z)
+    return list(z)
+
+
+def _value(ref, limbs):
+    return sum(v << (ref.base * i) for i, v in enumerate(limbs))
+
+
+def _canon(ref, v):
+    b = 1 << ref.base
+    return [(v >> (ref.base * i)) % b for i in range(ref.N)]
+
+
+def lazy_fixture(script, prime, seed, count=64):
+    """generic=False variants (rfc7748.c:20; pseudo.py:294-325, 1523-1528): lazy modadd/modsub/modneg."""
+    rng = random.Random(seed)
+    ref = Ref(script, prime, overrides={"generic": False})
+    assert ref.ns["algorithm"] is True and ref.ns["mp"] == 2
+    H = lambda limbs: [hx(v) for v in limbs]
+    A = [ref.split(rng.randrange(0, 2 * ref.p)) for _ in range(count)]
+    B = [ref.split(rng.randrange(0, 2 * ref.p)) for _ in range(count)]
+    fx = {"prime": prime, "generator": script, "generic": False, "mp": ref.ns["mp"], "A": [H(a) for a in A], "B": [H(b) for b in B], "ops": {}}
+    for f in ("modadd", "modsub"):
+        fx["ops"][f] = [H(ref.bi(f, a, b)) for a, b in zip(A, B)]
+    fx["ops"]["modneg"] = [H(ref.un("modneg", a)) for a in A]
+    return fx
+
+
+# ---------------------------------------------------------------- RFC 7748 big-integer model
+def _x_ladder(k_bytes, u_bytes, bits, p, a24, cof):
+    """RFC 7748 section 5 (decodeScalar / decodeUCoordinate / ladder), independent of the reference."""
+    nb = (bits + 7) // 8
+    k = bytearray(k_bytes)
+    k[0] &= 256 - (1 << cof)
+    if bits % 8:
+        k[nb - 1] &= (1 << (bits % 8)) - 1
+        k[nb - 1] |= 1 << (bits % 8 - 1)
+    else:
+        k[nb - 1] |= 0x80
+    kk = int.from_bytes(k, "little")
+    ub = bytearray(u_bytes)
+    if bits % 8:
+        ub[nb - 1] &= (1 << (bits % 8)) - 1
+    u = int.from_bytes(ub, "little") % p
+    x1, x2, z2, x3, z3, swap = u, 1, 0, u, 1, 0
+    for t in range(bits - 1, -1, -1):
+        kt = (kk >> t) & 1
+        swap ^= kt
+        if swap:
+            x2, x3, z2, z3 = x3, x2, z3, z2
+        swap = kt
+        A = (x2 + z2) % p; AA = A * A % p; B = (x2 - z2) % p; BB = B * B % p
+        E = (AA - BB) % p; C = (x3 + z3) % p; D = (x3 - z3) % p
+        DA = D * A % p; CB = C * B % p
+        x3 = (DA + CB) ** 2 % p; z3 = x1 * (DA - CB) ** 2 % p
+        x2 = AA * BB % p; z2 = E * (AA + a24 * E) % p
+    if swap:
+        x2, x3, z2, z3 = x3, x2, z3, z2
+    return (x2 * pow(z2, p - 2, p) % p).to_bytes(nb, "little")
+
+
+CURVES = {"X25519": (255, 2**255 - 19, 121665, 3, 9), "X448": (448, 2**448 - 2**224 - 1, 39081, 2, 5)}
+
+
+def ladder(curve, k, u):
+    bits, p, a24, cof, _ = CURVES[curve]
+    return _x_ladder(k, u, bits, p, a24, cof)
+
+
+def ladder_fixture(curve, seed, count=96):
+    bits, p, a24, cof, gen = CURVES[curve]
+    nb = (bits + 7) // 8
+    rng = random.Random(seed)
+    fx = {"curve": curve, "source": "RFC 7748 model (tests/golden/make_golden.py); reference KAT keys rfc7748.c:271-277"}
+    G = bytes([gen]) + bytes(nb - 1)
+    kat = []
+    if curve == "X25519":
+        sk = bytes.fromhex("77076d0a7318a57d3c16c17251b26645df4c2f87ebc0992ab177fba51db92c2a")
+        sk2 = bytes.fromhex("5dab087e624a8a4b79e17f8b83800ee66f3bb1292618b6fd1c2f8b27ff88e0eb")
+        exp1 = "8520f0098930a754748b7ddcb43ef75a0dbf3a0d26381af4eba4a98eaa9b4e6a"
+        exp2 = "de9edb7d7b7dc1b4d35b61c2ece435373f8343c85b78674dadfc7e146f882b4f"
+        shared = "4a5d9d5ba4ce2de1728e3bf480350f25e07e21c947d19e3376f09b3c1e161742"
+        it1 = "422c8e7a6227d7bca1350b3e2bb7279f7897b87bb6854b783c60e80311ae3079"
+        it1000 = "684cf59ba83309552800ef566f2f4d3c1c3887c49360e3875f2eb94d99532c51"
+        tv = [("a546e36bf0527c9d3b16154b82465edd62144c0ac1fc5a18506a2244ba449ac4",
+               "e6db6867583030db3594c1a424b15f7c726624ec26b3353b10a903a6d0ab1c4c",
+               "c3da55379de9c6908e94ea4df28d084f32eccf03491c71f754b4075577a28552"),
+              ("4b66e9d4d1b4673c5ad22691957d6af5c11b6421e0ea01d42ca4169e7918ba0d",
+               "e5210f12786811d3f4b7959d0538ae2c31dbe7106fc03c3efc4cd549c715a493",
+               "95cbde9476e8907d7aade45cb4b873f88b595a68799fa152e6f8f7647aac7957")]
+    else:
+        sk = bytes.fromhex("9a8f4925d1519f5775cf46b04b5800d4ee9ee8bae8bc5565d498c28dd9c9baf574a9419744897391006382a6f127ab1d9ac2d8c0a598726b")
+        sk2 = bytes.fromhex("1c306a7ac2a0e2e0990b294470cba339e6453772b075811d8fad0d1d6927c120bb5ee8972b0d3e21374c9c921b09d1b0366f10b65173992d")
+        exp1 = "9b08f7cc31b7e3e67d22d5aea121074a273bd2b83de09c63faa73d2c22c5d9bbc836647241d953d40c5b12da88120d53177f80e532c41fa0"
+        exp2 = "3eb7a829b0cd20f5bcfc0b599b6feccf6da4627107bdb0d4f345b43027d8b972fc3e34fb4232a13ca706dcb57aec3dae07bdc1c67bf33609"
+        shared = "07fff4181ac6cc95ec1c16a94a0f74d12da232ce40a77552281d282bb60c0b56fd2464c335543936521c24403085d59a449a5037514a879d"
+        it1 = "3f482c8a9f19b01e6c46ee9711d9dc14fd4bf67af30765c2ae2b846a4d23a8cd0db897086239492caf350b51f833868b9bc2b3bca9cf4113"
+        it1000 = "aa3b4749d55b9daf1e5b00288826c467274ce3ebbdd5c17b975e09d4af6c67cf10d087202db88286e2b79fceea3ec353ef54faa26e219f38"
+        tv = [("3d262fddf9ec8e88495266fea19a34d28882acef045104d0d1aae121700a779c984c24f8cdd78fbff44943eba368f54b29259a4f1c600ad3",
+               "06fce640fa3487bfda5f6cf2d5263f8aad88334cbd07437f020f08f9814dc031ddbdc38c19c6da2583fa5429db94ada18aa7a7fb4ef8a086",
+               "ce3e4ff95a60dc6697da1db1d85e6afbdf79b50a2412d7546d5f239fe14fbaadeb445fc66a01b0779d98223961111e21766282f73dd96b6f"),
+              ("203d494428b8399352665ddca42f9de8fef600908e0d461cb021f8c538345dd77c3e4806e25f46d3315c44e0a5b4371282dd2c8d5be3095f",
+               "0fbcc2f993cd56d3305b0b7d9e55d4c1a8fb5dbb52f8e9a1e9b6201b165d015894e56c4d3570bee52fe205e28a78b91cdfbde71ce8d157db",
+               "884a02576239ff7a2f2f63b2db6a9ff37047ac13568e1e30fe63c4a7ad1b3ee3a5700df34321d62077e63633c575c1c954514e99da7c179d")]
+    assert ladder(curve, sk, G).hex() == exp1
+    assert ladder(curve, sk2, G).hex() == exp2
+    assert ladder(curve, sk, bytes.fromhex(exp2)).hex() == shared
+    kat.append({"k": sk.hex(), "u": G.hex(), "out": exp1, "src": "rfc7748.c:271-277 key; RFC 7748 6.x public key"})
+    kat.append({"k": sk2.hex(), "u": G.hex(), "out": exp2, "src": "simd/rfc7748_simt.cu:245 key (X25519); RFC 7748 6.x"})
+    kat.append({"k": sk.hex(), "u": exp2, "out": shared, "src": "RFC 7748 6.x shared secret"})
+    for k_, u_, o_ in tv:
+        assert ladder(curve, bytes.fromhex(k_), bytes.fromhex(u_)).hex() == o_
+        kat.append({"k": k_, "u": u_, "out": o_, "src": "RFC 7748 5.2 test vector"})
+    # RFC 7748 5.2 iteration test (1 and 1000 iterations)
+    k = u = G
+    for i in range(1000):
+        k, u = ladder(curve, k, u), k
+        if i == 0:
+            assert k.hex() == it1
+    assert k.hex() == it1000
+    fx["iter"] = {"start": G.hex(), "after_1": it1, "after_1000": it1000}
+    # the reference main()'s own chain: LCG key, 5000 x (bk,bu->bv ; bk,bv->bu)  (rfc7748.c:297-305)
+    rnd = 1
+    bk = bytearray(nb)
+    for i in range(nb):
+        rnd = (5 * rnd + 1) & 0xFFFF
+        bk[i] = rnd % 256
+    bu = G
+    chain = {"bk": bytes(bk).hex(), "bu0": G.hex(), "checkpoints": {}}
+    for i in range(5000):
+        bv = ladder(curve, bytes(bk), bu)
+        bu = ladder(curve, bytes(bk), bv)
+        if i + 1 in (1, 10, 100, 1000, 5000):
+            chain["checkpoints"][str(i + 1)] = bu.hex()
+    # DH exchange that follows (rfc7748.c:321-333)
+    alice, bob = bytearray(nb), bytearray(nb)
+    for i in range(nb):
+        rnd = (5 * rnd + 1) & 0xFFFF; alice[i] = rnd % 256
+        rnd = (5 * rnd + 1) & 0xFFFF; bob[i] = rnd % 256
+    apk = ladder(curve, bytes(alice), G); bpk = ladder(curve, bytes(bob), G)
+    ssa = ladder(curve, bytes(alice), bpk); ssb = ladder(curve, bytes(bob), apk)
+    assert ssa == ssb
+    chain["dh"] = {"alice": bytes(alice).hex(), "bob": bytes(bob).hex(), "apk": apk.hex(), "bpk": bpk.hex(), "shared": ssa.hex()}
+    fx["ref_main_chain"] = chain
+    # seeded random pairs incl. awkward u: zero, one, p-1, p, p+1, 2^bits-1 (non-canonical), high bit set
+    pairs = []
+    special_u = [0, 1, p - 1, p, p + 1, (1 << (8 * nb)) - 1, (1 << bits) - 1, 2, gen]
+    for i in range(count):
+        kb = bytes(rng.randrange(256) for _ in range(nb))
+        if i < len(special_u):
+            ub = (special_u[i] % (1 << (8 * nb))).to_bytes(nb, "little")
+        else:
+            ub = bytes(rng.randrange(256) for _ in range(nb))
+        pairs.append({"k": kb.hex(), "u": ub.hex(), "out": ladder(curve, kb, ub).hex()})
+    pairs.append({"k": bytes(nb).hex(), "u": G.hex(), "out": ladder(curve, bytes(nb), G).hex()})
+    pairs.append({"k": (b"\xff" * nb).hex(), "u": G.hex(), "out": ladder(curve, b"\xff" * nb, G).hex()})
+    fx["kat"] = kat
+    fx["pairs"] = pairs
+    return fx
+
+
+def main():
+    out = {}
+    for script, prime, seed in (("pseudo.py", "X25519", 1001), ("monty.py", "NIST256", 1002), ("monty.py", "X448", 1003)):
+        fx, ref = field_fixture(script, prime, seed)
+        path = os.path.join(HERE, "field_%s.json" % prime)
+        json.dump(fx, open(path, "w"), indent=0, separators=(",", ":"))
+        print(prime, "time:", {k: v for k, v in fx["time"].items() if "check" in k})
+        out[prime] = path
+    for script, prime, seed in (("pseudo.py", "X25519", 2001), ("monty.py", "X448", 2003)):
+        fx = lazy_fixture(script, prime, seed)
+        json.dump(fx, open(os.path.join(HERE, "field_%s_lazy.json" % prime), "w"), indent=0, separators=(",", ":"))
+    for curve, seed in (("X25519", 3001), ("X448", 3003)):
+        fx = ladder_fixture(curve, seed)
+        json.dump(fx, open(os.path.join(HERE, "ladder_%s.json" % curve), "w"), indent=0, separators=(",", ":"))
+        print(curve, "ref main chain 5000:", fx["ref_main_chain"]["checkpoints"]["5000"], "dh:", fx["ref_main_chain"]["dh"]["shared"])
+
+
+if __name__ == "__main__":
+    main()

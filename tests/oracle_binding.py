@@ -1,0 +1,100 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Allowed importers: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_char_p, c_int, c_long, c_size_t, c_uint, c_uint64, c_void_p
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+U64P = POINTER(c_uint64)
+INTP = POINTER(c_int)
+
+PRIMES = {"X25519": (5, 51, 255, 32), "NIST256": (5, 52, 256, 32), "X448": (8, 56, 448, 56)}
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ODIR, "all"])
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        for P in PRIMES:
+            g = lambda f: getattr(lib, "%s_%s" % (f, P))
+            for f in ("modadd", "modsub", "modmul", "modadd_lazy", "modsub_lazy"):
+                g(f).argtypes = [U64P, U64P, U64P]; g(f).restype = None
+            for f in ("modneg", "modneg_lazy", "modsqr", "modcpy", "nres", "redc", "modpro"):
+                g(f).argtypes = [U64P, U64P]; g(f).restype = None
+            g("modinv").argtypes = [U64P, U64P, U64P]; g("modinv").restype = None
+            g("modmli").argtypes = [U64P, c_int, U64P]; g("modmli").restype = None
+            g("modnsqr").argtypes = [U64P, c_int]; g("modnsqr").restype = None
+            for f in ("flatten", "modfsb"):
+                g(f).argtypes = [U64P]; g(f).restype = c_uint64
+            for f in ("modis1", "modis0", "modsign"):
+                g(f).argtypes = [U64P]; g(f).restype = c_int
+            g("modcmp").argtypes = [U64P, U64P]; g("modcmp").restype = c_int
+            for f in ("modzer", "modone", "modhaf"):
+                g(f).argtypes = [U64P]; g(f).restype = None
+            g("modint").argtypes = [c_int, U64P]; g("modint").restype = None
+            g("mod2r").argtypes = [c_uint, U64P]; g("mod2r").restype = None
+            g("modcmv").argtypes = [c_int, U64P, U64P]; g("modcmv").restype = None
+            g("modcsw").argtypes = [c_int, U64P, U64P]; g("modcsw").restype = None
+            g("modshl").argtypes = [c_uint, U64P]; g("modshl").restype = None
+            g("modshr").argtypes = [c_uint, U64P]; g("modshr").restype = c_int
+            g("modexp").argtypes = [U64P, ctypes.c_char_p]; g("modexp").restype = None
+            g("modimp").argtypes = [ctypes.c_char_p, U64P]; g("modimp").restype = c_int
+            g("time_modmul").argtypes = [U64P, U64P, c_long]; g("time_modmul").restype = c_uint
+            g("time_modsqr").argtypes = [U64P, c_long]; g("time_modsqr").restype = c_uint
+            g("time_modinv").argtypes = [U64P, c_long]; g("time_modinv").restype = c_uint
+            for f in ("batch_modmul", "batch_modadd", "batch_modsub", "batch_modadd_lazy", "batch_modsub_lazy", "batch_modmul_shared"):
+                g(f).argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t]; g(f).restype = None
+            for f in ("batch_modsqr", "batch_modneg", "batch_modneg_lazy", "batch_nres", "batch_redc", "batch_modcpy", "batch_modinv"):
+                g(f).argtypes = [c_void_p, c_void_p, c_size_t, c_size_t]; g(f).restype = None
+            g("batch_modmli").argtypes = [c_void_p, c_int, c_void_p, c_size_t, c_size_t]; g("batch_modmli").restype = None
+            g("batch_modcsw").argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t]; g("batch_modcsw").restype = None
+            g("batch_modcmv").argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t]; g("batch_modcmv").restype = None
+            g("batch_modfsb").argtypes = [c_void_p, c_void_p, c_size_t, c_size_t]; g("batch_modfsb").restype = None
+            g("batch_modimp").argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t]; g("batch_modimp").restype = None
+            g("batch_modexp").argtypes = [c_void_p, c_void_p, c_size_t, c_size_t]; g("batch_modexp").restype = None
+        for C in ("X25519", "X448"):
+            f = getattr(lib, "rfc7748_" + C)
+            f.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]; f.restype = None
+            f = getattr(lib, "batch_rfc7748_" + C)
+            f.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]; f.restype = None
+        lib.oracle_parallel.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int]
+        lib.oracle_parallel.restype = c_int
+
+    def fn(self, name, prime):
+        return getattr(self.lib, "%s_%s" % (name, prime))
+
+    @staticmethod
+    def arr(prime, vals=None):
+        n = PRIMES[prime][0]
+        return (c_uint64 * n)(*(vals if vals is not None else [0] * n))
+
+    # element-level helpers returning python lists
+    def un(self, f, P, a):
+        z = self.arr(P)
+        self.fn(f, P)(self.arr(P, a), z)
+        return list(z)
+
+    def bi(self, f, P, a, b):
+        z = self.arr(P)
+        self.fn(f, P)(self.arr(P, a), self.arr(P, b), z)
+        return list(z)
+
+    def ladder(self, curve, k, u):
+        nb = PRIMES[curve][3]
+        out = ctypes.create_string_buffer(nb)
+        getattr(self.lib, "rfc7748_" + curve)(bytes(k), bytes(u), out)
+        return out.raw
+
+
+def load_oracle(build=True):
+    so = os.path.join(ODIR, "liboracle.so")
+    if build or not os.path.exists(so):
+        build_oracle()
+    return Oracle(ctypes.CDLL(so))

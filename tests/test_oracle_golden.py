@@ -1,0 +1,236 @@
+"""The CPU oracle against the golden vectors produced by running the reference
+(tests/golden/make_golden.py).  CPU-only; this is what pins the oracle."""
+import ctypes
+
+import pytest
+
+from tests.conftest import limbs, load_golden
+from tests.oracle_binding import PRIMES
+
+ALL = ["X25519", "NIST256", "X448"]
+
+
+@pytest.fixture(scope="module", params=ALL)
+def fx(request):
+    return request.param, load_golden("field_%s.json" % request.param)
+
+
+def test_macro_block(fx):
+    P, g = fx
+    N, radix, nbits, nbytes = PRIMES[P]
+    hdr = " ".join(g["params"]["header"])
+    assert "#define Nlimbs %d" % N in hdr and "#define Radix %d" % radix in hdr
+    assert "#define Nbits %d" % nbits in hdr and "#define Nbytes %d" % nbytes in hdr
+
+
+@pytest.mark.parametrize("op", ["modadd", "modsub", "modmul"])
+def test_binary_ops(oracle, fx, op):
+    P, g = fx
+    for a, b, want in zip(g["A"], g["B"], g["ops"][op]):
+        assert oracle.bi(op, P, limbs(a), limbs(b)) == limbs(want)
+
+
+@pytest.mark.parametrize("op", ["modneg", "modsqr", "redc", "nres"])
+def test_unary_ops(oracle, fx, op):
+    P, g = fx
+    for a, want in zip(g["A"], g["ops"][op]):
+        assert oracle.un(op, P, limbs(a)) == limbs(want)
+
+
+def test_nres_of_raw(oracle, fx):
+    P, g = fx
+    for a, want in zip(g["raw_a"], g["nres_raw_a"]):
+        assert oracle.un("nres", P, limbs(a)) == limbs(want)
+
+
+def test_chained_noncanonical(oracle, fx):
+    P, g = fx
+    o = g["ops"]
+    for i, (a, b) in enumerate(zip(g["A"], g["B"])):
+        a, b = limbs(a), limbs(b)
+        C = oracle.bi("modmul", P, a, b)
+        D = oracle.bi("modsub", P, a, b)
+        E = oracle.bi("modadd", P, a, b)
+        assert oracle.bi("modmul", P, C, D) == limbs(o["chain_mul_CD"][i])
+        assert oracle.un("modsqr", P, D) == limbs(o["chain_sqr_D"][i])
+        assert oracle.bi("modadd", P, D, E) == limbs(o["chain_add_DE"][i])
+        assert oracle.bi("modsub", P, E, C) == limbs(o["chain_sub_EC"][i])
+        assert oracle.un("redc", P, C) == limbs(o["chain_redc_C"][i])
+
+
+def test_aliasing(oracle, fx):
+    P, g = fx
+    for a, b, want in zip(g["A"], g["B"], g["ops"]["alias_chain"]):
+        x, y = oracle.arr(P, limbs(a)), oracle.arr(P, limbs(b))
+        oracle.fn("modmul", P)(x, y, x)
+        oracle.fn("modsqr", P)(x, x)
+        oracle.fn("modadd", P)(x, x, x)
+        oracle.fn("modsub", P)(x, y, x)
+        assert list(x) == limbs(want)
+
+
+def test_modmli(oracle, fx):
+    P, g = fx
+    ints = g["ops"]["modmli_ints"]
+    for a, row in zip(g["A"], g["ops"]["modmli"]):
+        for k, want in zip(ints, row):
+            z = oracle.arr(P)
+            oracle.fn("modmli", P)(oracle.arr(P, limbs(a)), k, z)
+            assert list(z) == limbs(want)
+
+
+def test_modfsb_flatten(oracle, fx):
+    P, g = fx
+    for f in ("modfsb", "flatten"):
+        for a, (want, ret) in zip(g["A"], g["ops"][f]):
+            x = oracle.arr(P, limbs(a))
+            r = oracle.fn(f, P)(x)
+            assert list(x) == limbs(want) and int(r) == ret
+
+
+def test_predicates(oracle, fx):
+    P, g = fx
+    o = g["ops"]
+    for i, (a, b) in enumerate(zip(g["A"], g["B"])):
+        x, y = oracle.arr(P, limbs(a)), oracle.arr(P, limbs(b))
+        assert oracle.fn("modis1", P)(x) == o["modis1"][i]
+        assert oracle.fn("modis0", P)(x) == o["modis0"][i]
+        assert oracle.fn("modsign", P)(x) == o["modsign"][i]
+        assert oracle.fn("modcmp", P)(x, y) == o["modcmp"][i]
+    assert any(o["modis0"]) and any(o["modis1"])  # the corner pool really hits both
+
+
+def test_modhaf_shifts(oracle, fx):
+    P, g = fx
+    for a, want in zip(g["A"], g["ops"]["modhaf"]):
+        x = oracle.arr(P, limbs(a))
+        oracle.fn("modhaf", P)(x)
+        assert list(x) == limbs(want)
+    for a, rec in zip(g["A"], g["ops"]["shifts"]):
+        x = oracle.arr(P, oracle.un("redc", P, limbs(a)))
+        oracle.fn("modshl", P)(rec["k"], x)
+        assert list(x) == limbs(rec["shl_of_redc"])
+        x = oracle.arr(P, limbs(a))
+        r = oracle.fn("modshr", P)(rec["k"], x)
+        assert list(x) == limbs(rec["shr"]) and r == rec["shr_ret"]
+
+
+def test_cond_move_swap(oracle, fx):
+    P, g = fx
+    for a, b, rec in zip(g["A"], g["B"], g["ops"]["cond"]):
+        x, y = oracle.arr(P, limbs(a)), oracle.arr(P, limbs(b))
+        oracle.fn("modcsw", P)(rec["d"], x, y)
+        assert list(x) == limbs(rec["csw_g"]) and list(y) == limbs(rec["csw_f"])
+        y = oracle.arr(P, limbs(b))
+        oracle.fn("modcmv", P)(rec["d"], oracle.arr(P, limbs(a)), y)
+        assert list(y) == limbs(rec["cmv_f"])
+
+
+def test_constants(oracle, fx):
+    P, g = fx
+    o = g["ops"]
+    x = oracle.arr(P); oracle.fn("modone", P)(x); assert list(x) == limbs(o["modone"])
+    x = oracle.arr(P, [7] * PRIMES[P][0]); oracle.fn("modzer", P)(x); assert list(x) == limbs(o["modzer"])
+    for k, want in o["modint"]:
+        x = oracle.arr(P); oracle.fn("modint", P)(k, x); assert list(x) == limbs(want)
+    for k, want in o["mod2r"]:
+        x = oracle.arr(P); oracle.fn("mod2r", P)(k, x); assert list(x) == limbs(want)
+
+
+def test_bytes_io(oracle, fx):
+    P, g = fx
+    nb = PRIMES[P][3]
+    for rec in g["ops"]["bytes"]:
+        x = oracle.arr(P)
+        r = oracle.fn("modimp", P)(bytes.fromhex(rec["bytes"]), x)
+        assert list(x) == limbs(rec["imp"]) and r == rec["imp_ret"]
+        out = ctypes.create_string_buffer(nb)
+        oracle.fn("modexp", P)(x, out)
+        assert out.raw.hex() == rec["exp"]
+    for a, want in zip(g["A"], g["ops"]["modexp_A"]):
+        out = ctypes.create_string_buffer(nb)
+        oracle.fn("modexp", P)(oracle.arr(P, limbs(a)), out)
+        assert out.raw.hex() == want
+
+
+def test_modinv_after_redc(oracle, fx):
+    """modpro/modinv use our own addition chain, so only the canonical value is comparable
+    (SURVEY 8(c) caveat 1); modinv(0) = 0."""
+    P, g = fx
+    for rec in g["ops"]["modinv"]:
+        z = oracle.arr(P)
+        oracle.fn("modinv", P)(oracle.arr(P, limbs(rec["x"])), None, z)
+        assert oracle.un("redc", P, list(z)) == limbs(rec["inv_redc"])
+        # progenitor path: h = modpro(x) supplied by the caller (rfc7748.c:226-227)
+        h = oracle.arr(P)
+        oracle.fn("modpro", P)(oracle.arr(P, limbs(rec["x"])), h)
+        z2 = oracle.arr(P)
+        oracle.fn("modinv", P)(oracle.arr(P, limbs(rec["x"])), h, z2)
+        assert list(z2) == list(z)
+
+
+def test_time_protocol_check_words(oracle, fx):
+    """time.c protocol (pseudo.py:1235-1250): 1k- and 100k-deep prefixes of the reference chains here;
+    the full 10^8-deep run is `oracle/time_oracle` (bench.py runs it as the cpu_baseline)."""
+    P, g = fx
+    t = g["time"]
+    N, radix = PRIMES[P][0], PRIMES[P][1]
+    mk = lambda v: [(int(v, 16) >> (radix * i)) & ((1 << radix) - 1) for i in range(N)]
+    for outer, tag in ((1, "1k"), (100, "100k")):
+        x, y = oracle.arr(P, mk(t["ra"])), oracle.arr(P, mk(t["rb"]))
+        assert oracle.fn("time_modmul", P)(x, y, outer) == int(t["modmul_check_" + tag], 16)
+        assert list(x) == limbs(t["modmul_z_" + tag])
+        x = oracle.arr(P, mk(t["rs"]))
+        assert oracle.fn("time_modsqr", P)(x, outer) == int(t["modsqr_check_" + tag], 16)
+        assert list(x) == limbs(t["modsqr_z_" + tag])
+    x = oracle.arr(P, mk(t["ri"]))
+    assert oracle.fn("time_modinv", P)(x, 3) == int(t["modinv_check_full"], 16)
+    assert list(x) == limbs(t["modinv_z_full"])
+
+
+@pytest.mark.parametrize("P", ["X25519", "X448"])
+def test_lazy_forms(oracle, P):
+    g = load_golden("field_%s_lazy.json" % P)
+    for a, b, wa, ws, wn in zip(g["A"], g["B"], g["ops"]["modadd"], g["ops"]["modsub"], g["ops"]["modneg"]):
+        a, b = limbs(a), limbs(b)
+        assert oracle.bi("modadd_lazy", P, a, b) == limbs(wa)
+        assert oracle.bi("modsub_lazy", P, a, b) == limbs(ws)
+        assert oracle.un("modneg_lazy", P, a) == limbs(wn)
+
+
+@pytest.mark.parametrize("C", ["X25519", "X448"])
+def test_ladder_kats(oracle, C):
+    g = load_golden("ladder_%s.json" % C)
+    for rec in g["kat"] + g["pairs"]:
+        assert oracle.ladder(C, bytes.fromhex(rec["k"]), bytes.fromhex(rec["u"])).hex() == rec["out"], rec
+    # aliasing bv == bu (rfc7748.c:329)
+    nb = PRIMES[C][3]
+    rec = g["kat"][0]
+    buf = ctypes.create_string_buffer(bytes.fromhex(rec["u"]), nb)
+    getattr(oracle.lib, "rfc7748_" + C)(bytes.fromhex(rec["k"]), buf, buf)
+    assert buf.raw.hex() == rec["out"]
+
+
+@pytest.mark.parametrize("C,iters", [("X25519", 100), ("X448", 10)])
+def test_ladder_reference_main_chain(oracle, C, iters):
+    """the reference main()'s LCG-keyed chain (rfc7748.c:297-305), prefix checkpoints + DH block."""
+    g = load_golden("ladder_%s.json" % C)["ref_main_chain"]
+    bk, bu = bytes.fromhex(g["bk"]), bytes.fromhex(g["bu0"])
+    for i in range(iters):
+        bv = oracle.ladder(C, bk, bu)
+        bu = oracle.ladder(C, bk, bv)
+        if str(i + 1) in g["checkpoints"]:
+            assert bu.hex() == g["checkpoints"][str(i + 1)]
+    dh = g["dh"]
+    assert oracle.ladder(C, bytes.fromhex(dh["alice"]), bytes.fromhex(dh["bpk"])).hex() == dh["shared"]
+    assert oracle.ladder(C, bytes.fromhex(dh["bob"]), bytes.fromhex(dh["apk"])).hex() == dh["shared"]
+
+
+def test_ladder_iteration_rfc(oracle):
+    g = load_golden("ladder_X25519.json")["iter"]
+    k = u = bytes.fromhex(g["start"])
+    for i in range(1000):
+        k, u = oracle.ladder("X25519", k, u), k
+        if i == 0:
+            assert k.hex() == g["after_1"]
+    assert k.hex() == g["after_1000"]
