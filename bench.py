@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X batched field engine.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): batched modmul modulo 2^255-19, 5 x 51-bit limbs, 2^24 field
+elements per GPU in limb-interleaved SoA, inputs resident in HBM before the timed region.  One step =
+one modmul pass over the batch (c[j] = a[j]*b[j], 120 algorithmic bytes per element).  With N GPUs
+every rank owns its own 2^24-element batch (independent units, no data-path collective): weak
+scaling; value = all ranks' modmuls / max-over-ranks time.
+
+Also reported in the same JSON line:
+  roofline      HBM roofline of the modmul kernel: algorithmic bytes per launch / mean launch time,
+                measured with HIP events on the launch stream over the timed region.
+  cpu_baseline  (rank 0, N=1 only) the CPU oracle -- a port of the reference's generated field.c --
+                on the host cores: all-core modmul throughput on a bounded sample, plus the
+                reference's time.c protocol (serial latency, check word) on one core.
+  x25519        BASELINE.json configs[4] shape: batched RFC 7748 X25519 ladder, 2^23 scalars per GPU,
+                with the RCCL gather of the 32-byte results timed separately.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_MODMUL = 120         # 3 arrays x 5 limbs x 8 B
+LOG2_ELEMS = int(os.environ.get("MA_BENCH_LOG2_ELEMS", "24"))
+LOG2_LADDER = int(os.environ.get("MA_BENCH_LOG2_LADDER", "23"))
+
+
+def cpu_baseline(n_sample_log2=22, passes=4):
+    """oracle (kind "port") timed on the host: all-core throughput + the time.c protocol."""
+    import numpy as np
+    from tests.oracle_binding import load_oracle
+    from tests.util import random_soa, vp
+    oracle = load_oracle(build=not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")))
+    cores = len(os.sched_getaffinity(0))
+    n = 1 << n_sample_log2
+    a, b = random_soa("X25519", n, 101), random_soa("X25519", n, 102)
+    c = np.empty_like(a)
+    oracle.lib.oracle_parallel(0, vp(a), vp(b), vp(c), n, n, cores)  # warm
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        oracle.lib.oracle_parallel(0, vp(a), vp(b), vp(c), n, n, cores)
+    dt = time.perf_counter() - t0
+    thr = passes * n / dt
+    # reference-faithful latency: time.c protocol, 10^7 dependent modmuls (scale=10) on one core
+    U = ctypes.c_uint64 * 5
+    mk = lambda v: U(*[(v >> (51 * i)) & ((1 << 51) - 1) for i in range(5)])
+    ra = 0x11dc60f4392456de3eb13b9046685257bdd640fb06671ad11c80317fa3b1799d
+    rb = 0x4b95423416419f828b9d2434e465e150bd9c66b3ad3c2d6d1a3d1fa7bc8960a9
+    x, y = mk(ra), mk(rb)
+    t0 = time.perf_counter()
+    chk = oracle.fn("time_modmul", "X25519")(x, y, 10000)
+    lat = (time.perf_counter() - t0) / 1e7
+    # ladder on all cores, bounded sample
+    m = 256 * cores
+    rng = np.random.default_rng(7)
+    k = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
+    u = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
+    o = np.empty_like(u)
+    t0 = time.perf_counter()
+    oracle.lib.oracle_parallel(3, vp(k), vp(u), vp(o), m, 0, cores)
+    lad = m / (time.perf_counter() - t0)
+    return {
+        "value": thr, "unit": "modmul/s", "cores": cores, "kind": "port",
+        "sample": "oracle modmul_X25519 over 2^%d seeded elements x %d passes, %d threads (%.1f s)" % (n_sample_log2, passes, cores, dt),
+        "time_c_protocol": {"ns_per_modmul": lat * 1e9, "cores": 1, "dependent_modmuls": 10**7, "check_word_scale10": hex(chk)},
+        "x25519_scalar_mults_per_s": lad, "x25519_sample": "%d ladders, %d threads" % (m, cores),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-ladder", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1" % (args.gpus, world), file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from modarith_amd.field import Field, rfc7748
+    F = Field("X25519", dev)
+    n = 1 << LOG2_ELEMS
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    a = torch.randint(0, 1 << 51, (5, n), dtype=torch.int64, device=dev, generator=gen)
+    b = torch.randint(0, 1 << 51, (5, n), dtype=torch.int64, device=dev, generator=gen)
+    c = torch.empty_like(a)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        F.modmul(a, b, out=c)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        F.modmul(a, b, out=c)
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps      # mean launch duration on the launch stream
+    if world > 1:
+        tt = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, kern_ms = float(tt[0]), float(tt[1])
+    value = world * n * args.steps / dt
+    achieved = BYTES_PER_MODMUL * n / (kern_ms * 1e-3) / 1e9
+
+    # size-independent correctness guard inside the bench: a*b == b*a and (a*b) canonical form is stable
+    chk = F.modmul(b, a)
+    assert torch.equal(chk, c), "modmul is not commutative bit-for-bit: kernel bug"
+    del chk
+
+    ladder = None
+    if not args.no_ladder:
+        m = 1 << LOG2_LADDER
+        k = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)
+        u = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)
+        o = torch.empty_like(u)
+        rfc7748("X25519", k[:4096], u[:4096], out=o[:4096])  # warm-up
+        barrier()
+        reps = 2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rfc7748("X25519", k, u, out=o)
+        barrier()
+        lt = (time.perf_counter() - t0) / reps
+        gather_ms = None
+        if world > 1:
+            outs = [torch.empty_like(o) for _ in range(world)] if rank == 0 else None
+            barrier()
+            t0 = time.perf_counter()
+            dist.gather(o, outs, dst=0)     # the only collective: final result gather over xGMI (RCCL)
+            barrier()
+            gather_ms = (time.perf_counter() - t0) * 1e3
+            tt = torch.tensor([lt, gather_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            lt, gather_ms = float(tt[0]), float(tt[1])
+        ladder = {"value": world * m / lt, "unit": "X25519 scalar-mults/s", "scalars_per_gpu": m, "ms_per_pass": lt * 1e3,
+                  "gather_ms": gather_ms, "io_bytes_per_scalar": 96,
+                  "bound": "VALU 32-bit integer multiply-add issue (not HBM)"}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu:
+            cpu = cpu_baseline()
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_modmul_X25519.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "256-bit modmul/s (2^255-19)", "value": value, "unit": "modmul/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "batched modmul 2^255-19, 5x51-bit limbs, 2^%d elements per GPU, limb-interleaved SoA" % LOG2_ELEMS,
+                       "elements_per_gpu": n, "parallelism": "independent batches, %d rank(s), no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "k_binary<P_X25519,OpMul,2>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_MODMUL * n},
+            "cpu_baseline": cpu,
+            "x25519": ladder,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

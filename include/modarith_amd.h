@@ -1,0 +1,168 @@
+/* include/modarith_amd.h -- C ABI of libmodarith_amd.so, the MI355X (gfx950) batched finite-field engine.
+ *
+ * This is the drop-in boundary for modarith's generated field arithmetic.  The reference has no
+ * linked library: consumers paste field.c at a marker (rfc7748.c:24-28, edwards.c:19-23, edge.c:5-9).
+ * Its only linked form is the transient test.so that the generators build with makestatic=False and
+ * drive through ctypes (pseudo.py:1689-1750, monty.py:2264-2325); those exported signatures are what
+ * this header reproduces, in two forms per function and prime:
+ *
+ *   <fn>_<PRIME>_ct(...)      scalar form, the reference signature verbatim with the generators'
+ *                             decorated name (decoration=True, pseudo.py:1940-1944).  Host pointers,
+ *                             one element; executed on the GPU (n = 1).  For tests and glue only.
+ *   <fn>_<PRIME>_batch(...)   batched form, the n-lane generalisation the reference itself uses for
+ *                             SIMD/SIMT (simd/pseudo_simd.py: same names and arity, spint widened to a
+ *                             lane vector, limb-major storage; simd/rfc7748_simt.cu:165-168 contiguous
+ *                             byte records).  DEVICE pointers.
+ *
+ * PRIME is one of X25519 (pseudo.py 64 X25519: 5 x 51-bit limbs), NIST256 (monty.py 64 NIST256:
+ * 5 x 52-bit, Montgomery form, R = 2^260), X448 (monty.py 64 X448: 8 x 56-bit, Montgomery form,
+ * R = 2^504).  spint = uint64_t as in the 64-bit field.c (pseudo.py:1394-1398).
+ *
+ * Batched layout: limb-interleaved SoA.  A batch of n elements is a u64 array buf[limb*ld + j],
+ * 0 <= limb < Nlimbs, 0 <= j < n, ld >= n the limb stride in elements ("lanes" of simd.h, j-major
+ * within a limb).  ld lets a call work on a slice [off, off+n) of a larger batch (pass buf+off).
+ * For the 16-byte fast path keep buffers 16-byte aligned and ld even.  Byte records
+ * (modimp/modexp/rfc7748) are contiguous AoS: rec[j*Nbytes + i].
+ * Ownership / aliasing: the caller owns every buffer, nothing is allocated or retained; an output
+ * may be the same buffer (same base, same ld) as an input, as in the reference (modsqr(a,a),
+ * modadd(z,z,z), modmul(z2,E,z2), rfc7748(alice,apk,apk)).  Partial overlap is not supported.
+ * Results are bit-identical to the reference's field.c, including non-canonical (< 2p) limbs;
+ * modpro/modinv use a different addition chain (the reference shells out to `addchain`), so their
+ * limbs are only comparable after redc.
+ * Errors: the reference signals none.  Batched calls return 0 or a hipError_t value (launch/device
+ * errors only); modarith_amd_last_error() describes the last failure on the calling thread.  Scalar
+ * _ct calls abort() on a device error (their reference signatures have no way to report one).
+ * Streams: `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on it.
+ * Threading: entry points are re-entrant; scalar _ct calls serialise on an internal staging buffer.
+ */
+#ifndef MODARITH_AMD_H
+#define MODARITH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t ma_spint; /* spint of the 64-bit field.c (pseudo.py:1395) */
+
+/* ---- library / device utilities (no counterpart in the reference: it has no runtime) ---- */
+int modarith_amd_abi_version(void);            /* = MODARITH_AMD_ABI */
+const char *modarith_amd_last_error(void);
+int modarith_amd_device_count(void);
+int modarith_amd_set_device(int dev);
+int modarith_amd_malloc(void **dptr, size_t bytes);
+int modarith_amd_free(void *dptr);
+int modarith_amd_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int modarith_amd_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int modarith_amd_sync(void *stream);
+/* element-major (spint x[n][nlimbs], how CPU callers hold arrays of elements) <-> SoA; nlimbs in {5,8} */
+int modarith_amd_aos_to_soa(const ma_spint *aos, ma_spint *soa, size_t n, int nlimbs, size_t ld, void *stream);
+int modarith_amd_soa_to_aos(const ma_spint *soa, ma_spint *aos, size_t n, int nlimbs, size_t ld, void *stream);
+/* per-prime macro block of field.c (pseudo.py:1403-1407): returns 0 if `prime` is unknown */
+int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbits, int *nbytes, int *montgomery);
+
+#define MODARITH_AMD_ABI 1
+
+/* One block of declarations per prime.  Reference emitters cited once here:
+ *   flatten  pseudo.py:255-269    modfsb pseudo.py:272-283     modadd pseudo.py:286-304
+ *   modsub   pseudo.py:307-326    modneg pseudo.py:329-348     modmli pseudo.py:705-728 / monty.py:876-978
+ *   modmul   pseudo.py:616-659 / monty.py:663-872              modsqr pseudo.py:663-702 / monty.py:982-1165
+ *   modcpy   pseudo.py:730-743    modnsqr pseudo.py:745-755    modpro pseudo.py:758-785
+ *   modinv   pseudo.py:788-812    nres pseudo.py:952-962 / monty.py:1386-1399
+ *   redc     pseudo.py:965-976 / monty.py:1402-1416            modis1 pseudo.py:877-891
+ *   modis0   pseudo.py:894-906    modzer 909-919  modone 922-934  modint 937-949
+ *   modcmv   pseudo.py:1017-1048  modcsw pseudo.py:979-1014    modshl 1052-1065  modshr 1068-1081
+ *   modhaf   pseudo.py:1084-1100  mod2r 1102-1112  modexp 1115-1127  modimp 1130-1146
+ *   modsign  pseudo.py:1149-1158  modcmp 1161-1174
+ *   generic=False modadd/modsub/modneg ("_lazy"): pseudo.py:294-302, 315-324, 337-346 with mp=2
+ */
+#define MODARITH_AMD_DECLARE(P)                                                                                         \
+    /* ---------------- scalar form: reference signatures, host pointers ---------------- */                            \
+    ma_spint flatten_##P##_ct(ma_spint *n);                                                                             \
+    ma_spint modfsb_##P##_ct(ma_spint *n);                                                                              \
+    void modadd_##P##_ct(const ma_spint *a, const ma_spint *b, ma_spint *n);                                            \
+    void modsub_##P##_ct(const ma_spint *a, const ma_spint *b, ma_spint *n);                                            \
+    void modneg_##P##_ct(const ma_spint *b, ma_spint *n);                                                               \
+    void modmli_##P##_ct(const ma_spint *a, int b, ma_spint *c);                                                        \
+    void modmul_##P##_ct(const ma_spint *a, const ma_spint *b, ma_spint *c);                                            \
+    void modsqr_##P##_ct(const ma_spint *a, ma_spint *c);                                                               \
+    void modcpy_##P##_ct(const ma_spint *a, ma_spint *c);                                                               \
+    void modnsqr_##P##_ct(ma_spint *a, int n);                                                                          \
+    void modpro_##P##_ct(const ma_spint *w, ma_spint *z);                                                               \
+    void modinv_##P##_ct(const ma_spint *x, const ma_spint *h, ma_spint *z); /* h may be NULL */                        \
+    void nres_##P##_ct(const ma_spint *m, ma_spint *n);                                                                 \
+    void redc_##P##_ct(const ma_spint *n, ma_spint *m);                                                                 \
+    int modis1_##P##_ct(const ma_spint *a);                                                                             \
+    int modis0_##P##_ct(const ma_spint *a);                                                                             \
+    void modzer_##P##_ct(ma_spint *a);                                                                                  \
+    void modone_##P##_ct(ma_spint *a);                                                                                  \
+    void modint_##P##_ct(int x, ma_spint *a);                                                                           \
+    void modcmv_##P##_ct(int b, const ma_spint *g, volatile ma_spint *f);                                               \
+    void modcsw_##P##_ct(int b, volatile ma_spint *g, volatile ma_spint *f);                                            \
+    void modshl_##P##_ct(unsigned int n, ma_spint *a);                                                                  \
+    int modshr_##P##_ct(unsigned int n, ma_spint *a);                                                                   \
+    void modhaf_##P##_ct(ma_spint *n);                                                                                  \
+    void mod2r_##P##_ct(unsigned int r, ma_spint *a);                                                                   \
+    void modexp_##P##_ct(const ma_spint *a, char *b);                                                                   \
+    int modimp_##P##_ct(const char *b, ma_spint *a);                                                                    \
+    int modsign_##P##_ct(const ma_spint *a);                                                                            \
+    int modcmp_##P##_ct(const ma_spint *a, const ma_spint *b);                                                          \
+    /* ---------------- batched form: device pointers, SoA, limb stride ld ---------------- */                          \
+    int modadd_##P##_batch(const ma_spint *a, const ma_spint *b, ma_spint *n_, size_t n, size_t ld, void *stream);      \
+    int modsub_##P##_batch(const ma_spint *a, const ma_spint *b, ma_spint *n_, size_t n, size_t ld, void *stream);      \
+    int modneg_##P##_batch(const ma_spint *b, ma_spint *n_, size_t n, size_t ld, void *stream);                         \
+    int modadd_lazy_##P##_batch(const ma_spint *a, const ma_spint *b, ma_spint *n_, size_t n, size_t ld, void *stream); \
+    int modsub_lazy_##P##_batch(const ma_spint *a, const ma_spint *b, ma_spint *n_, size_t n, size_t ld, void *stream); \
+    int modneg_lazy_##P##_batch(const ma_spint *b, ma_spint *n_, size_t n, size_t ld, void *stream);                    \
+    int modmul_##P##_batch(const ma_spint *a, const ma_spint *b, ma_spint *c, size_t n, size_t ld, void *stream);       \
+    /* shared multiplicand c[j] = a[j] * b0; b0 = Nlimbs limbs in HOST memory (nres/redc/curve-constant call sites) */  \
+    int modmuls_##P##_batch(const ma_spint *a, const ma_spint *b0_host, ma_spint *c, size_t n, size_t ld, void *stream);\
+    int modsqr_##P##_batch(const ma_spint *a, ma_spint *c, size_t n, size_t ld, void *stream);                          \
+    int modmli_##P##_batch(const ma_spint *a, int b, ma_spint *c, size_t n, size_t ld, void *stream);                   \
+    int modcpy_##P##_batch(const ma_spint *a, ma_spint *c, size_t n, size_t ld, void *stream);                          \
+    int modnsqr_##P##_batch(ma_spint *a, int k, size_t n, size_t ld, void *stream);                                     \
+    int modpro_##P##_batch(const ma_spint *w, ma_spint *z, size_t n, size_t ld, void *stream);                          \
+    int modinv_##P##_batch(const ma_spint *x, const ma_spint *h, ma_spint *z, size_t n, size_t ld, void *stream);       \
+    int nres_##P##_batch(const ma_spint *m, ma_spint *n_, size_t n, size_t ld, void *stream);                           \
+    int redc_##P##_batch(const ma_spint *n_, ma_spint *m, size_t n, size_t ld, void *stream);                           \
+    /* in place; flag (device int[n], may be NULL) receives the return value per element */                            \
+    int modfsb_##P##_batch(ma_spint *a, int *flag, size_t n, size_t ld, void *stream);                                  \
+    int flatten_##P##_batch(ma_spint *a, int *flag, size_t n, size_t ld, void *stream);                                 \
+    int modhaf_##P##_batch(ma_spint *a, size_t n, size_t ld, void *stream);                                             \
+    int modshl_##P##_batch(unsigned int k, ma_spint *a, size_t n, size_t ld, void *stream);                             \
+    int modshr_##P##_batch(unsigned int k, ma_spint *a, int *out, size_t n, size_t ld, void *stream);                   \
+    /* predicates: out = device int[n] */                                                                               \
+    int modis1_##P##_batch(const ma_spint *a, int *out, size_t n, size_t ld, void *stream);                             \
+    int modis0_##P##_batch(const ma_spint *a, int *out, size_t n, size_t ld, void *stream);                             \
+    int modsign_##P##_batch(const ma_spint *a, int *out, size_t n, size_t ld, void *stream);                            \
+    int modcmp_##P##_batch(const ma_spint *a, const ma_spint *b, int *out, size_t n, size_t ld, void *stream);          \
+    /* fills */                                                                                                         \
+    int modzer_##P##_batch(ma_spint *a, size_t n, size_t ld, void *stream);                                             \
+    int modone_##P##_batch(ma_spint *a, size_t n, size_t ld, void *stream);                                             \
+    int modint_##P##_batch(int x, ma_spint *a, size_t n, size_t ld, void *stream);                                      \
+    int mod2r_##P##_batch(unsigned int r, ma_spint *a, size_t n, size_t ld, void *stream);                              \
+    /* constant-time conditional move/swap, one selector d[j] in {0,1} per element (device int[n]) */                  \
+    int modcmv_##P##_batch(const int *d, const ma_spint *g, ma_spint *f, size_t n, size_t ld, void *stream);            \
+    int modcsw_##P##_batch(const int *d, ma_spint *g, ma_spint *f, size_t n, size_t ld, void *stream);                  \
+    /* byte records: device char[n*Nbytes], big-endian per record as modimp/modexp take them */                        \
+    int modimp_##P##_batch(const char *b, ma_spint *a, int *flag, size_t n, size_t ld, void *stream);                   \
+    int modexp_##P##_batch(const ma_spint *a, char *b, size_t n, size_t ld, void *stream);
+
+MODARITH_AMD_DECLARE(X25519)
+MODARITH_AMD_DECLARE(NIST256)
+MODARITH_AMD_DECLARE(X448)
+
+/* RFC 7748 ladder, bv = [bk] * bu (reference rfc7748.c:156 `void rfc7748(const char *bk,const char *bu,char *bv)`).
+ * Scalar form: host pointers, Nbytes each (32 / 56), RFC little-endian.  Batched form: device pointers,
+ * n contiguous records (simd/rfc7748_simt.cu:165-168,224); bv may alias bu. */
+void rfc7748_X25519(const char *bk, const char *bu, char *bv);
+void rfc7748_X448(const char *bk, const char *bu, char *bv);
+int rfc7748_X25519_batch(const char *bk, const char *bu, char *bv, size_t n, void *stream);
+int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODARITH_AMD_H */

@@ -1,0 +1,107 @@
+"""ctypes loader for libmodarith_amd.so (the C-ABI of include/modarith_amd.h).
+
+The reference drives its generated code the same way: compile to a shared object, load it with
+ctypes.CDLL and declare argtypes (pseudo.py:1702-1750).  There is NO fallback: if the HIP library
+has not been built, loading raises; nothing in the product path computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_size_t, c_uint, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmodarith_amd.so")
+PRIMES = ("X25519", "NIST256", "X448")
+LADDERS = ("X25519", "X448")
+
+_lib = None
+
+_P = c_void_p
+_SIG = {
+    # name: argtypes of the _batch form (device pointers as void*)
+    "modadd": [_P, _P, _P, c_size_t, c_size_t, _P],
+    "modsub": [_P, _P, _P, c_size_t, c_size_t, _P],
+    "modadd_lazy": [_P, _P, _P, c_size_t, c_size_t, _P],
+    "modsub_lazy": [_P, _P, _P, c_size_t, c_size_t, _P],
+    "modmul": [_P, _P, _P, c_size_t, c_size_t, _P],
+    "modmuls": [_P, _P, _P, c_size_t, c_size_t, _P],
+    "modneg": [_P, _P, c_size_t, c_size_t, _P],
+    "modneg_lazy": [_P, _P, c_size_t, c_size_t, _P],
+    "modsqr": [_P, _P, c_size_t, c_size_t, _P],
+    "modcpy": [_P, _P, c_size_t, c_size_t, _P],
+    "modpro": [_P, _P, c_size_t, c_size_t, _P],
+    "nres": [_P, _P, c_size_t, c_size_t, _P],
+    "redc": [_P, _P, c_size_t, c_size_t, _P],
+    "modinv": [_P, _P, _P, c_size_t, c_size_t, _P],
+    "modmli": [_P, c_int, _P, c_size_t, c_size_t, _P],
+    "modnsqr": [_P, c_int, c_size_t, c_size_t, _P],
+    "modfsb": [_P, _P, c_size_t, c_size_t, _P],
+    "flatten": [_P, _P, c_size_t, c_size_t, _P],
+    "modhaf": [_P, c_size_t, c_size_t, _P],
+    "modshl": [c_uint, _P, c_size_t, c_size_t, _P],
+    "modshr": [c_uint, _P, _P, c_size_t, c_size_t, _P],
+    "modis1": [_P, _P, c_size_t, c_size_t, _P],
+    "modis0": [_P, _P, c_size_t, c_size_t, _P],
+    "modsign": [_P, _P, c_size_t, c_size_t, _P],
+    "modcmp": [_P, _P, _P, c_size_t, c_size_t, _P],
+    "modzer": [_P, c_size_t, c_size_t, _P],
+    "modone": [_P, c_size_t, c_size_t, _P],
+    "modint": [c_int, _P, c_size_t, c_size_t, _P],
+    "mod2r": [c_uint, _P, c_size_t, c_size_t, _P],
+    "modcmv": [_P, _P, _P, c_size_t, c_size_t, _P],
+    "modcsw": [_P, _P, _P, c_size_t, c_size_t, _P],
+    "modimp": [_P, _P, _P, c_size_t, c_size_t, _P],
+    "modexp": [_P, _P, c_size_t, c_size_t, _P],
+}
+BATCH_FUNCS = tuple(_SIG)
+# scalar (_ct) names declared by the header, for the symbol-export test
+SCALAR_FUNCS = ("flatten", "modfsb", "modadd", "modsub", "modneg", "modmli", "modmul", "modsqr", "modcpy", "modnsqr",
+                "modpro", "modinv", "nres", "redc", "modis1", "modis0", "modzer", "modone", "modint", "modcmv",
+                "modcsw", "modshl", "modshr", "modhaf", "mod2r", "modexp", "modimp", "modsign", "modcmp")
+UTIL_FUNCS = ("modarith_amd_abi_version", "modarith_amd_last_error", "modarith_amd_device_count",
+              "modarith_amd_set_device", "modarith_amd_malloc", "modarith_amd_free", "modarith_amd_memcpy_h2d",
+              "modarith_amd_memcpy_d2h", "modarith_amd_sync", "modarith_amd_aos_to_soa", "modarith_amd_soa_to_aos",
+              "modarith_amd_field_info")
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library or raise: the engine has no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "modarith_amd: %s is missing -- build it with `python -m modarith_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for P in PRIMES:
+        for fn, args in _SIG.items():
+            f = getattr(lib, "%s_%s_batch" % (fn, P))
+            f.argtypes = args
+            f.restype = c_int
+    for C in LADDERS:
+        f = getattr(lib, "rfc7748_%s_batch" % C)
+        f.argtypes = [_P, _P, _P, c_size_t, _P]
+        f.restype = c_int
+        g = getattr(lib, "rfc7748_%s" % C)
+        g.argtypes = [c_char_p, c_char_p, c_char_p]
+        g.restype = None
+    lib.modarith_amd_last_error.restype = c_char_p
+    lib.modarith_amd_abi_version.restype = c_int
+    lib.modarith_amd_device_count.restype = c_int
+    lib.modarith_amd_aos_to_soa.argtypes = [_P, _P, c_size_t, c_int, c_size_t, _P]
+    lib.modarith_amd_soa_to_aos.argtypes = [_P, _P, c_size_t, c_int, c_size_t, _P]
+    lib.modarith_amd_field_info.argtypes = [c_char_p] + [ctypes.POINTER(c_int)] * 5
+    _lib = lib
+    return lib
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().modarith_amd_last_error().decode(errors="replace")
+        raise DeviceError("%s failed (hipError %d): %s" % (what, rc, msg))

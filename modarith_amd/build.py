@@ -1,0 +1,67 @@
+"""Build libmodarith_amd.so (HIP kernels + C-ABI shim) for gfx950, in-tree.
+
+  python -m modarith_amd.build [--force]
+
+Steps: (1) the parameter driver emits csrc/generated/params_<PRIME>.h (modarith_amd.emit),
+(2) hipcc compiles one translation unit per prime plus the common one, in parallel,
+(3) hipcc links modarith_amd/libmodarith_amd.so.  hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+
+from . import emit
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libmodarith_amd.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+UNITS = ["capi_common"] + ["capi_%s" % p for p in emit.BUILT_PRIMES]
+
+
+def _stamp() -> str:
+    h = hashlib.sha256()
+    for root, _, files in sorted(os.walk(CSRC)):
+        for f in sorted(files):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(HERE), "include", "modarith_amd.h"), "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(unit: str) -> str:
+    src = os.path.join(CSRC, unit + ".hip")
+    obj = os.path.join(OBJ, unit + ".o")
+    subprocess.check_call([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    emit.emit_all()
+    os.makedirs(OBJ, exist_ok=True)
+    stamp_file = os.path.join(OBJ, "stamp")
+    stamp = _stamp()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return LIB
+    if verbose:
+        print("[modarith_amd] compiling %d HIP units for %s ..." % (len(UNITS), ARCH), flush=True)
+    with cf.ThreadPoolExecutor(max_workers=min(4, len(UNITS))) as ex:
+        objs = list(ex.map(_compile, UNITS))
+    subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    if verbose:
+        print("[modarith_amd] built", LIB, flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,39 @@
+// modarith_amd/csrc/capi_common.h -- shared host-side helpers of the C-ABI shim (launch geometry,
+// error capture, scalar staging).  Host code only; no torch types anywhere in the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string>
+
+namespace ma {
+
+void set_error(const std::string& msg);
+int check_launch(const char* what);
+int max_blocks();          // grid cap for grid-stride streaming kernels (env MA_MAX_BLOCKS)
+int ladder_block();        // workgroup size of the ladder kernel (env MA_LADDER_BLOCK)
+
+inline unsigned grid_for(size_t nthreads, int block = 256) {
+    size_t b = (nthreads + (size_t)block - 1) / (size_t)block;
+    size_t cap = (size_t)max_blocks();
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// staging area for the scalar (_ct) entry points: a small device buffer guarded by a mutex
+struct Staging {
+    std::mutex mu;
+    unsigned char* dev = nullptr;
+    static constexpr size_t BYTES = 4096;
+    unsigned char* get();
+};
+Staging& staging();
+[[noreturn]] void die(const char* what, hipError_t e);
+
+}  // namespace ma

@@ -1,0 +1,122 @@
+// modarith_amd/csrc/capi_common.hip -- prime-independent part of the C-ABI shim (include/modarith_amd.h):
+// device/memory utilities, error reporting, AoS<->SoA converters, field_info.
+#include "../../include/modarith_amd.h"
+#include "capi_common.h"
+#include "kernels.h"
+#include <string.h>
+
+namespace ma {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string& msg) { g_err = msg; }
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(std::string(what) + ": " + hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+static int env_int(const char* name, int dflt, int lo, int hi) {
+    const char* s = getenv(name);
+    if (!s || !*s) return dflt;
+    long v = strtol(s, nullptr, 10);
+    if (v < lo) v = lo;
+    if (v > hi) v = hi;
+    return (int)v;
+}
+
+int max_blocks() {
+    static int v = env_int("MA_MAX_BLOCKS", 256 * 16, 1, 1 << 24);
+    return v;
+}
+int ladder_block() {
+    static int v = env_int("MA_LADDER_BLOCK", 64, 64, 1024) / 64 * 64;
+    return v;
+}
+
+unsigned char* Staging::get() {
+    if (!dev) {
+        hipError_t e = hipMalloc((void**)&dev, BYTES);
+        if (e != hipSuccess) die("hipMalloc(staging)", e);
+    }
+    return dev;
+}
+Staging& staging() {
+    static Staging s;
+    return s;
+}
+void die(const char* what, hipError_t e) {
+    fprintf(stderr, "modarith_amd: %s failed: %s\n", what, hipGetErrorString(e));
+    abort();
+}
+
+static int wrap(hipError_t e, const char* what) {
+    if (e != hipSuccess) {
+        set_error(std::string(what) + ": " + hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" {
+
+int modarith_amd_abi_version(void) { return MODARITH_AMD_ABI; }
+const char* modarith_amd_last_error(void) { return g_err.c_str(); }
+int modarith_amd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int modarith_amd_set_device(int dev) { return wrap(hipSetDevice(dev), "hipSetDevice"); }
+int modarith_amd_malloc(void** dptr, size_t bytes) { return wrap(hipMalloc(dptr, bytes), "hipMalloc"); }
+int modarith_amd_free(void* dptr) { return wrap(hipFree(dptr), "hipFree"); }
+int modarith_amd_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    return wrap(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream), "hipMemcpyAsync(h2d)");
+}
+int modarith_amd_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    return wrap(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), "hipMemcpyAsync(d2h)");
+}
+int modarith_amd_sync(void* stream) { return wrap(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize"); }
+
+int modarith_amd_aos_to_soa(const ma_spint* aos, ma_spint* soa, size_t n, int nlimbs, size_t ld, void* stream) {
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (nlimbs == 5) k_aos2soa<5><<<grid_for(n), BLOCK, 0, s>>>(aos, soa, n, ld);
+    else if (nlimbs == 8) k_aos2soa<8><<<grid_for(n), BLOCK, 0, s>>>(aos, soa, n, ld);
+    else { set_error("aos_to_soa: nlimbs must be 5 or 8"); return (int)hipErrorInvalidValue; }
+    return check_launch("aos_to_soa");
+}
+int modarith_amd_soa_to_aos(const ma_spint* soa, ma_spint* aos, size_t n, int nlimbs, size_t ld, void* stream) {
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (nlimbs == 5) k_soa2aos<5><<<grid_for(n), BLOCK, 0, s>>>(soa, aos, n, ld);
+    else if (nlimbs == 8) k_soa2aos<8><<<grid_for(n), BLOCK, 0, s>>>(soa, aos, n, ld);
+    else { set_error("soa_to_aos: nlimbs must be 5 or 8"); return (int)hipErrorInvalidValue; }
+    return check_launch("soa_to_aos");
+}
+
+int modarith_amd_field_info(const char* prime, int* nlimbs, int* radix, int* nbits, int* nbytes, int* montgomery) {
+    struct Row { const char* name; int nl, rx, nb, by, mo; };
+    static const Row rows[] = {{"X25519", 5, 51, 255, 32, 0}, {"NIST256", 5, 52, 256, 32, 1}, {"X448", 8, 56, 448, 56, 1}};
+    for (const Row& r : rows) {
+        if (strcmp(prime, r.name) == 0) {
+            if (nlimbs) *nlimbs = r.nl;
+            if (radix) *radix = r.rx;
+            if (nbits) *nbits = r.nb;
+            if (nbytes) *nbytes = r.by;
+            if (montgomery) *montgomery = r.mo;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,615 @@
+// modarith_amd/csrc/field.h -- per-thread field arithmetic for gfx950, one element per lane.
+//
+// Device-side counterpart of the functions modarith's generators emit into field.c
+// (pseudo.py:223-1174 for 2^n-c primes, monty.py:352-1650 for Montgomery-form primes), written as
+// C++ templates over a parameter struct P that the Python driver (modarith_amd/params.py ->
+// csrc/generated/params_<PRIME>.h) emits.  Every limb stays in VGPRs: all loops are unrolled at
+// compile time (static_for + if constexpr), so the shape of the prime (0, +-1, 2^k limbs) is
+// resolved by the compiler exactly as the reference resolves it at generation time.
+//
+// Results are bit-identical to the reference's 64-bit field.c for EVERY input (also out-of-contract
+// limbs): column sums are accumulated in a 128-bit integer with the same mask/shift points, and the
+// 64-bit wrap-around spots (ma=a*mm, ta=2a, the scratch word s, q-v, v-1) are kept where the
+// reference has them.  No MFMA: this is 64-bit integer carry-chain work.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace ma {
+
+using spint = uint64_t;
+using sspint = int64_t;
+using dpint = unsigned __int128;
+
+#define MA_DEV __device__ __forceinline__
+
+template <int I, int End, class Fn>
+MA_DEV void static_for(Fn&& fn) {
+    if constexpr (I < End) {
+        fn(std::integral_constant<int, I>{});
+        static_for<I + 1, End>(fn);
+    }
+}
+
+// 64x64 -> 128 product.  gfx950 has no 64-bit multiplier; the compiler lowers this to four
+// v_mad_u64_u32 plus carries.
+MA_DEV dpint mulw(spint a, spint b) { return (dpint)a * (dpint)b; }
+
+template <class P>
+struct Field {
+    static constexpr int N = P::N;
+    static constexpr int RADIX = P::RADIX;
+    static constexpr spint Q = (spint)1 << RADIX;
+    static constexpr spint MASK = Q - 1;
+
+    // ---------------------------------------------------------------- carries / normalisation
+    // pseudo.py:223-251, monty.py:352-380 (arithmetic-shift form)
+    static MA_DEV spint prop(spint* n) {
+        sspint carry = (sspint)n[0];
+        carry >>= RADIX;
+        n[0] &= MASK;
+        static_for<1, N - 1>([&](auto I) {
+            constexpr int i = I;
+            carry += (sspint)n[i];
+            n[i] = (spint)carry & MASK;
+            carry >>= RADIX;
+        });
+        n[N - 1] += (spint)carry;
+        return (spint)0 - ((n[N - 1] >> 1) >> 62);
+    }
+
+    // n += x*p under an AND selector (caddp/addp: pseudo.py:202-213, monty.py:301-332)
+    template <unsigned X>
+    static MA_DEV void addp(spint* n, spint sel) {
+        static_for<0, P::PP_CNT>([&](auto K) {
+            constexpr int k = K;
+            constexpr spint w = P::pp_val(k) * (spint)X;
+            if constexpr (P::pp_sgn(k) < 0) n[P::pp_idx(k)] -= w & sel;
+            else n[P::pp_idx(k)] += w & sel;
+        });
+    }
+    // n -= x*p (subp: pseudo.py:216-220, monty.py:335-349)
+    template <unsigned X>
+    static MA_DEV void subp(spint* n) {
+        static_for<0, P::PP_CNT>([&](auto K) {
+            constexpr int k = K;
+            constexpr spint w = P::pp_val(k) * (spint)X;
+            if constexpr (P::pp_sgn(k) < 0) n[P::pp_idx(k)] += w;
+            else n[P::pp_idx(k)] -= w;
+        });
+    }
+
+    // pseudo.py:255-269
+    static MA_DEV spint flatten(spint* n) {
+        spint carry = prop(n);
+        addp<1>(n, carry);
+        (void)prop(n);
+        return carry & 1;
+    }
+    // pseudo.py:272-283
+    static MA_DEV spint modfsb(spint* n) {
+        subp<1>(n);
+        return flatten(n);
+    }
+
+    // ---------------------------------------------------------------- add / sub / neg
+    // generic=True forms (pseudo.py:286-348, monty.py:417-490); out may alias in
+    static MA_DEV void modadd(const spint* a, const spint* b, spint* n) {
+        static_for<0, N>([&](auto I) { n[I] = a[I] + b[I]; });
+        subp<2>(n);
+        spint carry = prop(n);
+        addp<2>(n, carry);
+        (void)prop(n);
+    }
+    static MA_DEV void modsub(const spint* a, const spint* b, spint* n) {
+        static_for<0, N>([&](auto I) { n[I] = a[I] - b[I]; });
+        spint carry = prop(n);
+        addp<2>(n, carry);
+        (void)prop(n);
+    }
+    static MA_DEV void modneg(const spint* b, spint* n) {
+        static_for<0, N>([&](auto I) { n[I] = (spint)0 - b[I]; });
+        spint carry = prop(n);
+        addp<2>(n, carry);
+        (void)prop(n);
+    }
+    // generic=False forms with mp=2 (rfc7748.c:20; pseudo.py:294-325, monty.py:426-489)
+    static MA_DEV void modadd_lazy(const spint* a, const spint* b, spint* n) {
+        static_for<0, N>([&](auto I) { n[I] = a[I] + b[I]; });
+        (void)prop(n);
+    }
+    static MA_DEV void modsub_lazy(const spint* a, const spint* b, spint* n) {
+        static_for<0, N>([&](auto I) { n[I] = a[I] - b[I]; });
+        addp<2>(n, ~(spint)0);
+        (void)prop(n);
+    }
+    static MA_DEV void modneg_lazy(const spint* b, spint* n) {
+        static_for<0, N>([&](auto I) { n[I] = (spint)0 - b[I]; });
+        addp<2>(n, ~(spint)0);
+        (void)prop(n);
+    }
+
+    static MA_DEV void modcpy(const spint* a, spint* c) {
+        static_for<0, N>([&](auto I) { c[I] = a[I]; });
+    }
+
+    // ================================================================ pseudo-Mersenne family
+    // second reduction pass (pseudo.py:557-611)
+    static MA_DEV void pm_second_pass(dpint t, spint* v, spint* c) {
+        constexpr int XC = P::XCESS;
+        spint s, carry;
+        if constexpr (P::FRED) {
+            spint ut = (spint)t;
+            if constexpr (XC > 0) {
+                ut = (ut << XC) + (v[N - 1] >> (RADIX - XC));
+                v[N - 1] &= ((spint)1 << (RADIX - XC)) - 1;
+            }
+            if constexpr (P::M > 1) ut *= (spint)P::M;
+            s = v[0] + (ut & MASK);
+            c[0] = s & MASK;
+            if constexpr (P::CARRY_ON) {
+                ut = (s >> RADIX) + (ut >> RADIX);
+                s = v[1] + (ut & MASK);
+                c[1] = s & MASK;
+            }
+            carry = (s >> RADIX) + (ut >> RADIX);
+        } else {
+            dpint ut = t;
+            if constexpr (XC > 0) {
+                ut = (ut << XC) + (dpint)(v[N - 1] >> (RADIX - XC));
+                v[N - 1] &= ((spint)1 << (RADIX - XC)) - 1;
+            }
+            if constexpr (P::M > 1) ut *= (dpint)P::M;
+            s = v[0] + ((spint)ut & MASK);
+            c[0] = s & MASK;
+            if constexpr (P::CARRY_ON) {
+                ut = (dpint)(s >> RADIX) + (ut >> RADIX);
+                s = v[1] + ((spint)ut & MASK);
+                c[1] = s & MASK;
+            }
+            carry = (s >> RADIX) + (spint)(ut >> RADIX);
+        }
+        constexpr int k = P::CARRY_ON ? 2 : 1;
+        c[k] = v[k] + carry;
+        static_for<k + 1, N>([&](auto I) { c[I] = v[I]; });
+    }
+
+    // Comba rows, high half folded by mm (pseudo.py:616-659, getZM 390-438; overflow=False only)
+    static MA_DEV void pm_modmul(const spint* a, const spint* b, spint* c) {
+        static_assert(!P::OVERFLOW, "the overflow variants of pseudo.py are not built");
+        dpint t = 0;
+        spint v[N];
+        spint ma[N];
+        if constexpr (P::EPM) static_for<1, N>([&](auto I) { ma[I] = a[I] * (spint)P::MM; });
+        static_for<0, N>([&](auto ROW) {
+            constexpr int row = ROW;
+            if constexpr (P::EPM) {
+                static_for<row + 1, N>([&](auto K) {
+                    constexpr int k = K;
+                    t += mulw(ma[k], b[N + row - k]);
+                });
+            } else if constexpr (row < N - 1) {
+                dpint tt = 0;
+                static_for<row + 1, N>([&](auto K) {
+                    constexpr int k = K;
+                    tt += mulw(a[k], b[N + row - k]);
+                });
+                tt *= (dpint)P::MM;
+                t += tt;
+            }
+            static_for<0, row + 1>([&](auto K) {
+                constexpr int k = K;
+                t += mulw(a[k], b[row - k]);
+            });
+            v[row] = (spint)t & MASK;
+            t >>= RADIX;
+        });
+        pm_second_pass(t, v, c);
+    }
+
+    // squaring rows (pseudo.py:663-702, getZS 441-554)
+    static MA_DEV void pm_modsqr(const spint* a, spint* c) {
+        static_assert(!P::OVERFLOW, "the overflow variants of pseudo.py are not built");
+        dpint t = 0;
+        spint v[N];
+        spint ta[N], ma[N];
+        if constexpr (P::EPM) {
+            static_for<1, N>([&](auto I) { ta[I] = a[I] * (spint)2; });
+            static_for<1, N>([&](auto I) { ma[I] = a[I] * (spint)P::MM; });
+        }
+        static_for<0, N>([&](auto ROW) {
+            constexpr int row = ROW;
+            // folded (high) part: pairs (k, l) with k + l = N + row, row < k <= l < N
+            constexpr int hk0 = row + 1, hpairs = (N - 1 - hk0 + 1) / 2;  // strict pairs k < l
+            if constexpr (P::EPM) {
+                static_for<0, hpairs>([&](auto J) {
+                    constexpr int k = hk0 + J, l = N - 1 - J;
+                    t += mulw(ma[k], ta[l]);
+                });
+                if constexpr ((N - hk0) % 2 == 1) {
+                    constexpr int k = hk0 + hpairs;
+                    t += mulw(ma[k], a[k]);
+                }
+            } else if constexpr (row < N - 1) {
+                dpint tt = 0;
+                static_for<0, hpairs>([&](auto J) {
+                    constexpr int k = hk0 + J, l = N - 1 - J;
+                    tt += mulw(a[k], a[l]);
+                });
+                if constexpr (hpairs > 0) tt *= 2;
+                if constexpr ((N - hk0) % 2 == 1) {
+                    constexpr int k = hk0 + hpairs;
+                    tt += mulw(a[k], a[k]);
+                }
+                tt *= (dpint)P::MM;
+                t += tt;
+            }
+            // low part: pairs (k, l) with k + l = row
+            constexpr int lpairs = (row + 1) / 2;
+            if constexpr (P::EPM) {
+                static_for<0, lpairs>([&](auto J) {
+                    constexpr int k = J, l = row - J;
+                    t += mulw(a[k], ta[l]);
+                });
+                if constexpr (row % 2 == 0) t += mulw(a[row / 2], a[row / 2]);
+            } else {
+                dpint t2 = 0;
+                static_for<0, lpairs>([&](auto J) {
+                    constexpr int k = J, l = row - J;
+                    t2 += mulw(a[k], a[l]);
+                });
+                if constexpr (lpairs > 0) t2 *= 2;
+                if constexpr (row % 2 == 0) t2 += mulw(a[row / 2], a[row / 2]);
+                t += t2;
+            }
+            v[row] = (spint)t & MASK;
+            t >>= RADIX;
+        });
+        pm_second_pass(t, v, c);
+    }
+
+    // pseudo.py:705-728; (dpint)b sign-extends a negative int exactly as the emitted C does
+    static MA_DEV void pm_modmli(const spint* a, int b, spint* c) {
+        dpint t = 0;
+        spint v[N];
+        const dpint bw = (dpint)(__int128)b;
+        static_for<0, N>([&](auto I) {
+            t += (dpint)a[I] * bw;
+            v[I] = (spint)t & MASK;
+            t >>= RADIX;
+        });
+        pm_second_pass(t, v, c);
+    }
+
+    // ================================================================ Montgomery family (ndash == 1)
+    // Reduction contribution to column c: digit v_j meets signed prime limb l = c - j, 1 <= l <= LMAX
+    // (mul_process with the gone_neg / mask_set borrow convention: monty.py:597-627, 717-738, 778-838).
+    static constexpr int LMAX = P::MONTGOMERY ? (P::E ? N : N - 1) : 0;  // highest prime-limb index
+    static constexpr int JMAX = LMAX;                                   // highest digit index
+
+    template <int C>
+    static MA_DEV void monty_reduce(dpint& t, const spint* v) {
+        constexpr int NEG = P::NEG_LIMB;       // index (>=1) of the single -1 limb, or 0 if none
+        constexpr bool scratch = (NEG > 0) && (C > NEG);  // gone_neg at column start -> s = mask
+        spint s = MASK;
+        static_for<1, LMAX + 1>([&](auto L) {
+            constexpr int l = L;
+            constexpr int j = C - l;
+            if constexpr (j >= 0 && j <= JMAX && j < C) {
+                constexpr long long d = P::ppw(l);
+                if constexpr (d > 1) {
+                    if constexpr ((d & (d - 1)) == 0) {
+                        constexpr int e = __builtin_ctzll((unsigned long long)d);
+                        t += (dpint)v[j] << e;
+                    } else {
+                        t += mulw(v[j], (spint)d);
+                    }
+                } else if constexpr (d == 1) {
+                    if constexpr (scratch) s += v[j]; else t += (dpint)v[j];
+                } else if constexpr (d == -1) {
+                    if constexpr (scratch) s -= v[j];
+                    else t += (dpint)(spint)(Q - v[j]);   // first negative use (C == NEG, j == 0)
+                } else {
+                    static_assert(d == 0, "negative prime limbs other than -1 are not supported");
+                }
+            }
+        });
+        if constexpr (scratch) t += (dpint)s;
+    }
+
+    template <bool SQR>
+    static MA_DEV void monty_mul(const spint* a, const spint* b, spint* c) {
+        static_assert(P::NDASH == 1, "only Montgomery-friendly moduli (ndash == 1) are built");
+        constexpr int NCOL = P::E ? 2 * N : 2 * N - 1;
+        dpint t = 0;
+        spint v[JMAX + 1];
+        static_for<0, NCOL>([&](auto CC) {
+            constexpr int col = CC;
+            constexpr int lo = col < N ? 0 : col - (N - 1);
+            constexpr int hi = col < N ? col : N - 1;
+            if constexpr (lo <= hi) {
+                if constexpr (!SQR) {
+                    // getZMU / getZMD (monty.py:493-537)
+                    static_for<lo, hi + 1>([&](auto K) {
+                        constexpr int k = K;
+                        t += mulw(a[k], b[col - k]);
+                    });
+                } else {
+                    // getZSU / getZSD (monty.py:540-590): tot = 2*sum(cross) + square
+                    constexpr int pairs = (hi - lo + 1) / 2;
+                    dpint tot = 0;
+                    static_for<0, pairs>([&](auto J) {
+                        constexpr int k = lo + J;
+                        tot += mulw(a[k], a[col - k]);
+                    });
+                    if constexpr (pairs > 0) tot *= 2;
+                    if constexpr (col % 2 == 0) tot += mulw(a[col / 2], a[col / 2]);
+                    t += tot;
+                }
+            }
+            monty_reduce<col>(t, v);
+            if constexpr (col <= JMAX) v[col] = (spint)t & MASK;
+            else c[col - JMAX - 1] = (spint)t & MASK;
+            t >>= RADIX;
+        });
+        if constexpr (P::E) {
+            if constexpr (P::NEG_LIMB > 0) t += (dpint)(spint)(v[N] - (spint)1);
+            else t += (dpint)v[N];
+        } else {
+            if constexpr (P::NEG_LIMB > 0) t -= (dpint)1;
+        }
+        c[N - 1] = (spint)t;
+    }
+
+    // monty.py:876-978: trinomial fold, else Barrett-Dhem
+    static MA_DEV void monty_modmli(const spint* a, int b, spint* c) {
+        const dpint bw = (dpint)(__int128)b;
+        dpint t = 0;
+        if constexpr (P::TRIN > 0) {
+            static_for<0, N>([&](auto I) {
+                t += (dpint)a[I] * bw;
+                c[I] = (spint)t & MASK;
+                t >>= RADIX;
+            });
+            spint s = (spint)t;
+            if constexpr (P::XCESS > 0) {
+                s = (s << P::XCESS) + (c[N - 1] >> (RADIX - P::XCESS));
+                c[N - 1] &= ((spint)1 << (RADIX - P::XCESS)) - 1;
+            }
+            c[0] += s;
+            c[P::TRIN] += s;
+        } else {
+            static_for<0, N - 1>([&](auto I) {
+                t += (dpint)a[I] * bw;
+                c[I] = (spint)t & MASK;
+                t >>= RADIX;
+            });
+            t += (dpint)a[N - 1] * bw;
+            c[N - 1] = (spint)t;
+            spint h = (spint)(t >> P::BARRETT_SHIFT);
+            spint q = (spint)((mulw(h, (spint)P::BARRETT_R)) >> 64);
+            bool propc = P::ppw(0) > 0;
+            static_for<0, N>([&](auto I) {
+                constexpr int i = I;
+                constexpr long long d = P::ppw(i);
+                if constexpr (i >= 1 && i < N - 1 && d != 0) propc = true;
+                if constexpr (d == -1) c[i] += q;
+                else if constexpr (d == 1) c[i] -= q;
+                else if constexpr (d > 1 && (d & (d - 1)) == 0) {
+                    constexpr int e = __builtin_ctzll((unsigned long long)d);
+                    if constexpr (i < N - 1) {
+                        dpint w = (dpint)q << e;
+                        c[i] -= (spint)w & MASK;
+                        c[i + 1] -= (spint)(w >> RADIX);
+                    } else {
+                        c[i] -= q << e;
+                    }
+                } else if constexpr (d > 1) {
+                    if constexpr (i < N - 1) {
+                        dpint w = mulw(q, (spint)d);
+                        c[i] -= (spint)w & MASK;
+                        c[i + 1] -= (spint)(w >> RADIX);
+                    } else {
+                        c[i] -= q * (spint)d;
+                    }
+                } else {
+                    static_assert(d == 0, "negative prime limbs other than -1 are not supported");
+                }
+            });
+            if constexpr (P::E) c[N - 1] -= q << RADIX;
+            if (propc) (void)prop(c);
+        }
+    }
+
+    // ================================================================ family dispatch
+    static MA_DEV void modmul(const spint* a, const spint* b, spint* c) {
+        if constexpr (P::MONTGOMERY) monty_mul<false>(a, b, c); else pm_modmul(a, b, c);
+    }
+    static MA_DEV void modsqr(const spint* a, spint* c) {
+        if constexpr (P::MONTGOMERY) monty_mul<true>(a, a, c); else pm_modsqr(a, c);
+    }
+    static MA_DEV void modmli(const spint* a, int b, spint* c) {
+        if constexpr (P::MONTGOMERY) monty_modmli(a, b, c); else pm_modmli(a, b, c);
+    }
+    // pseudo.py:952-962 (copy) / monty.py:1386-1399 (multiply by R^2 mod p)
+    static MA_DEV void nres(const spint* m, spint* n) {
+        if constexpr (P::MONTGOMERY) {
+            spint r2[N];
+            static_for<0, N>([&](auto I) { r2[I] = P::r2(I); });
+            modmul(m, r2, n);
+        } else {
+            modcpy(m, n);
+        }
+    }
+    // pseudo.py:965-976 / monty.py:1402-1416
+    static MA_DEV void redc(const spint* n, spint* m) {
+        if constexpr (P::MONTGOMERY) {
+            spint one[N];
+            static_for<0, N>([&](auto I) { one[I] = (I == 0) ? 1 : 0; });
+            modmul(n, one, m);
+        } else {
+            modcpy(n, m);
+        }
+        (void)modfsb(m);
+    }
+
+    static MA_DEV void modnsqr(spint* a, int n) {
+        for (int i = 0; i < n; i++) modsqr(a, a);
+    }
+
+    // progenitor x^PE (pseudo.py:758-785).  The reference takes its addition chain from the external
+    // `addchain` tool; ours comes from the driver (P::modpro_chain).  Limbs differ, values do not.
+    static MA_DEV void modpro(const spint* w, spint* z) { P::template modpro_chain<Field<P>>(w, z); }
+
+    // pseudo.py:788-812
+    static MA_DEV void modinv(const spint* x, const spint* h, spint* z) {
+        spint s[N], t[N];
+        if (h == nullptr) modpro(x, t); else modcpy(h, t);
+        modcpy(x, s);
+        for (int i = 0; i < P::PM1D2 - 1; i++) {
+            modsqr(s, s);
+            modmul(s, x, s);
+        }
+        modnsqr(t, P::PM1D2 + 1);
+        modmul(s, t, z);
+    }
+
+    // pseudo.py:877-906
+    static MA_DEV int modis1(const spint* a) {
+        spint c[N], d = 0;
+        redc(a, c);
+        static_for<1, N>([&](auto I) { d |= c[I]; });
+        return (int)((spint)1 & ((d - (spint)1) >> RADIX) & (((c[0] ^ (spint)1) - (spint)1) >> RADIX));
+    }
+    static MA_DEV int modis0(const spint* a) {
+        spint c[N], d = 0;
+        redc(a, c);
+        static_for<0, N>([&](auto I) { d |= c[I]; });
+        return (int)((spint)1 & ((d - (spint)1) >> RADIX));
+    }
+    static MA_DEV void modzer(spint* a) { static_for<0, N>([&](auto I) { a[I] = 0; }); }
+    static MA_DEV void modint(int x, spint* a) {
+        a[0] = (spint)x;
+        static_for<1, N>([&](auto I) { a[I] = 0; });
+        nres(a, a);
+    }
+    static MA_DEV void modone(spint* a) { modint(1, a); }
+
+    // Constant-time conditional move / swap by lane predication (v_cndmask): no data-dependent
+    // branch or address.  Equal to the reference's PSCR arithmetic form for b in {0,1}
+    // (pseudo.py:979-1048; see oracle/field_common.inc for the algebra).
+    static MA_DEV void modcmv(int b, const spint* g, spint* f) {
+        const bool take = (b & 1) != 0;
+        static_for<0, N>([&](auto I) { f[I] = take ? g[I] : f[I]; });
+    }
+    static MA_DEV void modcsw(int b, spint* g, spint* f) {
+        const bool take = (b & 1) != 0;
+        static_for<0, N>([&](auto I) {
+            spint x = g[I], y = f[I];
+            g[I] = take ? y : x;
+            f[I] = take ? x : y;
+        });
+    }
+
+    // pseudo.py:1052-1081
+    static MA_DEV void modshl(unsigned n, spint* a) {
+        a[N - 1] = (a[N - 1] << n) + (a[N - 2] >> (RADIX - n));
+        static_for<0, N - 2>([&](auto J) {
+            constexpr int i = N - 2 - J;
+            a[i] = ((a[i] << n) & MASK) + (a[i - 1] >> (RADIX - n));
+        });
+        a[0] = (a[0] << n) & MASK;
+    }
+    static MA_DEV int modshr(unsigned n, spint* a) {
+        spint r = a[0] & (((spint)1 << n) - (spint)1);
+        static_for<0, N - 1>([&](auto I) {
+            constexpr int i = I;
+            a[i] = (a[i] >> n) + ((a[i + 1] << (RADIX - n)) & MASK);
+        });
+        a[N - 1] = a[N - 1] >> n;
+        return (int)r;
+    }
+    // pseudo.py:1084-1100
+    static MA_DEV void modhaf(spint* n) {
+        spint t[N];
+        (void)prop(n);
+        modcpy(n, t);
+        int lsb = modshr(1, t);
+        addp<1>(n, ~(spint)0);
+        (void)prop(n);
+        (void)modshr(1, n);
+        modcmv(1 - lsb, t, n);
+    }
+    // pseudo.py:1102-1112, monty.py:1578-1593
+    static MA_DEV void mod2r(unsigned r, spint* a) {
+        modzer(a);
+        if (r >= (unsigned)P::NBYTES * 8) return;
+        unsigned n = r / RADIX, m = r % RADIX;
+        static_for<0, N>([&](auto I) { a[I] = ((unsigned)I == n) ? ((spint)1 << m) : 0; });
+        if constexpr (P::MONTGOMERY) nres(a, a);
+    }
+    // pseudo.py:1149-1174
+    static MA_DEV int modsign(const spint* a) {
+        spint c[N];
+        redc(a, c);
+        return (int)(c[0] % 2);
+    }
+    static MA_DEV int modcmp(const spint* a, const spint* b) {
+        spint c[N], d[N];
+        int eq = 1;
+        redc(a, c);
+        redc(b, d);
+        static_for<0, N>([&](auto I) { eq &= (int)((((c[I] ^ d[I]) - 1) >> RADIX) & 1); });
+        return eq;
+    }
+
+    // Byte import/export.  The reference shifts in 8 bits at a time (pseudo.py:1115-1146); the limbs
+    // it ends with are a pure function of the integer the bytes spell: limb i = bits
+    // [RADIX*i, RADIX*(i+1)), the top limb taking every remaining bit, then modfsb + nres as there.
+    // Here the integer arrives / leaves as NW little-endian 64-bit words held in registers; kernels
+    // turn big-endian (modimp/modexp) or little-endian (rfc7748) byte records into such words.
+    static constexpr int NW = P::NBYTES / 8;
+    static_assert(P::NBYTES % 8 == 0, "byte records are moved as whole 64-bit words");
+
+    static MA_DEV void limbs_from_words(const spint* w, spint* a) {
+        static_for<0, N>([&](auto I) {
+            constexpr int i = I;
+            constexpr int o = RADIX * i, wi = o / 64, sh = o % 64;
+            spint val = 0;
+            if constexpr (wi < NW) {
+                val = w[wi] >> sh;
+                if constexpr (sh + RADIX > 64 && wi + 1 < NW) val |= w[wi + 1] << (64 - sh);
+            }
+            if constexpr (i < N - 1) val &= MASK;
+            a[i] = val;
+        });
+    }
+    // limbs must be canonical (< 2^RADIX each), as redc leaves them
+    static MA_DEV void words_from_limbs(const spint* c, spint* w) {
+        static_for<0, NW>([&](auto K) { w[K] = 0; });
+        static_for<0, N>([&](auto I) {
+            constexpr int i = I;
+            constexpr int o = RADIX * i, wi = o / 64, sh = o % 64;
+            if constexpr (wi < NW) {
+                w[wi] |= c[i] << sh;
+                if constexpr (sh + RADIX > 64 && wi + 1 < NW) w[wi + 1] |= c[i] >> (64 - sh);
+            }
+        });
+    }
+    // returns 1 if the value was < p (pseudo.py:1130-1146)
+    static MA_DEV int modimp_words(const spint* w, spint* a) {
+        limbs_from_words(w, a);
+        int res = (int)modfsb(a);
+        nres(a, a);
+        return res;
+    }
+    // pseudo.py:1115-1127
+    static MA_DEV void modexp_words(const spint* a, spint* w) {
+        spint c[N];
+        redc(a, c);
+        words_from_limbs(c, w);
+    }
+};
+
+}  // namespace ma

@@ -1,0 +1,260 @@
+// modarith_amd/csrc/kernels.h -- batched element-wise field kernels for gfx950.
+//
+// HBM layout: limb-interleaved SoA, buf[limb * ld + j] (u64), the n-lane generalisation of the
+// reference's SIMD "batched form" (simd/pseudo_simd.py: a[i] holds limb i of every lane).  One field
+// element per lane; lane j of a wave touches consecutive u64 of each limb row, so every limb load
+// is one fully coalesced 512-byte (EPT=1) or 1-KiB (EPT=2, 16 B per lane) wave access.  All limbs of
+// the operands are loaded before any arithmetic (independent loads in flight), results are stored
+// limb row by limb row.  The kernels are HBM-bound streaming kernels: grid-stride over at most
+// MA_MAX_BLOCKS workgroups of 256 threads.  No LDS is needed for per-lane data; the shared-multiplicand
+// variant broadcasts its common operand from kernel arguments (SGPRs), which is cheaper than LDS.
+#pragma once
+#include "field.h"
+
+namespace ma {
+
+constexpr int BLOCK = 256;
+
+template <int EPT> struct vec_of;
+template <> struct vec_of<1> { using type = spint; };
+template <> struct vec_of<2> { using type = ulonglong2; };
+
+// element index handled by (thread t, slot e): j = EPT*t + e  -> contiguous EPT*8 bytes per lane
+template <class P, int EPT>
+__device__ __forceinline__ void load_soa(const spint* base, size_t ld, size_t t, spint (*x)[P::N]) {
+    if constexpr (EPT == 1) {
+        static_for<0, P::N>([&](auto I) { x[0][I] = base[(size_t)I * ld + t]; });
+    } else {
+        static_for<0, P::N>([&](auto I) {
+            ulonglong2 v = *reinterpret_cast<const ulonglong2*>(base + (size_t)I * ld + 2 * t);
+            x[0][I] = v.x;
+            x[1][I] = v.y;
+        });
+    }
+}
+template <class P, int EPT>
+__device__ __forceinline__ void store_soa(spint* base, size_t ld, size_t t, spint (*x)[P::N]) {
+    if constexpr (EPT == 1) {
+        static_for<0, P::N>([&](auto I) { base[(size_t)I * ld + t] = x[0][I]; });
+    } else {
+        static_for<0, P::N>([&](auto I) {
+            ulonglong2 v;
+            v.x = x[0][I];
+            v.y = x[1][I];
+            *reinterpret_cast<ulonglong2*>(base + (size_t)I * ld + 2 * t) = v;
+        });
+    }
+}
+
+// ---- operation functors: apply() works on register-resident elements
+template <class P> struct OpMul { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P>::modmul(a, b, c); } };
+template <class P> struct OpAdd { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P>::modadd(a, b, c); } };
+template <class P> struct OpSub { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P>::modsub(a, b, c); } };
+template <class P> struct OpAddLazy { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P>::modadd_lazy(a, b, c); } };
+template <class P> struct OpSubLazy { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P>::modsub_lazy(a, b, c); } };
+template <class P> struct OpSqr { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modsqr(a, c); } };
+template <class P> struct OpNeg { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modneg(a, c); } };
+template <class P> struct OpNegLazy { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modneg_lazy(a, c); } };
+template <class P> struct OpNres { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::nres(a, c); } };
+template <class P> struct OpRedc { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::redc(a, c); } };
+template <class P> struct OpCpy { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modcpy(a, c); } };
+template <class P> struct OpInv { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modinv(a, nullptr, c); } };
+template <class P> struct OpPro { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modpro(a, c); } };
+
+// c[j] = op(a[j], b[j])
+template <class P, class Op, int EPT>
+__global__ __launch_bounds__(BLOCK) void k_binary(const spint* a, const spint* b,
+                                                  spint* c, size_t nthreads, size_t lda, size_t ldb, size_t ldc) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
+        spint x[EPT][P::N], y[EPT][P::N], z[EPT][P::N];
+        load_soa<P, EPT>(a, lda, t, x);
+        load_soa<P, EPT>(b, ldb, t, y);
+#pragma unroll
+        for (int e = 0; e < EPT; e++) Op::apply(x[e], y[e], z[e]);
+        store_soa<P, EPT>(c, ldc, t, z);
+    }
+}
+
+// c[j] = op(a[j])
+template <class P, class Op, int EPT>
+__global__ __launch_bounds__(BLOCK) void k_unary(const spint* a, spint* c, size_t nthreads,
+                                                 size_t lda, size_t ldc) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
+        spint x[EPT][P::N], z[EPT][P::N];
+        load_soa<P, EPT>(a, lda, t, x);
+#pragma unroll
+        for (int e = 0; e < EPT; e++) Op::apply(x[e], z[e]);
+        store_soa<P, EPT>(c, ldc, t, z);
+    }
+}
+
+// shared multiplicand: c[j] = a[j] * b0, b0 passed by value (lands in SGPRs, broadcast to all lanes)
+template <class P> struct Elem { spint l[P::N]; };
+template <class P, int EPT>
+__global__ __launch_bounds__(BLOCK) void k_mul_shared(const spint* a, Elem<P> b0, spint* c,
+                                                      size_t nthreads, size_t lda, size_t ldc) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
+        spint x[EPT][P::N], z[EPT][P::N];
+        load_soa<P, EPT>(a, lda, t, x);
+#pragma unroll
+        for (int e = 0; e < EPT; e++) Field<P>::modmul(x[e], b0.l, z[e]);
+        store_soa<P, EPT>(c, ldc, t, z);
+    }
+}
+
+// c[j] = a[j] * b (small integer)
+template <class P, int EPT>
+__global__ __launch_bounds__(BLOCK) void k_mli(const spint* a, int b, spint* c, size_t nthreads,
+                                               size_t lda, size_t ldc) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
+        spint x[EPT][P::N], z[EPT][P::N];
+        load_soa<P, EPT>(a, lda, t, x);
+#pragma unroll
+        for (int e = 0; e < EPT; e++) Field<P>::modmli(x[e], b, z[e]);
+        store_soa<P, EPT>(c, ldc, t, z);
+    }
+}
+
+// a[j] = a[j]^(2^k)
+template <class P>
+__global__ __launch_bounds__(BLOCK) void k_nsqr(spint* a, int k, size_t n, size_t ld) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
+        spint x[1][P::N];
+        load_soa<P, 1>(a, ld, t, x);
+        Field<P>::modnsqr(x[0], k);
+        store_soa<P, 1>(a, ld, t, x);
+    }
+}
+
+// z[j] = 1/x[j] with caller-supplied progenitor h[j] (modinv(x,h,z), pseudo.py:788-812)
+template <class P>
+__global__ __launch_bounds__(BLOCK) void k_inv_h(const spint* xs, const spint* hs,
+                                                 spint* zs, size_t n, size_t ldx, size_t ldh, size_t ldz) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
+        spint x[1][P::N], h[1][P::N], z[1][P::N];
+        load_soa<P, 1>(xs, ldx, t, x);
+        load_soa<P, 1>(hs, ldh, t, h);
+        Field<P>::modinv(x[0], h[0], z[0]);
+        store_soa<P, 1>(zs, ldz, t, z);
+    }
+}
+
+// constant-time conditional swap / move with a per-element selector d[j] in {0,1}
+// (simd/pseudo_simd.py:1121-1162: selector widened to one value per lane)
+template <class P, bool SWAP>
+__global__ __launch_bounds__(BLOCK) void k_cond(const int* d, spint* g, spint* f, size_t n,
+                                                size_t ldg, size_t ldf) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
+        spint x[1][P::N], y[1][P::N];
+        load_soa<P, 1>(g, ldg, t, x);
+        load_soa<P, 1>(f, ldf, t, y);
+        const int b = d[t];
+        if constexpr (SWAP) {
+            Field<P>::modcsw(b, x[0], y[0]);
+            store_soa<P, 1>(g, ldg, t, x);
+        } else {
+            Field<P>::modcmv(b, x[0], y[0]);
+        }
+        store_soa<P, 1>(f, ldf, t, y);
+    }
+}
+
+// in-place normalisers / predicates; KIND selects the function, optional int result per element
+enum { K_MODFSB = 0, K_FLATTEN, K_MODIS1, K_MODIS0, K_MODSIGN, K_MODHAF };
+template <class P, int KIND>
+__global__ __launch_bounds__(BLOCK) void k_inplace(spint* a, int* out, size_t n, size_t ld) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
+        spint x[1][P::N];
+        load_soa<P, 1>(a, ld, t, x);
+        int r = 0;
+        bool wr = false;
+        if constexpr (KIND == K_MODFSB) { r = (int)Field<P>::modfsb(x[0]); wr = true; }
+        if constexpr (KIND == K_FLATTEN) { r = (int)Field<P>::flatten(x[0]); wr = true; }
+        if constexpr (KIND == K_MODIS1) r = Field<P>::modis1(x[0]);
+        if constexpr (KIND == K_MODIS0) r = Field<P>::modis0(x[0]);
+        if constexpr (KIND == K_MODSIGN) r = Field<P>::modsign(x[0]);
+        if constexpr (KIND == K_MODHAF) { Field<P>::modhaf(x[0]); wr = true; }
+        if (wr) store_soa<P, 1>(a, ld, t, x);
+        if (out) out[t] = r;
+    }
+}
+
+template <class P>
+__global__ __launch_bounds__(BLOCK) void k_cmp(const spint* a, const spint* b, int* out,
+                                               size_t n, size_t lda, size_t ldb) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
+        spint x[1][P::N], y[1][P::N];
+        load_soa<P, 1>(a, lda, t, x);
+        load_soa<P, 1>(b, ldb, t, y);
+        out[t] = Field<P>::modcmp(x[0], y[0]);
+    }
+}
+
+// shifts by less than a word (modshl / modshr), in place; shr returns the shifted-out bits
+template <class P, bool LEFT>
+__global__ __launch_bounds__(BLOCK) void k_shift(unsigned k, spint* a, int* out, size_t n, size_t ld) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
+        spint x[1][P::N];
+        load_soa<P, 1>(a, ld, t, x);
+        int r = 0;
+        if constexpr (LEFT) Field<P>::modshl(k, x[0]); else r = Field<P>::modshr(k, x[0]);
+        store_soa<P, 1>(a, ld, t, x);
+        if (out) out[t] = r;
+    }
+}
+
+// fill with a constant element: modzer / modone / modint(x) / mod2r(r)
+enum { K_INT = 0, K_2R };
+template <class P, int KIND>
+__global__ __launch_bounds__(BLOCK) void k_fill(int val, spint* a, size_t n, size_t ld) {
+    spint x[1][P::N];
+    if constexpr (KIND == K_INT) {
+        if (val == 0) Field<P>::modzer(x[0]); else Field<P>::modint(val, x[0]);
+    } else {
+        Field<P>::mod2r((unsigned)val, x[0]);
+    }
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK)
+        store_soa<P, 1>(a, ld, t, x);
+}
+
+// bytes <-> limbs.  AoS records of NBYTES big-endian bytes (what modimp / modexp take), one record
+// per lane, moved as 64-bit words: word k of the integer = byte-swapped chunk NW-1-k of the record.
+template <class P>
+__global__ __launch_bounds__(BLOCK) void k_imp(const spint* bytes, spint* a, int* flag, size_t n, size_t ld) {
+    constexpr int NW = Field<P>::NW;
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
+        spint w[NW];
+        static_for<0, NW>([&](auto K) { w[K] = __builtin_bswap64(bytes[t * NW + (NW - 1 - K)]); });
+        spint x[1][P::N];
+        int r = Field<P>::modimp_words(w, x[0]);
+        store_soa<P, 1>(a, ld, t, x);
+        if (flag) flag[t] = r;
+    }
+}
+template <class P>
+__global__ __launch_bounds__(BLOCK) void k_exp(const spint* a, spint* bytes, size_t n, size_t ld) {
+    constexpr int NW = Field<P>::NW;
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
+        spint x[1][P::N];
+        load_soa<P, 1>(a, ld, t, x);
+        spint w[NW];
+        Field<P>::modexp_words(x[0], w);
+        static_for<0, NW>([&](auto K) { bytes[t * NW + (NW - 1 - K)] = __builtin_bswap64(w[K]); });
+    }
+}
+
+// element-major (AoS, spint x[n][N] as CPU callers hold elements) <-> limb-interleaved SoA
+template <int N>
+__global__ __launch_bounds__(BLOCK) void k_aos2soa(const spint* aos, spint* soa, size_t n, size_t ld) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK)
+#pragma unroll
+        for (int i = 0; i < N; i++) soa[(size_t)i * ld + t] = aos[t * N + i];
+}
+template <int N>
+__global__ __launch_bounds__(BLOCK) void k_soa2aos(const spint* soa, spint* aos, size_t n, size_t ld) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK)
+#pragma unroll
+        for (int i = 0; i < N; i++) aos[t * N + i] = soa[(size_t)i * ld + t];
+}
+
+}  // namespace ma

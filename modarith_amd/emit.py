@@ -1,0 +1,216 @@
+"""Emit the per-prime constant header the HIP kernels are compiled against.
+
+`python -m modarith_amd.emit` (also run by __graft_entry__.build()) writes
+modarith_amd/csrc/generated/params_<PRIME>.h for every built prime.  This is the counterpart of the
+reference generators printing literal constants into field.c (e.g. the macro block
+pseudo.py:1388-1411, the nres constant monty.py:1391-1394, the prime limbs in caddp/addp/subp): here
+the constants go into a `struct P_<PRIME>` of constexpr members consumed by csrc/field.h, and the
+kernels themselves are hand-written templates.
+
+The progenitor addition chain (x -> x^PE, used by modpro/modinv/modsqrt; reference: external
+`addchain` tool, pseudo.py:1582-1587 + 758-785) is produced by `addition_chain()` below: runs of ones
+built by a doubling ladder, then stitched together with squarings.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Tuple
+
+from .params import FieldParams, derive
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GEN_DIR = os.path.join(HERE, "csrc", "generated")
+BUILT_PRIMES = ("X25519", "NIST256", "X448")
+
+
+# ------------------------------------------------------------------ addition chain
+def _runs(e: int) -> List[Tuple[int, int]]:
+    """binary expansion of e from the top as [(ones, zeros_after), ...]."""
+    bits = bin(e)[2:]
+    out, i = [], 0
+    while i < len(bits):
+        j = i
+        while j < len(bits) and bits[j] == "1":
+            j += 1
+        k = j
+        while k < len(bits) and bits[k] == "0":
+            k += 1
+        out.append((j - i, k - j))
+        i = k
+    return out
+
+
+def _ones_plan(r: int, have: dict, steps: list):
+    """make x^(2^r-1) available as register name have[r]; binary ladder on r, memoised."""
+    if r in have:
+        return have[r]
+    if r % 2 == 0:
+        h = _ones_plan(r // 2, have, steps)
+        name = "o%d" % r
+        steps.append(("dbl", name, h, r // 2))       # name = h^(2^(r/2)) * h
+    else:
+        h = _ones_plan(r - 1, have, steps)
+        name = "o%d" % r
+        steps.append(("inc", name, h))               # name = h^2 * x
+    have[r] = name
+    return name
+
+
+def addition_chain(e: int):
+    """straight-line program computing x^e: list of steps
+       ("dbl", dst, src, k): dst = src^(2^k) * src      ("inc", dst, src): dst = src^2 * x
+       ("start", src): acc = src                         ("run", k, src): acc = acc^(2^k) * src
+       ("sqr", k): acc = acc^(2^k)
+    The leading run of ones is built by a doubling ladder (those squarings ARE the main chain); every
+    later run is stitched from the ladder's by-products, largest first, so it costs multiplications
+    only (e.g. NIST256: 253 squarings + 12 multiplications)."""
+    runs = _runs(e)
+    have = {1: "x"}
+    steps: list = []
+    _ones_plan(runs[0][0], have, steps)
+    prog = list(steps)
+    prog.append(("start", have[runs[0][0]]))
+    pending = runs[0][1]
+    for ones, zeros in runs[1:]:
+        left = ones
+        while left:
+            k = max(r for r in have if r <= left)
+            prog.append(("run", pending + k, have[k]))
+            pending = 0
+            left -= k
+        pending = zeros
+    if pending:
+        prog.append(("sqr", pending))
+    return prog
+
+
+def chain_cost(prog):
+    s = m = 0
+    for st in prog:
+        if st[0] == "dbl":
+            s += st[3]; m += 1
+        elif st[0] == "inc":
+            s += 1; m += 1
+        elif st[0] == "run":
+            s += st[1]; m += 1
+        elif st[0] == "sqr":
+            s += st[1]
+    return s, m
+
+
+def eval_chain(prog, x: int, p: int) -> int:
+    """big-integer evaluation of a chain (used by tests to prove it computes x^e)."""
+    reg = {"x": x % p}
+    acc = None
+    for st in prog:
+        if st[0] == "dbl":
+            reg[st[1]] = pow(reg[st[2]], 1 << st[3], p) * reg[st[2]] % p
+        elif st[0] == "inc":
+            reg[st[1]] = reg[st[2]] ** 2 * reg["x"] % p
+        elif st[0] == "start":
+            acc = reg[st[1]]
+        elif st[0] == "run":
+            acc = pow(acc, 1 << st[1], p) * reg[st[2]] % p
+        elif st[0] == "sqr":
+            acc = pow(acc, 1 << st[1], p)
+    return acc
+
+
+def _chain_cpp(prog, N: int) -> str:
+    lines = ["        spint x[%d], acc[%d];" % (N, N), "        F::modcpy(w, x);"]
+    declared = set()
+    for st in prog:
+        if st[0] in ("dbl", "inc"):
+            dst = st[1]
+            if dst not in declared:
+                lines.append("        spint %s[%d];" % (dst, N))
+                declared.add(dst)
+        if st[0] == "dbl":
+            _, dst, src, k = st
+            lines.append("        F::modcpy(%s, %s); F::modnsqr(%s, %d); F::modmul(%s, %s, %s);" % (src, dst, dst, k, dst, src, dst))
+        elif st[0] == "inc":
+            _, dst, src = st
+            lines.append("        F::modsqr(%s, %s); F::modmul(%s, x, %s);" % (src, dst, dst, dst))
+        elif st[0] == "start":
+            lines.append("        F::modcpy(%s, acc);" % st[1])
+        elif st[0] == "run":
+            lines.append("        F::modnsqr(acc, %d); F::modmul(acc, %s, acc);" % (st[1], st[2]))
+        elif st[0] == "sqr":
+            lines.append("        F::modnsqr(acc, %d);" % st[1])
+    lines.append("        F::modcpy(acc, z);")
+    return "\n".join(lines)
+
+
+# ------------------------------------------------------------------ header text
+def _hexu(v: int) -> str:
+    return "0x%xull" % v
+
+
+def _switch(name: str, ctype: str, values, fmt) -> str:
+    body = " ".join("case %d: return %s;" % (i, fmt(v)) for i, v in enumerate(values))
+    return "    static constexpr %s %s(int i) { switch (i) { %s default: return 0; } }" % (ctype, name, body)
+
+
+def header_text(fp: FieldParams) -> str:
+    N = fp.nlimbs
+    prog = addition_chain(fp.pe)
+    sq, mu = chain_cost(prog)
+    L = []
+    L.append("// GENERATED by modarith_amd/emit.py from modarith_amd/params.py -- do not edit.")
+    L.append("// prime %s = %s, family %s" % (fp.name, hex(fp.p), fp.family))
+    L.append("#pragma once")
+    L.append('#include "../field.h"')
+    L.append("namespace ma {")
+    L.append("struct P_%s {" % fp.name)
+    L.append('    static constexpr const char* NAME = "%s";' % fp.name)
+    L.append("    static constexpr int N = %d, RADIX = %d, NBITS = %d, NBYTES = %d, XCESS = %d, PM1D2 = %d;"
+             % (N, fp.radix, fp.n, fp.nbytes, fp.xcess, fp.pm1d2))
+    L.append("    static constexpr bool MONTGOMERY = %s;" % ("true" if fp.montgomery else "false"))
+    # pseudo-Mersenne block (dummies for Montgomery primes)
+    L.append("    static constexpr unsigned long long M = %s, MM = %s;" % (_hexu(fp.m if not fp.montgomery else 0), _hexu(fp.mm)))
+    L.append("    static constexpr bool OVERFLOW = %s, FRED = %s, EPM = %s, CARRY_ON = %s;"
+             % tuple("true" if b else "false" for b in (fp.overflow, fp.fred, fp.epm, fp.carry_on)))
+    # Montgomery block (dummies for pseudo-Mersenne primes)
+    neg = [i for i, v in enumerate(fp.ppw) if i > 0 and v == -1]
+    L.append("    static constexpr bool E = %s;" % ("true" if fp.E else "false"))
+    L.append("    static constexpr unsigned long long NDASH = %s;" % _hexu(fp.ndash))
+    L.append("    static constexpr int TRIN = %d, NEG_LIMB = %d;" % (fp.trin, neg[0] if neg else 0))
+    br = (1 << (fp.n + fp.radix)) // fp.p if fp.montgomery else 0
+    L.append("    static constexpr unsigned long long BARRETT_R = %s;  // floor(2^(n+Radix)/p) (monty.py:923)" % _hexu(br if br < 1 << 64 else 0))
+    L.append("    static constexpr int BARRETT_SHIFT = %d;                 // (n-64) %% Radix (monty.py:930)" % ((fp.n - 64) % fp.radix))
+    ppw = fp.ppw if fp.ppw else [0]
+    L.append(_switch("ppw", "long long", ppw, lambda v: "%dll" % v if abs(v) < 10 else ("0x%xll" % v)))
+    r2 = fp.r2 if fp.r2 else [0] * N
+    L.append(_switch("r2", "unsigned long long", r2, _hexu))
+    # non-zero prime limbs for caddp/addp/subp
+    L.append("    static constexpr int PP_CNT = %d;" % len(fp.pp))
+    L.append(_switch("pp_idx", "int", [t[0] for t in fp.pp], str))
+    L.append(_switch("pp_sgn", "int", [t[1] for t in fp.pp], str))
+    L.append(_switch("pp_val", "unsigned long long", [t[2] for t in fp.pp], _hexu))
+    L.append(_switch("roi", "unsigned long long", fp.roi, _hexu))
+    L.append("    // progenitor chain for PE = %s: %d squarings + %d multiplications" % (hex(fp.pe), sq, mu))
+    L.append("    template <class F>")
+    L.append("    static __device__ __forceinline__ void modpro_chain(const spint* w, spint* z) {")
+    L.append(_chain_cpp(prog, N))
+    L.append("    }")
+    L.append("};")
+    L.append("}  // namespace ma")
+    return "\n".join(L) + "\n"
+
+
+def emit_all(primes=BUILT_PRIMES, out_dir: str = GEN_DIR) -> List[str]:
+    os.makedirs(out_dir, exist_ok=True)
+    paths = []
+    for name in primes:
+        text = header_text(derive(name))
+        path = os.path.join(out_dir, "params_%s.h" % name)
+        if not os.path.exists(path) or open(path).read() != text:
+            with open(path, "w") as f:
+                f.write(text)
+        paths.append(path)
+    return paths
+
+
+if __name__ == "__main__":
+    for p in emit_all():
+        print(p)

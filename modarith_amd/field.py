@@ -1,0 +1,252 @@
+"""Host-side mirror of the reference's field API, batched: `Field("X25519").modmul(a, b)`.
+
+Same function names, argument order and meaning as the generated field.c
+(function list pseudo.py:1413-1445 / monty.py:1885-1918), with `spint x[Nlimbs]` widened to a batch:
+a torch int64 tensor of shape [Nlimbs, n] resident in HBM (limb-interleaved SoA; int64 is only the
+64-bit container, the limbs are unsigned).  Every method launches hand-written HIP kernels through
+the C-ABI of include/modarith_amd.h on torch's current stream; torch is used for device memory and
+streams only.  As in the reference, outputs may alias inputs (`out=a`).
+
+Conversions (`from_ints`, `to_ints`) are host-side helpers for tests and glue.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .params import FieldParams, derive
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Field:
+    """Batched field arithmetic for one of the built primes (X25519, NIST256, X448)."""
+
+    def __init__(self, prime: str, device: Optional[torch.device] = None):
+        if prime not in _lib.PRIMES:
+            raise ValueError("prime %r is not built; available: %s" % (prime, ", ".join(_lib.PRIMES)))
+        self.lib = _lib.load()
+        self.prime = prime
+        self.params: FieldParams = derive(prime)
+        self.N = self.params.nlimbs
+        self.radix = self.params.radix
+        self.nbytes = self.params.nbytes
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    # ------------------------------------------------------------------ buffers
+    def empty(self, n: int) -> torch.Tensor:
+        return torch.empty((self.N, n), dtype=torch.int64, device=self.device)
+
+    def from_limbs(self, limbs: Sequence[Sequence[int]]) -> torch.Tensor:
+        """list of per-element limb lists -> device batch [N, n]."""
+        arr = np.array(limbs, dtype=np.uint64).reshape(len(limbs), self.N).T.copy()
+        return torch.from_numpy(arr.view(np.int64)).to(self.device)
+
+    def to_limbs(self, t: torch.Tensor) -> List[List[int]]:
+        arr = t.detach().cpu().numpy().view(np.uint64)
+        return [[int(v) for v in arr[:, j]] for j in range(arr.shape[1])]
+
+    def from_ints(self, xs: Iterable[int]) -> torch.Tensor:
+        """plain integers -> limbs with the top limb unmasked (pseudo.py:1769-1775); NOT nres'd."""
+        return self.from_limbs([self.params.to_limbs(int(x)) for x in xs])
+
+    def to_ints(self, t: torch.Tensor) -> List[int]:
+        return [self.params.from_limbs(l) for l in self.to_limbs(t)]
+
+    # ------------------------------------------------------------------ plumbing
+    def _chk(self, *ts: torch.Tensor) -> int:
+        n = ts[0].shape[1]
+        for t in ts:
+            if t.dtype != torch.int64 or t.dim() != 2 or t.shape[0] != self.N or t.shape[1] != n:
+                raise ValueError("expected int64 tensors of shape [%d, n]" % self.N)
+            if not t.is_cuda:
+                raise ValueError("batches must live in device memory")
+            if t.stride(1) != 1:
+                raise ValueError("batches must be limb-major with unit element stride")
+        ld = ts[0].stride(0) if n > 1 or ts[0].stride(0) >= 1 else n
+        for t in ts:
+            if t.stride(0) != ld:
+                raise ValueError("all operands of one call must share the limb stride")
+        return n
+
+    def _call(self, fn: str, *args):
+        f = getattr(self.lib, "%s_%s_batch" % (fn, self.prime))
+        _lib.check(f(*args), "%s_%s_batch" % (fn, self.prime))
+
+    def _out(self, like: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
+        return out if out is not None else torch.empty_like(like)
+
+    def _bin(self, fn, a, b, out):
+        out = self._out(a, out)
+        n = self._chk(a, b, out)
+        self._call(fn, a.data_ptr(), b.data_ptr(), out.data_ptr(), n, a.stride(0), _stream())
+        return out
+
+    def _un(self, fn, a, out):
+        out = self._out(a, out)
+        n = self._chk(a, out)
+        self._call(fn, a.data_ptr(), out.data_ptr(), n, a.stride(0), _stream())
+        return out
+
+    def _ints(self, n: int) -> torch.Tensor:
+        return torch.empty(n, dtype=torch.int32, device=self.device)
+
+    # ------------------------------------------------------------------ the field.c API, batched
+    def modadd(self, a, b, out=None): return self._bin("modadd", a, b, out)
+    def modsub(self, a, b, out=None): return self._bin("modsub", a, b, out)
+    def modmul(self, a, b, out=None): return self._bin("modmul", a, b, out)
+    def modadd_lazy(self, a, b, out=None): return self._bin("modadd_lazy", a, b, out)
+    def modsub_lazy(self, a, b, out=None): return self._bin("modsub_lazy", a, b, out)
+    def modneg(self, a, out=None): return self._un("modneg", a, out)
+    def modneg_lazy(self, a, out=None): return self._un("modneg_lazy", a, out)
+    def modsqr(self, a, out=None): return self._un("modsqr", a, out)
+    def modcpy(self, a, out=None): return self._un("modcpy", a, out)
+    def modpro(self, a, out=None): return self._un("modpro", a, out)
+    def nres(self, a, out=None): return self._un("nres", a, out)
+    def redc(self, a, out=None): return self._un("redc", a, out)
+
+    def modmuls(self, a, b0: Sequence[int], out=None):
+        """shared multiplicand: out[j] = a[j] * b0 (one element, limbs on the host)."""
+        out = self._out(a, out)
+        n = self._chk(a, out)
+        host = (_lib.ctypes.c_uint64 * self.N)(*[int(v) for v in b0])
+        self._call("modmuls", a.data_ptr(), _lib.ctypes.cast(host, _lib.ctypes.c_void_p), out.data_ptr(), n, a.stride(0), _stream())
+        return out
+
+    def modmli(self, a, b: int, out=None):
+        out = self._out(a, out)
+        n = self._chk(a, out)
+        self._call("modmli", a.data_ptr(), int(b), out.data_ptr(), n, a.stride(0), _stream())
+        return out
+
+    def modnsqr(self, a, k: int):
+        n = self._chk(a)
+        self._call("modnsqr", a.data_ptr(), int(k), n, a.stride(0), _stream())
+        return a
+
+    def modinv(self, x, h=None, out=None):
+        out = self._out(x, out)
+        n = self._chk(x, out) if h is None else self._chk(x, h, out)
+        self._call("modinv", x.data_ptr(), None if h is None else h.data_ptr(), out.data_ptr(), n, x.stride(0), _stream())
+        return out
+
+    def modfsb(self, a):
+        """in place; returns the per-element flag (1 if the input was < p)."""
+        n = self._chk(a)
+        flag = self._ints(n)
+        self._call("modfsb", a.data_ptr(), flag.data_ptr(), n, a.stride(0), _stream())
+        return flag
+
+    def flatten(self, a):
+        n = self._chk(a)
+        flag = self._ints(n)
+        self._call("flatten", a.data_ptr(), flag.data_ptr(), n, a.stride(0), _stream())
+        return flag
+
+    def modhaf(self, a):
+        n = self._chk(a)
+        self._call("modhaf", a.data_ptr(), n, a.stride(0), _stream())
+        return a
+
+    def modshl(self, k: int, a):
+        n = self._chk(a)
+        self._call("modshl", int(k), a.data_ptr(), n, a.stride(0), _stream())
+        return a
+
+    def modshr(self, k: int, a):
+        n = self._chk(a)
+        out = self._ints(n)
+        self._call("modshr", int(k), a.data_ptr(), out.data_ptr(), n, a.stride(0), _stream())
+        return out
+
+    def _pred(self, fn, a):
+        n = self._chk(a)
+        out = self._ints(n)
+        self._call(fn, a.data_ptr(), out.data_ptr(), n, a.stride(0), _stream())
+        return out
+
+    def modis1(self, a): return self._pred("modis1", a)
+    def modis0(self, a): return self._pred("modis0", a)
+    def modsign(self, a): return self._pred("modsign", a)
+
+    def modcmp(self, a, b):
+        n = self._chk(a, b)
+        out = self._ints(n)
+        self._call("modcmp", a.data_ptr(), b.data_ptr(), out.data_ptr(), n, a.stride(0), _stream())
+        return out
+
+    def modzer(self, n: int):
+        a = self.empty(n)
+        self._call("modzer", a.data_ptr(), n, a.stride(0), _stream())
+        return a
+
+    def modone(self, n: int):
+        a = self.empty(n)
+        self._call("modone", a.data_ptr(), n, a.stride(0), _stream())
+        return a
+
+    def modint(self, x: int, n: int):
+        a = self.empty(n)
+        self._call("modint", int(x), a.data_ptr(), n, a.stride(0), _stream())
+        return a
+
+    def mod2r(self, r: int, n: int):
+        a = self.empty(n)
+        self._call("mod2r", int(r), a.data_ptr(), n, a.stride(0), _stream())
+        return a
+
+    def _sel(self, d: torch.Tensor, n: int) -> torch.Tensor:
+        if d.dtype != torch.int32 or d.numel() != n or not d.is_cuda or not d.is_contiguous():
+            raise ValueError("selector must be a contiguous int32 device tensor with one 0/1 entry per element")
+        return d
+
+    def modcmv(self, d, g, f):
+        """f[j] = g[j] where d[j] == 1 (constant time); d: int32 [n]."""
+        n = self._chk(g, f)
+        self._call("modcmv", self._sel(d, n).data_ptr(), g.data_ptr(), f.data_ptr(), n, g.stride(0), _stream())
+        return f
+
+    def modcsw(self, d, g, f):
+        """swap g[j], f[j] where d[j] == 1 (constant time)."""
+        n = self._chk(g, f)
+        self._call("modcsw", self._sel(d, n).data_ptr(), g.data_ptr(), f.data_ptr(), n, g.stride(0), _stream())
+        return g, f
+
+    def modimp(self, b: torch.Tensor):
+        """b: uint8 [n, Nbytes] big-endian records -> (batch, flag)."""
+        if b.dtype != torch.uint8 or b.dim() != 2 or b.shape[1] != self.nbytes or not b.is_contiguous() or not b.is_cuda:
+            raise ValueError("expected a contiguous uint8 device tensor [n, %d]" % self.nbytes)
+        n = b.shape[0]
+        a = self.empty(n)
+        flag = self._ints(n)
+        self._call("modimp", b.data_ptr(), a.data_ptr(), flag.data_ptr(), n, a.stride(0), _stream())
+        return a, flag
+
+    def modexp(self, a):
+        n = self._chk(a)
+        b = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device)
+        self._call("modexp", a.data_ptr(), b.data_ptr(), n, a.stride(0), _stream())
+        return b
+
+
+def rfc7748(curve: str, bk: torch.Tensor, bu: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Batched `rfc7748(bk, bu, bv)` (reference rfc7748.c:156): uint8 [n, Nbytes] RFC little-endian
+    records in device memory -> uint8 [n, Nbytes].  `out` may be `bu`."""
+    if curve not in _lib.LADDERS:
+        raise ValueError("curve must be one of %s" % (_lib.LADDERS,))
+    lib = _lib.load()
+    nb = 32 if curve == "X25519" else 56
+    for t in (bk, bu):
+        if t.dtype != torch.uint8 or t.dim() != 2 or t.shape[1] != nb or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError("expected contiguous uint8 device tensors [n, %d]" % nb)
+    if bk.shape[0] != bu.shape[0]:
+        raise ValueError("bk and bu must hold the same number of records")
+    out = out if out is not None else torch.empty_like(bu)
+    f = getattr(lib, "rfc7748_%s_batch" % curve)
+    _lib.check(f(bk.data_ptr(), bu.data_ptr(), out.data_ptr(), bk.shape[0], _stream()), "rfc7748_%s_batch" % curve)
+    return out

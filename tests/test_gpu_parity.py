@@ -1,0 +1,305 @@
+"""GPU parity: the HIP kernels, called through the C-ABI, against (1) the golden vectors produced by
+the reference and (2) the CPU oracle on seeded batches.  Bit-exact limbs everywhere (integer work);
+modpro/modinv are compared after redc (different addition chain, SURVEY 8(c) caveat 1)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests.conftest import limbs, load_golden
+from tests.oracle_binding import PRIMES
+from tests.util import oracle_bin, oracle_mli, oracle_un, random_soa, to_dev, to_np, vp
+
+pytestmark = pytest.mark.gpu
+ALL = ["X25519", "NIST256", "X448"]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module", params=ALL)
+def ctx(request, torch_cuda):
+    from modarith_amd.field import Field
+    P = request.param
+    return P, Field(P), load_golden("field_%s.json" % P)
+
+
+def dev(F, rows):
+    return F.from_limbs([limbs(r) for r in rows])
+
+
+def rows_of(F, t):
+    return F.to_limbs(t)
+
+
+# ---------------------------------------------------------------- against the reference's own outputs
+@pytest.mark.parametrize("op", ["modadd", "modsub", "modmul"])
+def test_golden_binary(ctx, op):
+    P, F, g = ctx
+    got = rows_of(F, getattr(F, op)(dev(F, g["A"]), dev(F, g["B"])))
+    assert got == [limbs(r) for r in g["ops"][op]]
+
+
+@pytest.mark.parametrize("op", ["modneg", "modsqr", "redc", "nres"])
+def test_golden_unary(ctx, op):
+    P, F, g = ctx
+    got = rows_of(F, getattr(F, op)(dev(F, g["A"])))
+    assert got == [limbs(r) for r in g["ops"][op]]
+
+
+def test_golden_chained_and_alias(ctx):
+    P, F, g = ctx
+    A, B = dev(F, g["A"]), dev(F, g["B"])
+    C, D, E = F.modmul(A, B), F.modsub(A, B), F.modadd(A, B)
+    o = g["ops"]
+    assert rows_of(F, F.modmul(C, D)) == [limbs(r) for r in o["chain_mul_CD"]]
+    assert rows_of(F, F.modsqr(D)) == [limbs(r) for r in o["chain_sqr_D"]]
+    assert rows_of(F, F.modadd(D, E)) == [limbs(r) for r in o["chain_add_DE"]]
+    assert rows_of(F, F.modsub(E, C)) == [limbs(r) for r in o["chain_sub_EC"]]
+    assert rows_of(F, F.redc(C)) == [limbs(r) for r in o["chain_redc_C"]]
+    # in-place aliasing, as the reference uses it (pseudo.py:752,1783,1793; rfc7748.c:214)
+    k = len(o["alias_chain"])
+    x, y = dev(F, g["A"][:k]), dev(F, g["B"][:k])
+    F.modmul(x, y, out=x)
+    F.modsqr(x, out=x)
+    F.modadd(x, x, out=x)
+    F.modsub(x, y, out=x)
+    assert rows_of(F, x) == [limbs(r) for r in o["alias_chain"]]
+
+
+def test_golden_modmli(ctx):
+    P, F, g = ctx
+    ints = g["ops"]["modmli_ints"]
+    rows = g["ops"]["modmli"]
+    A = dev(F, g["A"][:len(rows)])
+    for i, k in enumerate(ints):
+        assert rows_of(F, F.modmli(A, k)) == [limbs(r[i]) for r in rows]
+
+
+def test_golden_modfsb_flatten_predicates(ctx):
+    P, F, g = ctx
+    o = g["ops"]
+    for fn in ("modfsb", "flatten"):
+        x = dev(F, g["A"])
+        flag = getattr(F, fn)(x)
+        assert rows_of(F, x) == [limbs(r[0]) for r in o[fn]]
+        assert flag.cpu().tolist() == [r[1] for r in o[fn]]
+    A, B = dev(F, g["A"]), dev(F, g["B"])
+    assert F.modis1(A).cpu().tolist() == o["modis1"]
+    assert F.modis0(A).cpu().tolist() == o["modis0"]
+    assert F.modsign(A).cpu().tolist() == o["modsign"]
+    assert F.modcmp(A, B).cpu().tolist() == o["modcmp"]
+    x = dev(F, g["A"])
+    F.modhaf(x)
+    assert rows_of(F, x) == [limbs(r) for r in o["modhaf"]]
+
+
+def test_golden_shifts_cond_consts(ctx, torch_cuda):
+    torch = torch_cuda
+    P, F, g = ctx
+    o = g["ops"]
+    for i, rec in enumerate(o["shifts"]):
+        a = dev(F, [g["A"][i]])
+        x = F.redc(a)
+        F.modshl(rec["k"], x)
+        assert rows_of(F, x) == [limbs(rec["shl_of_redc"])]
+        y = dev(F, [g["A"][i]])
+        r = F.modshr(rec["k"], y)
+        assert rows_of(F, y) == [limbs(rec["shr"])] and r.cpu().tolist() == [rec["shr_ret"]]
+    k = len(o["cond"])
+    d = torch.tensor([r["d"] for r in o["cond"]], dtype=torch.int32, device="cuda")
+    gq, fq = dev(F, g["A"][:k]), dev(F, g["B"][:k])
+    F.modcsw(d, gq, fq)
+    assert rows_of(F, gq) == [limbs(r["csw_g"]) for r in o["cond"]]
+    assert rows_of(F, fq) == [limbs(r["csw_f"]) for r in o["cond"]]
+    f2 = dev(F, g["B"][:k])
+    F.modcmv(d, dev(F, g["A"][:k]), f2)
+    assert rows_of(F, f2) == [limbs(r["cmv_f"]) for r in o["cond"]]
+    assert rows_of(F, F.modone(3)) == [limbs(o["modone"])] * 3
+    assert rows_of(F, F.modzer(2)) == [limbs(o["modzer"])] * 2
+    for kk, want in o["modint"]:
+        assert rows_of(F, F.modint(kk, 1)) == [limbs(want)]
+    for kk, want in o["mod2r"]:
+        assert rows_of(F, F.mod2r(kk, 1)) == [limbs(want)]
+
+
+def test_golden_bytes(ctx, torch_cuda):
+    torch = torch_cuda
+    P, F, g = ctx
+    recs = g["ops"]["bytes"]
+    b = torch.tensor([list(bytes.fromhex(r["bytes"])) for r in recs], dtype=torch.uint8, device="cuda")
+    a, flag = F.modimp(b)
+    assert rows_of(F, a) == [limbs(r["imp"]) for r in recs]
+    assert flag.cpu().tolist() == [r["imp_ret"] for r in recs]
+    out = F.modexp(a).cpu().numpy()
+    assert [bytes(row).hex() for row in out] == [r["exp"] for r in recs]
+    k = len(g["ops"]["modexp_A"])
+    out = F.modexp(dev(F, g["A"][:k])).cpu().numpy()
+    assert [bytes(row).hex() for row in out] == g["ops"]["modexp_A"]
+
+
+def test_golden_modinv_after_redc(ctx):
+    P, F, g = ctx
+    recs = g["ops"]["modinv"]
+    x = dev(F, [r["x"] for r in recs])
+    z = F.modinv(x)
+    assert rows_of(F, F.redc(z)) == [limbs(r["inv_redc"]) for r in recs]
+    h = F.modpro(x)
+    z2 = F.modinv(x, h)
+    assert rows_of(F, z2) == rows_of(F, z)
+
+
+# ---------------------------------------------------------------- against the oracle, seeded batches
+N_BIG = (1 << 16) + 3  # odd on purpose: exercises the 16-byte path plus its scalar tail
+
+
+@pytest.mark.parametrize("P", ALL)
+def test_oracle_batch_all_ops(oracle, torch_cuda, P):
+    from modarith_amd.field import Field
+    F = Field(P)
+    a, b = random_soa(P, N_BIG, 11), random_soa(P, N_BIG, 12)
+    da, db = to_dev(a), to_dev(b)
+    for op in ("modmul", "modadd", "modsub", "modadd_lazy", "modsub_lazy"):
+        assert np.array_equal(to_np(getattr(F, op)(da, db)), oracle_bin(oracle, op, P, a, b)), op
+    for op in ("modsqr", "modneg", "modneg_lazy", "nres", "redc", "modcpy"):
+        assert np.array_equal(to_np(getattr(F, op)(da)), oracle_un(oracle, op, P, a)), op
+    for k in (121665, 39081, 1, 0x7fffffff, -3):
+        assert np.array_equal(to_np(F.modmli(da, k)), oracle_mli(oracle, P, a, k)), k
+    # shared multiplicand
+    b0 = [int(v) for v in b[:, 5]]
+    want = np.empty_like(a)
+    b0a = (ctypes.c_uint64 * len(b0))(*b0)
+    oracle.fn("batch_modmul_shared", P)(vp(a), b0a, vp(want), a.shape[1], a.shape[1])
+    assert np.array_equal(to_np(F.modmuls(da, b0)), want)
+
+
+@pytest.mark.parametrize("P", ALL)
+def test_oracle_unaligned_and_strided(oracle, torch_cuda, P):
+    """odd offsets / sub-batch views: the scalar-width path and a limb stride larger than n."""
+    import torch
+    from modarith_amd.field import Field
+    F = Field(P)
+    n = 1000
+    a, b = random_soa(P, n + 7, 21), random_soa(P, n + 7, 22)
+    da, db = to_dev(a), to_dev(b)
+    for off, cnt in ((1, 999), (0, 1), (3, 2), (2, 501), (0, n + 7)):
+        va, vb = da[:, off:off + cnt], db[:, off:off + cnt]
+        out = torch.zeros_like(da)
+        F.modmul(va, vb, out=out[:, off:off + cnt])
+        want = oracle_bin(oracle, "modmul", P, np.ascontiguousarray(a[:, off:off + cnt]), np.ascontiguousarray(b[:, off:off + cnt]))
+        got = to_np(out)
+        assert np.array_equal(got[:, off:off + cnt], want)
+        assert not got[:, :off].any() and not got[:, off + cnt:].any()  # nothing outside the slice is touched
+    assert F.modmul(da[:, :0], db[:, :0]).shape[1] == 0  # empty batch
+
+
+@pytest.mark.parametrize("P", ALL)
+def test_oracle_modinv_batch(oracle, torch_cuda, P):
+    from modarith_amd.field import Field
+    F = Field(P)
+    a = random_soa(P, 4099, 31)
+    z = F.redc(F.modinv(to_dev(a)))
+    want = oracle_un(oracle, "redc", P, oracle_un(oracle, "modinv", P, a))
+    assert np.array_equal(to_np(z), want)
+
+
+def test_properties_full_size(torch_cuda):
+    """BASELINE config 2 size (2^24 elements, 5x51): size-independent properties on the GPU alone:
+    (a*b)*c == a*(b*c), a*(b+c) == a*b + a*c, a*a == sqr(a), a * 1/a == 1 (all after redc)."""
+    torch = torch_cuda
+    from modarith_amd.field import Field
+    F = Field("X25519")
+    n = 1 << 24
+    g = torch.Generator(device="cuda").manual_seed(7)
+    def rnd():
+        t = torch.randint(0, 1 << 51, (5, n), dtype=torch.int64, device="cuda", generator=g)
+        return t
+    a, b, c = rnd(), rnd(), rnd()
+    lhs = F.redc(F.modmul(F.modmul(a, b), c))
+    rhs = F.redc(F.modmul(a, F.modmul(b, c)))
+    assert torch.equal(lhs, rhs)
+    lhs = F.redc(F.modmul(a, F.modadd(b, c)))
+    rhs = F.redc(F.modadd(F.modmul(a, b), F.modmul(a, c)))
+    assert torch.equal(lhs, rhs)
+    assert torch.equal(F.modsqr(a), F.modmul(a, a))
+    m = 1 << 18
+    x = a[:, :m].contiguous()
+    one = F.redc(F.modmul(x, F.modinv(x)))
+    assert int(F.modis1(one).sum()) + int(F.modis0(x).sum()) == m
+
+
+# ---------------------------------------------------------------- scalar (_ct) form: the reference's own self-test shape
+@pytest.mark.parametrize("P", ALL)
+def test_scalar_abi_reference_selftest_chain(oracle, torch_cuda, P):
+    """The generators' ctypes self-test (pseudo.py:1783-1796) without its modsqrt/modhaf tail:
+    nres, nres, modadd, modsub, modmul, modsqr, modinv, redc == inverse(((x-y)(x+y))^2), through the
+    scalar entry points with the reference's signatures."""
+    import random
+    from modarith_amd import _lib
+    from modarith_amd.params import derive
+    lib = _lib.load()
+    fp = derive(P)
+    N = fp.nlimbs
+    U = ctypes.c_uint64 * N
+    f = lambda name: getattr(lib, "%s_%s_ct" % (name, P))
+    rng = random.Random(99)
+    for _ in range(8):
+        x, y = rng.randrange(0, 2 * fp.p), rng.randrange(0, 2 * fp.p)
+        want = pow(((x - y) * (x + y)) ** 2 % fp.p, -1, fp.p)
+        ax, ay, at, az = U(*fp.to_limbs(x)), U(*fp.to_limbs(y)), U(), U()
+        f("nres")(ax, ax); f("nres")(ay, ay)
+        f("modadd")(ax, ay, at); f("modsub")(ax, ay, az)
+        f("modmul")(at, az, ax); f("modsqr")(ax, az)
+        f("modinv")(az, None, az)
+        f("redc")(az, az)
+        assert fp.from_limbs(list(az)) == want
+
+
+# ---------------------------------------------------------------- ladder
+@pytest.mark.parametrize("C", ["X25519", "X448"])
+def test_ladder_kats_and_pairs(torch_cuda, C):
+    torch = torch_cuda
+    from modarith_amd.field import rfc7748
+    g = load_golden("ladder_%s.json" % C)
+    recs = g["kat"] + g["pairs"]
+    k = torch.tensor([list(bytes.fromhex(r["k"])) for r in recs], dtype=torch.uint8, device="cuda")
+    u = torch.tensor([list(bytes.fromhex(r["u"])) for r in recs], dtype=torch.uint8, device="cuda")
+    out = rfc7748(C, k, u).cpu().numpy()
+    assert [bytes(row).hex() for row in out] == [r["out"] for r in recs]
+    # aliasing bv == bu (rfc7748.c:329)
+    u2 = u.clone()
+    rfc7748(C, k, u2, out=u2)
+    assert [bytes(row).hex() for row in u2.cpu().numpy()] == [r["out"] for r in recs]
+
+
+@pytest.mark.parametrize("C,n", [("X25519", 8192 + 5), ("X448", 2048 + 3)])
+def test_ladder_vs_oracle_random(oracle, torch_cuda, C, n):
+    torch = torch_cuda
+    from modarith_amd.field import rfc7748
+    nb = PRIMES[C][3]
+    rng = np.random.default_rng(5)
+    k = rng.integers(0, 256, size=(n, nb), dtype=np.uint8)
+    u = rng.integers(0, 256, size=(n, nb), dtype=np.uint8)
+    u[0] = 0; u[1] = 255; u[2, :] = 0; u[2, 0] = 9
+    want = np.empty_like(u)
+    oracle.lib.oracle_parallel(3 if C == "X25519" else 4, vp(k), vp(u), vp(want), n, 0, 8)
+    got = rfc7748(C, torch.from_numpy(k).cuda(), torch.from_numpy(u).cuda()).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_ladder_scalar_abi_chain(torch_cuda):
+    """reference main()'s chain shape (rfc7748.c:297-305) through the scalar entry point, 10 rounds."""
+    from modarith_amd import _lib
+    lib = _lib.load()
+    g = load_golden("ladder_X25519.json")["ref_main_chain"]
+    bk = bytes.fromhex(g["bk"])
+    bu = ctypes.create_string_buffer(bytes.fromhex(g["bu0"]), 32)
+    bv = ctypes.create_string_buffer(32)
+    for i in range(10):
+        lib.rfc7748_X25519(bk, bu, bv)
+        lib.rfc7748_X25519(bk, bv, bu)
+    assert bu.raw.hex() == g["checkpoints"]["10"]
