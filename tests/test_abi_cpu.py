@@ -1,0 +1,77 @@
+"""CPU-side checks of the boundary: the C-ABI library loads without a GPU and exports every symbol
+include/modarith_amd.h declares; host-side argument checking; no compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from modarith_amd import _lib, build
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "modarith_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(modarith_amd_\w+)\s*\(", text))
+    names.discard("modarith_amd_")
+    macro = text[text.index("#define MODARITH_AMD_DECLARE(P)"):text.index("MODARITH_AMD_DECLARE(X25519)")]
+    per_prime = re.findall(r"\b(\w+)_##P##_(ct|batch)\s*\(", macro)
+    primes = re.findall(r"^MODARITH_AMD_DECLARE\((\w+)\)", text, flags=re.M)
+    for fn, kind in per_prime:
+        for P in primes:
+            names.add("%s_%s_%s" % (fn, P, kind))
+    names.update(re.findall(r"\b(rfc7748_\w+)\s*\(", text))
+    return sorted(names), primes
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names, primes = _declared_symbols()
+    assert primes == ["X25519", "NIST256", "X448"]
+    assert len(names) > 200
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_binding_tables_cover_header(lib):
+    from modarith_amd import _lib
+    names, _ = _declared_symbols()
+    bound = {"%s_%s_batch" % (f, P) for f in _lib.BATCH_FUNCS for P in _lib.PRIMES}
+    bound |= {"%s_%s_ct" % (f, P) for f in _lib.SCALAR_FUNCS for P in _lib.PRIMES}
+    bound |= set(_lib.UTIL_FUNCS) | {"rfc7748_X25519", "rfc7748_X448", "rfc7748_X25519_batch", "rfc7748_X448_batch"}
+    assert bound == set(names)
+
+
+def test_field_info_matches_driver(lib):
+    from modarith_amd.params import derive
+    for P in ("X25519", "NIST256", "X448"):
+        vals = [ctypes.c_int() for _ in range(5)]
+        assert lib.modarith_amd_field_info(P.encode(), *[ctypes.byref(v) for v in vals]) == 1
+        fp = derive(P)
+        assert [v.value for v in vals] == [fp.nlimbs, fp.radix, fp.n, fp.nbytes, int(fp.montgomery)]
+    assert lib.modarith_amd_field_info(b"NOPE", None, None, None, None, None) == 0
+    assert lib.modarith_amd_abi_version() == 1
+
+
+def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
+    from modarith_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    """the product package must not reference the oracle (SURVEY/task rule: oracle is test infrastructure)"""
+    pkg = os.path.join(ROOT, "modarith_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".inc")):
+                text = open(os.path.join(root, f)).read()
+                assert "liboracle" not in text and "oracle_binding" not in text and "from tests" not in text, f

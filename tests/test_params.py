@@ -1,0 +1,73 @@
+"""The parameter driver (modarith_amd/params.py, emit.py) against the constants captured from the
+reference generators (tests/golden/field_*.json "params").  CPU only."""
+import os
+import random
+
+import pytest
+
+from modarith_amd import emit
+from modarith_amd.params import derive
+from tests.conftest import load_golden
+
+ALL = ["X25519", "NIST256", "X448"]
+
+
+def _i(v):
+    return int(v, 16) if isinstance(v, str) else int(v)
+
+
+@pytest.mark.parametrize("P", ALL)
+def test_driver_matches_reference_constants(P):
+    g = load_golden("field_%s.json" % P)["params"]
+    fp = derive(P)
+    assert (fp.n, fp.radix, fp.nlimbs, fp.xcess, fp.nbytes, fp.pm1d2) == (g["n"], g["base"], g["N"], g["xcess"], g["Nbytes"], g["PM1D2"])
+    assert fp.p == _i(g["p"]) and fp.pe == _i(g["PE"])
+    assert fp.roi == [_i(v) for v in g["ROI"]]
+    hdr = " ".join(g["header"])
+    for key, val in (("Nlimbs", fp.nlimbs), ("Radix", fp.radix), ("Nbits", fp.n), ("Nbytes", fp.nbytes)):
+        assert "#define %s %d" % (key, val) in hdr
+    assert ("#define MONTGOMERY" in hdr) == fp.montgomery
+    if fp.family == "pseudo":
+        assert (fp.m, fp.mm, fp.tw) == (_i(g["m"]), _i(g["mm"]), _i(g["TW"]))
+        assert (fp.overflow, fp.fred, fp.epm, fp.carry_on) == (g["overflow"], g["fred"], g["EPM"], g["carry_on"])
+    else:
+        assert fp.ppw == [(-_i(v[1:]) if v.startswith("-") else _i(v)) for v in g["ppw"]]
+        assert (fp.E, fp.R, fp.ndash, fp.trin) == (g["E"], _i(g["R"]), _i(g["ndash"]), g["trin"])
+        assert fp.r2 == [_i(v) for v in g["cw"]]
+        assert g["fullmonty"] is False and g["PM"] is False
+
+
+def test_reference_stdout_lines():
+    """the generators' own log lines (SURVEY 8(a) "pinned by")"""
+    log = "\n".join(load_golden("field_X25519.json")["params"]["log"])
+    assert "Chosen radix is 51 bits, using 5 limbs with excess of 0 bits" in log
+    assert "Tighter reduction" in log and "Fully Exploitable Pseudo-Mersenne detected" in log
+    log = "\n".join(load_golden("field_X448.json")["params"]["log"])
+    assert "Extra virtual limb added" in log and "lucky trinomial" in log
+
+
+@pytest.mark.parametrize("P", ALL + ["NIST384", "NIST224", "PM266", "C2065"])
+def test_addition_chain_computes_progenitor(P):
+    fp = derive(P)
+    prog = emit.addition_chain(fp.pe)
+    rng = random.Random(1)
+    for _ in range(4):
+        x = rng.randrange(2, fp.p)
+        assert emit.eval_chain(prog, x, fp.p) == pow(x, fp.pe, fp.p)
+    sq, mu = emit.chain_cost(prog)
+    assert sq <= fp.pe.bit_length() and mu <= 20  # near-optimal: squarings == bit length - 1 (+0)
+
+
+def test_generated_headers_are_current():
+    """csrc/generated/params_*.h in the tree equal what the driver emits now"""
+    for P in emit.BUILT_PRIMES:
+        path = os.path.join(emit.GEN_DIR, "params_%s.h" % P)
+        assert os.path.exists(path), "run python -m modarith_amd.emit"
+        assert open(path).read() == emit.header_text(derive(P))
+
+
+def test_limb_split_roundtrip():
+    for P in ALL:
+        fp = derive(P)
+        for x in (0, 1, fp.p - 1, fp.p, 2 * fp.p - 1):
+            assert fp.from_limbs(fp.to_limbs(x)) == x
