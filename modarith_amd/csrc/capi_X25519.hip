@@ -5,4 +5,5 @@
 #define MA_NAME X25519
 #define MA_LADDER_A24 121665
 #define MA_LADDER_COF 3
+#define MA_LADDER_FE26 1
 #include "capi_prime.inc"

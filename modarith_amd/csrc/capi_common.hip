@@ -38,6 +38,11 @@ int ladder_block() {
     return v;
 }
 
+bool ladder_use_field() {
+    static bool v = [] { const char* s = getenv("MA_LADDER_IMPL"); return s && strcmp(s, "field") == 0; }();
+    return v;
+}
+
 unsigned char* Staging::get() {
     if (!dev) {
         hipError_t e = hipMalloc((void**)&dev, BYTES);

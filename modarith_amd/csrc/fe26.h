@@ -1,0 +1,258 @@
+// modarith_amd/csrc/fe26.h -- GF(2^255-19) in ten 25.5-bit limbs for the fused X25519 ladder on gfx950.
+//
+// Why a second representation: inside the fused ladder only the final 32 output bytes are compared
+// with the reference (rfc7748.c:254 modexp does a full redc, so they are canonical), which frees the
+// internal limb form (SURVEY 7 "hard parts", 8(f4)).  On CDNA4 the native wide multiplier is
+// v_mad_u64_u32 (32x32+64 -> 64, measured ~2 issue slots); a 51-bit limb product costs four of them plus
+// a 128-bit carry fix-up (about 500 VALU instructions per modmul in the bit-exact 5x51 form).  With
+// limbs below 2^32 every partial product is ONE v_mad_u64_u32 accumulating straight into a 64-bit column
+// register: 100 of them per multiplication, 55 per squaring, no cross-word carries.
+//
+// Radix 2^25.5: limb i carries 26 bits (i even) or 25 bits (i odd); value = sum f_i * 2^ceil(25.5 i).
+// Unsigned limbs.  "tight" = as left by carry(): f_even < 2^26, f_odd < 2^25 (f_1 < 2^25 + 2^16).
+// add()/sub() of tight operands give limbs < 1.5*2^27 (even) / 1.5*2^26 (odd); mul()/sqr() accept such
+// operands on both sides: the largest column is 124.5 * (1.5*2^27)^2 < 2^62.2, and the pre-multiplied
+// factors 19*g_j, 38*f_j, 2*f_i stay below 2^32.  The ladder never multiplies anything that is more
+// than one add/sub away from a tight value (same discipline as the reference's generic=False form,
+// pseudo.py:1523-1528).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "field.h"
+
+namespace ma {
+
+struct Fe26 {
+    static constexpr uint32_t M26 = (1u << 26) - 1, M25 = (1u << 25) - 1;
+    // bit position of limb i
+    static constexpr int pos(int i) { return (51 * i + 1) / 2; }   // 0,26,51,77,102,128,153,179,204,230
+    static constexpr int bits(int i) { return (i & 1) ? 25 : 26; }
+
+    // reduce ten 64-bit columns to tight limbs
+    static MA_DEV void carry(uint64_t* h, uint32_t* r) {
+        static_for<0, 9>([&](auto I) {
+            constexpr int i = I;
+            h[i + 1] += h[i] >> bits(i);
+            r[i] = (uint32_t)h[i] & ((i & 1) ? M25 : M26);
+        });
+        uint64_t c9 = h[9] >> 25;
+        r[9] = (uint32_t)h[9] & M25;
+        uint64_t h0 = (uint64_t)r[0] + 19 * c9;      // c9 < 2^38: fits
+        r[0] = (uint32_t)h0 & M26;
+        r[1] += (uint32_t)(h0 >> 26);
+    }
+
+    static MA_DEV void mul(const uint32_t* f, const uint32_t* g, uint32_t* r) {
+        uint32_t g19[10], f2[10];
+        static_for<1, 10>([&](auto J) { g19[J] = 19u * g[J]; });
+        static_for<0, 5>([&](auto K) { f2[2 * K + 1] = 2u * f[2 * K + 1]; });
+        uint64_t h[10];
+        static_for<0, 10>([&](auto KK) {
+            constexpr int k = KK;
+            uint64_t acc = 0;
+            static_for<0, 10>([&](auto II) {
+                constexpr int i = II;
+                constexpr int j = (k - i + 10) % 10;
+                constexpr bool wrap = (i + j) >= 10;
+                constexpr bool dbl = (i & 1) && (j & 1);
+                const uint32_t a = dbl ? f2[i] : f[i];
+                const uint32_t b = wrap ? g19[j] : g[j];
+                acc += (uint64_t)a * b;
+            });
+            h[k] = acc;
+        });
+        carry(h, r);
+    }
+
+    static MA_DEV void sqr(const uint32_t* f, uint32_t* r) {
+        uint32_t f2[10], f19[10], f38[10];
+        static_for<0, 10>([&](auto I) { f2[I] = 2u * f[I]; });
+        static_for<5, 10>([&](auto J) { f19[J] = 19u * f[J]; });
+        static_for<0, 3>([&](auto K) { f38[2 * K + 5] = 38u * f[2 * K + 5]; });   // odd j >= 5
+        uint64_t h[10];
+        static_for<0, 10>([&](auto KK) {
+            constexpr int k = KK;
+            uint64_t acc = 0;
+            static_for<0, 10>([&](auto II) {
+                constexpr int i = II;
+                constexpr int j = (k - i + 10) % 10;
+                if constexpr (i <= j) {
+                    constexpr bool wrap = (i + j) >= 10;
+                    constexpr bool odd2 = (i & 1) && (j & 1);
+                    uint32_t a, b;
+                    if constexpr (i == j) {
+                        a = odd2 ? f2[i] : f[i];
+                        b = wrap ? f19[j] : f[j];
+                    } else {
+                        a = f2[i];                               // symmetric term counted twice
+                        b = wrap ? (odd2 ? f38[j] : f19[j]) : (odd2 ? f2[j] : f[j]);
+                    }
+                    acc += (uint64_t)a * b;
+                }
+            });
+            h[k] = acc;
+        });
+        carry(h, r);
+    }
+
+    // r = f * c for a small constant (a24 = 121665)
+    template <uint32_t C>
+    static MA_DEV void mul_small(const uint32_t* f, uint32_t* r) {
+        uint64_t h[10];
+        static_for<0, 10>([&](auto I) { h[I] = (uint64_t)f[I] * C; });
+        carry(h, r);
+    }
+
+    static MA_DEV void add(const uint32_t* f, const uint32_t* g, uint32_t* r) {
+        static_for<0, 10>([&](auto I) { r[I] = f[I] + g[I]; });
+    }
+    // r = f - g + 2p  (limbs of 2p: 2^27-38, 2^26-2, 2^27-2, 2^26-2, ...)
+    static MA_DEV void sub(const uint32_t* f, const uint32_t* g, uint32_t* r) {
+        static_for<0, 10>([&](auto I) {
+            constexpr int i = I;
+            constexpr uint32_t twop = (i == 0) ? 0x7ffffdau : ((i & 1) ? 0x3fffffeu : 0x7fffffeu);
+            r[i] = (f[i] + twop) - g[i];
+        });
+    }
+    static MA_DEV void cswap(bool b, uint32_t* f, uint32_t* g) {
+        static_for<0, 10>([&](auto I) {
+            uint32_t x = f[I], y = g[I];
+            f[I] = b ? y : x;
+            g[I] = b ? x : y;
+        });
+    }
+    static MA_DEV void copy(const uint32_t* f, uint32_t* r) { static_for<0, 10>([&](auto I) { r[I] = f[I]; }); }
+    static MA_DEV void set(uint32_t v, uint32_t* r) { static_for<0, 10>([&](auto I) { r[I] = (I == 0) ? v : 0u; }); }
+
+    static MA_DEV void sqn(uint32_t* f, int n) {
+#pragma unroll 1
+        for (int i = 0; i < n; i++) sqr(f, f);
+    }
+
+    // z^(p-2) = z^(2^255-21): 254 squarings + 11 multiplications (run ladder 1,2,4,5,10,20,40,50,100,200,250)
+    static MA_DEV void invert(const uint32_t* z, uint32_t* out) {
+        uint32_t t0[10], t1[10], t2[10], t3[10];
+        sqr(z, t0);                                   // 2
+        sqr(t0, t1); sqr(t1, t1);                     // 8
+        mul(z, t1, t1);                               // 9
+        mul(t0, t1, t0);                              // 11
+        sqr(t0, t2);                                  // 22
+        mul(t1, t2, t1);                              // 31 = 2^5-1
+        copy(t1, t2); sqn(t2, 5);  mul(t2, t1, t1);   // 2^10-1
+        copy(t1, t2); sqn(t2, 10); mul(t2, t1, t2);   // 2^20-1
+        copy(t2, t3); sqn(t3, 20); mul(t3, t2, t2);   // 2^40-1
+        sqn(t2, 10);               mul(t2, t1, t1);   // 2^50-1
+        copy(t1, t2); sqn(t2, 50); mul(t2, t1, t2);   // 2^100-1
+        copy(t2, t3); sqn(t3, 100); mul(t3, t2, t2);  // 2^200-1
+        sqn(t2, 50);               mul(t2, t1, t1);   // 2^250-1
+        sqn(t1, 5);                mul(t1, t0, out);  // 2^255-21
+    }
+
+    // 255-bit little-endian integer in four 64-bit words (bit 255 already cleared) -> limbs (tight).
+    // Non-canonical inputs (>= p) are fine: the value is reduced at export, as modimp/modfsb would.
+    static MA_DEV void from_words(const uint64_t* w, uint32_t* r) {
+        static_for<0, 10>([&](auto I) {
+            constexpr int i = I;
+            constexpr int o = pos(i), wi = o / 64, sh = o % 64;
+            uint64_t v = w[wi] >> sh;
+            if constexpr (sh + bits(i) > 64 && wi + 1 < 4) v |= w[wi + 1] << (64 - sh);
+            r[i] = (uint32_t)v & ((i & 1) ? M25 : M26);
+        });
+    }
+    // canonical export: value mod p as four little-endian 64-bit words
+    static MA_DEV void to_words(const uint32_t* f, uint64_t* w) {
+        uint64_t h[10];
+        uint32_t t[10];
+        static_for<0, 10>([&](auto I) { h[I] = f[I]; });
+        carry(h, t);                                   // tight (t1 may carry 2^16 extra)
+        static_for<0, 10>([&](auto I) { h[I] = t[I]; });
+        carry(h, t);                                   // now every limb strictly within its width, value < 2^255 + small
+        // q = 1 iff t >= p  <=>  t + 19 >= 2^255
+        uint32_t q = (t[0] + 19u) >> 26;
+        static_for<1, 10>([&](auto I) {
+            constexpr int i = I;
+            q = (t[i] + q) >> bits(i);
+        });
+        uint32_t c = 19u * q;                          // add 19 if >= p, then drop bit 255
+        static_for<0, 10>([&](auto I) {
+            constexpr int i = I;
+            uint32_t s = t[i] + c;
+            c = s >> bits(i);
+            t[i] = s & ((i & 1) ? M25 : M26);
+        });
+        static_for<0, 4>([&](auto K) { w[K] = 0; });
+        static_for<0, 10>([&](auto I) {
+            constexpr int i = I;
+            constexpr int o = pos(i), wi = o / 64, sh = o % 64;
+            w[wi] |= (uint64_t)t[i] << sh;
+            if constexpr (sh + bits(i) > 64 && wi + 1 < 4) w[wi + 1] |= (uint64_t)t[i] >> (64 - sh);
+        });
+    }
+};
+
+// Batched X25519 (rfc7748.c:156-256 per element) on the fe26 representation.
+__global__ __launch_bounds__(256) void k_x25519_fe26(const uint64_t* bk, const uint64_t* bu, uint64_t* bv, size_t n) {
+    using F = Fe26;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        uint64_t kw[4], uw[4];
+        static_for<0, 4>([&](auto K) { kw[K] = bk[t * 4 + K]; });
+        static_for<0, 4>([&](auto K) { uw[K] = bu[t * 4 + K]; });
+        uw[3] &= 0x7fffffffffffffffull;                     // mask bit 255 of u (rfc7748.c:171-172)
+        kw[0] &= ~7ull;                                     // clamp (rfc7748.c:135-141)
+        kw[3] = (kw[3] & 0x7fffffffffffffffull) | 0x4000000000000000ull;
+        // left-align: bit 254 -> bit 63 of kw[3]
+        kw[3] = (kw[3] << 1) | (kw[2] >> 63);
+        kw[2] = (kw[2] << 1) | (kw[1] >> 63);
+        kw[1] = (kw[1] << 1) | (kw[0] >> 63);
+        kw[0] <<= 1;
+
+        uint32_t x1[10], x2[10], z2[10], x3[10], z3[10];
+        F::from_words(uw, x1);
+        F::set(1, x2);
+        F::set(0, z2);
+        F::copy(x1, x3);
+        F::set(1, z3);
+
+        uint32_t swap = 0;
+#pragma unroll 1
+        for (int step = 0; step < 255; step++) {
+            const uint32_t kt = (uint32_t)(kw[3] >> 63);
+            kw[3] = (kw[3] << 1) | (kw[2] >> 63);
+            kw[2] = (kw[2] << 1) | (kw[1] >> 63);
+            kw[1] = (kw[1] << 1) | (kw[0] >> 63);
+            kw[0] <<= 1;
+            swap ^= kt;
+            F::cswap(swap != 0, x2, x3);
+            F::cswap(swap != 0, z2, z3);
+            swap = kt;
+            uint32_t A[10], B[10], C[10], D[10], AA[10], BB[10], E[10];
+            F::add(x2, z2, A);
+            F::add(x3, z3, C);
+            F::sub(x2, z2, B);
+            F::sub(x3, z3, D);
+            F::sqr(A, AA);
+            F::sqr(B, BB);
+            F::mul(D, A, D);          // DA
+            F::mul(C, B, C);          // CB
+            F::sub(D, C, z3);
+            F::sub(AA, BB, E);
+            F::mul_small<121665>(E, z2);
+            F::add(D, C, x3);
+            F::add(z2, AA, z2);
+            F::mul(z2, E, z2);
+            F::sqr(x3, x3);
+            F::sqr(z3, z3);
+            F::mul(z3, x1, z3);
+            F::mul(AA, BB, x2);
+        }
+        F::cswap(swap != 0, x2, x3);
+        F::cswap(swap != 0, z2, z3);
+        F::invert(z2, z2);
+        F::mul(x2, z2, x2);
+        uint64_t ow[4];
+        F::to_words(x2, ow);
+        static_for<0, 4>([&](auto K) { bv[t * 4 + K] = ow[K]; });
+    }
+}
+
+}  // namespace ma
