@@ -36,45 +36,54 @@ LOG2_ELEMS = int(os.environ.get("MA_BENCH_LOG2_ELEMS", "24"))
 LOG2_LADDER = int(os.environ.get("MA_BENCH_LOG2_LADDER", "23"))
 
 
-def cpu_baseline(n_sample_log2=22, passes=4):
-    """oracle (kind "port") timed on the host: all-core throughput + the time.c protocol."""
+def cpu_baseline(n_log2=LOG2_ELEMS, min_seconds=6.0):
+    """oracle (kind "port": CPU restatement of the reference's generated field.c, limb-exact against the
+    reference's golden vectors) timed on the host cores: all-core modmul throughput over the same
+    2^24-element workload, the reference's full time.c protocol on one core, and the ladder."""
     import numpy as np
     from tests.oracle_binding import load_oracle
     from tests.util import random_soa, vp
     oracle = load_oracle(build=not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")))
     cores = len(os.sched_getaffinity(0))
-    n = 1 << n_sample_log2
+    n = 1 << n_log2
     a, b = random_soa("X25519", n, 101), random_soa("X25519", n, 102)
     c = np.empty_like(a)
-    oracle.lib.oracle_parallel(0, vp(a), vp(b), vp(c), n, n, cores)  # warm
-    t0 = time.perf_counter()
-    for _ in range(passes):
+    oracle.lib.oracle_parallel(0, vp(a), vp(b), vp(c), n, n, cores)  # warm (page faults, thread start)
+    passes, t0 = 0, time.perf_counter()
+    while True:
         oracle.lib.oracle_parallel(0, vp(a), vp(b), vp(c), n, n, cores)
-    dt = time.perf_counter() - t0
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds or passes >= 1024:
+            break
     thr = passes * n / dt
-    # reference-faithful latency: time.c protocol, 10^7 dependent modmuls (scale=10) on one core
+    del a, b, c
+    # reference-faithful latency: the full time.c protocol, 10^8 dependent modmuls on one core
+    # (pseudo.py:1235-1250); the check word must be the reference's 0x116640
     U = ctypes.c_uint64 * 5
     mk = lambda v: U(*[(v >> (51 * i)) & ((1 << 51) - 1) for i in range(5)])
     ra = 0x11dc60f4392456de3eb13b9046685257bdd640fb06671ad11c80317fa3b1799d
     rb = 0x4b95423416419f828b9d2434e465e150bd9c66b3ad3c2d6d1a3d1fa7bc8960a9
     x, y = mk(ra), mk(rb)
     t0 = time.perf_counter()
-    chk = oracle.fn("time_modmul", "X25519")(x, y, 10000)
-    lat = (time.perf_counter() - t0) / 1e7
+    chk = oracle.fn("time_modmul", "X25519")(x, y, 100000)
+    lat = (time.perf_counter() - t0) / 1e8
+    assert chk == 0x116640, "time.c check word mismatch: %#x" % chk
     # ladder on all cores, bounded sample
-    m = 256 * cores
     rng = np.random.default_rng(7)
+    m = 512 * cores
     k = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
     u = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
     o = np.empty_like(u)
     t0 = time.perf_counter()
     oracle.lib.oracle_parallel(3, vp(k), vp(u), vp(o), m, 0, cores)
-    lad = m / (time.perf_counter() - t0)
+    ldt = time.perf_counter() - t0
     return {
         "value": thr, "unit": "modmul/s", "cores": cores, "kind": "port",
-        "sample": "oracle modmul_X25519 over 2^%d seeded elements x %d passes, %d threads (%.1f s)" % (n_sample_log2, passes, cores, dt),
-        "time_c_protocol": {"ns_per_modmul": lat * 1e9, "cores": 1, "dependent_modmuls": 10**7, "check_word_scale10": hex(chk)},
-        "x25519_scalar_mults_per_s": lad, "x25519_sample": "%d ladders, %d threads" % (m, cores),
+        "sample": "oracle modmul_X25519 over the 2^%d-element workload x %d passes, %d threads, %.1f s wall" % (n_log2, passes, cores, dt),
+        "time_c_protocol": {"ns_per_modmul": lat * 1e9, "modmul_per_s": 1.0 / lat, "cores": 1, "dependent_modmuls": 10**8,
+                            "check_word": hex(chk), "reference_check_word": "0x116640"},
+        "x25519_scalar_mults_per_s": m / ldt, "x25519_sample": "%d ladders, %d threads, %.1f s wall" % (m, cores, ldt),
     }
 
 

@@ -146,6 +146,12 @@ int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbi
     /* constant-time conditional move/swap, one selector d[j] in {0,1} per element (device int[n]) */                  \
     int modcmv_##P##_batch(const int *d, const ma_spint *g, ma_spint *f, size_t n, size_t ld, void *stream);            \
     int modcsw_##P##_batch(const int *d, ma_spint *g, ma_spint *f, size_t n, size_t ld, void *stream);                  \
+    /* the reference's timing protocol (time.c: pseudo.py:1177-1386; CUDA form simd/pseudo_cuda.py:1163-1231) run per  \
+       lane in registers: kind 0 = outer*200*5 dependent modmul on (x,y), 1 = outer*500*2 modsqr on x, 2 = outer*2     \
+       modinv on x; inputs are plain (not nres'd) limbs as time.c bakes them in; z[j] = redc(result), so              \
+       z[0][j] & 0xFFFFFF is the reference's check word */                                                            \
+    int time_protocol_##P##_batch(int kind, const ma_spint *x, const ma_spint *y, ma_spint *z, long outer, size_t n,    \
+                                  size_t ld, void *stream);                                                             \
     /* byte records: device char[n*Nbytes], big-endian per record as modimp/modexp take them */                        \
     int modimp_##P##_batch(const char *b, ma_spint *a, int *flag, size_t n, size_t ld, void *stream);                   \
     int modexp_##P##_batch(const ma_spint *a, char *b, size_t n, size_t ld, void *stream);

@@ -114,11 +114,12 @@ struct Fe26 {
             r[i] = (f[i] + twop) - g[i];
         });
     }
-    static MA_DEV void cswap(bool b, uint32_t* f, uint32_t* g) {
+    // constant-time swap by masking (mask = 0 or ~0 per lane); measured equal to v_cndmask pairs
+    static MA_DEV void cswap(uint32_t mask, uint32_t* f, uint32_t* g) {
         static_for<0, 10>([&](auto I) {
-            uint32_t x = f[I], y = g[I];
-            f[I] = b ? y : x;
-            g[I] = b ? x : y;
+            uint32_t t = (f[I] ^ g[I]) & mask;
+            f[I] ^= t;
+            g[I] ^= t;
         });
     }
     static MA_DEV void copy(const uint32_t* f, uint32_t* r) { static_for<0, 10>([&](auto I) { r[I] = f[I]; }); }
@@ -222,8 +223,8 @@ __global__ __launch_bounds__(256) void k_x25519_fe26(const uint64_t* bk, const u
             kw[1] = (kw[1] << 1) | (kw[0] >> 63);
             kw[0] <<= 1;
             swap ^= kt;
-            F::cswap(swap != 0, x2, x3);
-            F::cswap(swap != 0, z2, z3);
+            F::cswap(0u - swap, x2, x3);
+            F::cswap(0u - swap, z2, z3);
             swap = kt;
             uint32_t A[10], B[10], C[10], D[10], AA[10], BB[10], E[10];
             F::add(x2, z2, A);
@@ -245,8 +246,8 @@ __global__ __launch_bounds__(256) void k_x25519_fe26(const uint64_t* bk, const u
             F::mul(z3, x1, z3);
             F::mul(AA, BB, x2);
         }
-        F::cswap(swap != 0, x2, x3);
-        F::cswap(swap != 0, z2, z3);
+        F::cswap(0u - swap, x2, x3);
+        F::cswap(0u - swap, z2, z3);
         F::invert(z2, z2);
         F::mul(x2, z2, x2);
         uint64_t ow[4];

@@ -15,18 +15,36 @@ namespace ma {
 
 constexpr int BLOCK = 256;
 
-template <int EPT> struct vec_of;
-template <> struct vec_of<1> { using type = spint; };
-template <> struct vec_of<2> { using type = ulonglong2; };
+// Batches are streamed once (640 MiB+ per array, far beyond L2 / Infinity Cache): loads and stores carry
+// the non-temporal hint so they do not displace each other in the caches (measured +3..5 % on the
+// 3-stream pattern, profiles/r01_membench.log).
+typedef spint spint2 __attribute__((ext_vector_type(2)));
+#ifndef MA_NONTEMPORAL
+#define MA_NONTEMPORAL 1
+#endif
+template <class T> __device__ __forceinline__ T ld_stream(const T* p) {
+#if MA_NONTEMPORAL
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <class T> __device__ __forceinline__ void st_stream(T* p, T v) {
+#if MA_NONTEMPORAL
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 
 // element index handled by (thread t, slot e): j = EPT*t + e  -> contiguous EPT*8 bytes per lane
 template <class P, int EPT>
 __device__ __forceinline__ void load_soa(const spint* base, size_t ld, size_t t, spint (*x)[P::N]) {
     if constexpr (EPT == 1) {
-        static_for<0, P::N>([&](auto I) { x[0][I] = base[(size_t)I * ld + t]; });
+        static_for<0, P::N>([&](auto I) { x[0][I] = ld_stream(base + (size_t)I * ld + t); });
     } else {
         static_for<0, P::N>([&](auto I) {
-            ulonglong2 v = *reinterpret_cast<const ulonglong2*>(base + (size_t)I * ld + 2 * t);
+            spint2 v = ld_stream(reinterpret_cast<const spint2*>(base + (size_t)I * ld + 2 * t));
             x[0][I] = v.x;
             x[1][I] = v.y;
         });
@@ -35,13 +53,13 @@ __device__ __forceinline__ void load_soa(const spint* base, size_t ld, size_t t,
 template <class P, int EPT>
 __device__ __forceinline__ void store_soa(spint* base, size_t ld, size_t t, spint (*x)[P::N]) {
     if constexpr (EPT == 1) {
-        static_for<0, P::N>([&](auto I) { base[(size_t)I * ld + t] = x[0][I]; });
+        static_for<0, P::N>([&](auto I) { st_stream(base + (size_t)I * ld + t, x[0][I]); });
     } else {
         static_for<0, P::N>([&](auto I) {
-            ulonglong2 v;
+            spint2 v;
             v.x = x[0][I];
             v.y = x[1][I];
-            *reinterpret_cast<ulonglong2*>(base + (size_t)I * ld + 2 * t) = v;
+            st_stream(reinterpret_cast<spint2*>(base + (size_t)I * ld + 2 * t), v);
         });
     }
 }
@@ -240,6 +258,46 @@ __global__ __launch_bounds__(BLOCK) void k_exp(const spint* a, spint* bytes, siz
         spint w[NW];
         Field<P>::modexp_words(x[0], w);
         static_for<0, NW>([&](auto K) { bytes[t * NW + (NW - 1 - K)] = __builtin_bswap64(w[K]); });
+    }
+}
+
+// The reference's timing protocol on the GPU (time.c: pseudo.py:1177-1386; its CUDA form
+// simd/pseudo_cuda.py:1163-1231 runs the same dependent chains inside one thread): every lane runs the
+// serially dependent chain on its own operands, entirely in registers, and leaves redc(z).
+// KIND 0: `outer` x 200 x 5 modmul;  1: `outer` x 500 x 2 modsqr;  2: `outer` x 2 modinv.
+template <class P, int KIND>
+__global__ __launch_bounds__(BLOCK) void k_time(const spint* xs, const spint* ys, spint* zs, long outer, size_t n, size_t ld) {
+    using F = Field<P>;
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
+        spint x[1][P::N], y[1][P::N], z[1][P::N];
+        load_soa<P, 1>(xs, ld, t, x);
+        F::nres(x[0], x[0]);
+        if constexpr (KIND == 0) {
+            load_soa<P, 1>(ys, ld, t, y);
+            F::nres(y[0], y[0]);
+#pragma unroll 1
+            for (long i = 0; i < outer * 200; i++) {
+                F::modmul(x[0], y[0], z[0]);
+                F::modmul(z[0], x[0], y[0]);
+                F::modmul(y[0], z[0], x[0]);
+                F::modmul(x[0], y[0], z[0]);
+                F::modmul(z[0], x[0], y[0]);
+            }
+        } else if constexpr (KIND == 1) {
+#pragma unroll 1
+            for (long i = 0; i < outer * 500; i++) {
+                F::modsqr(x[0], z[0]);
+                F::modsqr(z[0], x[0]);
+            }
+        } else {
+#pragma unroll 1
+            for (long i = 0; i < outer; i++) {
+                F::modinv(x[0], nullptr, z[0]);
+                F::modinv(z[0], nullptr, x[0]);
+            }
+        }
+        F::redc(z[0], z[0]);
+        store_soa<P, 1>(zs, ld, t, z);
     }
 }
 

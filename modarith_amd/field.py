@@ -217,6 +217,17 @@ class Field:
         self._call("modcsw", self._sel(d, n).data_ptr(), g.data_ptr(), f.data_ptr(), n, g.stride(0), _stream())
         return g, f
 
+    def time_protocol(self, kind: str, x, y=None, outer: int = 1):
+        """The reference's time.c chains (pseudo.py:1177-1386) per lane, in registers: kind "modmul"
+        (outer*1000 dependent modmul on x,y), "modsqr" (outer*1000 modsqr), "modinv" (outer*2 modinv).
+        x, y: plain limbs (time.c applies nres itself).  Returns redc(z); z[0] & 0xFFFFFF is the check word."""
+        k = {"modmul": 0, "modsqr": 1, "modinv": 2}[kind]
+        y = x if y is None else y
+        z = torch.empty_like(x)
+        n = self._chk(x, y, z)
+        self._call("time_protocol", k, x.data_ptr(), y.data_ptr(), z.data_ptr(), int(outer), n, x.stride(0), _stream())
+        return z
+
     def modimp(self, b: torch.Tensor):
         """b: uint8 [n, Nbytes] big-endian records -> (batch, flag)."""
         if b.dtype != torch.uint8 or b.dim() != 2 or b.shape[1] != self.nbytes or not b.is_contiguous() or not b.is_cuda:

@@ -29,47 +29,44 @@ void modpro_NIST256(const spint *w, spint *z);
 spint modfsb_NIST256(spint *n);
 static spint prop_NIST256(spint *n);
 
-/* shape-aware reduction terms for column i (mul_process, monty.py:597-627): digit v_j meets prime
- * limb i-j; 2^44 and 2^36 become shifts, p4 a real multiply, the -1 limb is absorbed by v = t&mask */
-#define NIST256_REDUCE(i)                                                        \
-    do {                                                                         \
-        if ((i) >= 1 && (i) - 1 < NL) t += (dpint)v[(i) - 1] << 44;             \
-        if ((i) >= 3 && (i) - 3 < NL) t += (dpint)v[(i) - 3] << 36;             \
-        if ((i) >= 4 && (i) - 4 < NL) t += (dpint)v[(i) - 4] * (dpint)P4;       \
-    } while (0)
+/* Shape-aware reduction terms for column i (mul_process, monty.py:597-627): digit v_j meets prime limb
+ * i-j; 2^44 and 2^36 become shifts, p4 a real multiply, the -1 limb is absorbed by v = t & mask.
+ * Straight-line columns (oracle/columns.h) so the compiler sees what the generator would emit. */
+#include "columns.h"
+#define SH44(v) ((dpint)(v) << 44)
+#define SH36(v) ((dpint)(v) << 36)
+#define MP4(v) ((dpint)(v) * (dpint)P4)
+#define NIST256_BODY(COL)                                                                   \
+    const spint mask = ((spint)1 << RADIX) - 1;                                             \
+    dpint t = 0;                                                                            \
+    spint v0, v1, v2, v3, v4;                                                               \
+    t += COL(0);                                           v0 = (spint)t & mask; t >>= RADIX; \
+    t += COL(1); t += SH44(v0);                            v1 = (spint)t & mask; t >>= RADIX; \
+    t += COL(2); t += SH44(v1);                            v2 = (spint)t & mask; t >>= RADIX; \
+    t += COL(3); t += SH36(v0); t += SH44(v2);             v3 = (spint)t & mask; t >>= RADIX; \
+    t += COL(4); t += MP4(v0); t += SH36(v1); t += SH44(v3); v4 = (spint)t & mask; t >>= RADIX; \
+    t += COL(5); t += MP4(v1); t += SH36(v2); t += SH44(v4); c[0] = (spint)t & mask; t >>= RADIX; \
+    t += COL(6); t += MP4(v2); t += SH36(v3);              c[1] = (spint)t & mask; t >>= RADIX; \
+    t += COL(7); t += MP4(v3); t += SH36(v4);              c[2] = (spint)t & mask; t >>= RADIX; \
+    t += COL(8); t += MP4(v4);                             c[3] = (spint)t & mask; t >>= RADIX; \
+    c[4] = (spint)t;
 
 /* monty.py:663-872 (non-E branch 840-870), columns getZMU/getZMD 493-537 */
 void modmul_NIST256(const spint *a, const spint *b, spint *c) {
-    const spint mask = ((spint)1 << RADIX) - 1;
-    dpint t = 0;
-    spint v[NL];
-    for (int i = 0; i < 2 * NL - 1; i++) {
-        int lo = i < NL ? 0 : i - (NL - 1), hi = i < NL ? i : NL - 1;
-        for (int k = lo; k <= hi; k++) t += (dpint)a[k] * b[i - k];
-        NIST256_REDUCE(i);
-        if (i < NL) v[i] = (spint)t & mask; else c[i - NL] = (spint)t & mask;
-        t >>= RADIX;
-    }
-    c[NL - 1] = (spint)t;
+#define M(i, j) ((dpint)a[i] * b[j])
+#define COL(k) MULCOL5_##k
+    NIST256_BODY(COL)
+#undef COL
+#undef M
 }
 
 /* monty.py:982-1165, columns getZSU/getZSD 540-590: tot = 2*sum(cross) + square */
 void modsqr_NIST256(const spint *a, spint *c) {
-    const spint mask = ((spint)1 << RADIX) - 1;
-    dpint t = 0, tot;
-    spint v[NL];
-    for (int i = 0; i < 2 * NL - 1; i++) {
-        int k = i < NL ? 0 : i - (NL - 1);
-        tot = 0;
-        for (; k < i - k; k++) tot += (dpint)a[k] * a[i - k];
-        tot *= 2;
-        if (i % 2 == 0) tot += (dpint)a[i / 2] * a[i / 2];
-        t += tot;
-        NIST256_REDUCE(i);
-        if (i < NL) v[i] = (spint)t & mask; else c[i - NL] = (spint)t & mask;
-        t >>= RADIX;
-    }
-    c[NL - 1] = (spint)t;
+#define S(i, j) ((dpint)a[i] * a[j])
+#define COL(k) SQRCOL5_##k
+    NIST256_BODY(COL)
+#undef COL
+#undef S
 }
 
 /* Barrett-Dhem branch, monty.py:909-972: r = floor(2^(n+RADIX)/p), h = t >> ((n-64) % RADIX) */

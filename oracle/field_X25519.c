@@ -41,39 +41,46 @@ static inline void second_pass(dpint t, const spint *v, spint *c) {
     for (int i = 2; i < NL; i++) c[i] = v[i];
 }
 
-/* Comba rows with the high half pre-multiplied by mm (EPM): pseudo.py:616-659, getZM 390-438 */
+/* Comba rows with the high half pre-multiplied by mm (EPM): pseudo.py:616-659, getZM 390-438.
+ * Row r: t += sum_{k>r} ma_k*b_{5+r-k} + sum_{k<=r} a_k*b_{r-k}.  Straight-line, as the generator emits. */
 void modmul_X25519(const spint *a, const spint *b, spint *c) {
     const spint mask = ((spint)1 << RADIX) - 1;
+    const spint ma1 = a[1] * (spint)MM, ma2 = a[2] * (spint)MM, ma3 = a[3] * (spint)MM, ma4 = a[4] * (spint)MM;
     dpint t = 0;
-    spint ma[NL], v[NL];
-    for (int i = 1; i < NL; i++) ma[i] = a[i] * (spint)MM;
-    for (int row = 0; row < NL; row++) {
-        for (int k = row + 1, l = NL - 1; k < NL; k++, l--) t += (dpint)ma[k] * (dpint)b[l];
-        for (int k = 0; k <= row; k++) t += (dpint)a[k] * (dpint)b[row - k];
-        v[row] = (spint)t & mask;
-        t >>= RADIX;
-    }
+    spint v[NL];
+#define W(x, y) ((dpint)(x) * (dpint)(y))
+    t += W(ma1, b[4]) + W(ma2, b[3]) + W(ma3, b[2]) + W(ma4, b[1]) + W(a[0], b[0]);
+    v[0] = (spint)t & mask; t >>= RADIX;
+    t += W(ma2, b[4]) + W(ma3, b[3]) + W(ma4, b[2]) + W(a[0], b[1]) + W(a[1], b[0]);
+    v[1] = (spint)t & mask; t >>= RADIX;
+    t += W(ma3, b[4]) + W(ma4, b[3]) + W(a[0], b[2]) + W(a[1], b[1]) + W(a[2], b[0]);
+    v[2] = (spint)t & mask; t >>= RADIX;
+    t += W(ma4, b[4]) + W(a[0], b[3]) + W(a[1], b[2]) + W(a[2], b[1]) + W(a[3], b[0]);
+    v[3] = (spint)t & mask; t >>= RADIX;
+    t += W(a[0], b[4]) + W(a[1], b[3]) + W(a[2], b[2]) + W(a[3], b[1]) + W(a[4], b[0]);
+    v[4] = (spint)t & mask; t >>= RADIX;
     second_pass(t, v, c);
 }
 
 /* squaring rows with ta=2a, ma=19a (EPM): pseudo.py:663-702, getZS 441-554 */
 void modsqr_X25519(const spint *a, spint *c) {
     const spint mask = ((spint)1 << RADIX) - 1;
+    const spint ta1 = a[1] * (spint)2, ta2 = a[2] * (spint)2, ta3 = a[3] * (spint)2, ta4 = a[4] * (spint)2;
+    const spint ma1 = a[1] * (spint)MM, ma2 = a[2] * (spint)MM, ma3 = a[3] * (spint)MM, ma4 = a[4] * (spint)MM;
     dpint t = 0;
-    spint ta[NL], ma[NL], v[NL];
-    for (int i = 1; i < NL; i++) ta[i] = a[i] * (spint)2;
-    for (int i = 1; i < NL; i++) ma[i] = a[i] * (spint)MM;
-    for (int row = 0; row < NL; row++) {
-        int k = row + 1, l = NL - 1;
-        for (; k < l; k++, l--) t += (dpint)ma[k] * (dpint)ta[l];   /* folded cross terms, doubled */
-        if (k == l) t += (dpint)ma[k] * (dpint)a[k];                /* folded square term */
-        k = 0; l = row;
-        for (; k < l; k++, l--) t += (dpint)a[k] * (dpint)ta[l];    /* low cross terms, doubled */
-        if (k == l) t += (dpint)a[k] * (dpint)a[k];
-        v[row] = (spint)t & mask;
-        t >>= RADIX;
-    }
+    spint v[NL];
+    t += W(ma1, ta4) + W(ma2, ta3) + W(a[0], a[0]);
+    v[0] = (spint)t & mask; t >>= RADIX;
+    t += W(ma2, ta4) + W(ma3, a[3]) + W(a[0], ta1);
+    v[1] = (spint)t & mask; t >>= RADIX;
+    t += W(ma3, ta4) + W(a[0], ta2) + W(a[1], a[1]);
+    v[2] = (spint)t & mask; t >>= RADIX;
+    t += W(ma4, a[4]) + W(a[0], ta3) + W(a[1], ta2);
+    v[3] = (spint)t & mask; t >>= RADIX;
+    t += W(a[0], ta4) + W(a[1], ta3) + W(a[2], a[2]);
+    v[4] = (spint)t & mask; t >>= RADIX;
     second_pass(t, v, c);
+#undef W
 }
 
 /* pseudo.py:705-728; (dpint)b of a negative int sign-extends exactly as in the emitted C */

@@ -27,56 +27,50 @@ void redc_X448(const spint *n, spint *m);
 void modpro_X448(const spint *w, spint *z);
 spint modfsb_X448(spint *n);
 
-/* Reduction contribution of column i >= 4 (mul_process with the gone_neg/mask_set borrow convention,
- * monty.py:597-627, 717-738, 778-838): nine digits v0..v8 meet prime limbs -1 (index 0, implicit),
- * -1 (index 4) and +1 (index 8).  The first negative use adds q - v0; every later column starts a
- * 64-bit scratch at mask (= q-1, carrying the outstanding borrow), adds v_{i-8} and subtracts v_{i-4}. */
-static inline dpint x448_reduce(int i, const spint *v) {
-    const spint q = (spint)1 << RADIX, mask = q - 1;
-    if (i < 4) return 0;
-    if (i == 4) return (dpint)(spint)(q - v[0]);
-    spint s = mask;
-    if (i >= 8 && i - 8 <= 8) s += v[i - 8];
-    if (i - 4 <= 8) s -= v[i - 4];
-    return (dpint)s;
-}
+/* Reduction terms (mul_process with the gone_neg/mask_set borrow convention, monty.py:597-627, 717-738,
+ * 778-838): nine digits v0..v8 meet prime limbs -1 (index 0, implicit), -1 (index 4) and +1 (index 8).
+ * The first negative use adds q - v0; every later column starts a 64-bit scratch at mask (= q-1, carrying
+ * the outstanding borrow), adds v_{i-8} and subtracts v_{i-4}.  Straight-line columns (oracle/columns.h). */
+#include "columns.h"
+#define X448_BODY(COL)                                                                             \
+    const spint q = (spint)1 << RADIX, mask = q - 1;                                               \
+    dpint t = 0;                                                                                   \
+    spint v0, v1, v2, v3, v4, v5, v6, v7, v8, s;                                                   \
+    t += COL(0);                                        v0 = (spint)t & mask; t >>= RADIX;         \
+    t += COL(1);                                        v1 = (spint)t & mask; t >>= RADIX;         \
+    t += COL(2);                                        v2 = (spint)t & mask; t >>= RADIX;         \
+    t += COL(3);                                        v3 = (spint)t & mask; t >>= RADIX;         \
+    t += COL(4);  t += (dpint)(spint)(q - v0);          v4 = (spint)t & mask; t >>= RADIX;         \
+    t += COL(5);  s = mask; s -= v1;           t += (dpint)s; v5 = (spint)t & mask; t >>= RADIX;   \
+    t += COL(6);  s = mask; s -= v2;           t += (dpint)s; v6 = (spint)t & mask; t >>= RADIX;   \
+    t += COL(7);  s = mask; s -= v3;           t += (dpint)s; v7 = (spint)t & mask; t >>= RADIX;   \
+    t += COL(8);  s = mask; s += v0; s -= v4;  t += (dpint)s; v8 = (spint)t & mask; t >>= RADIX;   \
+    t += COL(9);  s = mask; s += v1; s -= v5;  t += (dpint)s; c[0] = (spint)t & mask; t >>= RADIX; \
+    t += COL(10); s = mask; s += v2; s -= v6;  t += (dpint)s; c[1] = (spint)t & mask; t >>= RADIX; \
+    t += COL(11); s = mask; s += v3; s -= v7;  t += (dpint)s; c[2] = (spint)t & mask; t >>= RADIX; \
+    t += COL(12); s = mask; s += v4; s -= v8;  t += (dpint)s; c[3] = (spint)t & mask; t >>= RADIX; \
+    t += COL(13); s = mask; s += v5;           t += (dpint)s; c[4] = (spint)t & mask; t >>= RADIX; \
+    t += COL(14); s = mask; s += v6;           t += (dpint)s; c[5] = (spint)t & mask; t >>= RADIX; \
+    s = mask; s += v7;                         t += (dpint)s; c[6] = (spint)t & mask; t >>= RADIX; \
+    t += (dpint)(spint)(v8 - (spint)1);        /* settle the borrow, monty.py:830-838 */           \
+    c[7] = (spint)t;
 
 /* monty.py:663-872, E branch 778-838 */
 void modmul_X448(const spint *a, const spint *b, spint *c) {
-    const spint mask = ((spint)1 << RADIX) - 1;
-    dpint t = 0;
-    spint v[NL + 1];
-    for (int i = 0; i < 2 * NL; i++) {           /* columns 0..15; column 15 has no product */
-        int lo = i < NL ? 0 : i - (NL - 1), hi = i < NL ? i : NL - 1;
-        for (int k = lo; k <= hi; k++) t += (dpint)a[k] * b[i - k];
-        t += x448_reduce(i, v);
-        if (i <= NL) v[i] = (spint)t & mask; else c[i - NL - 1] = (spint)t & mask;
-        t >>= RADIX;
-    }
-    t += (dpint)(spint)(v[NL] - (spint)1);       /* settle the borrow, monty.py:830-838 */
-    c[NL - 1] = (spint)t;
+#define M(i, j) ((dpint)a[i] * b[j])
+#define COL(k) MULCOL8_##k
+    X448_BODY(COL)
+#undef COL
+#undef M
 }
 
 /* monty.py:982-1165 */
 void modsqr_X448(const spint *a, spint *c) {
-    const spint mask = ((spint)1 << RADIX) - 1;
-    dpint t = 0, tot;
-    spint v[NL + 1];
-    for (int i = 0; i < 2 * NL; i++) {
-        if (i < 2 * NL - 1) {
-            int k = i < NL ? 0 : i - (NL - 1);
-            tot = 0;
-            for (; k < i - k; k++) tot += (dpint)a[k] * a[i - k];
-            tot *= 2;
-            if (i % 2 == 0) tot += (dpint)a[i / 2] * a[i / 2];
-            t += tot;
-        }
-        t += x448_reduce(i, v);
-        if (i <= NL) v[i] = (spint)t & mask; else c[i - NL - 1] = (spint)t & mask;
-        t >>= RADIX;
-    }
-    t += (dpint)(spint)(v[NL] - (spint)1);
-    c[NL - 1] = (spint)t;
+#define S(i, j) ((dpint)a[i] * a[j])
+#define COL(k) SQRCOL8_##k
+    X448_BODY(COL)
+#undef COL
+#undef S
 }
 
 /* trinomial branch, monty.py:888-907: fold the overflow word into limbs 0 and trin */

@@ -259,6 +259,28 @@ def test_scalar_abi_reference_selftest_chain(oracle, torch_cuda, P):
         assert fp.from_limbs(list(az)) == want
 
 
+# ---------------------------------------------------------------- time.c protocol on the device (row a15)
+@pytest.mark.parametrize("P", ALL)
+def test_time_protocol_check_words(torch_cuda, P):
+    """every lane runs the reference's dependent chains (pseudo.py:1235-1250) on the seed-42 operands;
+    the 24-bit check words and redc'd limbs must equal the reference's (golden "time", depth 10^3 / 10^5)."""
+    from modarith_amd.field import Field
+    F = Field(P)
+    g = load_golden("field_%s.json" % P)["time"]
+    N, radix = PRIMES[P][0], PRIMES[P][1]
+    mk = lambda v: [(int(v, 16) >> (radix * i)) & ((1 << radix) - 1) for i in range(N)]
+    lanes = 130
+    x, y = F.from_limbs([mk(g["ra"])] * lanes), F.from_limbs([mk(g["rb"])] * lanes)
+    xs, xi = F.from_limbs([mk(g["rs"])] * lanes), F.from_limbs([mk(g["ri"])] * lanes)
+    for outer, tag in ((1, "1k"), (100, "100k")):
+        z = F.to_limbs(F.time_protocol("modmul", x, y, outer))
+        assert z == [limbs(g["modmul_z_" + tag])] * lanes and z[0][0] & 0xFFFFFF == int(g["modmul_check_" + tag], 16)
+        z = F.to_limbs(F.time_protocol("modsqr", xs, None, outer))
+        assert z == [limbs(g["modsqr_z_" + tag])] * lanes and z[0][0] & 0xFFFFFF == int(g["modsqr_check_" + tag], 16)
+    z = F.to_limbs(F.time_protocol("modinv", xi, None, 2))
+    assert z == [limbs(g["modinv_z_full"])] * lanes and z[0][0] & 0xFFFFFF == int(g["modinv_check_full"], 16)
+
+
 # ---------------------------------------------------------------- ladder
 @pytest.mark.parametrize("C", ["X25519", "X448"])
 def test_ladder_kats_and_pairs(torch_cuda, C):
