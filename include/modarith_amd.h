@@ -70,6 +70,7 @@ int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbi
  *   modsub   pseudo.py:307-326    modneg pseudo.py:329-348     modmli pseudo.py:705-728 / monty.py:876-978
  *   modmul   pseudo.py:616-659 / monty.py:663-872              modsqr pseudo.py:663-702 / monty.py:982-1165
  *   modcpy   pseudo.py:730-743    modnsqr pseudo.py:745-755    modpro pseudo.py:758-785
+ *   modqr    pseudo.py:815-831    modsqrt pseudo.py:834-874
  *   modinv   pseudo.py:788-812    nres pseudo.py:952-962 / monty.py:1386-1399
  *   redc     pseudo.py:965-976 / monty.py:1402-1416            modis1 pseudo.py:877-891
  *   modis0   pseudo.py:894-906    modzer 909-919  modone 922-934  modint 937-949
@@ -92,6 +93,8 @@ int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbi
     void modnsqr_##P##_ct(ma_spint *a, int n);                                                                          \
     void modpro_##P##_ct(const ma_spint *w, ma_spint *z);                                                               \
     void modinv_##P##_ct(const ma_spint *x, const ma_spint *h, ma_spint *z); /* h may be NULL */                        \
+    int modqr_##P##_ct(const ma_spint *h, const ma_spint *x);                /* h may be NULL */                        \
+    void modsqrt_##P##_ct(const ma_spint *x, const ma_spint *h, ma_spint *r); /* h may be NULL */                       \
     void nres_##P##_ct(const ma_spint *m, ma_spint *n);                                                                 \
     void redc_##P##_ct(const ma_spint *n, ma_spint *m);                                                                 \
     int modis1_##P##_ct(const ma_spint *a);                                                                             \
@@ -125,6 +128,8 @@ int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbi
     int modnsqr_##P##_batch(ma_spint *a, int k, size_t n, size_t ld, void *stream);                                     \
     int modpro_##P##_batch(const ma_spint *w, ma_spint *z, size_t n, size_t ld, void *stream);                          \
     int modinv_##P##_batch(const ma_spint *x, const ma_spint *h, ma_spint *z, size_t n, size_t ld, void *stream);       \
+    int modsqrt_##P##_batch(const ma_spint *x, const ma_spint *h, ma_spint *r, size_t n, size_t ld, void *stream);      \
+    int modqr_##P##_batch(const ma_spint *h, const ma_spint *x, int *out, size_t n, size_t ld, void *stream);           \
     int nres_##P##_batch(const ma_spint *m, ma_spint *n_, size_t n, size_t ld, void *stream);                           \
     int redc_##P##_batch(const ma_spint *n_, ma_spint *m, size_t n, size_t ld, void *stream);                           \
     /* in place; flag (device int[n], may be NULL) receives the return value per element */                            \

@@ -34,6 +34,8 @@ _SIG = {
     "nres": [_P, _P, c_size_t, c_size_t, _P],
     "redc": [_P, _P, c_size_t, c_size_t, _P],
     "modinv": [_P, _P, _P, c_size_t, c_size_t, _P],
+    "modsqrt": [_P, _P, _P, c_size_t, c_size_t, _P],
+    "modqr": [_P, _P, _P, c_size_t, c_size_t, _P],
     "modmli": [_P, c_int, _P, c_size_t, c_size_t, _P],
     "modnsqr": [_P, c_int, c_size_t, c_size_t, _P],
     "modfsb": [_P, _P, c_size_t, c_size_t, _P],
@@ -58,7 +60,7 @@ _SIG = {
 BATCH_FUNCS = tuple(_SIG)
 # scalar (_ct) names declared by the header, for the symbol-export test
 SCALAR_FUNCS = ("flatten", "modfsb", "modadd", "modsub", "modneg", "modmli", "modmul", "modsqr", "modcpy", "modnsqr",
-                "modpro", "modinv", "nres", "redc", "modis1", "modis0", "modzer", "modone", "modint", "modcmv",
+                "modpro", "modinv", "modqr", "modsqrt", "nres", "redc", "modis1", "modis0", "modzer", "modone", "modint", "modcmv",
                 "modcsw", "modshl", "modshr", "modhaf", "mod2r", "modexp", "modimp", "modsign", "modcmp")
 UTIL_FUNCS = ("modarith_amd_abi_version", "modarith_amd_last_error", "modarith_amd_device_count",
               "modarith_amd_set_device", "modarith_amd_malloc", "modarith_amd_free", "modarith_amd_memcpy_h2d",

@@ -475,6 +475,44 @@ struct Field {
         modmul(s, t, z);
     }
 
+    // quadratic-residue test (pseudo.py:815-831)
+    static MA_DEV int modqr(const spint* h, const spint* x) {
+        spint r[N];
+        if (h == nullptr) {
+            modpro(x, r);
+            modsqr(r, r);
+        } else {
+            modsqr(h, r);
+        }
+        modmul(r, x, r);
+        if constexpr (P::PM1D2 > 1) modnsqr(r, P::PM1D2 - 1);
+        return modis1(r) | modis0(x);
+    }
+    // square root: Tonelli-Shanks on the progenitor (pseudo.py:834-874); the data-dependent choice is
+    // a lane-predicated modcmv, never a branch
+    static MA_DEV void modsqrt(const spint* x, const spint* h, spint* r) {
+        spint s[N], y[N];
+        if (h == nullptr) modpro(x, y); else modcpy(h, y);
+        modmul(y, x, s);
+        if constexpr (P::PM1D2 > 1) {
+            spint t[N], b[N], v[N], z[N];
+            static_for<0, N>([&](auto I) { z[I] = P::roi(I); });
+            modmul(s, y, t);
+            nres(z, z);
+            for (int k = P::PM1D2; k > 1; k--) {
+                modcpy(t, b);
+                modnsqr(b, k - 2);
+                int d = 1 - modis1(b);
+                modmul(s, z, v);
+                modcmv(d, v, s);
+                modsqr(z, z);
+                modmul(t, z, v);
+                modcmv(d, v, t);
+            }
+        }
+        modcpy(s, r);
+    }
+
     // pseudo.py:877-906
     static MA_DEV int modis1(const spint* a) {
         spint c[N], d = 0;

@@ -77,6 +77,7 @@ template <class P> struct OpNres { static MA_DEV void apply(const spint* a, spin
 template <class P> struct OpRedc { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::redc(a, c); } };
 template <class P> struct OpCpy { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modcpy(a, c); } };
 template <class P> struct OpInv { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modinv(a, nullptr, c); } };
+template <class P> struct OpSqrt { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modsqrt(a, nullptr, c); } };
 template <class P> struct OpPro { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modpro(a, c); } };
 
 // c[j] = op(a[j], b[j])
@@ -157,6 +158,22 @@ __global__ __launch_bounds__(BLOCK) void k_inv_h(const spint* xs, const spint* h
     }
 }
 
+// r[j] = sqrt(x[j]) / qr(x[j]) with caller-supplied progenitors h[j] (pseudo.py:815-874)
+template <class P, bool QR>
+__global__ __launch_bounds__(BLOCK) void k_sqrt_h(const spint* xs, const spint* hs, spint* rs, int* out, size_t n, size_t ld) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
+        spint x[1][P::N], h[1][P::N], r[1][P::N];
+        load_soa<P, 1>(xs, ld, t, x);
+        load_soa<P, 1>(hs, ld, t, h);
+        if constexpr (QR) {
+            out[t] = Field<P>::modqr(h[0], x[0]);
+        } else {
+            Field<P>::modsqrt(x[0], h[0], r[0]);
+            store_soa<P, 1>(rs, ld, t, r);
+        }
+    }
+}
+
 // constant-time conditional swap / move with a per-element selector d[j] in {0,1}
 // (simd/pseudo_simd.py:1121-1162: selector widened to one value per lane)
 template <class P, bool SWAP>
@@ -178,7 +195,7 @@ __global__ __launch_bounds__(BLOCK) void k_cond(const int* d, spint* g, spint* f
 }
 
 // in-place normalisers / predicates; KIND selects the function, optional int result per element
-enum { K_MODFSB = 0, K_FLATTEN, K_MODIS1, K_MODIS0, K_MODSIGN, K_MODHAF };
+enum { K_MODFSB = 0, K_FLATTEN, K_MODIS1, K_MODIS0, K_MODSIGN, K_MODHAF, K_MODQR };
 template <class P, int KIND>
 __global__ __launch_bounds__(BLOCK) void k_inplace(spint* a, int* out, size_t n, size_t ld) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
@@ -192,6 +209,7 @@ __global__ __launch_bounds__(BLOCK) void k_inplace(spint* a, int* out, size_t n,
         if constexpr (KIND == K_MODIS0) r = Field<P>::modis0(x[0]);
         if constexpr (KIND == K_MODSIGN) r = Field<P>::modsign(x[0]);
         if constexpr (KIND == K_MODHAF) { Field<P>::modhaf(x[0]); wr = true; }
+        if constexpr (KIND == K_MODQR) r = Field<P>::modqr(nullptr, x[0]);
         if (wr) store_soa<P, 1>(a, ld, t, x);
         if (out) out[t] = r;
     }

@@ -135,6 +135,19 @@ class Field:
         self._call("modinv", x.data_ptr(), None if h is None else h.data_ptr(), out.data_ptr(), n, x.stride(0), _stream())
         return out
 
+    def modsqrt(self, x, h=None, out=None):
+        out = self._out(x, out)
+        n = self._chk(x, out) if h is None else self._chk(x, h, out)
+        self._call("modsqrt", x.data_ptr(), None if h is None else h.data_ptr(), out.data_ptr(), n, x.stride(0), _stream())
+        return out
+
+    def modqr(self, h, x):
+        """1 where x is a quadratic residue (or zero); h = optional progenitors modpro(x)."""
+        n = self._chk(x) if h is None else self._chk(x, h)
+        out = self._ints(n)
+        self._call("modqr", None if h is None else h.data_ptr(), x.data_ptr(), out.data_ptr(), n, x.stride(0), _stream())
+        return out
+
     def modfsb(self, a):
         """in place; returns the per-element flag (1 if the input was < p)."""
         n = self._chk(a)

@@ -18,6 +18,8 @@
 #define PP_CNT 4
 static const int pp_idx[PP_CNT] = {0, 1, 3, 4};
 static const int pp_sgn[PP_CNT] = {-1, +1, +1, +1};
+/* non-trivial root of unity, plain limbs (pseudo.py:1616-1630 / monty.py:2178-2192) */
+static const spint roi[NL] = {0xffffffffffffeu, 0xfffffffffffu, 0x0u, 0x1000000000u, 0xffffffff0000u};
 static const spint pp_val[PP_CNT] = {1u, (spint)1 << 44, (spint)1 << 36, P4};
 
 void modmul_NIST256(const spint *a, const spint *b, spint *c);

@@ -19,6 +19,8 @@
 /* p = -19 + 2^51 * 2^(51*4): caddp/addp/subp touch limb 0 and limb N-1 (pseudo.py:202-220) */
 static const int pp_idx[PP_CNT] = {0, 4};
 static const int pp_sgn[PP_CNT] = {-1, +1};
+/* non-trivial root of unity, plain limbs (pseudo.py:1616-1630 / monty.py:2178-2192) */
+static const spint roi[NL] = {0x61b274a0ea0b0u, 0xd5a5fc8f189du, 0x7ef5e9cbd0c60u, 0x78595a6804c9eu, 0x2b8324804fc1du};
 static const spint pp_val[PP_CNT] = {19u, (spint)1 << 51};
 
 void modmul_X25519(const spint *a, const spint *b, spint *c);

@@ -17,6 +17,8 @@
 /* virtual limb (+1 at index 8) is applied as +2^56 at limb 7 (caddp "if E", monty.py:313-314) */
 static const int pp_idx[PP_CNT] = {0, 4, 7};
 static const int pp_sgn[PP_CNT] = {-1, -1, +1};
+/* non-trivial root of unity, plain limbs (pseudo.py:1616-1630 / monty.py:2178-2192) */
+static const spint roi[NL] = {0xfffffffffffffeu, 0xffffffffffffffu, 0xffffffffffffffu, 0xffffffffffffffu, 0xfffffffffffffeu, 0xffffffffffffffu, 0xffffffffffffffu, 0xffffffffffffffu};
 static const spint pp_val[PP_CNT] = {1u, 1u, (spint)1 << 56};
 
 void modmul_X448(const spint *a, const spint *b, spint *c);

@@ -463,7 +463,53 @@ def ladder_fixture(curve, seed, count=96):
     return fx
 
 
+def sqrt_model(val, p, pm1d2, pe, roi):
+    """value-level restatement of the generators' modsqrt (pseudo.py:834-874): deterministic for
+    residues and non-residues alike; independent of the addition chain."""
+    y = pow(val, pe, p)
+    s = y * val % p
+    if pm1d2 > 1:
+        t = s * y % p
+        z = roi
+        for k in range(pm1d2, 1, -1):
+            b = pow(t, 1 << (k - 2), p)
+            d = 0 if b == 1 else 1
+            if d:
+                s = s * z % p
+            z = z * z % p
+            if d:
+                t = t * z % p
+    return s
+
+
+def sqrt_fixture(script, prime, seed, count=64):
+    """modsqrt / modqr pins (the reference cannot emit them here: they call modpro, which needs the
+    external addchain tool).  Inputs are internal-form limbs produced by the reference's own nres;
+    expectations are big-integer values: root after redc, Euler criterion."""
+    rng = random.Random(seed)
+    ref = Ref(script, prime)
+    p, ns = ref.p, ref.ns
+    roi = sum(v << (ref.base * i) for i, v in enumerate(ns["ROI"]))
+    H = lambda limbs: [hx(v) for v in limbs]
+    recs = []
+    vals = [0, 1, 4, p - 1, 2, 3] + [rng.randrange(0, p) for _ in range(count - 6)]
+    for i, v in enumerate(vals):
+        if i % 3 == 2:
+            v = v * v % p                                  # force residues into the mix
+        x = ref.un("nres", ref.split(v + (p if i % 5 == 4 else 0)))   # some inputs in [p, 2p)
+        root = sqrt_model(v, p, ns["PM1D2"], ns["PE"], roi)
+        qr = 1 if v == 0 or pow(v, (p - 1) // 2, p) == 1 else 0
+        if qr:
+            assert root * root % p == v
+        recs.append({"x": H(x), "value": hx(v), "sqrt_redc": H(_canon(ref, root)), "qr": qr})
+    return {"prime": prime, "source": "value-level model of pseudo.py:815-874 on reference-nres'd inputs", "recs": recs}
+
+
 def main():
+    if "--sqrt-only" in sys.argv:
+        for script, prime, seed in (("pseudo.py", "X25519", 4001), ("monty.py", "NIST256", 4002), ("monty.py", "X448", 4003)):
+            json.dump(sqrt_fixture(script, prime, seed), open(os.path.join(HERE, "sqrt_%s.json" % prime), "w"), indent=0, separators=(",", ":"))
+        return
     out = {}
     for script, prime, seed in (("pseudo.py", "X25519", 1001), ("monty.py", "NIST256", 1002), ("monty.py", "X448", 1003)):
         fx, ref = field_fixture(script, prime, seed)
@@ -474,6 +520,8 @@ def main():
     for script, prime, seed in (("pseudo.py", "X25519", 2001), ("monty.py", "X448", 2003)):
         fx = lazy_fixture(script, prime, seed)
         json.dump(fx, open(os.path.join(HERE, "field_%s_lazy.json" % prime), "w"), indent=0, separators=(",", ":"))
+    for script, prime, seed in (("pseudo.py", "X25519", 4001), ("monty.py", "NIST256", 4002), ("monty.py", "X448", 4003)):
+        json.dump(sqrt_fixture(script, prime, seed), open(os.path.join(HERE, "sqrt_%s.json" % prime), "w"), indent=0, separators=(",", ":"))
     for curve, seed in (("X25519", 3001), ("X448", 3003)):
         fx = ladder_fixture(curve, seed)
         json.dump(fx, open(os.path.join(HERE, "ladder_%s.json" % curve), "w"), indent=0, separators=(",", ":"))

@@ -29,6 +29,10 @@ class Oracle:
             for f in ("modneg", "modneg_lazy", "modsqr", "modcpy", "nres", "redc", "modpro"):
                 g(f).argtypes = [U64P, U64P]; g(f).restype = None
             g("modinv").argtypes = [U64P, U64P, U64P]; g("modinv").restype = None
+            g("modsqrt").argtypes = [U64P, U64P, U64P]; g("modsqrt").restype = None
+            g("modqr").argtypes = [U64P, U64P]; g("modqr").restype = c_int
+            g("batch_modsqrt").argtypes = [c_void_p, c_void_p, c_size_t, c_size_t]; g("batch_modsqrt").restype = None
+            g("batch_modqr").argtypes = [c_void_p, c_void_p, c_size_t, c_size_t]; g("batch_modqr").restype = None
             g("modmli").argtypes = [U64P, c_int, U64P]; g("modmli").restype = None
             g("modnsqr").argtypes = [U64P, c_int]; g("modnsqr").restype = None
             for f in ("flatten", "modfsb"):

@@ -153,6 +153,18 @@ def test_golden_modinv_after_redc(ctx):
     assert rows_of(F, z2) == rows_of(F, z)
 
 
+def test_golden_modsqrt_modqr(ctx):
+    P, F, _ = ctx
+    recs = load_golden("sqrt_%s.json" % P)["recs"]
+    x = dev(F, [r["x"] for r in recs])
+    root = F.modsqrt(x)
+    assert rows_of(F, F.redc(root)) == [limbs(r["sqrt_redc"]) for r in recs]
+    assert F.modqr(None, x).cpu().tolist() == [r["qr"] for r in recs]
+    h = F.modpro(x)
+    assert rows_of(F, F.modsqrt(x, h)) == rows_of(F, root)
+    assert F.modqr(h, x).cpu().tolist() == [r["qr"] for r in recs]
+
+
 # ---------------------------------------------------------------- against the oracle, seeded batches
 N_BIG = (1 << 16) + 3  # odd on purpose: exercises the 16-byte path plus its scalar tail
 
@@ -205,6 +217,12 @@ def test_oracle_modinv_batch(oracle, torch_cuda, P):
     z = F.redc(F.modinv(to_dev(a)))
     want = oracle_un(oracle, "redc", P, oracle_un(oracle, "modinv", P, a))
     assert np.array_equal(to_np(z), want)
+    r = F.redc(F.modsqrt(to_dev(a)))
+    want = oracle_un(oracle, "redc", P, oracle_un(oracle, "modsqrt", P, a))
+    assert np.array_equal(to_np(r), want)
+    q = np.empty(a.shape[1], dtype=np.int32)
+    oracle.fn("batch_modqr", P)(vp(a), vp(q), a.shape[1], a.shape[1])
+    assert np.array_equal(F.modqr(None, to_dev(a)).cpu().numpy(), q)
 
 
 def test_properties_full_size(torch_cuda):
@@ -235,9 +253,9 @@ def test_properties_full_size(torch_cuda):
 # ---------------------------------------------------------------- scalar (_ct) form: the reference's own self-test shape
 @pytest.mark.parametrize("P", ALL)
 def test_scalar_abi_reference_selftest_chain(oracle, torch_cuda, P):
-    """The generators' ctypes self-test (pseudo.py:1783-1796) without its modsqrt/modhaf tail:
-    nres, nres, modadd, modsub, modmul, modsqr, modinv, redc == inverse(((x-y)(x+y))^2), through the
-    scalar entry points with the reference's signatures."""
+    """The generators' ctypes self-test (pseudo.py:1783-1796), the whole chain: nres, nres, modadd,
+    modsub, modmul, modsqr, modinv, modsqrt, modsqr, modhaf, modadd, modshl, modshr, redc
+    == inverse(((x-y)(x+y))^2), through the scalar entry points with the reference's signatures."""
     import random
     from modarith_amd import _lib
     from modarith_amd.params import derive
@@ -255,6 +273,9 @@ def test_scalar_abi_reference_selftest_chain(oracle, torch_cuda, P):
         f("modadd")(ax, ay, at); f("modsub")(ax, ay, az)
         f("modmul")(at, az, ax); f("modsqr")(ax, az)
         f("modinv")(az, None, az)
+        f("modsqrt")(az, None, az); f("modsqr")(az, az)
+        f("modhaf")(az); f("modadd")(az, az, az)
+        f("modshl")(1, az); f("modshr")(1, az)
         f("redc")(az, az)
         assert fp.from_limbs(list(az)) == want
 

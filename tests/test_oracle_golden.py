@@ -169,6 +169,49 @@ def test_modinv_after_redc(oracle, fx):
         assert list(z2) == list(z)
 
 
+def test_modsqrt_modqr(oracle, fx):
+    """modsqrt/modqr against the value-level pins (tests/golden/sqrt_*.json) and, for every input,
+    the progenitor-supplied form (edwards.c-style callers pass h = modpro(x))."""
+    P, _ = fx
+    g = load_golden("sqrt_%s.json" % P)
+    for rec in g["recs"]:
+        x = limbs(rec["x"])
+        r = oracle.arr(P)
+        oracle.fn("modsqrt", P)(oracle.arr(P, x), None, r)
+        assert oracle.un("redc", P, list(r)) == limbs(rec["sqrt_redc"])
+        assert oracle.fn("modqr", P)(None, oracle.arr(P, x)) == rec["qr"]
+        h = oracle.arr(P)
+        oracle.fn("modpro", P)(oracle.arr(P, x), h)
+        r2 = oracle.arr(P)
+        oracle.fn("modsqrt", P)(oracle.arr(P, x), h, r2)
+        assert list(r2) == list(r) and oracle.fn("modqr", P)(h, oracle.arr(P, x)) == rec["qr"]
+
+
+def test_reference_selftest_chain(oracle, fx):
+    """the generators' own acceptance test (pseudo.py:1762-1855): for random x,y < 2p the chain
+    nres,nres,modadd,modsub,modmul,modsqr,modinv,modsqrt,modsqr,modhaf,modadd,modshl,modshr,redc
+    must give inverse(((x-y)(x+y))^2 mod p)."""
+    import random
+    from modarith_amd.params import derive
+    P, _ = fx
+    fp = derive(P)
+    rng = random.Random(2024)
+    f = lambda name: oracle.fn(name, P)
+    for _ in range(200):
+        x, y = rng.randrange(0, 2 * fp.p), rng.randrange(0, 2 * fp.p)
+        want = pow(((x - y) * (x + y)) ** 2 % fp.p, -1, fp.p) if ((x - y) * (x + y)) % fp.p else 0
+        ax, ay, at, az = oracle.arr(P, fp.to_limbs(x)), oracle.arr(P, fp.to_limbs(y)), oracle.arr(P), oracle.arr(P)
+        f("nres")(ax, ax); f("nres")(ay, ay)
+        f("modadd")(ax, ay, at); f("modsub")(ax, ay, az)
+        f("modmul")(at, az, ax); f("modsqr")(ax, az)
+        f("modinv")(az, None, az)
+        f("modsqrt")(az, None, az); f("modsqr")(az, az)
+        f("modhaf")(az); f("modadd")(az, az, az)
+        f("modshl")(1, az); f("modshr")(1, az)
+        f("redc")(az, az)
+        assert fp.from_limbs(list(az)) == want
+
+
 def test_time_protocol_check_words(oracle, fx):
     """time.c protocol (pseudo.py:1235-1250): 1k- and 100k-deep prefixes of the reference chains here;
     the full 10^8-deep run is `oracle/time_oracle` (bench.py runs it as the cpu_baseline)."""
