@@ -101,16 +101,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # MA_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a box with fewer GPUs than ranks
+    backend = os.environ.get("MA_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible" % (world, ndev))
+    dev = torch.device("cuda", local % max(ndev, 1))
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world:
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1" % (args.gpus, world), file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")   # where collective payloads live
+
+    def max_over_ranks(vals):
+        tt = torch.tensor(vals, dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return [float(v) for v in tt]
 
     from modarith_amd.field import Field, rfc7748
     F = Field("X25519", dev)
@@ -138,9 +152,7 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps      # mean launch duration on the launch stream
     if world > 1:
-        tt = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, kern_ms = float(tt[0]), float(tt[1])
+        dt, kern_ms = max_over_ranks([dt, kern_ms])
     value = world * n * args.steps / dt
     achieved = BYTES_PER_MODMUL * n / (kern_ms * 1e-3) / 1e9
 
@@ -165,15 +177,17 @@ def main():
         lt = (time.perf_counter() - t0) / reps
         gather_ms = None
         if world > 1:
-            outs = [torch.empty_like(o) for _ in range(world)] if rank == 0 else None
+            from modarith_amd.dist import gather_records
+            payload = o if backend == "nccl" else o.cpu()
             barrier()
             t0 = time.perf_counter()
-            dist.gather(o, outs, dst=0)     # the only collective: final result gather over xGMI (RCCL)
+            allv = gather_records(payload, world * m, dst=0)   # the only collective: final result gather (RCCL over xGMI)
             barrier()
             gather_ms = (time.perf_counter() - t0) * 1e3
-            tt = torch.tensor([lt, gather_ms], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            lt, gather_ms = float(tt[0]), float(tt[1])
+            if rank == 0:
+                assert allv.shape[0] == world * m and torch.equal(allv[:m].to(o.device), o)
+            del allv
+            lt, gather_ms = max_over_ranks([lt, gather_ms])
         ladder = {"value": world * m / lt, "unit": "X25519 scalar-mults/s", "scalars_per_gpu": m, "ms_per_pass": lt * 1e3,
                   "gather_ms": gather_ms, "io_bytes_per_scalar": 96,
                   "bound": "VALU 32-bit integer multiply-add issue (not HBM)"}
