@@ -505,7 +505,208 @@ def sqrt_fixture(script, prime, seed, count=64):
     return {"prime": prime, "source": "value-level model of pseudo.py:815-874 on reference-nres'd inputs", "recs": recs}
 
 
+# ---------------------------------------------------------------- Edwards big-integer model
+class EdModel:
+    """a*x^2 + y^2 = 1 + d*x^2*y^2 over GF(p), extended coordinates on python ints.  Independent of the
+    reference code; constants are the ones curve.py:85-105 lists."""
+
+    def __init__(self, name):
+        if name == "ED25519":
+            self.p = 2**255 - 19
+            self.a, self.cof = -1, 3
+            self.d = 0x52036CEE2B6FFE738CC740797779E89800700A4D4141D8AB75EB4DCA135978A3
+            self.q = 0x1000000000000000000000000000000014DEF9DEA2F79CD65812631A5CF5D3ED
+            self.G = (0x216936D3CD6E53FEC0A4E231FDD6DC5C692CC7609525A7B2C9562D608F25D51A,
+                      0x6666666666666666666666666666666666666666666666666666666666666658)
+            self.nbytes = 32
+            # testcurve.c:57-63
+            self.tc = dict(order="1000000000000000000000000000000014DEF9DEA2F79CD65812631A5CF5D3ED",
+                           r1="66876CB6C86C76660666789A376F6790956A0D6A507657196D75D610E0C9D7B",
+                           r2="9978934937938999F9998765C8909870B885907FDF03764C13B05B94EE93672",
+                           n1="20347457078878f77b707c070707077a07707b7b07070707223252357134272",
+                           n2="35279279432f249b298a876788d86294e02842092769136c086038b1812383a")
+        else:
+            self.p = 2**448 - 2**224 - 1
+            self.a, self.cof = 1, 2
+            self.d = -39081 % self.p
+            self.q = (self.p + 1 - 28312320572429821613362531907042076847709625476988141958474579766324) // 4
+            self.G = (0x4f1970c66bed0ded221d15a622bf36da9e146570470f1767ea6de324a3d3a46412ae1af72ab66511433b80e18b00938e2626a82bc70cc05e,
+                      0x693f46716eb6bc248876203756c9c7624bea73736ca3984087789c1e05a0c2d73ad3ff1ce67c39c4fdbd132c4ed7c8ad9808795bf230fa14)
+            self.nbytes = 56
+            self.tc = None
+        assert self.on_curve(self.G)
+
+    def on_curve(self, P):
+        x, y = P
+        return (self.a * x * x + y * y - 1 - self.d * x * x * y * y) % self.p == 0
+
+    def add(self, P, Q):  # affine in, affine out (complete formulas)
+        p, a, d = self.p, self.a, self.d
+        x1, y1 = P
+        x2, y2 = Q
+        k = d * x1 * x2 * y1 * y2 % p
+        x3 = (x1 * y2 + y1 * x2) * pow(1 + k, -1, p) % p
+        y3 = (y1 * y2 - a * x1 * x2) * pow(1 - k, -1, p) % p
+        return (x3, y3)
+
+    # extended coordinates (X:Y:Z:T) for speed
+    def _ext_add(self, P, Q):
+        p, a, d = self.p, self.a, self.d
+        X1, Y1, Z1, T1 = P
+        X2, Y2, Z2, T2 = Q
+        A = X1 * X2 % p; B = Y1 * Y2 % p; C = T1 * d * T2 % p; D = Z1 * Z2 % p
+        E = ((X1 + Y1) * (X2 + Y2) - A - B) % p
+        F = (D - C) % p; G = (D + C) % p; H = (B - a * A) % p
+        return (E * F % p, G * H % p, F * G % p, E * H % p)
+
+    def mul(self, k, P):
+        O = (0, 1, 1, 0)
+        Q = (P[0], P[1], 1, P[0] * P[1] % self.p)
+        R = O
+        for bit in bin(k)[2:] if k else "":
+            R = self._ext_add(R, R)
+            if bit == "1":
+                R = self._ext_add(R, Q)
+        zi = pow(R[2], -1, self.p)
+        return (R[0] * zi % self.p, R[1] * zi % self.p)
+
+    def neg(self, P):
+        return ((-P[0]) % self.p, P[1])
+
+    def xy_hex(self, P):
+        return [P[0].to_bytes(self.nbytes, "big").hex(), P[1].to_bytes(self.nbytes, "big").hex()]
+
+    def recover_y(self, x, s):
+        """y from x and the parity s of y, or None if x is not on the curve"""
+        p = self.p
+        num = (1 - self.a * x * x) % p
+        den = (1 - self.d * x * x) % p
+        if den == 0:
+            return None
+        y2 = num * pow(den, -1, p) % p
+        return self._sqrt_sign(y2, s)
+
+    def recover_x(self, y, s):
+        p = self.p
+        num = (1 - y * y) % p
+        den = (self.a - self.d * y * y) % p
+        if den == 0:
+            return None
+        x2 = num * pow(den, -1, p) % p
+        return self._sqrt_sign(x2, s)
+
+    def _sqrt_sign(self, v, s):
+        p = self.p
+        if v == 0:
+            return 0
+        if pow(v, (p - 1) // 2, p) != 1:
+            return None
+        if p % 4 == 3:
+            r = pow(v, (p + 1) // 4, p)
+        else:
+            r = pow(v, (p + 3) // 8, p)
+            if r * r % p != v:
+                r = r * pow(2, (p - 1) // 4, p) % p
+        assert r * r % p == v
+        if r % 2 != s:
+            r = p - r
+        return r
+
+
+def edwards_fixture(name, seed, pairs=40):
+    import hashlib
+    rng = random.Random(seed)
+    M = EdModel(name)
+    nb, p, q, G = M.nbytes, M.p, M.q, M.G
+    O = (0, 1)
+    fx = {"curve": name, "source": "big-integer model (tests/golden/make_golden.py EdModel); constants curve.py:85-105",
+          "gen": M.xy_hex(G), "order": q.to_bytes(nb, "big").hex(), "cof": M.cof}
+    assert M.mul(q, G) == O
+    # scalar multiplications of the generator and of random points; scalars are raw NBYTES strings (the
+    # reference's fixed-window ecnXXXmul does not reduce them, edwards.c:435-482)
+    recs = []
+    for i in range(pairs):
+        k = [0, 1, 2, 8, 15, 16, 17, q - 1, q, q + 1, (1 << (8 * nb)) - 1, 0x88888888, 0x77777777][i] if i < 13 else rng.randrange(0, 1 << (8 * nb))
+        base = G if i % 2 == 0 else M.mul(rng.randrange(1, q), G)
+        recs.append({"e": k.to_bytes(nb, "big").hex(), "P": M.xy_hex(base), "eP": M.xy_hex(M.mul(k, base))})
+    fx["mul"] = recs
+    # add / dbl / sub / neg
+    ops = []
+    for i in range(16):
+        P = M.mul(rng.randrange(1, q), G)
+        Q = M.mul(rng.randrange(1, q), G) if i % 4 else (P if i % 8 == 0 else M.neg(P))
+        ops.append({"P": M.xy_hex(P), "Q": M.xy_hex(Q), "P+Q": M.xy_hex(M.add(P, Q)), "2P": M.xy_hex(M.add(P, P)),
+                    "P-Q": M.xy_hex(M.add(P, M.neg(Q))), "cofP": M.xy_hex(M.mul(1 << M.cof, P))})
+    fx["ops"] = ops
+    # compression / decompression: x + sign(y) and y + sign(x); off-curve coordinates must give O
+    comp = []
+    for i in range(24):
+        if i < 16:
+            P = M.mul(rng.randrange(1, q), G)
+            comp.append({"x": P[0].to_bytes(nb, "big").hex(), "y": P[1].to_bytes(nb, "big").hex(), "sx": P[0] & 1, "sy": P[1] & 1, "valid": 1})
+        else:
+            while True:
+                v = rng.randrange(2, p)
+                if M.recover_y(v, 0) is None and M.recover_x(v, 0) is None:
+                    break
+            comp.append({"x": v.to_bytes(nb, "big").hex(), "y": v.to_bytes(nb, "big").hex(), "sx": 0, "sy": 0, "valid": 0})
+    fx["compress"] = comp
+    # full (x,y) set with an off-curve pair
+    bad = (G[0], (G[1] + 1) % p)
+    fx["set_xy"] = [{"x": M.xy_hex(G)[0], "y": M.xy_hex(G)[1], "valid": 1}, {"x": M.xy_hex(bad)[0], "y": M.xy_hex(bad)[1], "valid": 0}]
+    # mul2: R = eP + fQ
+    m2 = []
+    for i in range(12):
+        P = M.mul(rng.randrange(1, q), G); Q = M.mul(rng.randrange(1, q), G)
+        e = rng.randrange(0, 1 << (8 * nb)) if i else 0
+        f = rng.randrange(0, 1 << (8 * nb)) if i != 1 else 0
+        m2.append({"e": e.to_bytes(nb, "big").hex(), "f": f.to_bytes(nb, "big").hex(), "P": M.xy_hex(P), "Q": M.xy_hex(Q),
+                   "R": M.xy_hex(M.add(M.mul(e, P), M.mul(f, Q)))})
+    fx["mul2"] = m2
+    if M.tc:
+        t = {k: int(v, 16) for k, v in M.tc.items()}
+        assert t["order"] == q and (t["r1"] + t["r2"]) == q
+        tc = {k: v.to_bytes(nb, "big").hex() for k, v in t.items()}
+        assert M.add(M.mul(t["r1"], G), M.mul(t["r2"], G)) == O
+        # the reference main()'s timing chain (testcurve.c:247-255): P = G; 10000 x P = n1*P
+        P = G
+        cps = {}
+        for i in range(10000):
+            P = M.mul(t["n1"], P)
+            if i + 1 in (1, 10, 100, 1000, 10000):
+                cps[str(i + 1)] = M.xy_hex(P)
+        tc["mul_chain"] = cps
+        # then 10000 x P = n1*P + n2*G (testcurve.c:274-276); checkpoints only up to 100
+        Q = G
+        cps2 = {}
+        for i in range(100):
+            P = M.add(M.mul(t["n1"], P), M.mul(t["n2"], Q))
+            if i + 1 in (1, 10, 100):
+                cps2[str(i + 1)] = M.xy_hex(P)
+        tc["mul2_chain_after_mul_chain"] = cps2
+        fx["testcurve"] = tc
+    if name == "ED25519":
+        # RFC 8032 7.1 TEST 1: public key = compress([clamp(SHA512(sk)[:32])] B)
+        sk = bytes.fromhex("9d61b19deffd5a60ba844af492ec2cc44449c5697b326919703bac031cae7f60")
+        h = bytearray(hashlib.sha512(sk).digest()[:32])
+        h[0] &= 248; h[31] &= 127; h[31] |= 64
+        a = int.from_bytes(h, "little")
+        A = M.mul(a, G)
+        enc = bytearray(A[1].to_bytes(32, "little"))
+        enc[31] |= (A[0] & 1) << 7
+        assert enc.hex() == "d75a980182b10ab7d54bfed3c964073a0ee172f3daa62325af021a68f707511a"
+        fx["rfc8032_test1"] = {"scalar_be": a.to_bytes(32, "big").hex(), "pk": enc.hex(), "A": M.xy_hex(A)}
+    return fx
+
+
 def main():
+    if "--edwards-only" in sys.argv:
+        for name, seed in (("ED25519", 5001), ("ED448", 5002)):
+            fx = edwards_fixture(name, seed, pairs=40 if name == "ED25519" else 20)
+            json.dump(fx, open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
+            if "testcurve" in fx:
+                print(name, "testcurve chain 10000:", fx["testcurve"]["mul_chain"]["10000"])
+        return
     if "--sqrt-only" in sys.argv:
         for script, prime, seed in (("pseudo.py", "X25519", 4001), ("monty.py", "NIST256", 4002), ("monty.py", "X448", 4003)):
             json.dump(sqrt_fixture(script, prime, seed), open(os.path.join(HERE, "sqrt_%s.json" % prime), "w"), indent=0, separators=(",", ":"))
@@ -522,6 +723,8 @@ def main():
         json.dump(fx, open(os.path.join(HERE, "field_%s_lazy.json" % prime), "w"), indent=0, separators=(",", ":"))
     for script, prime, seed in (("pseudo.py", "X25519", 4001), ("monty.py", "NIST256", 4002), ("monty.py", "X448", 4003)):
         json.dump(sqrt_fixture(script, prime, seed), open(os.path.join(HERE, "sqrt_%s.json" % prime), "w"), indent=0, separators=(",", ":"))
+    for name, seed in (("ED25519", 5001), ("ED448", 5002)):
+        json.dump(edwards_fixture(name, seed, pairs=40 if name == "ED25519" else 20), open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
     for curve, seed in (("X25519", 3001), ("X448", 3003)):
         fx = ladder_fixture(curve, seed)
         json.dump(fx, open(os.path.join(HERE, "ladder_%s.json" % curve), "w"), indent=0, separators=(",", ":"))

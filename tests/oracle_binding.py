@@ -68,6 +68,25 @@ class Oracle:
             f.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]; f.restype = None
             f = getattr(lib, "batch_rfc7748_" + C)
             f.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]; f.restype = None
+        # Edwards layer (oracle/edwards_oracle.c): point = struct {x[NL], y[NL], z[NL]}
+        self.ed = {}
+        for C, P in (("ed25519", "X25519"), ("ed448", "X448")):
+            nl = PRIMES[P][0]
+
+            class Pt(ctypes.Structure):
+                _fields_ = [("x", c_uint64 * nl), ("y", c_uint64 * nl), ("z", c_uint64 * nl)]
+            PP = POINTER(Pt)
+            g = lambda f: getattr(lib, "ecn_%s_%s" % (C, f))
+            sig = {"cpy": [PP, PP], "neg": [PP], "add": [PP, PP], "sub": [PP, PP], "dbl": [PP], "inf": [PP], "affine": [PP],
+                   "cof": [PP], "gen": [PP], "ran": [c_int, PP], "mul": [ctypes.c_char_p, PP],
+                   "mul2": [ctypes.c_char_p, PP, ctypes.c_char_p, PP, PP], "set": [c_int, ctypes.c_char_p, ctypes.c_char_p, PP]}
+            for f, a in sig.items():
+                g(f).argtypes = a; g(f).restype = None
+            g("isinf").argtypes = [PP]; g("isinf").restype = c_int
+            g("cmp").argtypes = [PP, PP]; g("cmp").restype = c_int
+            g("get").argtypes = [PP, ctypes.c_char_p, ctypes.c_char_p]; g("get").restype = c_int
+            g("batch_mul").argtypes = [c_void_p, c_void_p, c_size_t, c_size_t]; g("batch_mul").restype = None
+            self.ed[C] = (Pt, PRIMES[P][3])
         lib.oracle_parallel.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int]
         lib.oracle_parallel.restype = c_int
 
@@ -89,6 +108,28 @@ class Oracle:
         z = self.arr(P)
         self.fn(f, P)(self.arr(P, a), self.arr(P, b), z)
         return list(z)
+
+    # ---- Edwards helpers (C = "ed25519" | "ed448")
+    def ecn(self, C, f):
+        return getattr(self.lib, "ecn_%s_%s" % (C, f))
+
+    def ed_point(self, C, x_hex=None, y_hex=None):
+        Pt, nb = self.ed[C]
+        p = Pt()
+        if x_hex is None:
+            self.ecn(C, "inf")(ctypes.byref(p))
+        else:
+            self.ecn(C, "set")(0, bytes.fromhex(x_hex), bytes.fromhex(y_hex), ctypes.byref(p))
+        return p
+
+    def ed_xy(self, C, p):
+        """affine (x, y) hex of a copy of p"""
+        Pt, nb = self.ed[C]
+        q = Pt()
+        self.ecn(C, "cpy")(ctypes.byref(p), ctypes.byref(q))
+        x, y = ctypes.create_string_buffer(nb), ctypes.create_string_buffer(nb)
+        self.ecn(C, "get")(ctypes.byref(q), x, y)
+        return [x.raw.hex(), y.raw.hex()]
 
     def ladder(self, curve, k, u):
         nb = PRIMES[curve][3]
