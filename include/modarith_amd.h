@@ -173,6 +173,54 @@ void rfc7748_X448(const char *bk, const char *bu, char *bv);
 int rfc7748_X25519_batch(const char *bk, const char *bu, char *bv, size_t n, void *stream);
 int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void *stream);
 
+/* ---- Edwards curve layer on the field path: the API of curve.h:13-29 with XXX = _<curve>_
+ * (curve.py:344-345), for ED25519 (over the X25519 field) and ED448 (over the X448 field).
+ * A point is projective (x:y:z), `struct xyz` of curve.py:304-309.  Scalar form: host `point`, one element
+ * on the GPU.  Batched form: device SoA P[(c*Nlimbs + i)*ld + j], c = 0,1,2 for x,y,z -- a host point is
+ * that layout with ld = 1.  Scalars e and coordinates x,y are big-endian Nbytes records, as in the
+ * reference.  ecn_*_mul is the constant-time 4-bit fixed-window multiplication (edwards.c:435-482); its
+ * 9-entry table lives in a caller-provided device workspace of ecn_*_mul_workspace_bytes(n) bytes.
+ * Projective results equal the reference's limb for limb where it is deterministic (add, dbl, mul);
+ * set/get/affine/cmp involve modpro and are comparable as affine coordinates.  ecnXXXmul2 (not constant
+ * time in the reference) is not built yet. */
+#define MODARITH_AMD_DECLARE_EDWARDS(c, NL)                                                                             \
+    typedef struct { ma_spint x[NL], y[NL], z[NL]; } ma_point_##c##_t;                                                  \
+    int ecn_##c##_get(ma_point_##c##_t *P, char *x, char *y);                          /* edwards.c:221-239 */        \
+    void ecn_##c##_set(int s, const char *x, const char *y, ma_point_##c##_t *P);      /* edwards.c:347-366 */        \
+    void ecn_##c##_inf(ma_point_##c##_t *P);                                                                            \
+    int ecn_##c##_isinf(ma_point_##c##_t *P);                                                                           \
+    void ecn_##c##_neg(ma_point_##c##_t *P);                                                                            \
+    void ecn_##c##_add(ma_point_##c##_t *Q, ma_point_##c##_t *P);                      /* P += Q, edwards.c:73-111 */ \
+    void ecn_##c##_sub(ma_point_##c##_t *Q, ma_point_##c##_t *P);                                                       \
+    void ecn_##c##_dbl(ma_point_##c##_t *P);                                           /* edwards.c:123-145 */        \
+    void ecn_##c##_gen(ma_point_##c##_t *P);                                                                            \
+    void ecn_##c##_mul(const char *e, ma_point_##c##_t *P);                            /* edwards.c:435-482 */        \
+    int ecn_##c##_cmp(ma_point_##c##_t *P, ma_point_##c##_t *Q);                                                        \
+    void ecn_##c##_affine(ma_point_##c##_t *P);                                                                         \
+    void ecn_##c##_cpy(ma_point_##c##_t *Q, ma_point_##c##_t *P);                                                       \
+    void ecn_##c##_cof(ma_point_##c##_t *P);                                                                            \
+    size_t ecn_##c##_mul_workspace_bytes(size_t n);                                                                     \
+    int ecn_##c##_mul_batch(const char *e, ma_spint *P, size_t n, size_t ld, void *workspace, size_t workspace_bytes,   \
+                            void *stream);                                                                              \
+    int ecn_##c##_add_batch(const ma_spint *Q, ma_spint *P, size_t n, size_t ld, void *stream);                         \
+    int ecn_##c##_sub_batch(const ma_spint *Q, ma_spint *P, size_t n, size_t ld, void *stream);                         \
+    int ecn_##c##_cpy_batch(const ma_spint *Q, ma_spint *P, size_t n, size_t ld, void *stream);                         \
+    int ecn_##c##_dbl_batch(ma_spint *P, size_t n, size_t ld, void *stream);                                            \
+    int ecn_##c##_neg_batch(ma_spint *P, size_t n, size_t ld, void *stream);                                            \
+    int ecn_##c##_inf_batch(ma_spint *P, size_t n, size_t ld, void *stream);                                            \
+    int ecn_##c##_gen_batch(ma_spint *P, size_t n, size_t ld, void *stream);                                            \
+    int ecn_##c##_cof_batch(ma_spint *P, size_t n, size_t ld, void *stream);                                            \
+    int ecn_##c##_affine_batch(ma_spint *P, size_t n, size_t ld, void *stream);                                         \
+    int ecn_##c##_cmp_batch(const ma_spint *P, const ma_spint *Q, int *out, size_t n, size_t ld, void *stream);         \
+    int ecn_##c##_isinf_batch(const ma_spint *P, int *out, size_t n, size_t ld, void *stream);                          \
+    /* s: device int[n] of sign bits or NULL (= 0); x, y: device byte records, either may be NULL */                   \
+    int ecn_##c##_set_batch(const int *s, const char *x, const char *y, ma_spint *P, size_t n, size_t ld, void *stream);\
+    /* makes P affine in place; x, y, sign (device) may each be NULL */                                                \
+    int ecn_##c##_get_batch(ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld, void *stream);
+
+MODARITH_AMD_DECLARE_EDWARDS(ed25519, 5)
+MODARITH_AMD_DECLARE_EDWARDS(ed448, 8)
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmodarith_amd.so")
 PRIMES = ("X25519", "NIST256", "X448")
 LADDERS = ("X25519", "X448")
+CURVES = {"ed25519": (5, 32), "ed448": (8, 56)}       # curve -> (Nlimbs, Nbytes)
+ED_BATCH_FUNCS = ("mul", "add", "sub", "cpy", "dbl", "neg", "inf", "gen", "cof", "affine", "cmp", "isinf", "set", "get")
+ED_SCALAR_FUNCS = ("get", "set", "inf", "isinf", "neg", "add", "sub", "dbl", "gen", "mul", "cmp", "affine", "cpy", "cof",
+                   "mul_workspace_bytes")
 
 _lib = None
 
@@ -90,6 +94,22 @@ def load() -> ctypes.CDLL:
         g = getattr(lib, "rfc7748_%s" % C)
         g.argtypes = [c_char_p, c_char_p, c_char_p]
         g.restype = None
+    for C in CURVES:
+        nl, nb = CURVES[C]
+        g = lambda f: getattr(lib, "ecn_%s_%s" % (C, f))
+        g("mul_workspace_bytes").argtypes = [c_size_t]
+        g("mul_workspace_bytes").restype = c_size_t
+        g("mul_batch").argtypes = [_P, _P, c_size_t, c_size_t, _P, c_size_t, _P]
+        for f in ("add", "sub", "cpy"):
+            g(f + "_batch").argtypes = [_P, _P, c_size_t, c_size_t, _P]
+        for f in ("dbl", "neg", "inf", "gen", "cof", "affine"):
+            g(f + "_batch").argtypes = [_P, c_size_t, c_size_t, _P]
+        g("cmp_batch").argtypes = [_P, _P, _P, c_size_t, c_size_t, _P]
+        g("isinf_batch").argtypes = [_P, _P, c_size_t, c_size_t, _P]
+        g("set_batch").argtypes = [_P, _P, _P, _P, c_size_t, c_size_t, _P]
+        g("get_batch").argtypes = [_P, _P, _P, _P, c_size_t, c_size_t, _P]
+        for f in ED_BATCH_FUNCS:
+            g(f + "_batch").restype = c_int
     lib.modarith_amd_last_error.restype = c_char_p
     lib.modarith_amd_abi_version.restype = c_int
     lib.modarith_amd_device_count.restype = c_int

@@ -23,7 +23,7 @@ LIB = os.path.join(HERE, "libmodarith_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-UNITS = ["capi_common"] + ["capi_%s" % p for p in emit.BUILT_PRIMES]
+UNITS = ["capi_common"] + ["capi_%s" % p for p in emit.BUILT_PRIMES] + ["capi_%s" % c for c in emit.BUILT_CURVES]
 
 
 def _stamp() -> str:
@@ -53,7 +53,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     if verbose:
         print("[modarith_amd] compiling %d HIP units for %s ..." % (len(UNITS), ARCH), flush=True)
-    with cf.ThreadPoolExecutor(max_workers=min(4, len(UNITS))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(6, len(UNITS))) as ex:
         objs = list(ex.map(_compile, UNITS))
     subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
     with open(stamp_file, "w") as f:

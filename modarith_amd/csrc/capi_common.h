@@ -31,7 +31,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 struct Staging {
     std::mutex mu;
     unsigned char* dev = nullptr;
-    static constexpr size_t BYTES = 4096;
+    static constexpr size_t BYTES = 256 * 1024;   // holds the scalar ecn mul window table (64 lanes x 216 words)
     unsigned char* get();
 };
 Staging& staging();

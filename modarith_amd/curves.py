@@ -1,0 +1,56 @@
+"""Curve constants for the layers built on the field path: the table of curve.py:85-105
+(Edwards curves a*x^2 + y^2 = 1 + d*x^2*y^2) and its conversion to internal-form limbs
+(curve.py:244-298: plain limbs for a pseudo-Mersenne field, value*R mod p for a Montgomery field; a
+constant below 2^28 in magnitude stays a C int)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+from .params import FieldParams, derive
+
+
+@dataclass
+class EdwardsCurve:
+    name: str               # e.g. "ED25519"
+    field: str              # built field prime carrying it ("X25519" | "X448")
+    a: int                  # +1 or -1
+    d: int                  # curve constant B of curve.py (may be negative and small)
+    cof: int                # log2 of the cofactor
+    order: int              # prime group order q
+    gx: int
+    gy: int
+    fp: Optional[FieldParams] = None
+
+    @property
+    def small_b(self) -> bool:
+        return abs(self.d) < (1 << 28)      # curve.py:235-240
+
+    def internal(self, v: int) -> List[int]:
+        """field element -> internal-form limbs (top limb masked: the value is canonical)"""
+        fp = self.fp
+        if fp.montgomery:
+            v = v * fp.R % fp.p
+        return fp.to_limbs(v % fp.p, masked_top=True)
+
+
+CURVES = {
+    "ED25519": EdwardsCurve(
+        "ED25519", "X25519", -1,
+        0x52036CEE2B6FFE738CC740797779E89800700A4D4141D8AB75EB4DCA135978A3, 3,
+        0x1000000000000000000000000000000014DEF9DEA2F79CD65812631A5CF5D3ED,
+        0x216936D3CD6E53FEC0A4E231FDD6DC5C692CC7609525A7B2C9562D608F25D51A,
+        0x6666666666666666666666666666666666666666666666666666666666666658),
+    "ED448": EdwardsCurve(
+        "ED448", "X448", 1, -39081, 2,
+        (2**448 - 2**224 - 1 + 1 - 28312320572429821613362531907042076847709625476988141958474579766324) // 4,
+        0x4f1970c66bed0ded221d15a622bf36da9e146570470f1767ea6de324a3d3a46412ae1af72ab66511433b80e18b00938e2626a82bc70cc05e,
+        0x693f46716eb6bc248876203756c9c7624bea73736ca3984087789c1e05a0c2d73ad3ff1ce67c39c4fdbd132c4ed7c8ad9808795bf230fa14),
+}
+
+
+def curve(name: str) -> EdwardsCurve:
+    c = CURVES[name]
+    if c.fp is None:
+        c.fp = derive(c.field)
+    return c

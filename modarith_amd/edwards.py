@@ -1,0 +1,137 @@
+"""Host-side mirror of the reference's curve API (curve.h:13-29) for Edwards curves, batched.
+
+`Ed = Edwards("ED25519")`; a batch of n projective points is a torch int64 tensor [3, Nlimbs, n]
+(x, y, z limb-interleaved SoA).  Scalars and coordinates are uint8 [n, Nbytes] big-endian records, as
+the reference's `char *` arguments.  Methods keep the reference's names and argument order
+(`add(Q, P)` is P += Q) and launch the HIP kernels through the C-ABI on torch's current stream.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Edwards:
+    def __init__(self, curve: str, device: Optional[torch.device] = None):
+        self.name = curve.lower()
+        if self.name not in _lib.CURVES:
+            raise ValueError("curve %r is not built; available: %s" % (curve, ", ".join(_lib.CURVES)))
+        self.lib = _lib.load()
+        self.N, self.nbytes = _lib.CURVES[self.name]
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._ws = None
+
+    # ------------------------------------------------------------------ plumbing
+    def empty(self, n: int) -> torch.Tensor:
+        return torch.empty((3, self.N, n), dtype=torch.int64, device=self.device)
+
+    def _chk(self, *ps: torch.Tensor) -> int:
+        n = ps[0].shape[2]
+        for p in ps:
+            if p.dtype != torch.int64 or p.dim() != 3 or p.shape[0] != 3 or p.shape[1] != self.N or p.shape[2] != n \
+                    or not p.is_cuda or not p.is_contiguous():
+                raise ValueError("expected contiguous int64 device tensors of shape [3, %d, n]" % self.N)
+        return n
+
+    def _bytes(self, b: Optional[torch.Tensor], n: int):
+        if b is None:
+            return None
+        if b.dtype != torch.uint8 or b.shape != (n, self.nbytes) or not b.is_contiguous() or not b.is_cuda:
+            raise ValueError("expected a contiguous uint8 device tensor [n, %d]" % self.nbytes)
+        return b.data_ptr()
+
+    def _call(self, fn: str, *args):
+        f = getattr(self.lib, "ecn_%s_%s_batch" % (self.name, fn))
+        _lib.check(f(*args), "ecn_%s_%s_batch" % (self.name, fn))
+
+    # ------------------------------------------------------------------ curve.h API, batched
+    def inf(self, n: int):
+        P = self.empty(n)
+        self._call("inf", P.data_ptr(), n, n, _stream())
+        return P
+
+    def gen(self, n: int):
+        P = self.empty(n)
+        self._call("gen", P.data_ptr(), n, n, _stream())
+        return P
+
+    def cpy(self, Q):
+        P = torch.empty_like(Q)
+        n = self._chk(Q, P)
+        self._call("cpy", Q.data_ptr(), P.data_ptr(), n, n, _stream())
+        return P
+
+    def add(self, Q, P):
+        """P += Q"""
+        n = self._chk(Q, P)
+        self._call("add", Q.data_ptr(), P.data_ptr(), n, n, _stream())
+        return P
+
+    def sub(self, Q, P):
+        """P -= Q"""
+        n = self._chk(Q, P)
+        self._call("sub", Q.data_ptr(), P.data_ptr(), n, n, _stream())
+        return P
+
+    def _un(self, fn, P):
+        n = self._chk(P)
+        self._call(fn, P.data_ptr(), n, n, _stream())
+        return P
+
+    def dbl(self, P): return self._un("dbl", P)
+    def neg(self, P): return self._un("neg", P)
+    def cof(self, P): return self._un("cof", P)
+    def affine(self, P): return self._un("affine", P)
+
+    def mul(self, e: torch.Tensor, P: torch.Tensor):
+        """P = e*P for big-endian scalar records e (constant-time fixed window, edwards.c:435-482)"""
+        n = self._chk(P)
+        need = int(getattr(self.lib, "ecn_%s_mul_workspace_bytes" % self.name)(n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._call("mul", self._bytes(e, n), P.data_ptr(), n, n, self._ws.data_ptr(), self._ws.numel(), _stream())
+        return P
+
+    def cmp(self, P, Q):
+        n = self._chk(P, Q)
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        self._call("cmp", P.data_ptr(), Q.data_ptr(), out.data_ptr(), n, n, _stream())
+        return out
+
+    def isinf(self, P):
+        n = self._chk(P)
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        self._call("isinf", P.data_ptr(), out.data_ptr(), n, n, _stream())
+        return out
+
+    def set(self, s: Optional[torch.Tensor], x: Optional[torch.Tensor], y: Optional[torch.Tensor]):
+        """ecnXXXset: from (x, y), or from x and the sign s of y, or from y and the sign s of x;
+        off-curve input gives the point at infinity (edwards.c:246-366).  s: int32 [n] or None."""
+        ref = x if x is not None else y
+        n = ref.shape[0]
+        P = self.empty(n)
+        sp = None
+        if s is not None:
+            if s.dtype != torch.int32 or s.numel() != n or not s.is_cuda:
+                raise ValueError("s must be an int32 device tensor [n]")
+            sp = s.data_ptr()
+        self._call("set", sp, self._bytes(x, n), self._bytes(y, n), P.data_ptr(), n, n, _stream())
+        return P
+
+    def get(self, P, want_x: bool = True, want_y: bool = True):
+        """ecnXXXget: makes P affine in place; returns (x bytes | None, y bytes | None, sign of the omitted
+        coordinate as int32 [n])."""
+        n = self._chk(P)
+        x = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device) if want_x else None
+        y = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device) if want_y else None
+        sign = torch.empty(n, dtype=torch.int32, device=self.device)
+        self._call("get", P.data_ptr(), None if x is None else x.data_ptr(), None if y is None else y.data_ptr(),
+                   sign.data_ptr(), n, n, _stream())
+        return x, y, sign

@@ -198,9 +198,43 @@ def header_text(fp: FieldParams) -> str:
     return "\n".join(L) + "\n"
 
 
+BUILT_CURVES = ("ED25519", "ED448")
+
+
+def curve_header_text(name: str) -> str:
+    """constants of one Edwards curve as `struct C_<NAME>` (counterpart of curve.py's curve.c: COF,
+    CONSTANT_A, CONSTANT_B or constant_b[], constant_x[], constant_y[]; curve.py:244-298)."""
+    from .curves import curve
+    c = curve(name)
+    N = c.fp.nlimbs
+    L = ["// GENERATED by modarith_amd/emit.py from modarith_amd/curves.py -- do not edit.",
+         "// Edwards curve %s: %d*x^2 + y^2 = 1 + d*x^2*y^2 over the %s field" % (c.name, c.a, c.field),
+         "#pragma once",
+         '#include "params_%s.h"' % c.field,
+         "namespace ma {",
+         "struct C_%s {" % c.name,
+         "    using FieldParams = P_%s;" % c.field,
+         "    static constexpr int A = %d, COF = %d;" % (c.a, c.cof),
+         "    static constexpr bool B_SMALL = %s;" % ("true" if c.small_b else "false"),
+         "    static constexpr int B_INT = %d;       // CONSTANT_B when small (curve.py:256-257)" % (c.d if c.small_b else 0)]
+    bl = c.internal(c.d) if not c.small_b else [0] * N
+    L.append(_switch("b", "unsigned long long", bl, _hexu))
+    L.append(_switch("gx", "unsigned long long", c.internal(c.gx), _hexu))
+    L.append(_switch("gy", "unsigned long long", c.internal(c.gy), _hexu))
+    L += ["};", "}  // namespace ma"]
+    return "\n".join(L) + "\n"
+
+
 def emit_all(primes=BUILT_PRIMES, out_dir: str = GEN_DIR) -> List[str]:
     os.makedirs(out_dir, exist_ok=True)
     paths = []
+    for name in BUILT_CURVES:
+        text = curve_header_text(name)
+        path = os.path.join(out_dir, "curve_%s.h" % name)
+        if not os.path.exists(path) or open(path).read() != text:
+            with open(path, "w") as f:
+                f.write(text)
+        paths.append(path)
     for name in primes:
         text = header_text(derive(name))
         path = os.path.join(out_dir, "params_%s.h" % name)

@@ -28,6 +28,10 @@ def _declared_symbols():
         for P in primes:
             names.add("%s_%s_%s" % (fn, P, kind))
     names.update(re.findall(r"\b(rfc7748_\w+)\s*\(", text))
+    emacro = text[text.index("#define MODARITH_AMD_DECLARE_EDWARDS(c, NL)"):text.index("MODARITH_AMD_DECLARE_EDWARDS(ed25519, 5)")]
+    for fn in re.findall(r"\becn_##c##_(\w+)\s*\(", emacro):
+        for c in re.findall(r"^MODARITH_AMD_DECLARE_EDWARDS\((\w+),", text, flags=re.M):
+            names.add("ecn_%s_%s" % (c, fn))
     return sorted(names), primes
 
 
@@ -45,6 +49,8 @@ def test_binding_tables_cover_header(lib):
     bound = {"%s_%s_batch" % (f, P) for f in _lib.BATCH_FUNCS for P in _lib.PRIMES}
     bound |= {"%s_%s_ct" % (f, P) for f in _lib.SCALAR_FUNCS for P in _lib.PRIMES}
     bound |= set(_lib.UTIL_FUNCS) | {"rfc7748_X25519", "rfc7748_X448", "rfc7748_X25519_batch", "rfc7748_X448_batch"}
+    bound |= {"ecn_%s_%s_batch" % (c, f) for c in _lib.CURVES for f in _lib.ED_BATCH_FUNCS}
+    bound |= {"ecn_%s_%s" % (c, f) for c in _lib.CURVES for f in _lib.ED_SCALAR_FUNCS}
     assert bound == set(names)
 
 

@@ -1,0 +1,172 @@
+"""GPU parity of the batched Edwards layer: HIP kernels through the C-ABI against the
+big-integer fixtures (affine coordinates, canonical) and against the oracle's restatement of edwards.c
+limb for limb (projective coordinates) where the reference is deterministic: add, dbl, sub, mul."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+CURVES = [("ed25519", "ED25519"), ("ed448", "ED448")]
+
+
+@pytest.fixture(scope="module", params=CURVES)
+def cx(request):
+    import torch
+    assert torch.cuda.is_available()
+    from modarith_amd.edwards import Edwards
+    C, name = request.param
+    return C, Edwards(name), load_golden("edwards_%s.json" % name), torch
+
+
+def dev_bytes(torch, hexes):
+    return torch.tensor([list(bytes.fromhex(h)) for h in hexes], dtype=torch.uint8, device="cuda")
+
+
+def points(Ed, torch, xy_list):
+    return Ed.set(None, dev_bytes(torch, [p[0] for p in xy_list]), dev_bytes(torch, [p[1] for p in xy_list]))
+
+
+def xy_of(Ed, P):
+    x, y, _ = Ed.get(P.clone())
+    return [[bytes(a).hex(), bytes(b).hex()] for a, b in zip(x.cpu().numpy(), y.cpu().numpy())]
+
+
+def test_gen_inf(cx):
+    C, Ed, g, torch = cx
+    G = Ed.gen(3)
+    assert xy_of(Ed, G) == [g["gen"]] * 3
+    assert Ed.isinf(G).cpu().tolist() == [0, 0, 0] and Ed.isinf(Ed.inf(2)).cpu().tolist() == [1, 1]
+
+
+def test_mul_fixture(cx):
+    C, Ed, g, torch = cx
+    recs = g["mul"]
+    P = points(Ed, torch, [r["P"] for r in recs])
+    Ed.mul(dev_bytes(torch, [r["e"] for r in recs]), P)
+    assert xy_of(Ed, P) == [r["eP"] for r in recs]
+
+
+def test_ops_fixture(cx):
+    C, Ed, g, torch = cx
+    recs = g["ops"]
+    P0 = points(Ed, torch, [r["P"] for r in recs])
+    Q = points(Ed, torch, [r["Q"] for r in recs])
+    assert xy_of(Ed, Ed.add(Q, P0.clone())) == [r["P+Q"] for r in recs]
+    assert xy_of(Ed, Ed.dbl(P0.clone())) == [r["2P"] for r in recs]
+    assert xy_of(Ed, Ed.sub(Q, P0.clone())) == [r["P-Q"] for r in recs]
+    cofP = Ed.cof(P0.clone())
+    assert xy_of(Ed, cofP) == [r["cofP"] for r in recs]
+    two = Ed.dbl(P0.clone())
+    assert Ed.cmp(two, points(Ed, torch, [r["2P"] for r in recs])).cpu().tolist() == [1] * len(recs)
+    assert Ed.cmp(two, P0).cpu().tolist() == [0] * len(recs)
+    neg = Ed.neg(P0.clone())
+    assert Ed.isinf(Ed.add(neg, P0.clone())).cpu().tolist() == [1] * len(recs)
+
+
+def test_compress_decompress(cx):
+    C, Ed, g, torch = cx
+    recs = g["compress"]
+    xs, ys = dev_bytes(torch, [r["x"] for r in recs]), dev_bytes(torch, [r["y"] for r in recs])
+    sy = torch.tensor([r["sy"] for r in recs], dtype=torch.int32, device="cuda")
+    sx = torch.tensor([r["sx"] for r in recs], dtype=torch.int32, device="cuda")
+    valid = [r["valid"] for r in recs]
+    for P, (gx, gy) in ((Ed.set(sy, xs, None), (True, False)), (Ed.set(sx, None, ys), (False, True))):
+        assert Ed.isinf(P).cpu().tolist() == [1 - v for v in valid]
+        got = xy_of(Ed, P)
+        for r, xy in zip(recs, got):
+            if r["valid"]:
+                assert xy == [r["x"], r["y"]]
+        x, y, sign = Ed.get(P.clone(), want_x=gx, want_y=gy)
+        want_sign = [r["sy"] if gx else r["sx"] for r in recs]
+        assert [s for s, v in zip(sign.cpu().tolist(), valid) if v] == [s for s, v in zip(want_sign, valid) if v]
+    sxy = g["set_xy"]
+    P = points(Ed, torch, [[r["x"], r["y"]] for r in sxy])
+    assert Ed.isinf(P).cpu().tolist() == [1 - r["valid"] for r in sxy]
+
+
+def test_testcurve_and_rfc8032(cx):
+    C, Ed, g, torch = cx
+    if "testcurve" not in g:
+        pytest.skip("testcurve.c constants exist for ED25519 only in the fixture")
+    t = g["testcurve"]
+    lanes = 70
+    G = Ed.gen(lanes)
+    P = Ed.mul(dev_bytes(torch, [t["order"]] * lanes), G.clone())
+    assert Ed.isinf(P).cpu().tolist() == [1] * lanes                        # order*G = O (testcurve.c:224-229)
+    a = Ed.mul(dev_bytes(torch, [t["r1"]] * lanes), G.clone())
+    b = Ed.mul(dev_bytes(torch, [t["r2"]] * lanes), G.clone())
+    assert Ed.isinf(Ed.add(a, b)).cpu().tolist() == [1] * lanes             # r1*G + r2*G = O
+    # the reference main()'s chain P = n1*P (testcurve.c:247-255), 100 steps on every lane
+    n1 = dev_bytes(torch, [t["n1"]] * lanes)
+    P = G.clone()
+    for i in range(100):
+        Ed.mul(n1, P)
+        if str(i + 1) in t["mul_chain"]:
+            assert xy_of(Ed, P) == [t["mul_chain"][str(i + 1)]] * lanes
+    r = g["rfc8032_test1"]
+    A = Ed.mul(dev_bytes(torch, [r["scalar_be"]]), Ed.gen(1))
+    x, y, sx = Ed.get(A, want_x=False, want_y=True)
+    enc = bytearray(bytes(y.cpu().numpy()[0])[::-1])
+    enc[31] |= int(sx[0]) << 7
+    assert enc.hex() == r["pk"]
+
+
+@pytest.mark.parametrize("C,name,n", [("ed25519", "ED25519", 1500), ("ed448", "ED448", 300)])
+def test_projective_limbs_equal_oracle(oracle, C, name, n):
+    """add / dbl / mul leave the same projective limbs as the restated edwards.c (deterministic sequence
+    of bit-exact field operations), over seeded random points and scalars."""
+    import torch
+    from modarith_amd.edwards import Edwards
+    Ed = Edwards(name)
+    Pt, nb = oracle.ed[C]
+    nl = Ed.N
+    rng = np.random.default_rng(17)
+    k0 = rng.integers(0, 256, size=(n, nb), dtype=np.uint8)
+    e = rng.integers(0, 256, size=(n, nb), dtype=np.uint8)
+    # base points: k0 * G computed on the GPU, then both sides start from those exact limbs
+    base = Ed.mul(torch.from_numpy(k0).cuda(), Ed.gen(n))
+    soa = np.ascontiguousarray(base.cpu().numpy().view(np.uint64))            # [3, nl, n]
+    want_mul = soa.reshape(3 * nl, n).copy()
+    oracle.ecn(C, "batch_mul")(e.ctypes.data_as(ctypes.c_void_p), want_mul.ctypes.data_as(ctypes.c_void_p), n, n)
+    got = Ed.mul(torch.from_numpy(e).cuda(), base.clone()).cpu().numpy().view(np.uint64).reshape(3 * nl, n)
+    assert np.array_equal(got, want_mul)
+    # add and dbl on the first 64 points, element by element through the oracle's scalar functions
+    m = 64
+    Q = Ed.dbl(base[:, :, :m].contiguous().clone())
+    S = Ed.add(Q, base[:, :, :m].contiguous().clone())
+    qn, sn = Q.cpu().numpy().view(np.uint64), S.cpu().numpy().view(np.uint64)
+    for j in range(m):
+        p = Pt()
+        for c, name_ in enumerate(("x", "y", "z")):
+            for i in range(nl):
+                getattr(p, name_)[i] = int(soa[c, i, j])
+        q = Pt()
+        oracle.ecn(C, "cpy")(ctypes.byref(p), ctypes.byref(q))
+        oracle.ecn(C, "dbl")(ctypes.byref(q))
+        oracle.ecn(C, "add")(ctypes.byref(q), ctypes.byref(p))
+        for c, name_ in enumerate(("x", "y", "z")):
+            assert [int(v) for v in qn[c, :, j]] == list(getattr(q, name_))
+            assert [int(v) for v in sn[c, :, j]] == list(getattr(p, name_))
+
+
+def test_scalar_abi(oracle):
+    """curve.h-style scalar calls with host `point` structs: gen, mul, dbl, add, get"""
+    from modarith_amd import _lib
+    lib = _lib.load()
+    g = load_golden("edwards_ED25519.json")
+    Pt, nb = oracle.ed["ed25519"]
+    P, Q = Pt(), Pt()
+    lib.ecn_ed25519_gen(ctypes.byref(P))
+    rec = g["mul"][14]
+    lib.ecn_ed25519_set(0, bytes.fromhex(rec["P"][0]), bytes.fromhex(rec["P"][1]), ctypes.byref(P))
+    lib.ecn_ed25519_mul(bytes.fromhex(rec["e"]), ctypes.byref(P))
+    x, y = ctypes.create_string_buffer(nb), ctypes.create_string_buffer(nb)
+    lib.ecn_ed25519_get(ctypes.byref(P), x, y)
+    assert [x.raw.hex(), y.raw.hex()] == rec["eP"]
+    lib.ecn_ed25519_cpy(ctypes.byref(P), ctypes.byref(Q))
+    lib.ecn_ed25519_dbl(ctypes.byref(Q))
+    lib.ecn_ed25519_sub(ctypes.byref(P), ctypes.byref(Q))
+    assert lib.ecn_ed25519_cmp(ctypes.byref(P), ctypes.byref(Q)) == 1
