@@ -182,7 +182,7 @@ int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void 
  * 9-entry table lives in a caller-provided device workspace of ecn_*_mul_workspace_bytes(n) bytes.
  * Projective results equal the reference's limb for limb where it is deterministic (add, dbl, mul);
  * set/get/affine/cmp involve modpro and are comparable as affine coordinates.  ecnXXXmul2 (not constant
- * time in the reference) is not built yet. */
+ * time in the reference) runs a fixed number of steps per lane here: same point, after affine. */
 #define MODARITH_AMD_DECLARE_EDWARDS(c, NL)                                                                             \
     typedef struct { ma_spint x[NL], y[NL], z[NL]; } ma_point_##c##_t;                                                  \
     int ecn_##c##_get(ma_point_##c##_t *P, char *x, char *y);                          /* edwards.c:221-239 */        \
@@ -195,6 +195,8 @@ int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void 
     void ecn_##c##_dbl(ma_point_##c##_t *P);                                           /* edwards.c:123-145 */        \
     void ecn_##c##_gen(ma_point_##c##_t *P);                                                                            \
     void ecn_##c##_mul(const char *e, ma_point_##c##_t *P);                            /* edwards.c:435-482 */        \
+    void ecn_##c##_mul2(const char *e, ma_point_##c##_t *P, const char *f, ma_point_##c##_t *Q, ma_point_##c##_t *R);  \
+    void ecn_##c##_ran(int r, ma_point_##c##_t *P);                                    /* edwards.c:55-63 */          \
     int ecn_##c##_cmp(ma_point_##c##_t *P, ma_point_##c##_t *Q);                                                        \
     void ecn_##c##_affine(ma_point_##c##_t *P);                                                                         \
     void ecn_##c##_cpy(ma_point_##c##_t *Q, ma_point_##c##_t *P);                                                       \
@@ -202,6 +204,10 @@ int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void 
     size_t ecn_##c##_mul_workspace_bytes(size_t n);                                                                     \
     int ecn_##c##_mul_batch(const char *e, ma_spint *P, size_t n, size_t ld, void *workspace, size_t workspace_bytes,   \
                             void *stream);                                                                              \
+    /* R = eP + fQ (edwards.c:486-510); same workspace size as mul; R may be P or Q */                                 \
+    int ecn_##c##_mul2_batch(const char *e, const ma_spint *P, const char *f, const ma_spint *Q, ma_spint *R, size_t n, \
+                             size_t ld, void *workspace, size_t workspace_bytes, void *stream);                         \
+    int ecn_##c##_ran_batch(int r, ma_spint *P, size_t n, size_t ld, void *stream);                                     \
     int ecn_##c##_add_batch(const ma_spint *Q, ma_spint *P, size_t n, size_t ld, void *stream);                         \
     int ecn_##c##_sub_batch(const ma_spint *Q, ma_spint *P, size_t n, size_t ld, void *stream);                         \
     int ecn_##c##_cpy_batch(const ma_spint *Q, ma_spint *P, size_t n, size_t ld, void *stream);                         \

@@ -15,8 +15,8 @@ LIB_PATH = os.path.join(HERE, "libmodarith_amd.so")
 PRIMES = ("X25519", "NIST256", "X448")
 LADDERS = ("X25519", "X448")
 CURVES = {"ed25519": (5, 32), "ed448": (8, 56)}       # curve -> (Nlimbs, Nbytes)
-ED_BATCH_FUNCS = ("mul", "add", "sub", "cpy", "dbl", "neg", "inf", "gen", "cof", "affine", "cmp", "isinf", "set", "get")
-ED_SCALAR_FUNCS = ("get", "set", "inf", "isinf", "neg", "add", "sub", "dbl", "gen", "mul", "cmp", "affine", "cpy", "cof",
+ED_BATCH_FUNCS = ("mul", "mul2", "ran", "add", "sub", "cpy", "dbl", "neg", "inf", "gen", "cof", "affine", "cmp", "isinf", "set", "get")
+ED_SCALAR_FUNCS = ("mul2", "ran", "get", "set", "inf", "isinf", "neg", "add", "sub", "dbl", "gen", "mul", "cmp", "affine", "cpy", "cof",
                    "mul_workspace_bytes")
 
 _lib = None
@@ -100,6 +100,8 @@ def load() -> ctypes.CDLL:
         g("mul_workspace_bytes").argtypes = [c_size_t]
         g("mul_workspace_bytes").restype = c_size_t
         g("mul_batch").argtypes = [_P, _P, c_size_t, c_size_t, _P, c_size_t, _P]
+        g("mul2_batch").argtypes = [_P, _P, _P, _P, _P, c_size_t, c_size_t, _P, c_size_t, _P]
+        g("ran_batch").argtypes = [c_int, _P, c_size_t, c_size_t, _P]
         for f in ("add", "sub", "cpy"):
             g(f + "_batch").argtypes = [_P, _P, c_size_t, c_size_t, _P]
         for f in ("dbl", "neg", "inf", "gen", "cof", "affine"):

@@ -290,6 +290,67 @@ struct Edwards {
         }
     }
 
+    // R = e*P + f*Q (edwards.c:486-510).  The reference walks a joint sparse form (dnaf, 404-431) with
+    // data-dependent branches ("not constant time"); here every lane runs the same 8*NB+7 steps: digit
+    // w_i = bit_i(3e) - bit_i(e) + 3*(bit_i(3f) - bit_i(f)) in -4..4, table {O, P, Q-P, Q, Q+P} in the
+    // workspace, lookup by full scan + predicated negation, and an unconditional (complete) addition,
+    // adding O for a zero digit.  Same point, possibly another projective representative.
+    static constexpr int NW1 = NW + 1;
+    static MA_DEV void triple(const spint* x, spint* x3) {     // x3 = 3*x over NW+1 words
+        spint carry = 0;
+        static_for<0, NW>([&](auto K) {
+            dpint t = (dpint)x[K] * 3u + carry;
+            x3[K] = (spint)t;
+            carry = (spint)(t >> 64);
+        });
+        x3[NW] = carry;
+    }
+    static MA_DEV void mul2(const spint* ew, const Point& p, const spint* fw, const Point& q, Point& r, const Table& W) {
+        {
+            Point t;
+            inf(t); W.put(0, t);
+            W.put(1, p);
+            W.put(3, q);
+            cpy(q, t); sub(p, t); W.put(2, t);       // Q - P
+            cpy(q, t); add(p, t); W.put(4, t);       // Q + P
+        }
+        // left-aligned copies of e, 3e, f, 3f over NW+1 words; bit 8*NB+7 sits in bit 7 of the top word,
+        // so shift everything left by 56 first
+        spint e1[NW1], e3[NW1], f1[NW1], f3[NW1];
+        static_for<0, NW>([&](auto K) { e1[K] = ew[K]; f1[K] = fw[K]; });
+        e1[NW] = 0; f1[NW] = 0;
+        triple(ew, e3);
+        triple(fw, f3);
+        auto shl = [&](spint* v, int sh) {
+            static_for<0, NW1>([&](auto KK) {
+                constexpr int k = NW1 - 1 - KK;
+                v[k] <<= sh;
+                if constexpr (k > 0) v[k] |= v[k - 1] >> (64 - sh);
+            });
+        };
+        shl(e1, 56); shl(e3, 56); shl(f1, 56); shl(f3, 56);
+        inf(r);
+#pragma unroll 1
+        for (int i = 8 * NB + 7; i >= 1; i--) {
+            const int d = (int)(e3[NW] >> 63) - (int)(e1[NW] >> 63) + 3 * ((int)(f3[NW] >> 63) - (int)(f1[NW] >> 63));
+            shl(e1, 1); shl(e3, 1); shl(f1, 1); shl(f3, 1);
+            dbl(r);
+            const int m = d >> 31;
+            const int dabs = (d ^ m) - m;
+            Point t, sel;
+            inf(sel);
+#pragma unroll 1
+            for (int k = 0; k <= 4; k++) {
+                W.get(k, t);
+                cmv((((dabs ^ k) - 1) >> 31) & 1, t, sel);
+            }
+            cpy(sel, t);
+            neg(t);
+            cmv(m & 1, t, sel);
+            add(sel, r);
+        }
+    }
+
     // ---- SoA load / store of a point batch: P[(c*N + i)*ld + j]
     static MA_DEV void load(const spint* Pb, size_t ld, size_t j, Point& p) {
         static_for<0, N>([&](auto I) {
@@ -321,6 +382,37 @@ __global__ __launch_bounds__(64) void k_ed_mul(const spint* e, spint* Pb, size_t
         typename E::Point p;
         E::load(Pb, ld, t, p);
         E::mul(ew, p, W);
+        E::store(Pb, ld, t, p);
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(64) void k_ed_mul2(const spint* e, const spint* Pb, const spint* f, const spint* Qb, spint* Rb,
+                                                size_t n, size_t ld, spint* ws) {
+    using E = Edwards<C>;
+    const size_t lanes = (size_t)gridDim.x * blockDim.x;
+    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    typename E::Table W{ws + lane, lanes};
+    for (size_t t = lane; t < n; t += lanes) {
+        spint ew[E::NW], fw[E::NW];
+        static_for<0, E::NW>([&](auto K) { ew[K] = __builtin_bswap64(e[t * E::NW + (E::NW - 1 - K)]); });
+        static_for<0, E::NW>([&](auto K) { fw[K] = __builtin_bswap64(f[t * E::NW + (E::NW - 1 - K)]); });
+        typename E::Point p, q, r;
+        E::load(Pb, ld, t, p);
+        E::load(Qb, ld, t, q);
+        E::mul2(ew, p, fw, q, r, W);
+        E::store(Rb, ld, t, r);
+    }
+}
+
+// ecnXXXran: randomise the projective representative by a small factor r (edwards.c:55-63)
+template <class C>
+__global__ __launch_bounds__(BLOCK) void k_ed_ran(int r, spint* Pb, size_t n, size_t ld) {
+    using E = Edwards<C>;
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
+        typename E::Point p;
+        E::load(Pb, ld, t, p);
+        E::ran(r, p);
         E::store(Pb, ld, t, p);
     }
 }

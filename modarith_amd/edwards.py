@@ -99,6 +99,26 @@ class Edwards:
         self._call("mul", self._bytes(e, n), P.data_ptr(), n, n, self._ws.data_ptr(), self._ws.numel(), _stream())
         return P
 
+    def _workspace(self, n: int):
+        need = int(getattr(self.lib, "ecn_%s_mul_workspace_bytes" % self.name)(n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def mul2(self, e, P, f, Q):
+        """R = e*P + f*Q (ecnXXXmul2, edwards.c:486-510); returns a new batch"""
+        n = self._chk(P, Q)
+        R = torch.empty_like(P)
+        ws = self._workspace(n)
+        self._call("mul2", self._bytes(e, n), P.data_ptr(), self._bytes(f, n), Q.data_ptr(), R.data_ptr(), n, n,
+                   ws.data_ptr(), ws.numel(), _stream())
+        return R
+
+    def ran(self, r: int, P):
+        n = self._chk(P)
+        self._call("ran", int(r), P.data_ptr(), n, n, _stream())
+        return P
+
     def cmp(self, P, Q):
         n = self._chk(P, Q)
         out = torch.empty(n, dtype=torch.int32, device=self.device)

@@ -66,6 +66,22 @@ def test_ops_fixture(cx):
     assert Ed.isinf(Ed.add(neg, P0.clone())).cpu().tolist() == [1] * len(recs)
 
 
+def test_mul2_and_ran(cx):
+    C, Ed, g, torch = cx
+    recs = g["mul2"]
+    P = points(Ed, torch, [r["P"] for r in recs])
+    Q = points(Ed, torch, [r["Q"] for r in recs])
+    R = Ed.mul2(dev_bytes(torch, [r["e"] for r in recs]), P, dev_bytes(torch, [r["f"] for r in recs]), Q)
+    assert xy_of(Ed, R) == [r["R"] for r in recs]
+    if "testcurve" in g:                                            # r1*G + r2*G = O via mul2 (testcurve.c:231-237)
+        t = g["testcurve"]
+        G = Ed.gen(5)
+        R = Ed.mul2(dev_bytes(torch, [t["r1"]] * 5), G, dev_bytes(torch, [t["r2"]] * 5), G)
+        assert Ed.isinf(R).cpu().tolist() == [1] * 5
+    P2 = Ed.ran(7, P.clone())                                       # another representative of the same points
+    assert Ed.cmp(P2, P).cpu().tolist() == [1] * len(recs) and not torch.equal(P2, P)
+
+
 def test_compress_decompress(cx):
     C, Ed, g, torch = cx
     recs = g["compress"]
