@@ -346,3 +346,22 @@ def test_ladder_scalar_abi_chain(torch_cuda):
         lib.rfc7748_X25519(bk, bu, bv)
         lib.rfc7748_X25519(bk, bv, bu)
     assert bu.raw.hex() == g["checkpoints"]["10"]
+
+
+def test_c_drop_in_example(torch_cuda, tmp_path):
+    """examples/rfc7748_drop_in.c: the reference main()'s sequence (rfc7748.c:259-341) in plain C against
+    the library; stdout must carry the RFC vector, the reference chain checkpoint and DH secret."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "rfc7748_drop_in")
+    subprocess.check_call(["gcc", "-O2", os.path.join(root, "examples", "rfc7748_drop_in.c"), "-I", os.path.join(root, "include"),
+                           "-L", os.path.join(root, "modarith_amd"), "-l:libmodarith_amd.so",
+                           "-Wl,-rpath," + os.path.join(root, "modarith_amd"), "-o", exe])
+    out = subprocess.run([exe, "100"], capture_output=True, text=True, timeout=300).stdout.splitlines()
+    g = load_golden("ladder_X25519.json")
+    assert out[2] == g["kat"][0]["out"]
+    assert out[out.index("chain 100") + 1] == g["ref_main_chain"]["checkpoints"]["100"]
+    assert out[out.index("Alice shared secret") + 1] == g["ref_main_chain"]["dh"]["shared"]
+    assert out[out.index("Bob's shared secret") + 1] == g["ref_main_chain"]["dh"]["shared"]
+    assert out[-1] == "batched: equal"
