@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-ladder", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-others", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -161,6 +162,32 @@ def main():
     assert torch.equal(chk, c), "modmul is not commutative bit-for-bit: kernel bug"
     del chk
 
+    # the other single-GPU configs of BASELINE.json (configs[2], configs[3]) with the same protocol, short runs:
+    # parity for them is in tests/; these are side figures, not the headline
+    others = {}
+    if not args.no_others:
+        for P, ops in (("NIST256", ("modmul",)), ("X448", ("modmul", "modsqr"))):
+            Fp = Field(P, dev)
+            xa = torch.randint(0, 1 << Fp.radix, (Fp.N, n), dtype=torch.int64, device=dev, generator=gen)
+            xb = torch.randint(0, 1 << Fp.radix, (Fp.N, n), dtype=torch.int64, device=dev, generator=gen)
+            xc = torch.empty_like(xa)
+            for op in ops:
+                fn = (lambda: Fp.modmul(xa, xb, out=xc)) if op == "modmul" else (lambda: Fp.modsqr(xa, out=xc))
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(20):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 20
+                nbytes = (3 if op == "modmul" else 2) * 8 * Fp.N * n
+                others["%s_%s" % (P, op)] = {"ops_per_s_per_gpu": n / (ms * 1e-3), "GBps": nbytes / (ms * 1e-3) / 1e9,
+                                             "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms}
+            del xa, xb, xc
+
     ladder = None
     if not args.no_ladder:
         m = 1 << LOG2_LADDER
@@ -212,6 +239,7 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_MODMUL * n},
             "cpu_baseline": cpu,
             "x25519": ladder,
+            "other_configs": others,
         }
         print(json.dumps(out))
     if world > 1:

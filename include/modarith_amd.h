@@ -164,6 +164,21 @@ int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbi
 MODARITH_AMD_DECLARE(X25519)
 MODARITH_AMD_DECLARE(NIST256)
 MODARITH_AMD_DECLARE(X448)
+/* further primes of the generators' named lists (pseudo.py:1498-1548, monty.py:1966-2062) and the group orders
+ * curve.py:324-329 feeds to monty.py; same functions, constants from modarith_amd/params.py:
+ *   pseudo-Mersenne: NIST521 (9 x 58), PM266 (5 x 54), PM383 (7 x 55, non-EPM rows), NUMS256W (5 x 52)
+ *   Montgomery     : NIST384 (7 x 56), NIST224 (4 x 56 + virtual limb), SECP256K1 (5 x 52), all full reduction
+ *                    (ndash != 1); group orders NIST256Q, ED25519Q, ED448Q (general primes) */
+MODARITH_AMD_DECLARE(NIST521)
+MODARITH_AMD_DECLARE(PM266)
+MODARITH_AMD_DECLARE(PM383)
+MODARITH_AMD_DECLARE(NUMS256W)
+MODARITH_AMD_DECLARE(NIST384)
+MODARITH_AMD_DECLARE(NIST224)
+MODARITH_AMD_DECLARE(SECP256K1)
+MODARITH_AMD_DECLARE(NIST256Q)
+MODARITH_AMD_DECLARE(ED25519Q)
+MODARITH_AMD_DECLARE(ED448Q)
 
 /* RFC 7748 ladder, bv = [bk] * bu (reference rfc7748.c:156 `void rfc7748(const char *bk,const char *bu,char *bv)`).
  * Scalar form: host pointers, Nbytes each (32 / 56), RFC little-endian.  Batched form: device pointers,

@@ -12,7 +12,8 @@ from ctypes import c_char_p, c_int, c_size_t, c_uint, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmodarith_amd.so")
-PRIMES = ("X25519", "NIST256", "X448")
+PRIMES = ("X25519", "NIST256", "X448",
+          "NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1", "NIST256Q", "ED25519Q", "ED448Q")
 LADDERS = ("X25519", "X448")
 CURVES = {"ed25519": (5, 32), "ed448": (8, 56)}       # curve -> (Nlimbs, Nbytes)
 ED_BATCH_FUNCS = ("mul", "mul2", "ran", "add", "sub", "cpy", "dbl", "neg", "inf", "gen", "cof", "affine", "cmp", "isinf", "set", "get")

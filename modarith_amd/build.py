@@ -23,7 +23,8 @@ LIB = os.path.join(HERE, "libmodarith_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-UNITS = ["capi_common"] + ["capi_%s" % p for p in emit.BUILT_PRIMES] + ["capi_%s" % c for c in emit.BUILT_CURVES]
+UNITS = (["capi_common"] + ["capi_%s" % p for p in emit.CORE_PRIMES] + ["capi_%s" % c for c in emit.BUILT_CURVES]
+         + ["generated/capi_%s" % p for p in emit.EXTRA_PRIMES])
 
 
 def _stamp() -> str:
@@ -39,8 +40,8 @@ def _stamp() -> str:
 
 def _compile(unit: str) -> str:
     src = os.path.join(CSRC, unit + ".hip")
-    obj = os.path.join(OBJ, unit + ".o")
-    subprocess.check_call([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+    obj = os.path.join(OBJ, os.path.basename(unit) + ".o")
+    subprocess.run([HIPCC] + FLAGS + ["-c", src, "-o", obj], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
     return obj
 
 
@@ -53,7 +54,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     if verbose:
         print("[modarith_amd] compiling %d HIP units for %s ..." % (len(UNITS), ARCH), flush=True)
-    with cf.ThreadPoolExecutor(max_workers=min(6, len(UNITS))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(int(os.environ.get('MA_BUILD_JOBS', '7')), len(UNITS))) as ex:
         objs = list(ex.map(_compile, UNITS))
     subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
     with open(stamp_file, "w") as f:

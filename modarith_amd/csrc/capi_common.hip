@@ -110,7 +110,9 @@ int modarith_amd_soa_to_aos(const ma_spint* soa, ma_spint* aos, size_t n, int nl
 
 int modarith_amd_field_info(const char* prime, int* nlimbs, int* radix, int* nbits, int* nbytes, int* montgomery) {
     struct Row { const char* name; int nl, rx, nb, by, mo; };
-    static const Row rows[] = {{"X25519", 5, 51, 255, 32, 0}, {"NIST256", 5, 52, 256, 32, 1}, {"X448", 8, 56, 448, 56, 1}};
+    static const Row rows[] = {
+#include "generated/field_table.inc"
+    };
     for (const Row& r : rows) {
         if (strcmp(prime, r.name) == 0) {
             if (nlimbs) *nlimbs = r.nl;

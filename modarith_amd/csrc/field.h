@@ -318,9 +318,21 @@ struct Field {
         if constexpr (scratch) t += (dpint)s;
     }
 
+    // reduction digit of a column (monty.py:698-712, 740-751): t & mask when ndash == 1 ("Montgomery
+    // friendly"), else (t*ndash) & mask followed by t += v*p0 so that the low RADIX bits cancel
+    static MA_DEV spint monty_digit(dpint& t) {
+        if constexpr (P::NDASH == 1) {
+            return (spint)t & MASK;
+        } else {
+            static_assert(P::ppw(0) > 0, "full Montgomery reduction expects a positive low prime limb");
+            const spint v = ((spint)t * (spint)P::NDASH) & MASK;
+            if constexpr (P::ppw(0) == 1) t += (dpint)v; else t += mulw(v, (spint)P::ppw(0));
+            return v;
+        }
+    }
+
     template <bool SQR>
     static MA_DEV void monty_mul(const spint* a, const spint* b, spint* c) {
-        static_assert(P::NDASH == 1, "only Montgomery-friendly moduli (ndash == 1) are built");
         constexpr int NCOL = P::E ? 2 * N : 2 * N - 1;
         dpint t = 0;
         spint v[JMAX + 1];
@@ -349,7 +361,7 @@ struct Field {
                 }
             }
             monty_reduce<col>(t, v);
-            if constexpr (col <= JMAX) v[col] = (spint)t & MASK;
+            if constexpr (col <= JMAX) v[col] = monty_digit(t);
             else c[col - JMAX - 1] = (spint)t & MASK;
             t >>= RADIX;
         });
@@ -460,7 +472,15 @@ struct Field {
 
     // progenitor x^PE (pseudo.py:758-785).  The reference takes its addition chain from the external
     // `addchain` tool; ours comes from the driver (P::modpro_chain).  Limbs differ, values do not.
-    static MA_DEV void modpro(const spint* w, spint* z) { P::template modpro_chain<Field<P>>(w, z); }
+    // A real (non-inlined) device function: the chain is ~250 squarings + a dozen multiplications, so the call
+    // costs nothing, and every kernel of a translation unit that needs a progenitor (modpro, modinv, modsqrt,
+    // modqr, the ladders, point decompression) shares ONE copy of it instead of inlining its own.
+    static __device__ __attribute__((noinline)) void modpro(const spint* w, spint* z) {
+        spint x[N], r[N];
+        modcpy(w, x);
+        P::template modpro_chain<Field<P>>(x, r);
+        modcpy(r, z);
+    }
 
     // pseudo.py:788-812
     static MA_DEV void modinv(const spint* x, const spint* h, spint* z) {
@@ -607,8 +627,7 @@ struct Field {
     // [RADIX*i, RADIX*(i+1)), the top limb taking every remaining bit, then modfsb + nres as there.
     // Here the integer arrives / leaves as NW little-endian 64-bit words held in registers; kernels
     // turn big-endian (modimp/modexp) or little-endian (rfc7748) byte records into such words.
-    static constexpr int NW = P::NBYTES / 8;
-    static_assert(P::NBYTES % 8 == 0, "byte records are moved as whole 64-bit words");
+    static constexpr int NW = (P::NBYTES + 7) / 8;   // a short top word is zero-extended
 
     static MA_DEV void limbs_from_words(const spint* w, spint* a) {
         static_for<0, N>([&](auto I) {

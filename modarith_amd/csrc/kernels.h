@@ -253,14 +253,43 @@ __global__ __launch_bounds__(BLOCK) void k_fill(int val, spint* a, size_t n, siz
         store_soa<P, 1>(a, ld, t, x);
 }
 
-// bytes <-> limbs.  AoS records of NBYTES big-endian bytes (what modimp / modexp take), one record
-// per lane, moved as 64-bit words: word k of the integer = byte-swapped chunk NW-1-k of the record.
+// bytes <-> limbs.  AoS records of NBYTES big-endian bytes (what modimp / modexp take), one record per
+// lane.  When NBYTES is a multiple of 8 the record moves as 64-bit words (word k of the integer = the
+// byte-swapped chunk NW-1-k); otherwise (e.g. 66-byte NIST521 records) bytes are assembled one by one.
 template <class P>
-__global__ __launch_bounds__(BLOCK) void k_imp(const spint* bytes, spint* a, int* flag, size_t n, size_t ld) {
-    constexpr int NW = Field<P>::NW;
+__device__ __forceinline__ void load_be_record(const unsigned char* bytes, size_t t, spint* w) {
+    constexpr int NW = Field<P>::NW, NB = P::NBYTES;
+    if constexpr (NB % 8 == 0) {
+        const spint* src = reinterpret_cast<const spint*>(bytes) + t * NW;
+        static_for<0, NW>([&](auto K) { w[K] = __builtin_bswap64(src[NW - 1 - K]); });
+    } else {
+        const unsigned char* src = bytes + t * NB;
+        static_for<0, NW>([&](auto K) { w[K] = 0; });
+        static_for<0, NB>([&](auto B) {
+            constexpr int pos = NB - 1 - B;                 // byte significance (0 = least)
+            w[pos / 8] |= (spint)src[B] << (8 * (pos % 8));
+        });
+    }
+}
+template <class P>
+__device__ __forceinline__ void store_be_record(unsigned char* bytes, size_t t, const spint* w) {
+    constexpr int NW = Field<P>::NW, NB = P::NBYTES;
+    if constexpr (NB % 8 == 0) {
+        spint* dst = reinterpret_cast<spint*>(bytes) + t * NW;
+        static_for<0, NW>([&](auto K) { dst[NW - 1 - K] = __builtin_bswap64(w[K]); });
+    } else {
+        unsigned char* dst = bytes + t * NB;
+        static_for<0, NB>([&](auto B) {
+            constexpr int pos = NB - 1 - B;
+            dst[B] = (unsigned char)(w[pos / 8] >> (8 * (pos % 8)));
+        });
+    }
+}
+template <class P>
+__global__ __launch_bounds__(BLOCK) void k_imp(const unsigned char* bytes, spint* a, int* flag, size_t n, size_t ld) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
-        spint w[NW];
-        static_for<0, NW>([&](auto K) { w[K] = __builtin_bswap64(bytes[t * NW + (NW - 1 - K)]); });
+        spint w[Field<P>::NW];
+        load_be_record<P>(bytes, t, w);
         spint x[1][P::N];
         int r = Field<P>::modimp_words(w, x[0]);
         store_soa<P, 1>(a, ld, t, x);
@@ -268,14 +297,13 @@ __global__ __launch_bounds__(BLOCK) void k_imp(const spint* bytes, spint* a, int
     }
 }
 template <class P>
-__global__ __launch_bounds__(BLOCK) void k_exp(const spint* a, spint* bytes, size_t n, size_t ld) {
-    constexpr int NW = Field<P>::NW;
+__global__ __launch_bounds__(BLOCK) void k_exp(const spint* a, unsigned char* bytes, size_t n, size_t ld) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N];
         load_soa<P, 1>(a, ld, t, x);
-        spint w[NW];
+        spint w[Field<P>::NW];
         Field<P>::modexp_words(x[0], w);
-        static_for<0, NW>([&](auto K) { bytes[t * NW + (NW - 1 - K)] = __builtin_bswap64(w[K]); });
+        store_be_record<P>(bytes, t, w);
     }
 }
 

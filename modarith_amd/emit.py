@@ -20,7 +20,9 @@ from .params import FieldParams, derive
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GEN_DIR = os.path.join(HERE, "csrc", "generated")
-BUILT_PRIMES = ("X25519", "NIST256", "X448")
+CORE_PRIMES = ("X25519", "NIST256", "X448")            # BASELINE.json configs; their capi_<P>.hip are hand-written
+EXTRA_PRIMES = ("NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1", "NIST256Q", "ED25519Q", "ED448Q")
+BUILT_PRIMES = CORE_PRIMES + EXTRA_PRIMES
 
 
 # ------------------------------------------------------------------ addition chain
@@ -116,6 +118,30 @@ def eval_chain(prog, x: int, p: int) -> int:
     return acc
 
 
+MAX_UNROLLED_MULS = 24   # beyond this the progenitor is a square-and-multiply loop (general primes)
+
+
+def _binary_cpp(pe: int, N: int) -> str:
+    """square-and-multiply over the bits of PE, for exponents without long runs (group orders and other
+    general primes): one copy of modsqr and one of modmul in the instruction stream; the exponent is a
+    public constant, so the branch is uniform across the wave"""
+    nb = pe.bit_length()
+    words = [(pe >> (64 * i)) & ((1 << 64) - 1) for i in range((nb + 63) // 64)]
+    sw = " ".join("case %d: w = 0x%xull; break;" % (i, v) for i, v in enumerate(words))
+    return "\n".join([
+        "        spint x[%d], acc[%d];" % (N, N),
+        "        F::modcpy(w_, x);",
+        "        F::modcpy(w_, acc);",
+        "#pragma unroll 1",
+        "        for (int i = %d; i >= 0; i--) {" % (nb - 2),
+        "            unsigned long long w = 0;",
+        "            switch (i >> 6) { %s }" % sw,
+        "            F::modsqr(acc, acc);",
+        "            if ((w >> (i & 63)) & 1) F::modmul(acc, x, acc);",
+        "        }",
+        "        F::modcpy(acc, z);"])
+
+
 def _chain_cpp(prog, N: int) -> str:
     lines = ["        spint x[%d], acc[%d];" % (N, N), "        F::modcpy(w, x);"]
     declared = set()
@@ -188,11 +214,19 @@ def header_text(fp: FieldParams) -> str:
     L.append(_switch("pp_sgn", "int", [t[1] for t in fp.pp], str))
     L.append(_switch("pp_val", "unsigned long long", [t[2] for t in fp.pp], _hexu))
     L.append(_switch("roi", "unsigned long long", fp.roi, _hexu))
-    L.append("    // progenitor chain for PE = %s: %d squarings + %d multiplications" % (hex(fp.pe), sq, mu))
-    L.append("    template <class F>")
-    L.append("    static __device__ __forceinline__ void modpro_chain(const spint* w, spint* z) {")
-    L.append(_chain_cpp(prog, N))
-    L.append("    }")
+    if mu <= MAX_UNROLLED_MULS:
+        L.append("    // progenitor chain for PE = %s: %d squarings + %d multiplications" % (hex(fp.pe), sq, mu))
+        L.append("    template <class F>")
+        L.append("    static __device__ __forceinline__ void modpro_chain(const spint* w, spint* z) {")
+        L.append(_chain_cpp(prog, N))
+        L.append("    }")
+    else:
+        L.append("    // progenitor for PE = %s: no run structure, square-and-multiply loop (%d squarings + %d multiplications)"
+                 % (hex(fp.pe), fp.pe.bit_length() - 1, bin(fp.pe).count("1") - 1))
+        L.append("    template <class F>")
+        L.append("    static __device__ __forceinline__ void modpro_chain(const spint* w_, spint* z) {")
+        L.append(_binary_cpp(fp.pe, N))
+        L.append("    }")
     L.append("};")
     L.append("}  // namespace ma")
     return "\n".join(L) + "\n"
@@ -225,9 +259,35 @@ def curve_header_text(name: str) -> str:
     return "\n".join(L) + "\n"
 
 
+def capi_unit_text(name: str) -> str:
+    """translation unit with the C-ABI entry points of one field-only prime"""
+    return ("// GENERATED by modarith_amd/emit.py -- do not edit.\n"
+            "// C-ABI entry points for %s (field only); body: ../capi_prime.inc\n"
+            '#include "params_%s.h"\n#define MA_P ma::P_%s\n#define MA_NAME %s\n#include "../capi_prime.inc"\n' % (name, name, name, name))
+
+
+def field_table_text(primes=BUILT_PRIMES) -> str:
+    """rows of modarith_amd_field_info(): the macro block of each prime's field.c (pseudo.py:1403-1407)"""
+    rows = []
+    for name in primes:
+        fp = derive(name)
+        rows.append('    {"%s", %d, %d, %d, %d, %d},' % (name, fp.nlimbs, fp.radix, fp.n, fp.nbytes, 1 if fp.montgomery else 0))
+    return "// GENERATED by modarith_amd/emit.py -- do not edit.\n" + "\n".join(rows) + "\n"
+
+
+def _write(path: str, text: str) -> str:
+    if not os.path.exists(path) or open(path).read() != text:
+        with open(path, "w") as f:
+            f.write(text)
+    return path
+
+
 def emit_all(primes=BUILT_PRIMES, out_dir: str = GEN_DIR) -> List[str]:
     os.makedirs(out_dir, exist_ok=True)
-    paths = []
+    paths = [_write(os.path.join(out_dir, "field_table.inc"), field_table_text(primes))]
+    for name in EXTRA_PRIMES:
+        if name in primes:
+            paths.append(_write(os.path.join(out_dir, "capi_%s.hip" % name), capi_unit_text(name)))
     for name in BUILT_CURVES:
         text = curve_header_text(name)
         path = os.path.join(out_dir, "curve_%s.h" % name)

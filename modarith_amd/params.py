@@ -35,8 +35,23 @@ NAMED = {
     "PM266": (2**266 - 3, "pseudo"),
     "C2065": (2**206 - 5, "pseudo"),
     "PM336": (2**336 - 3, "pseudo"),
+    "PM383": (2**383 - 187, "pseudo"),
     "NUMS256W": (2**256 - 189, "pseudo"),
+    "NIST521": (2**521 - 1, "pseudo"),
+    "SECP256K1": (2**256 - 2**32 - 977, "monty"),        # pseudo.py's overflow variant is not built
+    # group orders (curve.py:324-329 runs monty.py on "00<decimal q>"): general primes, full Montgomery
+    "NIST256Q": (0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551, "monty"),
+    "ED25519Q": (0x1000000000000000000000000000000014DEF9DEA2F79CD65812631A5CF5D3ED, "monty"),
+    "ED448Q": ((2**448 - 2**224 - 1 + 1 - 28312320572429821613362531907042076847709625476988141958474579766324) // 4, "monty"),
 }
+
+# how each built name is spelled on the reference generators' command line (group orders: "00" + decimal)
+def reference_argv(name: str):
+    p, fam = NAMED[name]
+    script = "pseudo.py" if fam == "pseudo" else "monty.py"
+    if name.endswith("Q"):
+        return script, "00" + str(p)
+    return script, name
 
 
 @dataclass

@@ -168,9 +168,10 @@ def element_pool(ref, rng, count):
     return [ref.split(v) for v in vals[:count]], vals[:count]
 
 
-def field_fixture(script, prime, seed, count=160):
+def field_fixture(script, prime, seed, count=160, full_time=True, name=None):
     rng = random.Random(seed)
     ref = Ref(script, prime)
+    prime = name or prime
     N, p = ref.N, ref.p
     fx = {"prime": prime, "generator": script, "generic": True, "params": params_of(ref), "seed": seed}
     araw, aval = element_pool(ref, rng, count)
@@ -287,7 +288,7 @@ def field_fixture(script, prime, seed, count=160):
     tm = {"ra": hx(ra), "rb": hx(rb), "rs": hx(rs), "ri": hx(ri)}
     b = 1 << ref.base
     mk = lambda v: [(v >> (ref.base * i)) % b for i in range(N)]  # makebig (pseudo.py:190-199)
-    for outer, tag in ((1, "1k"), (100, "100k"), (100000, "full")):
+    for outer, tag in ((1, "1k"), (100, "100k"), (100000, "full"))[:3 if full_time else 2]:
         x, y = ref.arr(mk(ra)), ref.arr(mk(rb))
         tm["modmul_check_" + tag] = hx(ref.lib.chain_modmul(x, y, outer))
         tm["modmul_z_" + tag] = H(list(x))
@@ -482,7 +483,7 @@ def sqrt_model(val, p, pm1d2, pe, roi):
     return s
 
 
-def sqrt_fixture(script, prime, seed, count=64):
+def sqrt_fixture(script, prime, seed, count=64, name=None):
     """modsqrt / modqr pins (the reference cannot emit them here: they call modpro, which needs the
     external addchain tool).  Inputs are internal-form limbs produced by the reference's own nres;
     expectations are big-integer values: root after redc, Euler criterion."""
@@ -502,7 +503,7 @@ def sqrt_fixture(script, prime, seed, count=64):
         if qr:
             assert root * root % p == v
         recs.append({"x": H(x), "value": hx(v), "sqrt_redc": H(_canon(ref, root)), "qr": qr})
-    return {"prime": prime, "source": "value-level model of pseudo.py:815-874 on reference-nres'd inputs", "recs": recs}
+    return {"prime": name or prime, "source": "value-level model of pseudo.py:815-874 on reference-nres'd inputs", "recs": recs}
 
 
 # ---------------------------------------------------------------- Edwards big-integer model
@@ -699,7 +700,24 @@ def edwards_fixture(name, seed, pairs=40):
     return fx
 
 
+def extras():
+    """further primes and group orders built by the engine (modarith_amd.emit.EXTRA_PRIMES): the same
+    fixture recipe, fewer pairs, straight from the reference generators"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from modarith_amd.emit import EXTRA_PRIMES
+    from modarith_amd.params import reference_argv
+    for k, name in enumerate(EXTRA_PRIMES):
+        script, arg = reference_argv(name)
+        fx, _ = field_fixture(script, arg, 6000 + k, count=64, full_time=False, name=name)
+        json.dump(fx, open(os.path.join(HERE, "field_%s.json" % name), "w"), indent=0, separators=(",", ":"))
+        json.dump(sqrt_fixture(script, arg, 7000 + k, count=24, name=name), open(os.path.join(HERE, "sqrt_%s.json" % name), "w"), indent=0, separators=(",", ":"))
+        print(name, fx["params"]["log"][0])
+
+
 def main():
+    if "--extras-only" in sys.argv:
+        extras()
+        return
     if "--edwards-only" in sys.argv:
         for name, seed in (("ED25519", 5001), ("ED448", 5002)):
             fx = edwards_fixture(name, seed, pairs=40 if name == "ED25519" else 20)
@@ -723,6 +741,7 @@ def main():
         json.dump(fx, open(os.path.join(HERE, "field_%s_lazy.json" % prime), "w"), indent=0, separators=(",", ":"))
     for script, prime, seed in (("pseudo.py", "X25519", 4001), ("monty.py", "NIST256", 4002), ("monty.py", "X448", 4003)):
         json.dump(sqrt_fixture(script, prime, seed), open(os.path.join(HERE, "sqrt_%s.json" % prime), "w"), indent=0, separators=(",", ":"))
+    extras()
     for name, seed in (("ED25519", 5001), ("ED448", 5002)):
         json.dump(edwards_fixture(name, seed, pairs=40 if name == "ED25519" else 20), open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
     for curve, seed in (("X25519", 3001), ("X448", 3003)):

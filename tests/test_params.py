@@ -9,7 +9,8 @@ from modarith_amd import emit
 from modarith_amd.params import derive
 from tests.conftest import load_golden
 
-ALL = ["X25519", "NIST256", "X448"]
+ALL = ["X25519", "NIST256", "X448", "NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1",
+       "NIST256Q", "ED25519Q", "ED448Q"]
 
 
 def _i(v):
@@ -34,7 +35,7 @@ def test_driver_matches_reference_constants(P):
         assert fp.ppw == [(-_i(v[1:]) if v.startswith("-") else _i(v)) for v in g["ppw"]]
         assert (fp.E, fp.R, fp.ndash, fp.trin) == (g["E"], _i(g["R"]), _i(g["ndash"]), g["trin"])
         assert fp.r2 == [_i(v) for v in g["cw"]]
-        assert g["fullmonty"] is False and g["PM"] is False
+        assert g["fullmonty"] is (fp.ndash != 1) and g["PM"] is False
 
 
 def test_reference_stdout_lines():
@@ -46,7 +47,7 @@ def test_reference_stdout_lines():
     assert "Extra virtual limb added" in log and "lucky trinomial" in log
 
 
-@pytest.mark.parametrize("P", ALL + ["NIST384", "NIST224", "PM266", "C2065"])
+@pytest.mark.parametrize("P", ALL + ["C2065"])
 def test_addition_chain_computes_progenitor(P):
     fp = derive(P)
     prog = emit.addition_chain(fp.pe)
@@ -55,7 +56,9 @@ def test_addition_chain_computes_progenitor(P):
         x = rng.randrange(2, fp.p)
         assert emit.eval_chain(prog, x, fp.p) == pow(x, fp.pe, fp.p)
     sq, mu = emit.chain_cost(prog)
-    assert sq <= fp.pe.bit_length() and mu <= 20  # near-optimal: squarings == bit length - 1 (+0)
+    assert sq <= fp.pe.bit_length()               # squarings == bit length - 1: the leading run ladder is the main chain
+    if not P.endswith("Q"):
+        assert mu <= 20                           # shaped primes: long runs of ones; general primes take the loop form
 
 
 def test_generated_headers_are_current():
