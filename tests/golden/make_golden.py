@@ -700,6 +700,137 @@ def edwards_fixture(name, seed, pairs=40):
     return fx
 
 
+class WsModel:
+    """y^2 = x^3 + a*x + b over GF(p), affine big-integer arithmetic with None as the point at infinity.
+    Constants of curve.py:157-166 (NIST256)."""
+
+    def __init__(self, name):
+        assert name == "NIST256"
+        self.p = 2**256 - 2**224 + 2**192 + 2**96 - 1
+        self.a = -3
+        self.b = 0x5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b
+        self.q = 0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551
+        self.G = (0x6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296,
+                  0x4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5)
+        self.nbytes = 32
+        # testcurve.c:29-35
+        self.tc = dict(order="FFFFFFFF00000000FFFFFFFFFFFFFFFFBCE6FAADA7179E84F3B9CAC2FC632551",
+                       r1="166876CB6C86C76660666789A376F6790956A0D6A507657196D75D610E0C9D7B",
+                       r2="E99789339379389A9F9998765C890986B39059D7021039135CE26D61EE5687D6",
+                       n1="C20347457078878f77b707c070707077a07707b7b07070707223252357134272",
+                       n2="D35279279432f249b298a876788d86294e02842092769136c086038b1812383a")
+        assert self.on_curve(self.G)
+
+    def on_curve(self, P):
+        x, y = P
+        return (y * y - x * x * x - self.a * x - self.b) % self.p == 0
+
+    def add(self, P, Q):
+        p = self.p
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        x1, y1 = P
+        x2, y2 = Q
+        if x1 == x2:
+            if (y1 + y2) % p == 0:
+                return None
+            lam = (3 * x1 * x1 + self.a) * pow(2 * y1, -1, p) % p
+        else:
+            lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (lam * lam - x1 - x2) % p
+        return (x3, (lam * (x1 - x3) - y1) % p)
+
+    def neg(self, P):
+        return None if P is None else (P[0], (-P[1]) % self.p)
+
+    def mul(self, k, P):
+        # Jacobian-free: double-and-add on affine points with python ints is fast enough for fixtures
+        R = None
+        for bit in bin(k)[2:] if k else "":
+            R = self.add(R, R)
+            if bit == "1":
+                R = self.add(R, P)
+        return R
+
+    def xy_hex(self, P):
+        """affine coordinates as the reference's ecnXXXget leaves them; infinity is (0, 1) after affine()"""
+        if P is None:
+            return [(0).to_bytes(self.nbytes, "big").hex(), (1).to_bytes(self.nbytes, "big").hex()]
+        return [P[0].to_bytes(self.nbytes, "big").hex(), P[1].to_bytes(self.nbytes, "big").hex()]
+
+    def recover_y(self, x, s):
+        p = self.p
+        v = (x * x * x + self.a * x + self.b) % p
+        if v == 0:
+            return 0
+        if pow(v, (p - 1) // 2, p) != 1:
+            return None
+        r = pow(v, (p + 1) // 4, p)
+        return r if r % 2 == s else p - r
+
+
+def weierstrass_fixture(name, seed, pairs=32):
+    rng = random.Random(seed)
+    M = WsModel(name)
+    nb, p, q, G = M.nbytes, M.p, M.q, M.G
+    fx = {"curve": name, "source": "big-integer model (tests/golden/make_golden.py WsModel); constants curve.py:157-166",
+          "gen": M.xy_hex(G), "order": q.to_bytes(nb, "big").hex()}
+    assert M.mul(q, G) is None
+    recs = []
+    for i in range(pairs):
+        k = [0, 1, 2, 8, 15, 16, 17, q - 1, q, q + 1, (1 << (8 * nb)) - 1, 0x88888888, 0x77777777][i] if i < 13 else rng.randrange(0, 1 << (8 * nb))
+        base = G if i % 2 == 0 else M.mul(rng.randrange(1, q), G)
+        R = M.mul(k, base)
+        recs.append({"e": k.to_bytes(nb, "big").hex(), "P": M.xy_hex(base), "eP": M.xy_hex(R), "inf": int(R is None)})
+    fx["mul"] = recs
+    ops = []
+    for i in range(16):
+        P = M.mul(rng.randrange(1, q), G)
+        Q = M.mul(rng.randrange(1, q), G) if i % 4 else (P if i % 8 == 0 else M.neg(P))
+        S, D = M.add(P, Q), M.add(P, M.neg(Q))
+        ops.append({"P": M.xy_hex(P), "Q": M.xy_hex(Q), "P+Q": M.xy_hex(S), "P+Q_inf": int(S is None), "2P": M.xy_hex(M.add(P, P)),
+                    "P-Q": M.xy_hex(D), "P-Q_inf": int(D is None)})
+    fx["ops"] = ops
+    comp = []
+    for i in range(20):
+        if i < 14:
+            P = M.mul(rng.randrange(1, q), G)
+            comp.append({"x": P[0].to_bytes(nb, "big").hex(), "y": P[1].to_bytes(nb, "big").hex(), "sy": P[1] & 1, "valid": 1})
+        else:
+            while True:
+                v = rng.randrange(2, p)
+                if M.recover_y(v, 0) is None:
+                    break
+            comp.append({"x": v.to_bytes(nb, "big").hex(), "y": v.to_bytes(nb, "big").hex(), "sy": 0, "valid": 0})
+    fx["compress"] = comp
+    bad = (G[0], (G[1] + 1) % p)
+    fx["set_xy"] = [{"x": M.xy_hex(G)[0], "y": M.xy_hex(G)[1], "valid": 1}, {"x": M.xy_hex(bad)[0], "y": M.xy_hex(bad)[1], "valid": 0}]
+    m2 = []
+    for i in range(10):
+        P = M.mul(rng.randrange(1, q), G); Q = M.mul(rng.randrange(1, q), G)
+        e = rng.randrange(0, 1 << (8 * nb)) if i else 0
+        f = rng.randrange(0, 1 << (8 * nb)) if i != 1 else 0
+        R = M.add(M.mul(e, P), M.mul(f, Q))
+        m2.append({"e": e.to_bytes(nb, "big").hex(), "f": f.to_bytes(nb, "big").hex(), "P": M.xy_hex(P), "Q": M.xy_hex(Q),
+                   "R": M.xy_hex(R), "inf": int(R is None)})
+    fx["mul2"] = m2
+    t = {k: int(v, 16) for k, v in M.tc.items()}
+    assert t["order"] == q and (t["r1"] + t["r2"]) == q
+    tc = {k: v.to_bytes(nb, "big").hex() for k, v in t.items()}
+    assert M.add(M.mul(t["r1"], G), M.mul(t["r2"], G)) is None
+    P = G
+    cps = {}
+    for i in range(1000):
+        P = M.mul(t["n1"], P)
+        if i + 1 in (1, 10, 100, 1000):
+            cps[str(i + 1)] = M.xy_hex(P)
+    tc["mul_chain"] = cps
+    fx["testcurve"] = tc
+    return fx
+
+
 def extras():
     """further primes and group orders built by the engine (modarith_amd.emit.EXTRA_PRIMES): the same
     fixture recipe, fewer pairs, straight from the reference generators"""
@@ -717,6 +848,9 @@ def extras():
 def main():
     if "--extras-only" in sys.argv:
         extras()
+        return
+    if "--weierstrass-only" in sys.argv:
+        json.dump(weierstrass_fixture("NIST256", 8001), open(os.path.join(HERE, "weierstrass_NIST256.json"), "w"), indent=0, separators=(",", ":"))
         return
     if "--edwards-only" in sys.argv:
         for name, seed in (("ED25519", 5001), ("ED448", 5002)):
@@ -742,6 +876,7 @@ def main():
     for script, prime, seed in (("pseudo.py", "X25519", 4001), ("monty.py", "NIST256", 4002), ("monty.py", "X448", 4003)):
         json.dump(sqrt_fixture(script, prime, seed), open(os.path.join(HERE, "sqrt_%s.json" % prime), "w"), indent=0, separators=(",", ":"))
     extras()
+    json.dump(weierstrass_fixture("NIST256", 8001), open(os.path.join(HERE, "weierstrass_NIST256.json"), "w"), indent=0, separators=(",", ":"))
     for name, seed in (("ED25519", 5001), ("ED448", 5002)):
         json.dump(edwards_fixture(name, seed, pairs=40 if name == "ED25519" else 20), open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
     for curve, seed in (("X25519", 3001), ("X448", 3003)):

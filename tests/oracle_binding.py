@@ -70,7 +70,7 @@ class Oracle:
             f.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]; f.restype = None
         # Edwards layer (oracle/edwards_oracle.c): point = struct {x[NL], y[NL], z[NL]}
         self.ed = {}
-        for C, P in (("ed25519", "X25519"), ("ed448", "X448")):
+        for C, P in (("ed25519", "X25519"), ("ed448", "X448"), ("nist256", "NIST256")):
             nl = PRIMES[P][0]
 
             class Pt(ctypes.Structure):
