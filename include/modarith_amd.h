@@ -188,7 +188,7 @@ void rfc7748_X448(const char *bk, const char *bu, char *bv);
 int rfc7748_X25519_batch(const char *bk, const char *bu, char *bv, size_t n, void *stream);
 int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void *stream);
 
-/* ---- Edwards curve layer on the field path: the API of curve.h:13-29 with XXX = _<curve>_
+/* ---- Curve layer on the field path: the API of curve.h:13-29 with XXX = _<curve>_
  * (curve.py:344-345), for ED25519 (over the X25519 field) and ED448 (over the X448 field).
  * A point is projective (x:y:z), `struct xyz` of curve.py:304-309.  Scalar form: host `point`, one element
  * on the GPU.  Batched form: device SoA P[(c*Nlimbs + i)*ld + j], c = 0,1,2 for x,y,z -- a host point is
@@ -241,6 +241,9 @@ int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void 
 
 MODARITH_AMD_DECLARE_EDWARDS(ed25519, 5)
 MODARITH_AMD_DECLARE_EDWARDS(ed448, 8)
+/* NIST P-256 in short-Weierstrass form (weierstrass.c: complete add/dbl 68-281, setxy 366-410, mul 494-543, mul2
+ * 545-569) -- the same curve.h API and layouts; ecn_nist256_set needs x (y optional), ecn_nist256_cof is a no-op. */
+MODARITH_AMD_DECLARE_EDWARDS(nist256, 5)
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ LIB = os.path.join(HERE, "libmodarith_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-UNITS = (["capi_common"] + ["capi_%s" % p for p in emit.CORE_PRIMES] + ["capi_%s" % c for c in emit.BUILT_CURVES]
+UNITS = (["capi_common"] + ["capi_%s" % p for p in emit.CORE_PRIMES] + ["capi_%s" % c for c in emit.BUILT_CURVES] + ["capi_%sW" % c for c in emit.BUILT_WCURVES]
          + ["generated/capi_%s" % p for p in emit.EXTRA_PRIMES])
 
 

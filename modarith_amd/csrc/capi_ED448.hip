@@ -1,5 +1,6 @@
-// modarith_amd/csrc/capi_ED448.hip -- C-ABI entry points of the batched Edwards layer for ED448.
+// modarith_amd/csrc/capi_ED448.hip -- C-ABI entry points of the batched curve layer for ED448 (Edwards).
 #include "generated/curve_ED448.h"
-#define MA_C ma::C_ED448
+#include "edwards.h"
+#define MA_CURVE_CLASS ma::Edwards<ma::C_ED448>
 #define MA_CNAME ed448
-#include "capi_edwards.inc"
+#include "capi_curve.inc"

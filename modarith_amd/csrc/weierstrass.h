@@ -1,0 +1,216 @@
+// modarith_amd/csrc/weierstrass.h -- short-Weierstrass formulas of the batched curve layer.
+//
+// Device-side counterpart of the formulas in the reference's weierstrass.c: projective points (X:Y:Z) on
+// y^2 = x^3 + a*x + b with the complete addition / doubling of Renes-Costello-Batina (eprint 2015/1060) in the
+// operation order of weierstrass.c:68-281 (a = -3 and a = 0 branches, large-constant b), built from the
+// bit-exact Field<P> functions.  Everything curve-independent is in curve.h.
+#pragma once
+#include "curve.h"
+
+namespace ma {
+
+template <class C>
+struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
+    using Base = CurveOps<Weierstrass<C>, typename C::FieldParams>;
+    using P = typename C::FieldParams;
+    using F = Field<P>;
+    using Point = typename Base::Point;
+    using Base::cmv;
+    using Base::cpy;
+    static constexpr int N = P::N;
+    static constexpr bool HAS_Y_ONLY_SET = false;   // weierstrass.c:417-428: x is mandatory
+
+    static MA_DEV void const_b(spint* b) { static_for<0, N>([&](auto I) { b[I] = C::b(I); }); }
+    static MA_DEV void const_b3(spint* b) { static_for<0, N>([&](auto I) { b[I] = C::b3(I); }); }
+
+    static MA_DEV void neg(Point& p) { F::modneg(p.y, p.y); }                          // weierstrass.c:61-64
+    static MA_DEV void inf(Point& p) { F::modzer(p.x); F::modone(p.y); F::modzer(p.z); }  // weierstrass.c:284-289
+    static MA_DEV int isinf(const Point& p) { return F::modis0(p.x) & F::modis0(p.z); }   // weierstrass.c:292-296
+    static MA_DEV void cof(Point&) {}                                                  // weierstrass.c:413-414
+
+    // P += Q, complete (weierstrass.c:68-175)
+    static MA_DEV void add(const Point& q, Point& p) {
+        spint B[N], T0[N], T1[N], T2[N], T3[N], T4[N];
+        F::modmul(p.x, q.x, T0);
+        F::modmul(p.y, q.y, T1);
+        F::modmul(p.z, q.z, T2);
+        F::modadd(p.x, p.y, T3);
+        F::modadd(q.x, q.y, T4);
+        F::modmul(T3, T4, T3);
+        F::modadd(T0, T1, T4);
+        F::modsub(T3, T4, T3);
+        F::modadd(p.y, p.z, T4);
+        F::modadd(q.y, q.z, B);
+        F::modmul(T4, B, T4);
+        F::modadd(T1, T2, B);
+        F::modsub(T4, B, T4);
+        F::modadd(p.x, p.z, p.x);
+        F::modadd(q.z, q.x, p.y);
+        F::modmul(p.x, p.y, p.x);
+        F::modadd(T0, T2, p.y);
+        F::modsub(p.x, p.y, p.y);
+        if constexpr (C::A == 0) {
+            F::modadd(T0, T0, p.x);
+            F::modadd(T0, p.x, T0);
+            const_b3(B);
+            F::modmul(T2, B, T2);
+            F::modmul(p.y, B, p.y);
+            F::modadd(T1, T2, p.z);
+            F::modsub(T1, T2, T1);
+            F::modmul(p.y, T4, p.x);
+            F::modmul(T3, T1, T2);
+            F::modsub(T2, p.x, p.x);
+            F::modmul(p.y, T0, p.y);
+            F::modmul(T1, p.z, T1);
+            F::modadd(p.y, T1, p.y);
+            F::modmul(T0, T3, T0);
+            F::modmul(p.z, T4, p.z);
+            F::modadd(p.z, T0, p.z);
+        } else {
+            static_assert(C::A == 0 || C::A == -3, "weierstrass.c handles a = 0 and a = -3");
+            const_b(B);
+            F::modmul(B, T2, p.z);
+            F::modsub(p.y, p.z, p.x);
+            F::modmul(p.y, B, p.y);
+            F::modadd(p.x, p.x, p.z);
+            F::modadd(p.x, p.z, p.x);
+            F::modsub(T1, p.x, p.z);
+            F::modadd(p.x, T1, p.x);
+            F::modadd(T2, T2, T1);
+            F::modadd(T2, T1, T2);
+            F::modsub(p.y, T2, p.y);
+            F::modsub(p.y, T0, p.y);
+            F::modadd(p.y, p.y, T1);
+            F::modadd(p.y, T1, p.y);
+            F::modadd(T0, T0, T1);
+            F::modadd(T0, T1, T0);
+            F::modsub(T0, T2, T0);
+            F::modmul(T4, p.y, T1);
+            F::modmul(T0, p.y, T2);
+            F::modmul(p.x, p.z, p.y);
+            F::modadd(p.y, T2, p.y);
+            F::modmul(p.x, T3, p.x);
+            F::modsub(p.x, T1, p.x);
+            F::modmul(p.z, T4, p.z);
+            F::modmul(T3, T0, T1);
+            F::modadd(p.z, T1, p.z);
+        }
+    }
+
+    // P = 2P, complete (weierstrass.c:187-281)
+    static MA_DEV void dbl(Point& p) {
+        spint B[N], T0[N], T1[N], T2[N], T3[N], T4[N];
+        if constexpr (C::A == 0) {
+            F::modsqr(p.y, T0);
+            F::modadd(T0, T0, T3);
+            F::modadd(T3, T3, T3);
+            F::modadd(T3, T3, T3);
+            F::modmul(p.x, p.y, T4);
+            F::modmul(p.y, p.z, T1);
+            F::modsqr(p.z, T2);
+            const_b3(B);
+            F::modmul(T2, B, T2);
+            F::modmul(T2, T3, p.x);
+            F::modadd(T0, T2, p.y);
+            F::modmul(T3, T1, p.z);
+            F::modadd(T2, T2, T1);
+            F::modadd(T2, T1, T2);
+            F::modsub(T0, T2, T0);
+            F::modmul(p.y, T0, p.y);
+            F::modadd(p.y, p.x, p.y);
+            F::modmul(T0, T4, p.x);
+            F::modadd(p.x, p.x, p.x);
+        } else {
+            F::modsqr(p.x, T0);
+            F::modsqr(p.y, T1);
+            F::modsqr(p.z, T2);
+            F::modmul(p.x, p.y, T3);
+            F::modmul(p.y, p.z, T4);
+            F::modadd(T3, T3, T3);
+            F::modmul(p.z, p.x, p.z);
+            F::modadd(p.z, p.z, p.z);
+            const_b(B);
+            F::modmul(T2, B, p.y);
+            F::modsub(p.y, p.z, p.y);
+            F::modmul(p.z, B, p.z);
+            F::modadd(p.y, p.y, p.x);
+            F::modadd(p.y, p.x, p.y);
+            F::modsub(T1, p.y, p.x);
+            F::modadd(p.y, T1, p.y);
+            F::modmul(p.y, p.x, p.y);
+            F::modmul(p.x, T3, p.x);
+            F::modadd(T2, T2, T3);
+            F::modadd(T2, T3, T2);
+            F::modsub(p.z, T2, p.z);
+            F::modsub(p.z, T0, p.z);
+            F::modadd(p.z, p.z, T3);
+            F::modadd(p.z, T3, p.z);
+            F::modadd(T0, T0, T3);
+            F::modadd(T0, T3, T0);
+            F::modsub(T0, T2, T0);
+            F::modmul(T0, p.z, T0);
+            F::modadd(p.y, T0, p.y);
+            F::modadd(T4, T4, T4);
+            F::modmul(p.z, T4, p.z);
+            F::modsub(p.x, p.z, p.x);
+            F::modmul(T4, T1, p.z);
+            F::modadd(p.z, p.z, p.z);
+            F::modadd(p.z, p.z, p.z);
+        }
+    }
+
+    // weierstrass.c:299-310; Z == 0 handled by a predicated overwrite with (0 : 1 : 0)
+    static MA_DEV void affine(Point& p) {
+        spint I[N];
+        Point o;
+        inf(o);
+        const int z0 = F::modis0(p.z);
+        F::modinv(p.z, nullptr, I);
+        F::modone(p.z);
+        F::modmul(p.x, I, p.x);
+        F::modmul(p.y, I, p.y);
+        cmv(z0, o, p);
+    }
+
+    // setxy (weierstrass.c:366-410).  MODE 0: (x, y); MODE 1: x and the sign s of y.  Off-curve -> infinity.
+    template <int MODE>
+    static MA_DEV void setxy(int s, const spint* x, const spint* y, Point& p) {
+        static_assert(MODE == 0 || MODE == 1, "weierstrass.c sets a point from x (and optionally y)");
+        spint T[N], V[N], H[N], B[N];
+        Point o;
+        inf(o);
+        F::modcpy(x, p.x);
+        F::modsqr(x, V);
+        F::modmul(V, x, V);
+        if constexpr (C::A == -3) {
+            F::modsub(V, x, V);
+            F::modsub(V, x, V);
+            F::modsub(V, x, V);
+        }
+        const_b(B);
+        F::modadd(V, B, V);
+        if constexpr (MODE == 0) {
+            F::modsqr(y, T);
+            const int ok = F::modcmp(T, V);
+            F::modcpy(y, p.y);
+            F::modone(p.z);
+            cmv(1 - ok, o, p);
+        } else {
+            F::modpro(V, H);
+            const int ok = F::modqr(H, V);
+            F::modsqrt(V, H, p.y);
+            const int d = (F::modsign(p.y) - s) & 1;
+            F::modneg(p.y, T);
+            F::modcmv(d, T, p.y);
+            F::modone(p.z);
+            cmv(1 - ok, o, p);
+        }
+    }
+    static MA_DEV void gen(Point& p) {                                                  // weierstrass.c:431-440
+        spint gx[N], gy[N];
+        static_for<0, N>([&](auto I) { gx[I] = C::gx(I); gy[I] = C::gy(I); });
+        setxy<0>(0, gx, gy, p);
+    }
+};
+
+}  // namespace ma

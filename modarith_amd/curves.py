@@ -49,6 +49,42 @@ CURVES = {
 }
 
 
+@dataclass
+class WeierstrassCurve:
+    name: str
+    field: str
+    a: int                  # -3 or 0 (weierstrass.c handles these two)
+    b: int
+    order: int
+    gx: int
+    gy: int
+    fp: Optional[FieldParams] = None
+
+    def internal(self, v: int) -> List[int]:
+        fp = self.fp
+        if fp.montgomery:
+            v = v * fp.R % fp.p
+        return fp.to_limbs(v % fp.p, masked_top=True)
+
+
+W_CURVES = {
+    # curve.py:157-166
+    "NIST256": WeierstrassCurve(
+        "NIST256", "NIST256", -3,
+        0x5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b,
+        0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551,
+        0x6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296,
+        0x4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5),
+}
+
+
+def wcurve(name: str) -> WeierstrassCurve:
+    c = W_CURVES[name]
+    if c.fp is None:
+        c.fp = derive(c.field)
+    return c
+
+
 def curve(name: str) -> EdwardsCurve:
     c = CURVES[name]
     if c.fp is None:

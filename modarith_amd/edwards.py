@@ -19,6 +19,9 @@ def _stream() -> int:
 
 
 class Edwards:
+    """Batched curve API; despite the name it serves every built curve of the reference's curve layer:
+    Edwards ("ED25519", "ED448") and short Weierstrass ("NIST256").  `Curve` is an alias."""
+
     def __init__(self, curve: str, device: Optional[torch.device] = None):
         self.name = curve.lower()
         if self.name not in _lib.CURVES:
@@ -155,3 +158,6 @@ class Edwards:
         self._call("get", P.data_ptr(), None if x is None else x.data_ptr(), None if y is None else y.data_ptr(),
                    sign.data_ptr(), n, n, _stream())
         return x, y, sign
+
+
+Curve = Edwards

@@ -282,12 +282,38 @@ def _write(path: str, text: str) -> str:
     return path
 
 
+BUILT_WCURVES = ("NIST256",)
+
+
+def wcurve_header_text(name: str) -> str:
+    """constants of one short-Weierstrass curve (curve.py's curve.c: CONSTANT_A, constant_b[], constant_b3[],
+    constant_x[], constant_y[]; curve.py:244-298)"""
+    from .curves import wcurve
+    c = wcurve(name)
+    L = ["// GENERATED by modarith_amd/emit.py from modarith_amd/curves.py -- do not edit.",
+         "// Weierstrass curve %s: y^2 = x^3 %+d*x + b over the %s field" % (c.name, c.a, c.field),
+         "#pragma once",
+         '#include "params_%s.h"' % c.field,
+         "namespace ma {",
+         "struct C_%s {" % c.name,
+         "    using FieldParams = P_%s;" % c.field,
+         "    static constexpr int A = %d;" % c.a,
+         _switch("b", "unsigned long long", c.internal(c.b), _hexu),
+         _switch("b3", "unsigned long long", c.internal(3 * c.b), _hexu),
+         _switch("gx", "unsigned long long", c.internal(c.gx), _hexu),
+         _switch("gy", "unsigned long long", c.internal(c.gy), _hexu),
+         "};", "}  // namespace ma"]
+    return "\n".join(L) + "\n"
+
+
 def emit_all(primes=BUILT_PRIMES, out_dir: str = GEN_DIR) -> List[str]:
     os.makedirs(out_dir, exist_ok=True)
     paths = [_write(os.path.join(out_dir, "field_table.inc"), field_table_text(primes))]
     for name in EXTRA_PRIMES:
         if name in primes:
             paths.append(_write(os.path.join(out_dir, "capi_%s.hip" % name), capi_unit_text(name)))
+    for name in BUILT_WCURVES:
+        paths.append(_write(os.path.join(out_dir, "curve_%s.h" % name), wcurve_header_text(name)))
     for name in BUILT_CURVES:
         text = curve_header_text(name)
         path = os.path.join(out_dir, "curve_%s.h" % name)
