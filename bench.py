@@ -78,12 +78,18 @@ def cpu_baseline(n_log2=LOG2_ELEMS, min_seconds=6.0):
     t0 = time.perf_counter()
     oracle.lib.oracle_parallel(3, vp(k), vp(u), vp(o), m, 0, cores)
     ldt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.lib.oracle_parallel(3, vp(k), vp(u), vp(o), 256, 0, 1)       # one thread, for the effective parallelism
+    l1 = 256 / (time.perf_counter() - t0)
     return {
         "value": thr, "unit": "modmul/s", "cores": cores, "kind": "port",
         "sample": "oracle modmul_X25519 over the 2^%d-element workload x %d passes, %d threads, %.1f s wall" % (n_log2, passes, cores, dt),
         "time_c_protocol": {"ns_per_modmul": lat * 1e9, "modmul_per_s": 1.0 / lat, "cores": 1, "dependent_modmuls": 10**8,
                             "check_word": hex(chk), "reference_check_word": "0x116640"},
         "x25519_scalar_mults_per_s": m / ldt, "x25519_sample": "%d ladders, %d threads, %.1f s wall" % (m, cores, ldt),
+        "x25519_one_thread_per_s": l1,
+        "effective_parallelism": {"x25519": (m / ldt) / l1, "modmul": thr * lat,
+                                  "note": "all-thread rate / one-thread rate; well below `cores` when the host is shared or the CPU quota is smaller than the visible core count (modmul over 2 GB of SoA arrays is also DRAM-bound)"},
     }
 
 
