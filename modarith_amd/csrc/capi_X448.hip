@@ -5,4 +5,5 @@
 #define MA_NAME X448
 #define MA_LADDER_A24 39081
 #define MA_LADDER_COF 2
+#define MA_LADDER_FE28 1
 #include "capi_prime.inc"

@@ -1,0 +1,250 @@
+// modarith_amd/csrc/fe28.h -- GF(2^448 - 2^224 - 1) in sixteen 28-bit limbs for the fused X448 ladder on gfx950.
+//
+// Same idea as fe26.h: rfc7748() ends in modexp (full redc), so only canonical bytes leave the kernel and the
+// internal limb form is free.  With limbs below 2^32 every partial product is one v_mad_u64_u32 into a 64-bit
+// column register (256 per multiplication, 136 per squaring) instead of four plus a 128-bit fix-up for the
+// 56-bit limbs of the bit-exact field.
+//
+// Radix 2^28, value = sum f_i 2^(28 i), phi = 2^224 is limb 8, 2^448 = phi + 1 (mod p).
+// "tight" = as left by carry(): f_i < 2^28 (f_1, f_9 < 2^28 + 2^9).  add() of tight operands gives limbs < 2^29;
+// sub() adds 2p and carries back to tight.  mul()/sqr() accept limbs < 2^29 on both sides: the raw columns
+// c_0..c_30 hold at most 16 products of 2^58, and the folded column r_m = c_m + c_{m+8} + 2 c_{m+16} (m >= 8) or
+// c_m + c_{m+16} + c_{m+24} (m < 8) at most 38 of them: < 2^63.3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "field.h"
+
+namespace ma {
+
+struct Fe28 {
+    static constexpr uint32_t M28 = (1u << 28) - 1;
+
+    // fold the 31 raw columns (2^448 = 2^224 + 1) and carry to tight limbs
+    static MA_DEV void reduce(const uint64_t* c, uint32_t* r) {
+        uint64_t h[16];
+        static_for<0, 16>([&](auto MM) {
+            constexpr int m = MM;
+            uint64_t v = c[m];
+            if constexpr (m < 8) {
+                v += c[m + 16];
+                if constexpr (m + 24 <= 30) v += c[m + 24];
+            } else {
+                v += c[m + 8];
+                if constexpr (m + 16 <= 30) v += 2 * c[m + 16];
+            }
+            h[m] = v;
+        });
+        carry(h, r);
+    }
+
+    // sixteen 64-bit columns -> tight limbs; the carry out of limb 15 re-enters at limbs 0 and 8
+    static MA_DEV void carry(uint64_t* h, uint32_t* r) {
+        static_for<0, 15>([&](auto I) {
+            constexpr int i = I;
+            h[i + 1] += h[i] >> 28;
+            r[i] = (uint32_t)h[i] & M28;
+        });
+        const uint64_t top = h[15] >> 28;          // < 2^36
+        r[15] = (uint32_t)h[15] & M28;
+        const uint64_t h0 = (uint64_t)r[0] + top;
+        const uint64_t h8 = (uint64_t)r[8] + top;
+        r[0] = (uint32_t)h0 & M28;
+        r[1] += (uint32_t)(h0 >> 28);
+        r[8] = (uint32_t)h8 & M28;
+        r[9] += (uint32_t)(h8 >> 28);
+    }
+
+    static MA_DEV void mul(const uint32_t* f, const uint32_t* g, uint32_t* r) {
+        uint64_t c[31];
+        static_for<0, 31>([&](auto KK) {
+            constexpr int k = KK;
+            constexpr int lo = k < 16 ? 0 : k - 15, hi = k < 16 ? k : 15;
+            uint64_t acc = 0;
+            static_for<lo, hi + 1>([&](auto II) {
+                constexpr int i = II;
+                acc += (uint64_t)f[i] * g[k - i];
+            });
+            c[k] = acc;
+        });
+        reduce(c, r);
+    }
+
+    static MA_DEV void sqr(const uint32_t* f, uint32_t* r) {
+        uint32_t f2[16];
+        static_for<0, 16>([&](auto I) { f2[I] = 2u * f[I]; });
+        uint64_t c[31];
+        static_for<0, 31>([&](auto KK) {
+            constexpr int k = KK;
+            constexpr int lo = k < 16 ? 0 : k - 15, hi = k < 16 ? k : 15;
+            uint64_t acc = 0;
+            static_for<lo, hi + 1>([&](auto II) {
+                constexpr int i = II;
+                constexpr int j = k - i;
+                if constexpr (i < j) acc += (uint64_t)f2[i] * f[j];
+                else if constexpr (i == j) acc += (uint64_t)f[i] * f[i];
+            });
+            c[k] = acc;
+        });
+        reduce(c, r);
+    }
+
+    template <uint32_t C>
+    static MA_DEV void mul_small(const uint32_t* f, uint32_t* r) {
+        uint64_t h[16];
+        static_for<0, 16>([&](auto I) { h[I] = (uint64_t)f[I] * C; });
+        carry(h, r);
+    }
+
+    static MA_DEV void add(const uint32_t* f, const uint32_t* g, uint32_t* r) {
+        static_for<0, 16>([&](auto I) { r[I] = f[I] + g[I]; });
+    }
+    // r = f - g + 2p, carried back to tight (limbs of 2p: 2^29-2, limb 8: 2^29-4)
+    static MA_DEV void sub(const uint32_t* f, const uint32_t* g, uint32_t* r) {
+        uint64_t h[16];
+        static_for<0, 16>([&](auto I) {
+            constexpr int i = I;
+            constexpr uint32_t twop = (i == 8) ? 0x1ffffffcu : 0x1ffffffeu;
+            h[i] = (uint64_t)((f[i] + twop) - g[i]);
+        });
+        carry(h, r);
+    }
+    static MA_DEV void cswap(uint32_t mask, uint32_t* f, uint32_t* g) {
+        static_for<0, 16>([&](auto I) {
+            uint32_t t = (f[I] ^ g[I]) & mask;
+            f[I] ^= t;
+            g[I] ^= t;
+        });
+    }
+    static MA_DEV void copy(const uint32_t* f, uint32_t* r) { static_for<0, 16>([&](auto I) { r[I] = f[I]; }); }
+    static MA_DEV void set(uint32_t v, uint32_t* r) { static_for<0, 16>([&](auto I) { r[I] = (I == 0) ? v : 0u; }); }
+    static MA_DEV void sqn(uint32_t* f, int n) {
+#pragma unroll 1
+        for (int i = 0; i < n; i++) sqr(f, f);
+    }
+
+    // z^(p-2), p-2 = 2^448 - 2^224 - 3 = [223 ones][0][222 ones][0][1]: 447 squarings + 13 multiplications
+    static MA_DEV void invert(const uint32_t* z, uint32_t* out) {
+        uint32_t a[16], b[16], d[16];
+        sqr(z, a);   mul(a, z, a);                    // 2^2-1
+        sqr(a, b);   mul(b, z, b);                    // 2^3-1
+        copy(b, a);  sqn(a, 3);   mul(a, b, a);       // 2^6-1
+        copy(a, d);  sqn(d, 6);   mul(d, a, d);       // 2^12-1
+        copy(d, a);  sqn(a, 12);  mul(a, d, a);       // 2^24-1
+        sqn(a, 3);                mul(a, b, a);       // 2^27-1
+        copy(a, d);  sqn(d, 27);  mul(d, a, d);       // 2^54-1
+        copy(d, a);  sqn(a, 54);  mul(a, d, a);       // 2^108-1
+        sqn(a, 3);                mul(a, b, a);       // 2^111-1
+        copy(a, d);  sqn(d, 111); mul(d, a, d);       // 2^222-1   (d)
+        sqr(d, a);                mul(a, z, a);       // 2^223-1   (a)
+        sqn(a, 223);              mul(a, d, a);       // [223 ones][0][222 ones]
+        sqn(a, 2);                mul(a, z, out);     // ... [0][1]
+    }
+
+    // 448-bit little-endian integer in seven 64-bit words -> limbs (tight)
+    static MA_DEV void from_words(const uint64_t* w, uint32_t* r) {
+        static_for<0, 16>([&](auto I) {
+            constexpr int i = I;
+            constexpr int o = 28 * i, wi = o / 64, sh = o % 64;
+            uint64_t v = w[wi] >> sh;
+            if constexpr (sh + 28 > 64 && wi + 1 < 7) v |= w[wi + 1] << (64 - sh);
+            r[i] = (uint32_t)v & M28;
+        });
+    }
+    // canonical export: value mod p as seven little-endian 64-bit words
+    static MA_DEV void to_words(const uint32_t* f, uint64_t* w) {
+        uint64_t h[16];
+        uint32_t t[16], u[16];
+        static_for<0, 16>([&](auto I) { h[I] = f[I]; });
+        carry(h, t);
+        static_for<0, 16>([&](auto I) { h[I] = t[I]; });
+        carry(h, t);                                   // every limb < 2^28 except t1/t9 by at most 1; value < 2^448 + small
+        // u = t + 2^224 + 1; q = carry out of bit 448  <=>  t >= p
+        uint32_t c = 1;
+        static_for<0, 16>([&](auto I) {
+            constexpr int i = I;
+            uint32_t s = t[i] + c + ((i == 8) ? 1u : 0u);
+            u[i] = s & M28;
+            c = s >> 28;
+        });
+        const uint32_t mask = 0u - c;                  // all ones if t >= p: take u (= t - p), else keep t
+        // t may still hold a limb equal to 2^28 (t1 / t9): normalise it with one more pass before selecting
+        uint32_t cc = 0;
+        static_for<0, 16>([&](auto I) {
+            constexpr int i = I;
+            uint32_t s = t[i] + cc;
+            t[i] = s & M28;
+            cc = s >> 28;
+        });
+        static_for<0, 16>([&](auto I) { t[I] = (u[I] & mask) | (t[I] & ~mask); });
+        static_for<0, 7>([&](auto K) { w[K] = 0; });
+        static_for<0, 16>([&](auto I) {
+            constexpr int i = I;
+            constexpr int o = 28 * i, wi = o / 64, sh = o % 64;
+            w[wi] |= (uint64_t)t[i] << sh;
+            if constexpr (sh + 28 > 64 && wi + 1 < 7) w[wi + 1] |= (uint64_t)t[i] >> (64 - sh);
+        });
+    }
+};
+
+// Batched X448 (rfc7748.c:156-256 per element, A24 = 39081, COF = 2) on the fe28 representation.
+__global__ __launch_bounds__(256, 2) void k_x448_fe28(const uint64_t* bk, const uint64_t* bu, uint64_t* bv, size_t n) {
+    using F = Fe28;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        uint64_t kw[7], uw[7];
+        static_for<0, 7>([&](auto K) { kw[K] = bk[t * 7 + K]; });
+        static_for<0, 7>([&](auto K) { uw[K] = bu[t * 7 + K]; });
+        kw[0] &= ~3ull;                                       // clamp (rfc7748.c:135-141): Nbits % 8 == 0
+        kw[6] |= 0x8000000000000000ull;                       // bit 447 set; already left-aligned
+
+        uint32_t x1[16], x2[16], z2[16], x3[16], z3[16];
+        F::from_words(uw, x1);
+        F::set(1, x2);
+        F::set(0, z2);
+        F::copy(x1, x3);
+        F::set(1, z3);
+
+        uint32_t swap = 0;
+#pragma unroll 1
+        for (int step = 0; step < 448; step++) {
+            const uint32_t kt = (uint32_t)(kw[6] >> 63);
+            static_for<0, 7>([&](auto KK) {
+                constexpr int k = 6 - KK;
+                kw[k] <<= 1;
+                if constexpr (k > 0) kw[k] |= kw[k - 1] >> 63;
+            });
+            swap ^= kt;
+            F::cswap(0u - swap, x2, x3);
+            F::cswap(0u - swap, z2, z3);
+            swap = kt;
+            uint32_t A[16], B[16], C[16], D[16], AA[16], BB[16], E[16];
+            F::add(x2, z2, A);
+            F::add(x3, z3, C);
+            F::sub(x2, z2, B);
+            F::sub(x3, z3, D);
+            F::sqr(A, AA);
+            F::sqr(B, BB);
+            F::mul(D, A, D);
+            F::mul(C, B, C);
+            F::sub(D, C, z3);
+            F::sub(AA, BB, E);
+            F::mul_small<39081>(E, z2);
+            F::add(D, C, x3);
+            F::add(z2, AA, z2);
+            F::mul(z2, E, z2);
+            F::sqr(x3, x3);
+            F::sqr(z3, z3);
+            F::mul(z3, x1, z3);
+            F::mul(AA, BB, x2);
+        }
+        F::cswap(0u - swap, x2, x3);
+        F::cswap(0u - swap, z2, z3);
+        F::invert(z2, z2);
+        F::mul(x2, z2, x2);
+        uint64_t ow[7];
+        F::to_words(x2, ow);
+        static_for<0, 7>([&](auto K) { bv[t * 7 + K] = ow[K]; });
+    }
+}
+
+}  // namespace ma
