@@ -234,7 +234,7 @@ struct CurveOps {
 
 // ---------------------------------------------------------------- kernels
 template <class Crv>
-__global__ __launch_bounds__(64) void k_ed_mul(const spint* e, spint* Pb, size_t n, size_t ld, spint* ws) {
+__global__ __launch_bounds__(64, 2) void k_ed_mul(const spint* e, spint* Pb, size_t n, size_t ld, spint* ws) {
     using E = Crv;
     const size_t lanes = (size_t)gridDim.x * blockDim.x;
     const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64) void k_ed_mul(const spint* e, spint* Pb, size_t
 }
 
 template <class Crv>
-__global__ __launch_bounds__(64) void k_ed_mul2(const spint* e, const spint* Pb, const spint* f, const spint* Qb, spint* Rb,
+__global__ __launch_bounds__(64, 2) void k_ed_mul2(const spint* e, const spint* Pb, const spint* f, const spint* Qb, spint* Rb,
                                                 size_t n, size_t ld, spint* ws) {
     using E = Crv;
     const size_t lanes = (size_t)gridDim.x * blockDim.x;
