@@ -15,7 +15,7 @@ namespace ma {
 template <class Crv, class P_>
 struct CurveOps {
     using P = P_;
-    using F = Field<P>;
+    using F = Field<P, true>;   // FAST product path where the driver proved it (P::SPLIT > 0), else exact
     static constexpr int N = P::N;
     static constexpr int NB = P::NBYTES;
     static constexpr int NW = NB / 8;

@@ -36,12 +36,51 @@ MA_DEV void static_for(Fn&& fn) {
 // v_mad_u64_u32 plus carries.
 MA_DEV dpint mulw(spint a, spint b) { return (dpint)a * (dpint)b; }
 
-template <class P>
+// Column-sum policies.  Exact: every partial product is a full 64x64->128 multiply added into a 128-bit
+// accumulator, identical to the reference for ALL inputs.  Split (FAST): operands are cut once at bit H into two
+// 32-bit halves and the four half-products of a limb product go straight into three 64-bit accumulators
+// (s0 + s1*2^H + s2*2^2H), one v_mad_u64_u32 each and no cross-word carries; the column value is the same
+// integer, hence the same result, as long as every limb is below 2^(RADIX+2) -- which covers everything the
+// reference's own functions produce or accept (tight, [p,2p) with the top limb unmasked, generic=False sums).
+// The driver (emit.py) proves the accumulator bounds per prime and sets P::SPLIT (0 = not available).
+template <bool FAST, int H>
+struct Wide;
+template <int H>
+struct Wide<false, H> {
+    using Opd = spint;
+    static MA_DEV Opd prep(spint a) { return a; }
+    struct Col {
+        dpint t = 0;
+        MA_DEV void mac(Opd a, Opd b) { t += (dpint)a * (dpint)b; }
+        MA_DEV dpint sum() const { return t; }
+    };
+};
+template <int H>
+struct Wide<true, H> {
+    struct Opd { uint32_t lo, hi; };
+    static MA_DEV Opd prep(spint a) { return Opd{(uint32_t)a & ((1u << H) - 1u), (uint32_t)(a >> H)}; }
+    struct Col {
+        uint64_t s0 = 0, s1 = 0, s2 = 0;
+        MA_DEV void mac(Opd a, Opd b) {
+            s0 += (uint64_t)a.lo * b.lo;
+            s1 += (uint64_t)a.lo * b.hi;
+            s1 += (uint64_t)a.hi * b.lo;
+            s2 += (uint64_t)a.hi * b.hi;
+        }
+        MA_DEV dpint sum() const { return (dpint)s0 + ((dpint)s1 << H) + ((dpint)s2 << (2 * H)); }
+    };
+};
+
+template <class P, bool FAST_ = false>
 struct Field {
     static constexpr int N = P::N;
     static constexpr int RADIX = P::RADIX;
     static constexpr spint Q = (spint)1 << RADIX;
     static constexpr spint MASK = Q - 1;
+    static constexpr bool FAST = FAST_ && (P::SPLIT > 0);
+    using W = Wide<FAST, (P::SPLIT > 0 ? P::SPLIT : 32)>;
+    using Opd = typename W::Opd;
+    using Col = typename W::Col;
 
     // ---------------------------------------------------------------- carries / normalisation
     // pseudo.py:223-251, monty.py:352-380 (arithmetic-shift form)
@@ -180,28 +219,32 @@ struct Field {
         static_assert(!P::OVERFLOW, "the overflow variants of pseudo.py are not built");
         dpint t = 0;
         spint v[N];
-        spint ma[N];
-        if constexpr (P::EPM) static_for<1, N>([&](auto I) { ma[I] = a[I] * (spint)P::MM; });
+        Opd A[N], B[N], MA[N];
+        static_for<0, N>([&](auto I) { A[I] = W::prep(a[I]); B[I] = W::prep(b[I]); });
+        if constexpr (P::EPM) static_for<1, N>([&](auto I) { MA[I] = W::prep(a[I] * (spint)P::MM); });
         static_for<0, N>([&](auto ROW) {
             constexpr int row = ROW;
+            Col col;
             if constexpr (P::EPM) {
                 static_for<row + 1, N>([&](auto K) {
                     constexpr int k = K;
-                    t += mulw(ma[k], b[N + row - k]);
+                    col.mac(MA[k], B[N + row - k]);
                 });
             } else if constexpr (row < N - 1) {
-                dpint tt = 0;
+                Col hi;
                 static_for<row + 1, N>([&](auto K) {
                     constexpr int k = K;
-                    tt += mulw(a[k], b[N + row - k]);
+                    hi.mac(A[k], B[N + row - k]);
                 });
+                dpint tt = hi.sum();
                 tt *= (dpint)P::MM;
                 t += tt;
             }
             static_for<0, row + 1>([&](auto K) {
                 constexpr int k = K;
-                t += mulw(a[k], b[row - k]);
+                col.mac(A[k], B[row - k]);
             });
+            t += col.sum();
             v[row] = (spint)t & MASK;
             t >>= RADIX;
         });
@@ -213,34 +256,38 @@ struct Field {
         static_assert(!P::OVERFLOW, "the overflow variants of pseudo.py are not built");
         dpint t = 0;
         spint v[N];
-        spint ta[N], ma[N];
+        Opd A[N], TA[N], MA[N];
+        static_for<0, N>([&](auto I) { A[I] = W::prep(a[I]); });
         if constexpr (P::EPM) {
-            static_for<1, N>([&](auto I) { ta[I] = a[I] * (spint)2; });
-            static_for<1, N>([&](auto I) { ma[I] = a[I] * (spint)P::MM; });
+            static_for<1, N>([&](auto I) { TA[I] = W::prep(a[I] * (spint)2); });
+            static_for<1, N>([&](auto I) { MA[I] = W::prep(a[I] * (spint)P::MM); });
         }
         static_for<0, N>([&](auto ROW) {
             constexpr int row = ROW;
             // folded (high) part: pairs (k, l) with k + l = N + row, row < k <= l < N
             constexpr int hk0 = row + 1, hpairs = (N - 1 - hk0 + 1) / 2;  // strict pairs k < l
+            Col col;
             if constexpr (P::EPM) {
                 static_for<0, hpairs>([&](auto J) {
                     constexpr int k = hk0 + J, l = N - 1 - J;
-                    t += mulw(ma[k], ta[l]);
+                    col.mac(MA[k], TA[l]);
                 });
                 if constexpr ((N - hk0) % 2 == 1) {
                     constexpr int k = hk0 + hpairs;
-                    t += mulw(ma[k], a[k]);
+                    col.mac(MA[k], A[k]);
                 }
             } else if constexpr (row < N - 1) {
-                dpint tt = 0;
+                Col cross, sq;
                 static_for<0, hpairs>([&](auto J) {
                     constexpr int k = hk0 + J, l = N - 1 - J;
-                    tt += mulw(a[k], a[l]);
+                    cross.mac(A[k], A[l]);
                 });
+                dpint tt = cross.sum();
                 if constexpr (hpairs > 0) tt *= 2;
                 if constexpr ((N - hk0) % 2 == 1) {
                     constexpr int k = hk0 + hpairs;
-                    tt += mulw(a[k], a[k]);
+                    sq.mac(A[k], A[k]);
+                    tt += sq.sum();
                 }
                 tt *= (dpint)P::MM;
                 t += tt;
@@ -250,17 +297,22 @@ struct Field {
             if constexpr (P::EPM) {
                 static_for<0, lpairs>([&](auto J) {
                     constexpr int k = J, l = row - J;
-                    t += mulw(a[k], ta[l]);
+                    col.mac(A[k], TA[l]);
                 });
-                if constexpr (row % 2 == 0) t += mulw(a[row / 2], a[row / 2]);
+                if constexpr (row % 2 == 0) col.mac(A[row / 2], A[row / 2]);
+                t += col.sum();
             } else {
-                dpint t2 = 0;
+                Col cross, sq;
                 static_for<0, lpairs>([&](auto J) {
                     constexpr int k = J, l = row - J;
-                    t2 += mulw(a[k], a[l]);
+                    cross.mac(A[k], A[l]);
                 });
+                dpint t2 = cross.sum();
                 if constexpr (lpairs > 0) t2 *= 2;
-                if constexpr (row % 2 == 0) t2 += mulw(a[row / 2], a[row / 2]);
+                if constexpr (row % 2 == 0) {
+                    sq.mac(A[row / 2], A[row / 2]);
+                    t2 += sq.sum();
+                }
                 t += t2;
             }
             v[row] = (spint)t & MASK;
@@ -289,7 +341,7 @@ struct Field {
     static constexpr int JMAX = LMAX;                                   // highest digit index
 
     template <int C>
-    static MA_DEV void monty_reduce(dpint& t, const spint* v) {
+    static MA_DEV void monty_reduce(dpint& t, Col& col, const spint* v, const Opd* V) {
         constexpr int NEG = P::NEG_LIMB;       // index (>=1) of the single -1 limb, or 0 if none
         constexpr bool scratch = (NEG > 0) && (C > NEG);  // gone_neg at column start -> s = mask
         spint s = MASK;
@@ -303,7 +355,7 @@ struct Field {
                         constexpr int e = __builtin_ctzll((unsigned long long)d);
                         t += (dpint)v[j] << e;
                     } else {
-                        t += mulw(v[j], (spint)d);
+                        col.mac(V[j], W::prep((spint)d));
                     }
                 } else if constexpr (d == 1) {
                     if constexpr (scratch) s += v[j]; else t += (dpint)v[j];
@@ -326,7 +378,13 @@ struct Field {
         } else {
             static_assert(P::ppw(0) > 0, "full Montgomery reduction expects a positive low prime limb");
             const spint v = ((spint)t * (spint)P::NDASH) & MASK;
-            if constexpr (P::ppw(0) == 1) t += (dpint)v; else t += mulw(v, (spint)P::ppw(0));
+            if constexpr (P::ppw(0) == 1) {
+                t += (dpint)v;
+            } else {
+                Col c0;
+                c0.mac(W::prep(v), W::prep((spint)P::ppw(0)));
+                t += c0.sum();
+            }
             return v;
         }
     }
@@ -336,33 +394,44 @@ struct Field {
         constexpr int NCOL = P::E ? 2 * N : 2 * N - 1;
         dpint t = 0;
         spint v[JMAX + 1];
+        Opd V[JMAX + 1];
+        Opd A[N], B[N];
+        static_for<0, N>([&](auto I) { A[I] = W::prep(a[I]); });
+        if constexpr (!SQR) static_for<0, N>([&](auto I) { B[I] = W::prep(b[I]); });
         static_for<0, NCOL>([&](auto CC) {
             constexpr int col = CC;
             constexpr int lo = col < N ? 0 : col - (N - 1);
             constexpr int hi = col < N ? col : N - 1;
+            Col acc;
             if constexpr (lo <= hi) {
                 if constexpr (!SQR) {
                     // getZMU / getZMD (monty.py:493-537)
                     static_for<lo, hi + 1>([&](auto K) {
                         constexpr int k = K;
-                        t += mulw(a[k], b[col - k]);
+                        acc.mac(A[k], B[col - k]);
                     });
                 } else {
                     // getZSU / getZSD (monty.py:540-590): tot = 2*sum(cross) + square
                     constexpr int pairs = (hi - lo + 1) / 2;
-                    dpint tot = 0;
+                    Col cross;
                     static_for<0, pairs>([&](auto J) {
                         constexpr int k = lo + J;
-                        tot += mulw(a[k], a[col - k]);
+                        cross.mac(A[k], A[col - k]);
                     });
+                    dpint tot = cross.sum();
                     if constexpr (pairs > 0) tot *= 2;
-                    if constexpr (col % 2 == 0) tot += mulw(a[col / 2], a[col / 2]);
                     t += tot;
+                    if constexpr (col % 2 == 0) acc.mac(A[col / 2], A[col / 2]);
                 }
             }
-            monty_reduce<col>(t, v);
-            if constexpr (col <= JMAX) v[col] = monty_digit(t);
-            else c[col - JMAX - 1] = (spint)t & MASK;
+            monty_reduce<col>(t, acc, v, V);
+            t += acc.sum();
+            if constexpr (col <= JMAX) {
+                v[col] = monty_digit(t);
+                V[col] = W::prep(v[col]);
+            } else {
+                c[col - JMAX - 1] = (spint)t & MASK;
+            }
             t >>= RADIX;
         });
         if constexpr (P::E) {
@@ -400,7 +469,7 @@ struct Field {
             t += (dpint)a[N - 1] * bw;
             c[N - 1] = (spint)t;
             spint h = (spint)(t >> P::BARRETT_SHIFT);
-            spint q = (spint)((mulw(h, (spint)P::BARRETT_R)) >> 64);
+            spint q = (spint)(((dpint)h * (dpint)(spint)P::BARRETT_R) >> 64);
             bool propc = P::ppw(0) > 0;
             static_for<0, N>([&](auto I) {
                 constexpr int i = I;
@@ -419,7 +488,7 @@ struct Field {
                     }
                 } else if constexpr (d > 1) {
                     if constexpr (i < N - 1) {
-                        dpint w = mulw(q, (spint)d);
+                        dpint w = (dpint)q * (dpint)(spint)d;
                         c[i] -= (spint)w & MASK;
                         c[i + 1] -= (spint)(w >> RADIX);
                     } else {
@@ -478,7 +547,7 @@ struct Field {
     static __device__ __attribute__((noinline)) void modpro(const spint* w, spint* z) {
         spint x[N], r[N];
         modcpy(w, x);
-        P::template modpro_chain<Field<P>>(x, r);
+        P::template modpro_chain<Field<P, FAST_>>(x, r);
         modcpy(r, z);
     }
 

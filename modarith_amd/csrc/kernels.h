@@ -65,18 +65,18 @@ __device__ __forceinline__ void store_soa(spint* base, size_t ld, size_t t, spin
 }
 
 // ---- operation functors: apply() works on register-resident elements
-template <class P> struct OpMul { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P>::modmul(a, b, c); } };
+template <class P, bool FAST = false> struct OpMul { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P, FAST>::modmul(a, b, c); } };
 template <class P> struct OpAdd { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P>::modadd(a, b, c); } };
 template <class P> struct OpSub { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P>::modsub(a, b, c); } };
 template <class P> struct OpAddLazy { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P>::modadd_lazy(a, b, c); } };
 template <class P> struct OpSubLazy { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P>::modsub_lazy(a, b, c); } };
-template <class P> struct OpSqr { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modsqr(a, c); } };
+template <class P, bool FAST = false> struct OpSqr { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::modsqr(a, c); } };
 template <class P> struct OpNeg { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modneg(a, c); } };
 template <class P> struct OpNegLazy { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modneg_lazy(a, c); } };
-template <class P> struct OpNres { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::nres(a, c); } };
-template <class P> struct OpRedc { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::redc(a, c); } };
+template <class P, bool FAST = false> struct OpNres { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::nres(a, c); } };
+template <class P, bool FAST = false> struct OpRedc { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::redc(a, c); } };
 template <class P> struct OpCpy { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modcpy(a, c); } };
-template <class P> struct OpInv { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modinv(a, nullptr, c); } };
+template <class P, bool FAST = false> struct OpInv { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::modinv(a, nullptr, c); } };
 template <class P> struct OpSqrt { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modsqrt(a, nullptr, c); } };
 template <class P> struct OpPro { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modpro(a, c); } };
 

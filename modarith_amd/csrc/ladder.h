@@ -16,7 +16,7 @@ namespace ma {
 
 template <class P, int A24, int COF>
 __global__ __launch_bounds__(256) void k_rfc7748(const spint* bk, const spint* bu, spint* bv, size_t n) {
-    using F = Field<P>;
+    using F = Field<P, true>;   // FAST product path where available: every input of a field call is in contract here
     constexpr int N = P::N, NW = F::NW, NBITS = P::NBITS;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         spint kw[NW], uw[NW];

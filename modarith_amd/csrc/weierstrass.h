@@ -13,7 +13,7 @@ template <class C>
 struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
     using Base = CurveOps<Weierstrass<C>, typename C::FieldParams>;
     using P = typename C::FieldParams;
-    using F = Field<P>;
+    using F = Field<P, true>;
     using Point = typename Base::Point;
     using Base::cmv;
     using Base::cpy;

@@ -177,6 +177,29 @@ def _switch(name: str, ctype: str, values, fmt) -> str:
     return "    static constexpr %s %s(int i) { switch (i) { %s default: return 0; } }" % (ctype, name, body)
 
 
+def split_point(fp: FieldParams) -> int:
+    """Bit position H at which csrc/field.h's FAST product path cuts operands into 32-bit halves, or 0 if the
+    three 64-bit column accumulators (s0 + s1*2^H + s2*2^2H) cannot be proven overflow-free for this prime.
+    Contract: every limb < 2^(radix+2) (tight limbs, [p,2p) with the top limb unmasked, generic=False sums);
+    pre-multiplied operands (ma = mm*a, ta = 2a) are wider by bits(mm) / 1 bit.  n = most products per column."""
+    W = fp.radix + 2
+    if fp.family == "pseudo":
+        wa = W + (fp.mm.bit_length() if fp.epm else 0)
+        wb = W + (1 if fp.epm else 0)
+        n = fp.nlimbs
+    else:
+        wa, wb, n = W, W, 2 * fp.nlimbs
+    lim = 1 << 64
+    best, best_cost = 0, None
+    for H in range(20, 33):
+        if wa - H > 32 or wb - H > 32:
+            continue
+        s0, s1, s2 = n << (2 * H), n * ((1 << wa) + (1 << wb)), n << max(wa + wb - 2 * H, 0)
+        if s0 < lim and s1 < lim and s2 < lim and (best_cost is None or max(s0, s2) < best_cost):
+            best, best_cost = H, max(s0, s2)
+    return best
+
+
 def header_text(fp: FieldParams) -> str:
     N = fp.nlimbs
     prog = addition_chain(fp.pe)
@@ -192,6 +215,7 @@ def header_text(fp: FieldParams) -> str:
     L.append("    static constexpr int N = %d, RADIX = %d, NBITS = %d, NBYTES = %d, XCESS = %d, PM1D2 = %d;"
              % (N, fp.radix, fp.n, fp.nbytes, fp.xcess, fp.pm1d2))
     L.append("    static constexpr bool MONTGOMERY = %s;" % ("true" if fp.montgomery else "false"))
+    L.append("    static constexpr int SPLIT = %d;   // FAST product path: operand cut position, 0 = not provable (emit.split_point)" % split_point(fp))
     # pseudo-Mersenne block (dummies for Montgomery primes)
     L.append("    static constexpr unsigned long long M = %s, MM = %s;" % (_hexu(fp.m if not fp.montgomery else 0), _hexu(fp.mm)))
     L.append("    static constexpr bool OVERFLOW = %s, FRED = %s, EPM = %s, CARRY_ON = %s;"
