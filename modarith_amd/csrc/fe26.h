@@ -42,26 +42,36 @@ struct Fe26 {
         r[1] += (uint32_t)(h0 >> 26);
     }
 
+    // Columns are computed in order and the carry out of column k is the INITIAL accumulator value of column
+    // k+1, so it rides for free in that column's first v_mad_u64_u32 (no separate 64-bit add per limb).
+    static MA_DEV void wrap(uint64_t c9, uint32_t* r) {
+        uint64_t h0 = (uint64_t)r[0] + 19 * c9;      // c9 < 2^38
+        r[0] = (uint32_t)h0 & M26;
+        r[1] += (uint32_t)(h0 >> 26);
+    }
     static MA_DEV void mul(const uint32_t* f, const uint32_t* g, uint32_t* r) {
         uint32_t g19[10], f2[10];
         static_for<1, 10>([&](auto J) { g19[J] = 19u * g[J]; });
         static_for<0, 5>([&](auto K) { f2[2 * K + 1] = 2u * f[2 * K + 1]; });
-        uint64_t h[10];
+        uint64_t c = 0;
+        uint32_t t[10];
         static_for<0, 10>([&](auto KK) {
             constexpr int k = KK;
-            uint64_t acc = 0;
+            uint64_t acc = c;
             static_for<0, 10>([&](auto II) {
                 constexpr int i = II;
                 constexpr int j = (k - i + 10) % 10;
-                constexpr bool wrap = (i + j) >= 10;
+                constexpr bool wrp = (i + j) >= 10;
                 constexpr bool dbl = (i & 1) && (j & 1);
                 const uint32_t a = dbl ? f2[i] : f[i];
-                const uint32_t b = wrap ? g19[j] : g[j];
+                const uint32_t b = wrp ? g19[j] : g[j];
                 acc += (uint64_t)a * b;
             });
-            h[k] = acc;
+            t[k] = (uint32_t)acc & ((k & 1) ? M25 : M26);
+            c = acc >> bits(k);
         });
-        carry(h, r);
+        static_for<0, 10>([&](auto I) { r[I] = t[I]; });
+        wrap(c, r);
     }
 
     static MA_DEV void sqr(const uint32_t* f, uint32_t* r) {
@@ -69,30 +79,33 @@ struct Fe26 {
         static_for<0, 10>([&](auto I) { f2[I] = 2u * f[I]; });
         static_for<5, 10>([&](auto J) { f19[J] = 19u * f[J]; });
         static_for<0, 3>([&](auto K) { f38[2 * K + 5] = 38u * f[2 * K + 5]; });   // odd j >= 5
-        uint64_t h[10];
+        uint64_t c = 0;
+        uint32_t t[10];
         static_for<0, 10>([&](auto KK) {
             constexpr int k = KK;
-            uint64_t acc = 0;
+            uint64_t acc = c;
             static_for<0, 10>([&](auto II) {
                 constexpr int i = II;
                 constexpr int j = (k - i + 10) % 10;
                 if constexpr (i <= j) {
-                    constexpr bool wrap = (i + j) >= 10;
+                    constexpr bool wrp = (i + j) >= 10;
                     constexpr bool odd2 = (i & 1) && (j & 1);
                     uint32_t a, b;
                     if constexpr (i == j) {
                         a = odd2 ? f2[i] : f[i];
-                        b = wrap ? f19[j] : f[j];
+                        b = wrp ? f19[j] : f[j];
                     } else {
                         a = f2[i];                               // symmetric term counted twice
-                        b = wrap ? (odd2 ? f38[j] : f19[j]) : (odd2 ? f2[j] : f[j]);
+                        b = wrp ? (odd2 ? f38[j] : f19[j]) : (odd2 ? f2[j] : f[j]);
                     }
                     acc += (uint64_t)a * b;
                 }
             });
-            h[k] = acc;
+            t[k] = (uint32_t)acc & ((k & 1) ? M25 : M26);
+            c = acc >> bits(k);
         });
-        carry(h, r);
+        static_for<0, 10>([&](auto I) { r[I] = t[I]; });
+        wrap(c, r);
     }
 
     // r = f * c for a small constant (a24 = 121665)

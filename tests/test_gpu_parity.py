@@ -366,3 +366,47 @@ def test_c_drop_in_example(torch_cuda, tmp_path):
     assert out[out.index("Alice shared secret") + 1] == g["ref_main_chain"]["dh"]["shared"]
     assert out[out.index("Bob's shared secret") + 1] == g["ref_main_chain"]["dh"]["shared"]
     assert out[-1] == "batched: equal"
+
+
+@pytest.mark.parametrize("P", EXTRA)
+def test_extra_primes_vs_generic_oracle(oracle, torch_cuda, P):
+    """the ten further primes: seeded batches against the run-time generic oracle (oracle/field_generic.c, itself
+    pinned to the reference's golden vectors by tests/test_generic_oracle.py)"""
+    from modarith_amd.field import Field
+    from modarith_amd.params import derive
+    from tests.generic_oracle import Generic
+    G = Generic(oracle.lib, P)
+    F = Field(P)
+    fp = derive(P)
+    n = 4099
+    rng = np.random.default_rng(77)
+    def rnd(seed_off):
+        out = rng.integers(0, 1 << fp.radix, size=(fp.nlimbs, n), dtype=np.uint64)
+        out[fp.nlimbs - 1] = rng.integers(0, 1 << (fp.n - fp.radix * (fp.nlimbs - 1)), size=n, dtype=np.uint64)
+        return np.ascontiguousarray(out)
+    a, b = rnd(0), rnd(1)
+    da, db = to_dev(a), to_dev(b)
+    def gen(op, x, y=None):
+        c = np.empty_like(x)
+        G.lib.gen_batch(G.R, op, vp(x), vp(y) if y is not None else None, vp(c), n, n)
+        return c
+    assert np.array_equal(to_np(F.modmul(da, db)), gen(0, a, b))
+    assert np.array_equal(to_np(F.modadd(da, db)), gen(1, a, b))
+    assert np.array_equal(to_np(F.modsub(da, db)), gen(2, a, b))
+    assert np.array_equal(to_np(F.modsqr(da)), gen(3, a))
+    assert np.array_equal(to_np(F.modneg(da)), gen(4, a))
+    assert np.array_equal(to_np(F.nres(da)), gen(5, a))
+    assert np.array_equal(to_np(F.redc(da)), gen(6, a))
+    for k in (3, 121665, 0x7fffffff):
+        c = np.empty_like(a)
+        G.lib.gen_batch_mli(G.R, vp(a), k, vp(c), n, n)
+        assert np.array_equal(to_np(F.modmli(da, k)), c)
+    m = 257
+    sa = np.ascontiguousarray(a[:, :m])
+    ci, cs = np.empty_like(sa), np.empty_like(sa)
+    G.lib.gen_batch(G.R, 7, vp(sa), None, vp(ci), m, m)
+    G.lib.gen_batch(G.R, 8, vp(sa), None, vp(cs), m, m)
+    red = lambda x: (lambda c: (G.lib.gen_batch(G.R, 6, vp(x), None, vp(c), m, m), c)[1])(np.empty_like(x))
+    dsa = to_dev(sa)
+    assert np.array_equal(to_np(F.redc(F.modinv(dsa))), red(ci))
+    assert np.array_equal(to_np(F.redc(F.modsqrt(dsa))), red(cs))
