@@ -410,3 +410,24 @@ def test_extra_primes_vs_generic_oracle(oracle, torch_cuda, P):
     dsa = to_dev(sa)
     assert np.array_equal(to_np(F.redc(F.modinv(dsa))), red(ci))
     assert np.array_equal(to_np(F.redc(F.modsqrt(dsa))), red(cs))
+
+
+def test_error_reporting(torch_cuda):
+    """the reference signals no errors; the shim reports only misuse it cannot execute: misaligned byte records,
+    a too-small ecn workspace.  The message is retrievable and the call leaves no sticky device error."""
+    import torch
+    from modarith_amd import _lib
+    lib = _lib.load()
+    buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    rc = lib.rfc7748_X25519_batch(buf.data_ptr() + 1, buf.data_ptr(), out.data_ptr(), 4, None)
+    assert rc != 0 and b"aligned" in lib.modarith_amd_last_error()
+    P = torch.zeros((3, 5, 8), dtype=torch.int64, device="cuda")
+    rc = lib.ecn_ed25519_mul_batch(buf.data_ptr(), P.data_ptr(), 8, 8, None, 0, None)
+    assert rc != 0 and b"workspace" in lib.modarith_amd_last_error()
+    with pytest.raises(_lib.DeviceError):
+        _lib.check(rc, "ecn_ed25519_mul_batch")
+    # a correct call afterwards works
+    from modarith_amd.field import Field
+    F = Field("X25519")
+    assert F.modis0(F.modzer(3)).cpu().tolist() == [1, 1, 1]

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of a host-resident batch (for DESIGN.md section 5; never the bench `value`):
+pinned host SoA operands -> H2D, modmul, D2H of the result, 2^24 elements of 2^255-19."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from modarith_amd.field import Field
+F = Field("X25519")
+n = 1 << 24
+ha = torch.randint(0, 1 << 51, (5, n), dtype=torch.int64).pin_memory()
+hb = torch.randint(0, 1 << 51, (5, n), dtype=torch.int64).pin_memory()
+hc = torch.empty((5, n), dtype=torch.int64).pin_memory()
+da, db, dc = torch.empty_like(ha, device="cuda"), torch.empty_like(hb, device="cuda"), torch.empty_like(hc, device="cuda")
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    da.copy_(ha, non_blocking=True); db.copy_(hb, non_blocking=True)
+    F.modmul(da, db, out=dc)
+    hc.copy_(dc, non_blocking=True)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("PCIe-inclusive: %.1f ms per 2^24 modmul = %.3e modmul/s (%.1f GB/s over the link)" % (dt * 1e3, n / dt, 120 * n / dt / 1e9))
