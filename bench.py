@@ -225,6 +225,30 @@ def main():
                   "gather_ms": gather_ms, "io_bytes_per_scalar": 96,
                   "bound": "VALU 32-bit integer multiply-add issue (not HBM)"}
 
+    verified = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        # spot-check the timed outputs against the CPU oracle (checker only, outside every timed region):
+        # first / last 4096 and a strided sample of the modmul batch and of the ladder records
+        import numpy as np
+        from tests.oracle_binding import load_oracle
+        from tests.util import vp
+        oracle = load_oracle(build=not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")))
+        idx = torch.cat([torch.arange(0, 4096), torch.arange(n - 4096, n), torch.arange(0, n, max(n // 4096, 1))]).unique().to(dev)
+        ha = np.ascontiguousarray(a[:, idx].cpu().numpy().view(np.uint64))
+        hb = np.ascontiguousarray(b[:, idx].cpu().numpy().view(np.uint64))
+        hc = np.empty_like(ha)
+        oracle.fn("batch_modmul", "X25519")(vp(ha), vp(hb), vp(hc), ha.shape[1], ha.shape[1])
+        assert np.array_equal(c[:, idx].cpu().numpy().view(np.uint64), hc), "modmul differs from the oracle"
+        verified = {"modmul_elements": int(idx.numel())}
+        if ladder is not None:
+            m = k.shape[0]
+            lidx = torch.cat([torch.arange(0, 4096), torch.arange(m - 4096, m), torch.arange(0, m, max(m // 2048, 1))]).unique().to(dev)
+            hk = np.ascontiguousarray(k[lidx].cpu().numpy()); hu = np.ascontiguousarray(u[lidx].cpu().numpy())
+            ho = np.empty_like(hu)
+            oracle.lib.oracle_parallel(3, vp(hk), vp(hu), vp(ho), hk.shape[0], 0, len(os.sched_getaffinity(0)))
+            assert np.array_equal(o[lidx].cpu().numpy(), ho), "rfc7748 differs from the oracle"
+            verified["x25519_records"] = int(lidx.numel())
+
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu:
@@ -246,6 +270,7 @@ def main():
             "cpu_baseline": cpu,
             "x25519": ladder,
             "other_configs": others,
+            "verified_against_oracle": verified,
         }
         print(json.dumps(out))
     if world > 1:
