@@ -628,7 +628,12 @@ struct Field {
     // (pseudo.py:979-1048; see oracle/field_common.inc for the algebra).
     static MA_DEV void modcmv(int b, const spint* g, spint* f) {
         const bool take = (b & 1) != 0;
-        static_for<0, N>([&](auto I) { f[I] = take ? g[I] : f[I]; });
+        // both values are loaded before the choice: `take ? g[I] : f[I]` is an lvalue conditional, i.e. a choice
+        // of ADDRESS, which sends private arrays to scratch behind flat pointers
+        static_for<0, N>([&](auto I) {
+            const spint x = g[I], y = f[I];
+            f[I] = take ? x : y;
+        });
     }
     static MA_DEV void modcsw(int b, spint* g, spint* f) {
         const bool take = (b & 1) != 0;
