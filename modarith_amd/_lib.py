@@ -11,7 +11,7 @@ import os
 from ctypes import c_char_p, c_int, c_size_t, c_uint, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmodarith_amd.so")
+LIB_PATH = os.environ.get("MA_LIB", os.path.join(HERE, "libmodarith_amd.so"))   # MA_LIB: a variant build under test
 PRIMES = ("X25519", "NIST256", "X448",
           "NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1", "NIST256Q", "ED25519Q", "ED448Q")
 LADDERS = ("X25519", "X448")

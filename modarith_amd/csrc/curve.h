@@ -70,7 +70,10 @@ struct CurveOps {
     static MA_DEV void select(int b, const Table& W, Point& p) {
         const int m = b >> 31;
         const int babs = (b ^ m) - m;
-#pragma unroll 1
+#ifndef MA_SELECT_UNROLL
+#define MA_SELECT_UNROLL 1
+#endif
+#pragma unroll MA_SELECT_UNROLL
         for (int k = 0; k <= 8; k++) {
             Point w;
             W.get(k, w);
@@ -233,8 +236,11 @@ struct CurveOps {
 };
 
 // ---------------------------------------------------------------- kernels
+#ifndef MA_MUL_WPS
+#define MA_MUL_WPS 2          // resident waves per SIMD the scalar-multiplication kernels are register-budgeted for
+#endif
 template <class Crv>
-__global__ __launch_bounds__(64, 2) void k_ed_mul(const spint* e, spint* Pb, size_t n, size_t ld, spint* ws) {
+__global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul(const spint* e, spint* Pb, size_t n, size_t ld, spint* ws) {
     using E = Crv;
     const size_t lanes = (size_t)gridDim.x * blockDim.x;
     const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(64, 2) void k_ed_mul(const spint* e, spint* Pb, siz
 }
 
 template <class Crv>
-__global__ __launch_bounds__(64, 2) void k_ed_mul2(const spint* e, const spint* Pb, const spint* f, const spint* Qb, spint* Rb,
+__global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul2(const spint* e, const spint* Pb, const spint* f, const spint* Qb, spint* Rb,
                                                 size_t n, size_t ld, spint* ws) {
     using E = Crv;
     const size_t lanes = (size_t)gridDim.x * blockDim.x;

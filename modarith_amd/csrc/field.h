@@ -69,6 +69,31 @@ struct Wide<true, H> {
         }
         MA_DEV dpint sum() const { return (dpint)s0 + ((dpint)s1 << H) + ((dpint)s2 << (2 * H)); }
     };
+    // The running column value t of the product loops ("t += products; v = t & mask; t >>= Radix") kept as
+    // t = c + s0 + s1*2^H + s2*2^2H and never assembled into 128 bits: c holds the previous column's t >> Radix
+    // plus the one-word terms.  digit() returns t & mask and leaves t >> Radix in c using 64-bit operations
+    // only; it needs Radix - H <= 32, Radix <= 2H < 64 and c + s0 + 2^Radix < 2^64, which the driver proves
+    // per prime (emit.chain_ok -> P::CHAIN) under the same limb contract as SPLIT.  Same integers, same limbs.
+    template <int R>
+    struct Acc {
+        uint64_t s0 = 0, s1 = 0, s2 = 0, c = 0;
+        MA_DEV void mac(Opd a, Opd b) {
+            s0 += (uint64_t)a.lo * b.lo;
+            s1 += (uint64_t)a.lo * b.hi;
+            s1 += (uint64_t)a.hi * b.lo;
+            s2 += (uint64_t)a.hi * b.hi;
+        }
+        MA_DEV void add(uint64_t x) { c += x; }
+        MA_DEV void add_twice(const Col& o) { s0 += o.s0 << 1; s1 += o.s1 << 1; s2 += o.s2 << 1; }
+        MA_DEV uint64_t low() const { return c + s0 + (s1 << H) + (s2 << (2 * H)); }   // t mod 2^64
+        MA_DEV uint64_t digit() {
+            constexpr int L = R - H;
+            const uint64_t lo = s0 + ((uint64_t)((uint32_t)s1 & (uint32_t)(((uint64_t)1 << L) - 1u)) << H) + c;
+            c = (lo >> R) + (s1 >> L) + (s2 << (2 * H - R));
+            s0 = s1 = s2 = 0;
+            return lo & (((uint64_t)1 << R) - 1u);
+        }
+    };
 };
 
 template <class P, bool FAST_ = false>
@@ -81,6 +106,7 @@ struct Field {
     using W = Wide<FAST, (P::SPLIT > 0 ? P::SPLIT : 32)>;
     using Opd = typename W::Opd;
     using Col = typename W::Col;
+    static constexpr bool CHAINED = FAST && P::CHAIN;    // product loops on the 64-bit column chain (Wide::Acc)
 
     // ---------------------------------------------------------------- carries / normalisation
     // pseudo.py:223-251, monty.py:352-380 (arithmetic-shift form)
@@ -321,6 +347,58 @@ struct Field {
         pm_second_pass(t, v, c);
     }
 
+    // the same rows on the 64-bit column chain (EPM primes; see Wide::Acc)
+    static MA_DEV void pm_modmul_chain(const spint* a, const spint* b, spint* c) {
+        static_assert(P::EPM && !P::OVERFLOW, "chained products are built for the EPM form only");
+        typename W::template Acc<RADIX> t;
+        spint v[N];
+        Opd A[N], B[N], MA[N];
+        static_for<0, N>([&](auto I) { A[I] = W::prep(a[I]); B[I] = W::prep(b[I]); });
+        static_for<1, N>([&](auto I) { MA[I] = W::prep(a[I] * (spint)P::MM); });
+        static_for<0, N>([&](auto ROW) {
+            constexpr int row = ROW;
+            static_for<row + 1, N>([&](auto K) {
+                constexpr int k = K;
+                t.mac(MA[k], B[N + row - k]);
+            });
+            static_for<0, row + 1>([&](auto K) {
+                constexpr int k = K;
+                t.mac(A[k], B[row - k]);
+            });
+            v[row] = t.digit();
+        });
+        pm_second_pass((dpint)t.c, v, c);
+    }
+    static MA_DEV void pm_modsqr_chain(const spint* a, spint* c) {
+        static_assert(P::EPM && !P::OVERFLOW, "chained products are built for the EPM form only");
+        typename W::template Acc<RADIX> t;
+        spint v[N];
+        Opd A[N], TA[N], MA[N];
+        static_for<0, N>([&](auto I) { A[I] = W::prep(a[I]); });
+        static_for<1, N>([&](auto I) { TA[I] = W::prep(a[I] * (spint)2); });
+        static_for<1, N>([&](auto I) { MA[I] = W::prep(a[I] * (spint)P::MM); });
+        static_for<0, N>([&](auto ROW) {
+            constexpr int row = ROW;
+            constexpr int hk0 = row + 1, hpairs = (N - 1 - hk0 + 1) / 2;
+            static_for<0, hpairs>([&](auto J) {
+                constexpr int k = hk0 + J, l = N - 1 - J;
+                t.mac(MA[k], TA[l]);
+            });
+            if constexpr ((N - hk0) % 2 == 1) {
+                constexpr int k = hk0 + hpairs;
+                t.mac(MA[k], A[k]);
+            }
+            constexpr int lpairs = (row + 1) / 2;
+            static_for<0, lpairs>([&](auto J) {
+                constexpr int k = J, l = row - J;
+                t.mac(A[k], TA[l]);
+            });
+            if constexpr (row % 2 == 0) t.mac(A[row / 2], A[row / 2]);
+            v[row] = t.digit();
+        });
+        pm_second_pass((dpint)t.c, v, c);
+    }
+
     // pseudo.py:705-728; (dpint)b sign-extends a negative int exactly as the emitted C does
     static MA_DEV void pm_modmli(const spint* a, int b, spint* c) {
         dpint t = 0;
@@ -443,6 +521,88 @@ struct Field {
         c[N - 1] = (spint)t;
     }
 
+    // the same columns on the 64-bit column chain (see Wide::Acc): shifts of a digit become products with a
+    // constant power of two (one half of which is zero), one-word terms go to the carry word
+    template <int C, class AccT>
+    static MA_DEV void monty_reduce_chain(AccT& t, const spint* v, const Opd* V) {
+        constexpr int NEG = P::NEG_LIMB;
+        constexpr bool scratch = (NEG > 0) && (C > NEG);
+        spint s = MASK;
+        static_for<1, LMAX + 1>([&](auto L) {
+            constexpr int l = L;
+            constexpr int j = C - l;
+            if constexpr (j >= 0 && j <= JMAX && j < C) {
+                constexpr long long d = P::ppw(l);
+                if constexpr (d > 1) {
+                    t.mac(V[j], W::prep((spint)d));
+                } else if constexpr (d == 1) {
+                    if constexpr (scratch) s += v[j]; else t.add(v[j]);
+                } else if constexpr (d == -1) {
+                    if constexpr (scratch) s -= v[j];
+                    else t.add(Q - v[j]);
+                } else {
+                    static_assert(d == 0, "negative prime limbs other than -1 are not supported");
+                }
+            }
+        });
+        if constexpr (scratch) t.add(s);
+    }
+    template <bool SQR>
+    static MA_DEV void monty_mul_chain(const spint* a, const spint* b, spint* c) {
+        constexpr int NCOL = P::E ? 2 * N : 2 * N - 1;
+        typename W::template Acc<RADIX> t;
+        spint v[JMAX + 1];
+        Opd V[JMAX + 1];
+        Opd A[N], B[N];
+        static_for<0, N>([&](auto I) { A[I] = W::prep(a[I]); });
+        if constexpr (!SQR) static_for<0, N>([&](auto I) { B[I] = W::prep(b[I]); });
+        static_for<0, NCOL>([&](auto CC) {
+            constexpr int col = CC;
+            constexpr int lo = col < N ? 0 : col - (N - 1);
+            constexpr int hi = col < N ? col : N - 1;
+            if constexpr (lo <= hi) {
+                if constexpr (!SQR) {
+                    static_for<lo, hi + 1>([&](auto K) {
+                        constexpr int k = K;
+                        t.mac(A[k], B[col - k]);
+                    });
+                } else {
+                    constexpr int pairs = (hi - lo + 1) / 2;
+                    Col cross;
+                    static_for<0, pairs>([&](auto J) {
+                        constexpr int k = lo + J;
+                        cross.mac(A[k], A[col - k]);
+                    });
+                    if constexpr (pairs > 0) t.add_twice(cross);
+                    if constexpr (col % 2 == 0) t.mac(A[col / 2], A[col / 2]);
+                }
+            }
+            monty_reduce_chain<col>(t, v, V);
+            if constexpr (col <= JMAX) {
+                if constexpr (P::NDASH == 1) {
+                    v[col] = t.digit();
+                } else {
+                    static_assert(P::ppw(0) > 0, "full Montgomery reduction expects a positive low prime limb");
+                    v[col] = (t.low() * (spint)P::NDASH) & MASK;
+                    if constexpr (P::ppw(0) == 1) t.add(v[col]);
+                    else t.mac(W::prep(v[col]), W::prep((spint)P::ppw(0)));
+                    (void)t.digit();       // the low Radix bits are zero now
+                }
+                V[col] = W::prep(v[col]);
+            } else {
+                c[col - JMAX - 1] = t.digit();
+            }
+        });
+        spint top = t.c;
+        if constexpr (P::E) {
+            if constexpr (P::NEG_LIMB > 0) top += v[N] - (spint)1;
+            else top += v[N];
+        } else {
+            if constexpr (P::NEG_LIMB > 0) top -= (spint)1;
+        }
+        c[N - 1] = top;
+    }
+
     // monty.py:876-978: trinomial fold, else Barrett-Dhem
     static MA_DEV void monty_modmli(const spint* a, int b, spint* c) {
         const dpint bw = (dpint)(__int128)b;
@@ -505,10 +665,18 @@ struct Field {
 
     // ================================================================ family dispatch
     static MA_DEV void modmul(const spint* a, const spint* b, spint* c) {
-        if constexpr (P::MONTGOMERY) monty_mul<false>(a, b, c); else pm_modmul(a, b, c);
+        if constexpr (P::MONTGOMERY) {
+            if constexpr (CHAINED) monty_mul_chain<false>(a, b, c); else monty_mul<false>(a, b, c);
+        } else {
+            if constexpr (CHAINED) pm_modmul_chain(a, b, c); else pm_modmul(a, b, c);
+        }
     }
     static MA_DEV void modsqr(const spint* a, spint* c) {
-        if constexpr (P::MONTGOMERY) monty_mul<true>(a, a, c); else pm_modsqr(a, c);
+        if constexpr (P::MONTGOMERY) {
+            if constexpr (CHAINED) monty_mul_chain<true>(a, a, c); else monty_mul<true>(a, a, c);
+        } else {
+            if constexpr (CHAINED) pm_modsqr_chain(a, c); else pm_modsqr(a, c);
+        }
     }
     static MA_DEV void modmli(const spint* a, int b, spint* c) {
         if constexpr (P::MONTGOMERY) monty_modmli(a, b, c); else pm_modmli(a, b, c);

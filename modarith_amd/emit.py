@@ -200,6 +200,38 @@ def split_point(fp: FieldParams) -> int:
     return best
 
 
+def chain_ok(fp: FieldParams) -> bool:
+    """True if csrc/field.h may run the product loops of this prime on the 64-bit column chain (Wide::Acc):
+    t = c + s0 + s1*2^H + s2*2^2H with digit() = (t & mask, t >> Radix) in one-word arithmetic.  Proven here,
+    under split_point's limb contract (every limb < 2^(radix+2)): Radix - H <= 32, Radix <= 2H < 64, and the
+    one-word sum c + s0 + 2^Radix stays below 2^64, where c <= max(t) >> Radix plus the one-word terms added
+    in that column.  Column maxima: pseudo-Mersenne (EPM form only) N products of a (mm*a | a) by a (b | 2a)
+    limb; Montgomery N products a*b plus N products digit * prime limb (both < 2^Radix) plus N+2 one-word
+    terms below 2^(Radix+1)."""
+    H = split_point(fp)
+    R, N, W = fp.radix, fp.nlimbs, fp.radix + 2
+    if H == 0 or R - H > 32 or 2 * H < R or 2 * H >= 64:
+        return False
+    if fp.family == "pseudo":
+        if not fp.epm or fp.overflow:
+            return False
+        col = N * (((1 << W) * fp.mm) * (1 << (W + 1)))
+        words = 0
+        s0 = N << (2 * H)
+    else:
+        col = N * (1 << W) ** 2 + (N + 1) * (1 << R) ** 2     # + the digit * p0 product of a full reduction
+        words = (N + 2) << (R + 1)
+        n = 2 * N + 1
+        s0 = n << (2 * H)
+        if n << (W + 1) >= 1 << 64 or n << (2 * max(W - H, 0)) >= 1 << 64:   # s1, s2 with that extra product
+            return False
+    # carry fixed point: c = (col + words + c) >> R
+    c = 0
+    for _ in range(4):
+        c = ((col + words + c) >> R) + 2
+    return c + words + s0 + (1 << R) < (1 << 64)
+
+
 def header_text(fp: FieldParams) -> str:
     N = fp.nlimbs
     prog = addition_chain(fp.pe)
@@ -216,6 +248,7 @@ def header_text(fp: FieldParams) -> str:
              % (N, fp.radix, fp.n, fp.nbytes, fp.xcess, fp.pm1d2))
     L.append("    static constexpr bool MONTGOMERY = %s;" % ("true" if fp.montgomery else "false"))
     L.append("    static constexpr int SPLIT = %d;   // FAST product path: operand cut position, 0 = not provable (emit.split_point)" % split_point(fp))
+    L.append("    static constexpr bool CHAIN = %s;   // FAST product loops on the 64-bit column chain (emit.chain_ok)" % ("true" if chain_ok(fp) else "false"))
     # pseudo-Mersenne block (dummies for Montgomery primes)
     L.append("    static constexpr unsigned long long M = %s, MM = %s;" % (_hexu(fp.m if not fp.montgomery else 0), _hexu(fp.mm)))
     L.append("    static constexpr bool OVERFLOW = %s, FRED = %s, EPM = %s, CARRY_ON = %s;"
