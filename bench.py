@@ -115,8 +115,14 @@ def main():
         raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible" % (world, ndev))
     dev = torch.device("cuda", local % max(ndev, 1))
     torch.cuda.set_device(dev)
-    if world > 1:
+    # MA_BENCH_FORCE_DIST=1 initialises the process group even for one rank, so that the RCCL code path (init, max
+    # over ranks, barrier, result gather) can be exercised on a single-GPU box
+    use_dist = world > 1 or os.environ.get("MA_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
         else:
@@ -142,7 +148,7 @@ def main():
     c = torch.empty_like(a)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -158,7 +164,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps      # mean launch duration on the launch stream
-    if world > 1:
+    if use_dist:
         dt, kern_ms = max_over_ranks([dt, kern_ms])
     value = world * n * args.steps / dt
     achieved = BYTES_PER_MODMUL * n / (kern_ms * 1e-3) / 1e9
@@ -209,7 +215,7 @@ def main():
         barrier()
         lt = (time.perf_counter() - t0) / reps
         gather_ms = None
-        if world > 1:
+        if use_dist:
             from modarith_amd.dist import gather_records
             payload = o if backend == "nccl" else o.cpu()
             barrier()
@@ -273,7 +279,7 @@ def main():
             "verified_against_oracle": verified,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,40 @@
+"""bench.py on the GPU box: the JSON contract of the headline line, and the RCCL code path (process-group init,
+max-over-ranks all_reduce, barrier, result gather) exercised with a one-rank group -- the 8-GPU run is the driver's."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, env_extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = _run(["--steps", "20", "--warmup", "5", "--no-cpu", "--no-others"], {})
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "u64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.3 < r["frac"] < 1.0
+    # value and the roofline describe the same launches: modmul/s * 120 B within 10 % of the achieved rate
+    assert abs(d["value"] * 120 / 1e9 - r["achieved"]) / r["achieved"] < 0.10
+    assert d["x25519"]["value"] > 1e7
+
+
+def test_bench_rccl_path_one_rank():
+    d = _run(["--steps", "10", "--warmup", "3", "--no-cpu", "--no-others"], {"MA_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29533"})
+    assert d["n_gpus"] == 1 and d["x25519"]["gather_ms"] is not None and d["x25519"]["gather_ms"] > 0
