@@ -31,7 +31,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // staging area for the scalar (_ct) entry points: a small device buffer guarded by a mutex
 struct Staging {
     std::mutex mu;
-    unsigned char* dev = nullptr;
+    static constexpr int MAX_DEVICES = 64;
+    unsigned char* dev[MAX_DEVICES] = {};         // one buffer per device of this process, made on first use
     static constexpr size_t BYTES = 256 * 1024;   // holds the scalar ecn mul window table (64 lanes x 216 words)
     unsigned char* get();
 };

@@ -48,11 +48,15 @@ bool ladder_use_field() {
 }
 
 unsigned char* Staging::get() {
-    if (!dev) {
-        hipError_t e = hipMalloc((void**)&dev, BYTES);
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) die("hipGetDevice(staging)", e);
+    if (d < 0 || d >= MAX_DEVICES) die("staging: device index out of range", hipErrorInvalidDevice);
+    if (!dev[d]) {
+        e = hipMalloc((void**)&dev[d], BYTES);
         if (e != hipSuccess) die("hipMalloc(staging)", e);
     }
-    return dev;
+    return dev[d];
 }
 Staging& staging() {
     static Staging s;
@@ -61,6 +65,16 @@ Staging& staging() {
 void die(const char* what, hipError_t e) {
     fprintf(stderr, "modarith_amd: %s failed: %s\n", what, hipGetErrorString(e));
     abort();
+}
+
+// element-major (AoS, spint x[n][N] as CPU callers hold elements) <-> limb-interleaved SoA; any limb count
+static __global__ __launch_bounds__(BLOCK) void k_aos2soa(const spint* aos, spint* soa, size_t n, int nlimbs, size_t ld) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK)
+        for (int i = 0; i < nlimbs; i++) soa[(size_t)i * ld + t] = aos[t * (size_t)nlimbs + i];
+}
+static __global__ __launch_bounds__(BLOCK) void k_soa2aos(const spint* soa, spint* aos, size_t n, int nlimbs, size_t ld) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK)
+        for (int i = 0; i < nlimbs; i++) aos[t * (size_t)nlimbs + i] = soa[(size_t)i * ld + t];
 }
 
 static int wrap(hipError_t e, const char* what) {
@@ -97,18 +111,14 @@ int modarith_amd_sync(void* stream) { return wrap(hipStreamSynchronize((hipStrea
 
 int modarith_amd_aos_to_soa(const ma_spint* aos, ma_spint* soa, size_t n, int nlimbs, size_t ld, void* stream) {
     if (n == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    if (nlimbs == 5) k_aos2soa<5><<<grid_for(n), BLOCK, 0, s>>>(aos, soa, n, ld);
-    else if (nlimbs == 8) k_aos2soa<8><<<grid_for(n), BLOCK, 0, s>>>(aos, soa, n, ld);
-    else { set_error("aos_to_soa: nlimbs must be 5 or 8"); return (int)hipErrorInvalidValue; }
+    if (nlimbs < 1 || nlimbs > 64 || ld < n) { set_error("aos_to_soa: need 1 <= nlimbs <= 64 and ld >= n"); return (int)hipErrorInvalidValue; }
+    k_aos2soa<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(aos, soa, n, nlimbs, ld);
     return check_launch("aos_to_soa");
 }
 int modarith_amd_soa_to_aos(const ma_spint* soa, ma_spint* aos, size_t n, int nlimbs, size_t ld, void* stream) {
     if (n == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    if (nlimbs == 5) k_soa2aos<5><<<grid_for(n), BLOCK, 0, s>>>(soa, aos, n, ld);
-    else if (nlimbs == 8) k_soa2aos<8><<<grid_for(n), BLOCK, 0, s>>>(soa, aos, n, ld);
-    else { set_error("soa_to_aos: nlimbs must be 5 or 8"); return (int)hipErrorInvalidValue; }
+    if (nlimbs < 1 || nlimbs > 64 || ld < n) { set_error("soa_to_aos: need 1 <= nlimbs <= 64 and ld >= n"); return (int)hipErrorInvalidValue; }
+    k_soa2aos<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(soa, aos, n, nlimbs, ld);
     return check_launch("soa_to_aos");
 }
 

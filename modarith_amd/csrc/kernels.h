@@ -347,18 +347,4 @@ __global__ __launch_bounds__(BLOCK) void k_time(const spint* xs, const spint* ys
     }
 }
 
-// element-major (AoS, spint x[n][N] as CPU callers hold elements) <-> limb-interleaved SoA
-template <int N>
-__global__ __launch_bounds__(BLOCK) void k_aos2soa(const spint* aos, spint* soa, size_t n, size_t ld) {
-    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK)
-#pragma unroll
-        for (int i = 0; i < N; i++) soa[(size_t)i * ld + t] = aos[t * N + i];
-}
-template <int N>
-__global__ __launch_bounds__(BLOCK) void k_soa2aos(const spint* soa, spint* aos, size_t n, size_t ld) {
-    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK)
-#pragma unroll
-        for (int i = 0; i < N; i++) aos[t * N + i] = soa[(size_t)i * ld + t];
-}
-
 }  // namespace ma

@@ -58,6 +58,23 @@ class Field:
     def to_ints(self, t: torch.Tensor) -> List[int]:
         return [self.params.from_limbs(l) for l in self.to_limbs(t)]
 
+    def from_aos(self, aos: torch.Tensor) -> torch.Tensor:
+        """element-major device array int64 [n, N] (`spint x[n][Nlimbs]`, how CPU callers of field.c hold
+        elements) -> limb-interleaved batch [N, n], converted on the device."""
+        if aos.dtype != torch.int64 or aos.dim() != 2 or aos.shape[1] != self.N or not aos.is_cuda or not aos.is_contiguous():
+            raise ValueError("expected a contiguous int64 device tensor of shape [n, %d]" % self.N)
+        n = aos.shape[0]
+        out = torch.empty((self.N, n), dtype=torch.int64, device=aos.device)
+        _lib.check(self.lib.modarith_amd_aos_to_soa(aos.data_ptr(), out.data_ptr(), n, self.N, max(n, 1), _stream()), "aos_to_soa")
+        return out
+
+    def to_aos(self, soa: torch.Tensor) -> torch.Tensor:
+        """limb-interleaved batch [N, n] -> element-major int64 [n, N], on the device."""
+        n = self._chk(soa)
+        out = torch.empty((n, self.N), dtype=torch.int64, device=soa.device)
+        _lib.check(self.lib.modarith_amd_soa_to_aos(soa.data_ptr(), out.data_ptr(), n, self.N, soa.stride(0) if n else 1, _stream()), "soa_to_aos")
+        return out
+
     # ------------------------------------------------------------------ plumbing
     def _chk(self, *ts: torch.Tensor) -> int:
         n = ts[0].shape[1]

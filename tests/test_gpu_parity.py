@@ -412,6 +412,23 @@ def test_extra_primes_vs_generic_oracle(oracle, torch_cuda, P):
     assert np.array_equal(to_np(F.redc(F.modsqrt(dsa))), red(cs))
 
 
+@pytest.mark.parametrize("P", ["X25519", "X448", "NIST224", "NIST384", "NIST521"])
+def test_aos_soa_converters(torch_cuda, P):
+    """element-major <-> limb-interleaved on the device, for 4/5/7/8/9-limb fields, incl. a padded limb stride"""
+    torch = torch_cuda
+    from modarith_amd.field import Field
+    F = Field(P)
+    n = 1003
+    aos = torch.randint(0, 1 << 62, (n, F.N), dtype=torch.int64, device="cuda")
+    soa = F.from_aos(aos)
+    assert soa.shape == (F.N, n) and torch.equal(soa, aos.t())
+    assert torch.equal(F.to_aos(soa), aos)
+    wide = torch.zeros((F.N, n + 13), dtype=torch.int64, device="cuda")
+    wide[:, :n] = soa
+    assert torch.equal(F.to_aos(wide[:, :n]), aos)          # ld = n + 13
+    assert F.from_aos(aos[:0]).shape == (F.N, 0)
+
+
 def test_error_reporting(torch_cuda):
     """the reference signals no errors; the shim reports only misuse it cannot execute: misaligned byte records,
     a too-small ecn workspace.  The message is retrievable and the call leaves no sticky device error."""
