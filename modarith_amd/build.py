@@ -22,7 +22,10 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmodarith_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -amdgpu-codegenprepare-mul24=0: the IR-level 24-bit-multiply formation of this compiler miscompiles the fused split-product
+# chains of C2065 (4 x 52-bit limbs; wrong for every lane, right at -O0, right with this switch: tools/diag_fast_chain.py);
+# the DAG-level mul24 selection stays on.  Measured cost on the VALU-bound kernels: see DESIGN.md.
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-codegenprepare-mul24=0"]
 UNITS = (["capi_common"] + ["capi_%s" % p for p in emit.CORE_PRIMES] + ["capi_%s" % c for c in emit.BUILT_CURVES] + ["capi_%sW" % c for c in emit.BUILT_WCURVES]
          + ["generated/capi_%s" % p for p in emit.EXTRA_PRIMES])
 

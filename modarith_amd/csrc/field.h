@@ -106,7 +106,11 @@ struct Field {
     using W = Wide<FAST, (P::SPLIT > 0 ? P::SPLIT : 32)>;
     using Opd = typename W::Opd;
     using Col = typename W::Col;
-    static constexpr bool CHAINED = FAST && P::CHAIN;    // product loops on the 64-bit column chain (Wide::Acc)
+    #ifdef MA_NO_CHAIN
+    static constexpr bool CHAINED = false;
+#else
+    static constexpr bool CHAINED = FAST && P::CHAIN;
+#endif    // product loops on the 64-bit column chain (Wide::Acc)
 
     // ---------------------------------------------------------------- carries / normalisation
     // pseudo.py:223-251, monty.py:352-380 (arithmetic-shift form)
@@ -703,7 +707,10 @@ struct Field {
         (void)modfsb(m);
     }
 
+    // rolled on purpose: the chains call this with constant counts up to a few hundred, and a fully unrolled
+    // progenitor is tens of thousands of instructions per prime
     static MA_DEV void modnsqr(spint* a, int n) {
+#pragma unroll 1
         for (int i = 0; i < n; i++) modsqr(a, a);
     }
 

@@ -311,9 +311,9 @@ __global__ __launch_bounds__(BLOCK) void k_exp(const spint* a, unsigned char* by
 // simd/pseudo_cuda.py:1163-1231 runs the same dependent chains inside one thread): every lane runs the
 // serially dependent chain on its own operands, entirely in registers, and leaves redc(z).
 // KIND 0: `outer` x 200 x 5 modmul;  1: `outer` x 500 x 2 modsqr;  2: `outer` x 2 modinv.
-template <class P, int KIND>
+template <class P, int KIND, bool FAST = false>
 __global__ __launch_bounds__(BLOCK) void k_time(const spint* xs, const spint* ys, spint* zs, long outer, size_t n, size_t ld) {
-    using F = Field<P>;
+    using F = Field<P, FAST>;
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N], y[1][P::N], z[1][P::N];
         load_soa<P, 1>(xs, ld, t, x);

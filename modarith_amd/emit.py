@@ -21,7 +21,8 @@ from .params import FieldParams, derive
 HERE = os.path.dirname(os.path.abspath(__file__))
 GEN_DIR = os.path.join(HERE, "csrc", "generated")
 CORE_PRIMES = ("X25519", "NIST256", "X448")            # BASELINE.json configs; their capi_<P>.hip are hand-written
-EXTRA_PRIMES = ("NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1", "NIST256Q", "ED25519Q", "ED448Q")
+EXTRA_PRIMES = ("NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1", "NIST256Q", "ED25519Q", "ED448Q",
+                "C2065", "PM336", "PM512", "GM270", "GM240", "GM360", "GM480", "GM384", "GM512", "TWEEDLE", "SIDH434", "SIDH503")
 BUILT_PRIMES = CORE_PRIMES + EXTRA_PRIMES
 
 

@@ -39,11 +39,25 @@ NAMED = {
     "NUMS256W": (2**256 - 189, "pseudo"),
     "NIST521": (2**521 - 1, "pseudo"),
     "SECP256K1": (2**256 - 2**32 - 977, "monty"),        # pseudo.py's overflow variant is not built
+    # further named moduli of monty.py's list (monty.py:1990-2075)
+    "GM270": (2**270 - 2**162 - 1, "monty"),
+    "GM240": (2**240 - 2**183 - 1, "monty"),
+    "GM360": (2**360 - 2**171 - 1, "monty"),
+    "GM480": (2**480 - 2**240 - 1, "monty"),
+    "GM384": (2**384 - 2**186 - 1, "monty"),
+    "GM512": (2**512 - 2**127 - 1, "monty"),
+    "PM512": (2**512 - 569, "pseudo"),
+    "TWEEDLE": (0x40000000000000000000000000000000038aa127696286c9842cafd400000001, "monty"),
+    "SIDH434": (2**216 * 3**137 - 1, "monty"),
+    "SIDH503": (2**250 * 3**159 - 1, "monty"),
     # group orders (curve.py:324-329 runs monty.py on "00<decimal q>"): general primes, full Montgomery
     "NIST256Q": (0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551, "monty"),
     "ED25519Q": (0x1000000000000000000000000000000014DEF9DEA2F79CD65812631A5CF5D3ED, "monty"),
     "ED448Q": ((2**448 - 2**224 - 1 + 1 - 28312320572429821613362531907042076847709625476988141958474579766324) // 4, "monty"),
 }
+
+# per-name radix choices the generators hard-wire for 64-bit words (monty.py:2002-2037, `if WL==64: base=...`)
+RADIX_64 = {"GM240": 61, "GM360": 57, "GM480": 60, "GM384": 62, "GM512": 58}
 
 # how each built name is spelled on the reference generators' command line (group orders: "00" + decimal)
 def reference_argv(name: str):
@@ -282,4 +296,6 @@ def derive(name: str, family: Optional[str] = None, radix: Optional[int] = None)
     if fam is None:
         n = p.bit_length()
         fam = "pseudo" if ((1 << n) - p) < (1 << 32) else "monty"
+    if radix is None and fam == "monty":
+        radix = RADIX_64.get(name)
     return derive_pseudo(name, p, radix) if fam == "pseudo" else derive_monty(name, p, radix)

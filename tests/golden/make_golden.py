@@ -837,7 +837,10 @@ def extras():
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
     from modarith_amd.emit import EXTRA_PRIMES
     from modarith_amd.params import reference_argv
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]       # optional: regenerate just these
     for k, name in enumerate(EXTRA_PRIMES):
+        if only and name not in only:
+            continue
         script, arg = reference_argv(name)
         fx, _ = field_fixture(script, arg, 6000 + k, count=64, full_time=False, name=name)
         json.dump(fx, open(os.path.join(HERE, "field_%s.json" % name), "w"), indent=0, separators=(",", ":"))

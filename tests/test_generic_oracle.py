@@ -1,13 +1,14 @@
 """The run-time generic oracle (oracle/field_generic.c) against the reference-generated golden vectors of
 EVERY built prime -- the three BASELINE primes (where it must also agree with the per-prime restatements) and
-the ten further ones, for which it is the CPU oracle.  CPU only."""
+the further ones, for which it is the CPU oracle.  CPU only."""
 import pytest
 
 from tests.conftest import limbs, load_golden
 from tests.generic_oracle import Generic
 
-ALL = ["X25519", "NIST256", "X448", "NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1",
-       "NIST256Q", "ED25519Q", "ED448Q"]
+from modarith_amd.emit import BUILT_PRIMES
+
+ALL = list(BUILT_PRIMES)
 
 
 @pytest.fixture(scope="module", params=ALL)

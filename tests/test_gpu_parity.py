@@ -12,7 +12,7 @@ from tests.util import oracle_bin, oracle_mli, oracle_un, random_soa, to_dev, to
 
 pytestmark = pytest.mark.gpu
 ALL = ["X25519", "NIST256", "X448"]                      # BASELINE.json configs: golden vectors AND oracle batches
-EXTRA = ["NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1", "NIST256Q", "ED25519Q", "ED448Q"]
+EXTRA = list(__import__("modarith_amd.emit", fromlist=["EXTRA_PRIMES"]).EXTRA_PRIMES)   # further primes: golden vectors + generic oracle
 
 
 @pytest.fixture(scope="module")
@@ -370,7 +370,7 @@ def test_c_drop_in_example(torch_cuda, tmp_path):
 
 @pytest.mark.parametrize("P", EXTRA)
 def test_extra_primes_vs_generic_oracle(oracle, torch_cuda, P):
-    """the ten further primes: seeded batches against the run-time generic oracle (oracle/field_generic.c, itself
+    """the further primes: seeded batches against the run-time generic oracle (oracle/field_generic.c, itself
     pinned to the reference's golden vectors by tests/test_generic_oracle.py)"""
     from modarith_amd.field import Field
     from modarith_amd.params import derive
