@@ -448,3 +448,49 @@ def test_error_reporting(torch_cuda):
     from modarith_amd.field import Field
     F = Field("X25519")
     assert F.modis0(F.modzer(3)).cpu().tolist() == [1, 1, 1]
+
+
+def test_stream_capture_into_hip_graph(torch_cuda):
+    """the batched entry points only enqueue kernels on the caller's stream (no allocation, no synchronisation), so a
+    sequence of them can be captured into a hipGraph and replayed on new data: launch-bound small batches pay one
+    graph launch instead of one launch per call."""
+    torch = torch_cuda
+    from modarith_amd.field import Field, rfc7748
+    F = Field("X25519")
+    n = 512
+    g = torch.Generator(device="cuda").manual_seed(9)
+    a = torch.randint(0, 1 << 51, (5, n), dtype=torch.int64, device="cuda", generator=g)
+    b = torch.randint(0, 1 << 51, (5, n), dtype=torch.int64, device="cuda", generator=g)
+    k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    u = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    t1, t2, t3, out = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a), torch.empty_like(u)
+
+    def body():
+        F.modmul(a, b, out=t1)
+        F.modsqr(t1, out=t2)
+        F.modadd(t2, a, out=t3)
+        F.modinv(t3, out=t1)
+        rfc7748("X25519", k, u, out=out)
+
+    body()                                   # eager reference (also loads the code objects before capture)
+    torch.cuda.synchronize()
+    want = (t1.clone(), t3.clone(), out.clone())
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            body()
+    for buf in (t1, t2, t3, out):
+        buf.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(t1, want[0]) and torch.equal(t3, want[1]) and torch.equal(out, want[2])
+    # new inputs in the captured buffers, replay again
+    a.copy_(b)
+    u.copy_(k)
+    graph.replay()
+    torch.cuda.synchronize()
+    got = (t1.clone(), t3.clone(), out.clone())
+    body()
+    torch.cuda.synchronize()
+    assert torch.equal(t1, got[0]) and torch.equal(t3, got[1]) and torch.equal(out, got[2])

@@ -31,6 +31,9 @@ for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\s*s_endpgm", t, re.S | re.M):
         s["nop"] += op == "s_nop"
         if op.startswith("s_cbranch") or op == "s_branch":
             br[blk].append(l.split()[-1])
+            # the fall-through code after a branch is its own block
+            sub = blk.split("+")[0] + "+%d" % (sum(1 for b in order if b.split("+")[0] == blk.split("+")[0]))
+            blk = sub; order.append(blk); stats[blk] = dict.fromkeys(keys, 0); br[blk] = []
     for b in order:
         if stats[b]["n"]:
             print("  %-10s %s -> %s" % (b, " ".join("%s=%d" % kv for kv in stats[b].items()), ",".join(br[b])))
