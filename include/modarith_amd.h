@@ -57,7 +57,15 @@ int modarith_amd_free(void *dptr);
 int modarith_amd_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int modarith_amd_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int modarith_amd_sync(void *stream);
-/* element-major (spint x[n][nlimbs], how CPU callers hold arrays of elements) <-> SoA; nlimbs in {5,8} */
+/* streams and page-locked host memory, so that a plain-C caller holding its data on the host can overlap the
+ * upload of chunk i+1, the kernels of chunk i and the download of chunk i-1:
+ * stream_wait makes `stream` wait for everything enqueued on `other` so far (an event underneath) */
+int modarith_amd_stream_create(void **stream);
+int modarith_amd_stream_destroy(void *stream);
+int modarith_amd_stream_wait(void *stream, void *other);
+int modarith_amd_host_alloc(void **hptr, size_t bytes);
+int modarith_amd_host_free(void *hptr);
+/* element-major (spint x[n][nlimbs], how CPU callers hold arrays of elements) <-> SoA; any limb count */
 int modarith_amd_aos_to_soa(const ma_spint *aos, ma_spint *soa, size_t n, int nlimbs, size_t ld, void *stream);
 int modarith_amd_soa_to_aos(const ma_spint *soa, ma_spint *aos, size_t n, int nlimbs, size_t ld, void *stream);
 /* per-prime macro block of field.c (pseudo.py:1403-1407): returns 0 if `prime` is unknown */

@@ -71,6 +71,7 @@ SCALAR_FUNCS = ("flatten", "modfsb", "modadd", "modsub", "modneg", "modmli", "mo
 UTIL_FUNCS = ("modarith_amd_abi_version", "modarith_amd_last_error", "modarith_amd_device_count",
               "modarith_amd_set_device", "modarith_amd_malloc", "modarith_amd_free", "modarith_amd_memcpy_h2d",
               "modarith_amd_memcpy_d2h", "modarith_amd_sync", "modarith_amd_aos_to_soa", "modarith_amd_soa_to_aos",
+              "modarith_amd_stream_create", "modarith_amd_stream_destroy", "modarith_amd_stream_wait", "modarith_amd_host_alloc", "modarith_amd_host_free",
               "modarith_amd_field_info")
 
 
@@ -120,6 +121,16 @@ def load() -> ctypes.CDLL:
     lib.modarith_amd_aos_to_soa.argtypes = [_P, _P, c_size_t, c_int, c_size_t, _P]
     lib.modarith_amd_soa_to_aos.argtypes = [_P, _P, c_size_t, c_int, c_size_t, _P]
     lib.modarith_amd_field_info.argtypes = [c_char_p] + [ctypes.POINTER(c_int)] * 5
+    lib.modarith_amd_malloc.argtypes = [ctypes.POINTER(c_void_p), c_size_t]
+    lib.modarith_amd_free.argtypes = [_P]
+    lib.modarith_amd_memcpy_h2d.argtypes = [_P, _P, c_size_t, _P]
+    lib.modarith_amd_memcpy_d2h.argtypes = [_P, _P, c_size_t, _P]
+    lib.modarith_amd_sync.argtypes = [_P]
+    lib.modarith_amd_stream_create.argtypes = [ctypes.POINTER(c_void_p)]
+    lib.modarith_amd_stream_destroy.argtypes = [_P]
+    lib.modarith_amd_stream_wait.argtypes = [_P, _P]
+    lib.modarith_amd_host_alloc.argtypes = [ctypes.POINTER(c_void_p), c_size_t]
+    lib.modarith_amd_host_free.argtypes = [_P]
     _lib = lib
     return lib
 

@@ -108,6 +108,24 @@ int modarith_amd_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stre
     return wrap(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), "hipMemcpyAsync(d2h)");
 }
 int modarith_amd_sync(void* stream) { return wrap(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize"); }
+int modarith_amd_stream_create(void** stream) {
+    hipStream_t s = nullptr;
+    int rc = wrap(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    *stream = (void*)s;
+    return rc;
+}
+int modarith_amd_stream_destroy(void* stream) { return wrap(hipStreamDestroy((hipStream_t)stream), "hipStreamDestroy"); }
+int modarith_amd_stream_wait(void* stream, void* other) {
+    hipEvent_t ev;
+    int rc = wrap(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+    if (rc) return rc;
+    rc = wrap(hipEventRecord(ev, (hipStream_t)other), "hipEventRecord");
+    if (!rc) rc = wrap(hipStreamWaitEvent((hipStream_t)stream, ev, 0), "hipStreamWaitEvent");
+    hipError_t e = hipEventDestroy(ev);      // safe: destruction is deferred until the event has completed
+    return rc ? rc : wrap(e, "hipEventDestroy");
+}
+int modarith_amd_host_alloc(void** hptr, size_t bytes) { return wrap(hipHostMalloc(hptr, bytes, hipHostMallocDefault), "hipHostMalloc"); }
+int modarith_amd_host_free(void* hptr) { return wrap(hipHostFree(hptr), "hipHostFree"); }
 
 int modarith_amd_aos_to_soa(const ma_spint* aos, ma_spint* soa, size_t n, int nlimbs, size_t ld, void* stream) {
     if (n == 0) return 0;

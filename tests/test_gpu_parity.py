@@ -494,3 +494,22 @@ def test_stream_capture_into_hip_graph(torch_cuda):
     body()
     torch.cuda.synchronize()
     assert torch.equal(t1, got[0]) and torch.equal(t3, got[1]) and torch.equal(out, got[2])
+
+
+@pytest.mark.parametrize("P,fn", [("X25519", "modmul"), ("X448", "modsqr"), ("NIST256", "modadd")])
+def test_host_pipeline_through_c_abi(oracle, torch_cuda, P, fn):
+    """host-resident batch, chunked upload / kernel / download on three streams through the exported utilities only
+    (modarith_amd/hostio.py), ragged last chunk, against the oracle"""
+    from modarith_amd.hostio import PinnedArray, map_host
+    N = PRIMES[P][0]
+    n = 3 * 4096 + 1234
+    a, b, c = PinnedArray(N, n), PinnedArray(N, n), PinnedArray(N, n)
+    a.array[:] = random_soa(P, n, 91)
+    b.array[:] = random_soa(P, n, 92)
+    c.array[:] = 0
+    map_host(P, fn, a, b, c, chunk=4096)
+    ha, hb = np.ascontiguousarray(a.array), np.ascontiguousarray(b.array)
+    want = oracle_bin(oracle, fn, P, ha, hb) if fn in ("modmul", "modadd") else oracle_un(oracle, fn, P, ha)
+    assert np.array_equal(c.array, want)
+    for x in (a, b, c):
+        x.close()
