@@ -106,11 +106,7 @@ struct Field {
     using W = Wide<FAST, (P::SPLIT > 0 ? P::SPLIT : 32)>;
     using Opd = typename W::Opd;
     using Col = typename W::Col;
-    #ifdef MA_NO_CHAIN
-    static constexpr bool CHAINED = false;
-#else
-    static constexpr bool CHAINED = FAST && P::CHAIN;
-#endif    // product loops on the 64-bit column chain (Wide::Acc)
+    static constexpr bool CHAINED = FAST && P::CHAIN;    // product loops on the 64-bit column chain (Wide::Acc)
 
     // ---------------------------------------------------------------- carries / normalisation
     // pseudo.py:223-251, monty.py:352-380 (arithmetic-shift form)
