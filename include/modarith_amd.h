@@ -263,9 +263,11 @@ int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void 
 
 MODARITH_AMD_DECLARE_EDWARDS(ed25519, 5)
 MODARITH_AMD_DECLARE_EDWARDS(ed448, 8)
-/* NIST P-256 in short-Weierstrass form (weierstrass.c: complete add/dbl 68-281, setxy 366-410, mul 494-543, mul2
- * 545-569) -- the same curve.h API and layouts; ecn_nist256_set needs x (y optional), ecn_nist256_cof is a no-op. */
+/* NIST P-256 and P-384 in short-Weierstrass form (weierstrass.c: complete add/dbl 68-281, setxy 366-410, mul 494-543,
+ * mul2 545-569; constants curve.py:157-177) -- the same curve.h API and layouts; ecn_<c>_set needs x (y optional),
+ * ecn_<c>_cof is a no-op. */
 MODARITH_AMD_DECLARE_EDWARDS(nist256, 5)
+MODARITH_AMD_DECLARE_EDWARDS(nist384, 7)
 
 #ifdef __cplusplus
 }

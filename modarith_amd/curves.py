@@ -75,6 +75,14 @@ W_CURVES = {
         0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551,
         0x6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296,
         0x4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5),
+    # curve.py:168-177
+    "NIST384": WeierstrassCurve(
+        "NIST384", "NIST384", -3,
+        27580193559959705877849011840389048093056905856361568521428707301988689241309860865136260764883745107765439761230575,
+        39402006196394479212279040100143613805079739270465446667948293404245721771496870329047266088258938001861606973112319 + 1
+        - 1388124618062372383606759648309780106643088307173319169677,
+        0xaa87ca22be8b05378eb1c71ef320ad746e1d3b628ba79b9859f741e082542a385502f25dbf55296c3a545e3872760ab7,
+        0x3617de4a96262c6f5d9e98bf9292dc29f8f41dbd289a147ce9da3113b5f0b8c00a60b1ce1d7e819d7a431d7c90ea0e5f),
 }
 
 

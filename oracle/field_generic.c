@@ -13,27 +13,7 @@
 #include "oracle_types.h"
 #include <string.h>
 
-#define GMAXN 12
-
-typedef struct {
-    int family;          /* 0 = pseudo-Mersenne, 1 = Montgomery */
-    int n, radix, nbits, nbytes, xcess, pm1d2;
-    /* pseudo-Mersenne */
-    spint m, mm;
-    int epm, fred, carry_on;
-    /* Montgomery */
-    long long ppw[GMAXN + 1];   /* signed prime limbs, + virtual limb if E */
-    int E, trin, neg_limb;
-    spint ndash, barrett_r;
-    spint r2[GMAXN];
-    /* caddp / addp / subp */
-    int pp_cnt, pp_idx[GMAXN], pp_sgn[GMAXN];
-    spint pp_val[GMAXN];
-    /* progenitor exponent, little-endian 64-bit words, and a 2^pm1d2-th root of unity (plain limbs) */
-    int pe_words;
-    spint pe[GMAXN];
-    spint roi[GMAXN];
-} gparams;
+#include "field_generic.h"
 
 #define N (P->n)
 #define MASK ((((spint)1) << P->radix) - 1)

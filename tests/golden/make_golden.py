@@ -705,20 +705,36 @@ class WsModel:
     Constants of curve.py:157-166 (NIST256)."""
 
     def __init__(self, name):
-        assert name == "NIST256"
-        self.p = 2**256 - 2**224 + 2**192 + 2**96 - 1
-        self.a = -3
-        self.b = 0x5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b
-        self.q = 0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551
-        self.G = (0x6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296,
-                  0x4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5)
-        self.nbytes = 32
-        # testcurve.c:29-35
-        self.tc = dict(order="FFFFFFFF00000000FFFFFFFFFFFFFFFFBCE6FAADA7179E84F3B9CAC2FC632551",
-                       r1="166876CB6C86C76660666789A376F6790956A0D6A507657196D75D610E0C9D7B",
-                       r2="E99789339379389A9F9998765C890986B39059D7021039135CE26D61EE5687D6",
-                       n1="C20347457078878f77b707c070707077a07707b7b07070707223252357134272",
-                       n2="D35279279432f249b298a876788d86294e02842092769136c086038b1812383a")
+        if name == "NIST256":
+            self.p = 2**256 - 2**224 + 2**192 + 2**96 - 1
+            self.a = -3
+            self.b = 0x5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b
+            self.q = 0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551
+            self.G = (0x6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296,
+                      0x4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5)
+            self.nbytes = 32
+            # testcurve.c:29-35
+            self.tc = dict(order="FFFFFFFF00000000FFFFFFFFFFFFFFFFBCE6FAADA7179E84F3B9CAC2FC632551",
+                           r1="166876CB6C86C76660666789A376F6790956A0D6A507657196D75D610E0C9D7B",
+                           r2="E99789339379389A9F9998765C890986B39059D7021039135CE26D61EE5687D6",
+                           n1="C20347457078878f77b707c070707077a07707b7b07070707223252357134272",
+                           n2="D35279279432f249b298a876788d86294e02842092769136c086038b1812383a")
+        elif name == "NIST384":                       # curve.py:168-177
+            self.p = 2**384 - 2**128 - 2**96 + 2**32 - 1
+            self.a = -3
+            self.b = 27580193559959705877849011840389048093056905856361568521428707301988689241309860865136260764883745107765439761230575
+            self.q = self.p + 1 - 1388124618062372383606759648309780106643088307173319169677
+            self.G = (0xaa87ca22be8b05378eb1c71ef320ad746e1d3b628ba79b9859f741e082542a385502f25dbf55296c3a545e3872760ab7,
+                      0x3617de4a96262c6f5d9e98bf9292dc29f8f41dbd289a147ce9da3113b5f0b8c00a60b1ce1d7e819d7a431d7c90ea0e5f)
+            self.nbytes = 48
+            # testcurve.c:36-42
+            self.tc = dict(order="ffffffffffffffffffffffffffffffffffffffffffffffffc7634d81f4372ddf581a0db248b0a77aecec196accc52973",
+                           r1="bd9c66b3ad3c2d6d1a3d1fa7bc8960a923b8c1e9392456de3eb13b9046685257bdd640fb06671ad11c80317fa3b1799d",
+                           r2="4263994c52c3d292e5c2e05843769f56dc473e16c6dba92188b211f1adcedb879a43ccb742498ca9d06be7eb2913afd6",
+                           n1="9a1de644815ef6d13b8faa1837f8a88b17fc695a07a0ca6e0822e8f36c031199972a846916419f828b9d2434e465e150",
+                           n2="4737819096da1dac72ff5d2a386ecbe06b65a6a48b8148f6b38a088ca65ed389b74d0fb132e706298fadc1a606cb0fb3")
+        else:
+            raise ValueError(name)
         assert self.on_curve(self.G)
 
     def on_curve(self, P):
@@ -775,7 +791,7 @@ def weierstrass_fixture(name, seed, pairs=32):
     rng = random.Random(seed)
     M = WsModel(name)
     nb, p, q, G = M.nbytes, M.p, M.q, M.G
-    fx = {"curve": name, "source": "big-integer model (tests/golden/make_golden.py WsModel); constants curve.py:157-166",
+    fx = {"curve": name, "source": "big-integer model (tests/golden/make_golden.py WsModel); constants curve.py:157-177",
           "gen": M.xy_hex(G), "order": q.to_bytes(nb, "big").hex()}
     assert M.mul(q, G) is None
     recs = []
@@ -853,7 +869,8 @@ def main():
         extras()
         return
     if "--weierstrass-only" in sys.argv:
-        json.dump(weierstrass_fixture("NIST256", 8001), open(os.path.join(HERE, "weierstrass_NIST256.json"), "w"), indent=0, separators=(",", ":"))
+        for k, wname in enumerate(("NIST256", "NIST384")):
+            json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else 24), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
         return
     if "--edwards-only" in sys.argv:
         for name, seed in (("ED25519", 5001), ("ED448", 5002)):
@@ -879,7 +896,8 @@ def main():
     for script, prime, seed in (("pseudo.py", "X25519", 4001), ("monty.py", "NIST256", 4002), ("monty.py", "X448", 4003)):
         json.dump(sqrt_fixture(script, prime, seed), open(os.path.join(HERE, "sqrt_%s.json" % prime), "w"), indent=0, separators=(",", ":"))
     extras()
-    json.dump(weierstrass_fixture("NIST256", 8001), open(os.path.join(HERE, "weierstrass_NIST256.json"), "w"), indent=0, separators=(",", ":"))
+    for k, wname in enumerate(("NIST256", "NIST384")):
+        json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else 24), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
     for name, seed in (("ED25519", 5001), ("ED448", 5002)):
         json.dump(edwards_fixture(name, seed, pairs=40 if name == "ED25519" else 20), open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
     for curve, seed in (("X25519", 3001), ("X448", 3003)):

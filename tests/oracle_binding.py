@@ -13,6 +13,10 @@ U64P = POINTER(c_uint64)
 INTP = POINTER(c_int)
 
 PRIMES = {"X25519": (5, 51, 255, 32), "NIST256": (5, 52, 256, 32), "X448": (8, 56, 448, 56)}
+# primes whose field.c function set is the generic oracle bound to the constants captured from the reference
+# (oracle/field_<P>.c with oracle_bind_<P>): they carry a curve-layer oracle
+BOUND_PRIMES = {"NIST384": (7, 56, 384, 48)}
+ORACLE_CURVES = (("ed25519", "X25519"), ("ed448", "X448"), ("nist256", "NIST256"), ("nist384", "NIST384"))
 
 
 def build_oracle():
@@ -22,7 +26,16 @@ def build_oracle():
 class Oracle:
     def __init__(self, lib):
         self.lib = lib
-        for P in PRIMES:
+        self._bound = {}
+        for P in BOUND_PRIMES:
+            from tests.generic_oracle import params_from_golden
+            self._bound[P] = params_from_golden(P)             # kept alive; the C side copies it
+            bind = getattr(lib, "oracle_bind_" + P)
+            bind.argtypes = [c_void_p]; bind.restype = c_int
+            assert bind(ctypes.byref(self._bound[P])) == 0, "parameter block does not match oracle/field_%s.c" % P
+        allp = dict(PRIMES); allp.update(BOUND_PRIMES)
+        self.primes = allp
+        for P in allp:
             g = lambda f: getattr(lib, "%s_%s" % (f, P))
             for f in ("modadd", "modsub", "modmul", "modadd_lazy", "modsub_lazy"):
                 g(f).argtypes = [U64P, U64P, U64P]; g(f).restype = None
@@ -70,8 +83,8 @@ class Oracle:
             f.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]; f.restype = None
         # Edwards layer (oracle/edwards_oracle.c): point = struct {x[NL], y[NL], z[NL]}
         self.ed = {}
-        for C, P in (("ed25519", "X25519"), ("ed448", "X448"), ("nist256", "NIST256")):
-            nl = PRIMES[P][0]
+        for C, P in ORACLE_CURVES:
+            nl = allp[P][0]
 
             class Pt(ctypes.Structure):
                 _fields_ = [("x", c_uint64 * nl), ("y", c_uint64 * nl), ("z", c_uint64 * nl)]
@@ -86,7 +99,7 @@ class Oracle:
             g("cmp").argtypes = [PP, PP]; g("cmp").restype = c_int
             g("get").argtypes = [PP, ctypes.c_char_p, ctypes.c_char_p]; g("get").restype = c_int
             g("batch_mul").argtypes = [c_void_p, c_void_p, c_size_t, c_size_t]; g("batch_mul").restype = None
-            self.ed[C] = (Pt, PRIMES[P][3])
+            self.ed[C] = (Pt, allp[P][3])
         lib.oracle_parallel.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int]
         lib.oracle_parallel.restype = c_int
 
@@ -95,7 +108,7 @@ class Oracle:
 
     @staticmethod
     def arr(prime, vals=None):
-        n = PRIMES[prime][0]
+        n = (PRIMES.get(prime) or BOUND_PRIMES[prime])[0]
         return (c_uint64 * n)(*(vals if vals is not None else [0] * n))
 
     # element-level helpers returning python lists

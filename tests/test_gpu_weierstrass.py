@@ -1,4 +1,4 @@
-"""GPU parity of the batched Weierstrass layer (NIST P-256): HIP kernels through the C-ABI
+"""GPU parity of the batched Weierstrass layer (NIST P-256 and P-384): HIP kernels through the C-ABI
 against the big-integer fixture (affine, canonical) and against the oracle's restatement of weierstrass.c
 limb for limb (projective coordinates) for add, dbl, mul."""
 import ctypes
@@ -12,12 +12,14 @@ pytestmark = pytest.mark.gpu
 C = "nist256"
 
 
-@pytest.fixture(scope="module")
-def cx():
+@pytest.fixture(scope="module", params=["NIST256", "NIST384"])
+def cx(request):
+    global C
     import torch
     assert torch.cuda.is_available()
     from modarith_amd.edwards import Curve
-    return Curve("NIST256"), load_golden("weierstrass_NIST256.json"), torch
+    C = request.param.lower()
+    return Curve(request.param), load_golden("weierstrass_%s.json" % request.param), torch
 
 
 def dev_bytes(torch, hexes):

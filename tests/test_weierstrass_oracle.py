@@ -1,10 +1,23 @@
-"""The oracle's Weierstrass layer (restatement of weierstrass.c, NIST P-256) against the big-integer
-fixtures (tests/golden/weierstrass_NIST256.json) and the testcurve.c checks.  CPU only."""
+"""The oracle's Weierstrass layer (restatement of weierstrass.c; NIST P-256 on the per-prime field restatement, NIST
+P-384 on the generic field oracle bound to the reference's constants) against the big-integer fixtures
+(tests/golden/weierstrass_<CURVE>.json) and the testcurve.c checks.  CPU only."""
 import ctypes
+
+import pytest
 
 from tests.conftest import load_golden
 
 C = "nist256"
+
+
+@pytest.fixture(autouse=True, params=["nist256", "nist384"])
+def _curve(request):
+    global C
+    C = request.param
+
+
+def gold():
+    return load_golden("weierstrass_%s.json" % C.upper())
 
 
 def pt(o, xy):
@@ -12,7 +25,7 @@ def pt(o, xy):
 
 
 def test_generator_and_mul(oracle):
-    o, g = oracle, load_golden("weierstrass_NIST256.json")
+    o, g = oracle, gold()
     Pt, nb = o.ed[C]
     p = Pt()
     o.ecn(C, "gen")(ctypes.byref(p))
@@ -25,7 +38,7 @@ def test_generator_and_mul(oracle):
 
 
 def test_add_dbl_sub(oracle):
-    o, g = oracle, load_golden("weierstrass_NIST256.json")
+    o, g = oracle, gold()
     for rec in g["ops"]:
         P, Q = pt(o, rec["P"]), pt(o, rec["Q"])
         o.ecn(C, "add")(ctypes.byref(Q), ctypes.byref(P))          # complete: also P+P and P+(-P)
@@ -41,7 +54,7 @@ def test_add_dbl_sub(oracle):
 
 
 def test_decompress_and_set(oracle):
-    o, g = oracle, load_golden("weierstrass_NIST256.json")
+    o, g = oracle, gold()
     Pt, nb = o.ed[C]
     for rec in g["compress"]:
         p = Pt()
@@ -58,7 +71,7 @@ def test_decompress_and_set(oracle):
 
 
 def test_mul2_and_testcurve(oracle):
-    o, g = oracle, load_golden("weierstrass_NIST256.json")
+    o, g = oracle, gold()
     Pt, nb = o.ed[C]
     for rec in g["mul2"]:
         P, Q, R = pt(o, rec["P"]), pt(o, rec["Q"]), Pt()
