@@ -18,7 +18,20 @@ struct CurveOps {
     using F = Field<P, true>;   // FAST product path where the driver proved it (P::SPLIT > 0), else exact
     static constexpr int N = P::N;
     static constexpr int NB = P::NBYTES;
-    static constexpr int NW = NB / 8;
+    static constexpr int NW = (NB + 7) / 8;          // 64-bit words of a scalar / coordinate record
+    static constexpr int PADB = 8 * NW - NB;         // unused top bytes of the top word (6 for the 66-byte NIST521 records)
+    // v <<= S over W words, S a compile-time bit count
+    template <int S, int W>
+    static MA_DEV void shl_words(spint* v) {
+        constexpr int ws = S / 64, bs = S % 64;
+        static_for<0, W>([&](auto KK) {
+            constexpr int k = W - 1 - KK;
+            spint x = 0;
+            if constexpr (k - ws >= 0) x = v[k - ws] << bs;
+            if constexpr (bs != 0 && k - ws - 1 >= 0) x |= v[k - ws - 1] >> (64 - bs);
+            v[k] = x;
+        });
+    }
     struct Point { spint x[N], y[N], z[N]; };
 
     static MA_DEV void cpy(const Point& q, Point& p) { F::modcpy(q.x, p.x); F::modcpy(q.y, p.y); F::modcpy(q.z, p.z); }
@@ -106,11 +119,14 @@ struct CurveOps {
         }
 
         // recoding carries: c_0 = 0, c_{j+1} = (nibble_j + c_j > 7)   (edwards.c:461-467)
+        // the scalar left-aligned in NW words (a no-op shift when Nbytes is a multiple of 8): the padding nibbles at
+        // the bottom are zero, produce no carry and are never reached by the 2*NB-digit loop
         spint nib[NW], car[NW];
         static_for<0, NW>([&](auto K) { nib[K] = ew[K]; car[K] = 0; });
+        shl_words<8 * PADB, NW>(nib);
         unsigned c = 0;
         static_for<0, NW>([&](auto K) {
-            spint word = ew[K], cw = 0;
+            spint word = nib[K], cw = 0;
 #pragma unroll 1
             for (int j = 0; j < 16; j++) {
                 cw |= (spint)c << j;
@@ -139,7 +155,7 @@ struct CurveOps {
             });
             // carries: 16 valid bits per word at the top; after consuming 16 of them move to the next word
             car[NW - 1] <<= 1;
-            if ((i & 15) == 0) {
+            if (((2 * NB - i) & 15) == 0) {          // 16 digits consumed: the next carry word moves up
                 static_for<0, NW - 1>([&](auto KK) {
                     constexpr int k = NW - 1 - KK;
                     car[k] = car[k - 1];
@@ -178,26 +194,20 @@ struct CurveOps {
             cpy(q, t); sub(p, t); W.put(2, t);       // Q - P
             cpy(q, t); Crv::add(p, t); W.put(4, t);       // Q + P
         }
-        // left-aligned copies of e, 3e, f, 3f over NW+1 words; bit 8*NB+7 sits in bit 7 of the top word,
-        // so shift everything left by 56 first
+        // left-aligned copies of e, 3e, f, 3f over NW+1 words: bit 8*NB+7 goes to bit 63 of the top word, i.e. a left
+        // shift by 56 bits plus the record's padding bytes
         spint e1[NW1], e3[NW1], f1[NW1], f3[NW1];
         static_for<0, NW>([&](auto K) { e1[K] = ew[K]; f1[K] = fw[K]; });
         e1[NW] = 0; f1[NW] = 0;
         triple(ew, e3);
         triple(fw, f3);
-        auto shl = [&](spint* v, int sh) {
-            static_for<0, NW1>([&](auto KK) {
-                constexpr int k = NW1 - 1 - KK;
-                v[k] <<= sh;
-                if constexpr (k > 0) v[k] |= v[k - 1] >> (64 - sh);
-            });
-        };
-        shl(e1, 56); shl(e3, 56); shl(f1, 56); shl(f3, 56);
+        shl_words<56 + 8 * PADB, NW1>(e1); shl_words<56 + 8 * PADB, NW1>(e3);
+        shl_words<56 + 8 * PADB, NW1>(f1); shl_words<56 + 8 * PADB, NW1>(f3);
         Crv::inf(r);
 #pragma unroll 1
         for (int i = 8 * NB + 7; i >= 1; i--) {
             const int d = (int)(e3[NW] >> 63) - (int)(e1[NW] >> 63) + 3 * ((int)(f3[NW] >> 63) - (int)(f1[NW] >> 63));
-            shl(e1, 1); shl(e3, 1); shl(f1, 1); shl(f3, 1);
+            shl_words<1, NW1>(e1); shl_words<1, NW1>(e3); shl_words<1, NW1>(f1); shl_words<1, NW1>(f3);
             Crv::dbl(r);
             const int m = d >> 31;
             const int dabs = (d ^ m) - m;
@@ -237,15 +247,14 @@ struct CurveOps {
 // 170 VGPRs measured the same throughput, one wave at 512 VGPRs 20 % less
 #define MA_MUL_WPS 2
 template <class Crv>
-__global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul(const spint* e, spint* Pb, size_t n, size_t ld, spint* ws) {
+__global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul(const unsigned char* e, spint* Pb, size_t n, size_t ld, spint* ws) {
     using E = Crv;
     const size_t lanes = (size_t)gridDim.x * blockDim.x;
     const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     typename E::Table W{ws + lane, lanes};
     for (size_t t = lane; t < n; t += lanes) {
         spint ew[E::NW];
-        // big-endian byte record -> little-endian words
-        static_for<0, E::NW>([&](auto K) { ew[K] = __builtin_bswap64(e[t * E::NW + (E::NW - 1 - K)]); });
+        load_be_record<typename E::P>(e, t, ew);         // big-endian byte record -> little-endian words
         typename E::Point p;
         E::load(Pb, ld, t, p);
         E::mul(ew, p, W);
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul(const spint* e, spint
 }
 
 template <class Crv>
-__global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul2(const spint* e, const spint* Pb, const spint* f, const spint* Qb, spint* Rb,
+__global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul2(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, spint* Rb,
                                                 size_t n, size_t ld, spint* ws) {
     using E = Crv;
     const size_t lanes = (size_t)gridDim.x * blockDim.x;
@@ -262,8 +271,8 @@ __global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul2(const spint* e, cons
     typename E::Table W{ws + lane, lanes};
     for (size_t t = lane; t < n; t += lanes) {
         spint ew[E::NW], fw[E::NW];
-        static_for<0, E::NW>([&](auto K) { ew[K] = __builtin_bswap64(e[t * E::NW + (E::NW - 1 - K)]); });
-        static_for<0, E::NW>([&](auto K) { fw[K] = __builtin_bswap64(f[t * E::NW + (E::NW - 1 - K)]); });
+        load_be_record<typename E::P>(e, t, ew);
+        load_be_record<typename E::P>(f, t, fw);
         typename E::Point p, q, r;
         E::load(Pb, ld, t, p);
         E::load(Qb, ld, t, q);
@@ -322,18 +331,18 @@ __global__ __launch_bounds__(BLOCK) void k_ed_pred(const spint* Pb, const spint*
 
 // ecnXXXset (edwards.c:347-366): big-endian coordinate records x and/or y (either may be null), s = sign array or null
 template <class Crv, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_ed_set(const int* s, const spint* xb, const spint* yb, spint* Pb, size_t n, size_t ld) {
+__global__ __launch_bounds__(BLOCK) void k_ed_set(const int* s, const unsigned char* xb, const unsigned char* yb, spint* Pb, size_t n, size_t ld) {
     using E = Crv;
     using F = typename E::F;
     constexpr int NW = E::NW;
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint X[E::N], Y[E::N], w[NW];
         if constexpr (MODE != 2) {
-            static_for<0, NW>([&](auto K) { w[K] = __builtin_bswap64(xb[t * NW + (NW - 1 - K)]); });
+            load_be_record<typename E::P>(xb, t, w);
             (void)F::modimp_words(w, X);
         }
         if constexpr (MODE != 1) {
-            static_for<0, NW>([&](auto K) { w[K] = __builtin_bswap64(yb[t * NW + (NW - 1 - K)]); });
+            load_be_record<typename E::P>(yb, t, w);
             (void)F::modimp_words(w, Y);
         }
         typename E::Point p;
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(BLOCK) void k_ed_set(const int* s, const spint* xb,
 
 // ecnXXXget (edwards.c:221-239): makes P affine (written back), exports x and/or y, sign of the omitted coordinate
 template <class Crv>
-__global__ __launch_bounds__(BLOCK) void k_ed_get(spint* Pb, spint* xb, spint* yb, int* sign, size_t n, size_t ld) {
+__global__ __launch_bounds__(BLOCK) void k_ed_get(spint* Pb, unsigned char* xb, unsigned char* yb, int* sign, size_t n, size_t ld) {
     using E = Crv;
     using F = typename E::F;
     constexpr int NW = E::NW;
@@ -356,11 +365,11 @@ __global__ __launch_bounds__(BLOCK) void k_ed_get(spint* Pb, spint* xb, spint* y
         spint w[NW];
         if (xb) {
             F::modexp_words(p.x, w);
-            static_for<0, NW>([&](auto K) { xb[t * NW + (NW - 1 - K)] = __builtin_bswap64(w[K]); });
+            store_be_record<typename E::P>(xb, t, w);
         }
         if (yb) {
             F::modexp_words(p.y, w);
-            static_for<0, NW>([&](auto K) { yb[t * NW + (NW - 1 - K)] = __builtin_bswap64(w[K]); });
+            store_be_record<typename E::P>(yb, t, w);
         }
         if (sign) {
             int sg = 0;

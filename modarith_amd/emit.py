@@ -340,7 +340,7 @@ def _write(path: str, text: str) -> str:
     return path
 
 
-BUILT_WCURVES = ("NIST256", "NIST384")
+BUILT_WCURVES = ("NIST256", "NIST384", "NIST521")
 
 
 def wcurve_header_text(name: str) -> str:

@@ -17,23 +17,4 @@
 #define NBYTES 48
 #define PM1D2 1
 
-static gparams bound;
-int oracle_bind_NIST384(const gparams *p) {
-    if (p->n != NL || p->radix != RADIX || p->nbits != NBITS || p->nbytes != NBYTES || p->pm1d2 != PM1D2) return 1;
-    bound = *p;
-    return 0;
-}
-#define PP_CNT (bound.pp_cnt)
-#define pp_idx (bound.pp_idx)
-#define pp_sgn (bound.pp_sgn)
-#define pp_val (bound.pp_val)
-#define roi (bound.roi)
-
-void modmul_NIST384(const spint *a, const spint *b, spint *c) { gen_modmul(&bound, a, b, c); }
-void modsqr_NIST384(const spint *a, spint *c) { gen_modsqr(&bound, a, c); }
-void modmli_NIST384(const spint *a, int b, spint *c) { gen_modmli(&bound, a, b, c); }
-void nres_NIST384(const spint *m, spint *n) { gen_nres(&bound, m, n); }
-void redc_NIST384(const spint *n, spint *m) { gen_redc(&bound, n, m); }
-void modpro_NIST384(const spint *w, spint *z) { gen_modpro(&bound, w, z); }
-
-#include "field_common.inc"
+#include "field_bound.inc"

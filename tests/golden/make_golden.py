@@ -733,6 +733,20 @@ class WsModel:
                            r2="4263994c52c3d292e5c2e05843769f56dc473e16c6dba92188b211f1adcedb879a43ccb742498ca9d06be7eb2913afd6",
                            n1="9a1de644815ef6d13b8faa1837f8a88b17fc695a07a0ca6e0822e8f36c031199972a846916419f828b9d2434e465e150",
                            n2="4737819096da1dac72ff5d2a386ecbe06b65a6a48b8148f6b38a088ca65ed389b74d0fb132e706298fadc1a606cb0fb3")
+        elif name == "NIST521":                       # curve.py:179-188
+            self.p = 2**521 - 1
+            self.a = -3
+            self.b = 0x51953EB9618E1C9A1F929A21A0B68540EEA2DA725B99B315F3B8B489918EF109E156193951EC7E937B1652C0BD3BB1BF073573DF883D2C34F1EF451FD46B503F00
+            self.q = 0x1fffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffa51868783bf2f966b7fcc0148f709a5d03bb5c9b8899c47aebb6fb71e91386409
+            self.G = (0xC6858E06B70404E9CD9E3ECB662395B4429C648139053FB521F828AF606B4D3DBAA14B5E77EFE75928FE1DC127A2FFA8DE3348B3C1856A429BF97E7E31C2E5BD66,
+                      0x11839296A789A3BC0045C8A5FB42C7D1BD998F54449579B446817AFBD17273E662C97EE72995EF42640C550B9013FAD0761353C7086A272C24088BE94769FD16650)
+            self.nbytes = 66
+            # testcurve.c:43-49
+            self.tc = dict(order="1fffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffa51868783bf2f966b7fcc0148f709a5d03bb5c9b8899c47aebb6fb71e91386409",
+                           r1="d8972a846916419f828b9d2434e465e150bd9c66b3ad3c2d6d1a3d1fa7bc8960a923b8c1e9392456de3eb13b9046685257bdd640fb06671ad11c80317fa3b1799d",
+                           r2="12768d57b96e9be607d7462dbcb1b9a1eaf4263994c52c3d292e5c2e05843769f512dcdc59a860b3f8d411ac5b8b0a153787ddf88bd83352cdd9eef859eed86ea6c",
+                           n1="e5386ecbe06b65a6a48b8148f6b38a088ca65ed389b74d0fb132e706298fadc1a606cb0fb39a1de644815ef6d13b8faa1837f8a88b17fc695a07a0ca6e0822e8f3",
+                           n2="acc37459eef50bea63371ecd7b27cd813047229389571aa8766c307511b2b9437a28df6ec4ce4a2bbdc241330b01a9e71fde8a774bcf36d58b4737819096da1dac")
         else:
             raise ValueError(name)
         assert self.on_curve(self.G)
@@ -791,7 +805,7 @@ def weierstrass_fixture(name, seed, pairs=32):
     rng = random.Random(seed)
     M = WsModel(name)
     nb, p, q, G = M.nbytes, M.p, M.q, M.G
-    fx = {"curve": name, "source": "big-integer model (tests/golden/make_golden.py WsModel); constants curve.py:157-177",
+    fx = {"curve": name, "source": "big-integer model (tests/golden/make_golden.py WsModel); constants curve.py:157-188",
           "gen": M.xy_hex(G), "order": q.to_bytes(nb, "big").hex()}
     assert M.mul(q, G) is None
     recs = []
@@ -869,8 +883,8 @@ def main():
         extras()
         return
     if "--weierstrass-only" in sys.argv:
-        for k, wname in enumerate(("NIST256", "NIST384")):
-            json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else 24), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
+        for k, wname in enumerate(("NIST256", "NIST384", "NIST521")):
+            json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else 24 - 4 * (k - 1)), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
         return
     if "--edwards-only" in sys.argv:
         for name, seed in (("ED25519", 5001), ("ED448", 5002)):
@@ -896,8 +910,8 @@ def main():
     for script, prime, seed in (("pseudo.py", "X25519", 4001), ("monty.py", "NIST256", 4002), ("monty.py", "X448", 4003)):
         json.dump(sqrt_fixture(script, prime, seed), open(os.path.join(HERE, "sqrt_%s.json" % prime), "w"), indent=0, separators=(",", ":"))
     extras()
-    for k, wname in enumerate(("NIST256", "NIST384")):
-        json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else 24), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
+    for k, wname in enumerate(("NIST256", "NIST384", "NIST521")):
+        json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else 24 - 4 * (k - 1)), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
     for name, seed in (("ED25519", 5001), ("ED448", 5002)):
         json.dump(edwards_fixture(name, seed, pairs=40 if name == "ED25519" else 20), open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
     for curve, seed in (("X25519", 3001), ("X448", 3003)):

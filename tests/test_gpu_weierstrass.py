@@ -1,4 +1,4 @@
-"""GPU parity of the batched Weierstrass layer (NIST P-256 and P-384): HIP kernels through the C-ABI
+"""GPU parity of the batched Weierstrass layer (NIST P-256, P-384 and P-521): HIP kernels through the C-ABI
 against the big-integer fixture (affine, canonical) and against the oracle's restatement of weierstrass.c
 limb for limb (projective coordinates) for add, dbl, mul."""
 import ctypes
@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 C = "nist256"
 
 
-@pytest.fixture(scope="module", params=["NIST256", "NIST384"])
+@pytest.fixture(scope="module", params=["NIST256", "NIST384", "NIST521"])
 def cx(request):
     global C
     import torch
