@@ -219,7 +219,9 @@ int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void 
  * 9-entry table lives in a caller-provided device workspace of ecn_*_mul_workspace_bytes(n) bytes.
  * Projective results equal the reference's limb for limb where it is deterministic (add, dbl, mul);
  * set/get/affine/cmp involve modpro and are comparable as affine coordinates.  ecnXXXmul2 (not constant
- * time in the reference) runs a fixed number of steps per lane here: same point, after affine. */
+ * time in the reference) runs a fixed number of steps per lane here: same point, after affine.
+ * Input points must have limbs below 2^(Radix+2) -- true of every point these functions or the reference's
+ * produce; the field-level functions above have no such condition. */
 #define MODARITH_AMD_DECLARE_EDWARDS(c, NL)                                                                             \
     typedef struct { ma_spint x[NL], y[NL], z[NL]; } ma_point_##c##_t;                                                  \
     int ecn_##c##_get(ma_point_##c##_t *P, char *x, char *y);                          /* edwards.c:221-239 */        \

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Soak runs on the GPU box (not part of the pytest suites: minutes, not seconds).
+
+  soak.py field   exact vs split/chain products on 2^22 elements per prime whose limbs are drawn from the contract's
+                  edge classes (0, 1, 2^R-1, 2^R, 2^(R+1)-1, 2^(R+2)-1, random), plus 48-operation chains from
+                  in-range values: the two product policies must agree bit for bit (checksums compared across two child processes, MA_FORCE_FAST=0/1)
+  soak.py curves  2^16 random scalars x random points per curve, fused ecn mul on the GPU against the CPU oracle,
+                  projective limbs compared
+"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def field_child(out):
+    import json, torch
+    from modarith_amd.field import Field
+    from modarith_amd.params import derive
+    from modarith_amd import emit
+    res = {}
+    n = 1 << 22
+    for name in emit.BUILT_PRIMES:
+        fp = derive(name)
+        if emit.split_point(fp) == 0:
+            continue
+        F = Field(name)
+        R = fp.radix
+        g = torch.Generator(device="cuda").manual_seed(1234)
+        edges = torch.tensor([0, 1, (1 << R) - 1, 1 << R, (1 << (R + 1)) - 1, (1 << (R + 2)) - 1, 0x5555555555555 & ((1 << R) - 1)], dtype=torch.int64, device="cuda")
+        def draw():
+            cls = torch.randint(0, 10, (fp.nlimbs, n), device="cuda", generator=g)
+            rnd = torch.randint(0, 1 << R, (fp.nlimbs, n), dtype=torch.int64, device="cuda", generator=g)
+            return torch.where(cls < 7, edges[cls.clamp(max=6)], rnd)
+        a, b = draw(), draw()
+        outs = [F.modmul(a, b), F.modsqr(a), F.modmul(b, b)]
+        if fp.montgomery:
+            outs += [F.nres(a), F.redc(a)]
+        # chained, from in-range values (tight limbs, value below 2^Nbits): results fed back as the functions leave them.
+        # (Edge-class limbs are integers up to 4*2^(N*Radix), far outside the < 2p domain of the reference's functions;
+        # their single products agree above, but their outputs are not valid inputs any more.)
+        x = torch.randint(0, 1 << R, (fp.nlimbs, n), dtype=torch.int64, device="cuda", generator=g)
+        x[fp.nlimbs - 1] &= (1 << max(fp.n - R * (fp.nlimbs - 1) - 1, 1)) - 1
+        y = x.flip(1).contiguous()
+        c = F.modmul(x, y)
+        for _ in range(16):
+            c = F.modmul(c, y); c = F.modsqr(c); y = F.modadd(c, x)
+        outs.append(c)
+        res[name] = [[int(o.sum().item()) & (2**64 - 1), int(o.flatten().cumsum(0)[-1].item()) & (2**64 - 1),
+                      int((o ^ (o >> 17)).sum().item()) & (2**64 - 1)] for o in outs]
+    json.dump(res, open(out, "w"))
+
+
+def field():
+    import json
+    outs = []
+    for fast in ("0", "1"):
+        f = "/tmp/soak_field_%s.json" % fast
+        subprocess.run([sys.executable, __file__, "field-child", f], env=dict(os.environ, MA_FORCE_FAST=fast), check=True)
+        outs.append(json.load(open(f)))
+    names = ["modmul(a,b)", "modsqr(a)", "modmul(b,b)", "nres(a)|chain", "redc(a)", "chain"]
+    for k in outs[0]:
+        if outs[0][k] != outs[1][k]:
+            print(k, "differs in:", [names[i] if len(outs[0][k]) == 6 or i < 3 else "chain" for i in range(len(outs[0][k])) if outs[0][k][i] != outs[1][k][i]])
+    bad = [k for k in outs[0] if outs[0][k] != outs[1][k]]
+    print("field soak: %d primes, 2^22 edge-class elements each, exact == split/chain: %s" % (len(outs[0]), "ALL EQUAL" if not bad else "MISMATCH " + str(bad)))
+    return 1 if bad else 0
+
+
+def curves():
+    import ctypes, numpy as np, torch
+    from modarith_amd.edwards import Curve
+    from tests.oracle_binding import load_oracle
+    from tests.util import vp
+    o = load_oracle(build=not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")))
+    rc = 0
+    n = 1 << 16
+    for name in ("ED25519", "NIST256", "ED448", "NIST384"):
+        C = Curve(name)
+        g = torch.Generator(device="cuda").manual_seed(77)
+        e0 = torch.randint(0, 256, (n, C.nbytes), dtype=torch.uint8, device="cuda", generator=g)
+        P = C.mul(e0, C.gen(n))                       # random points (GPU), then the run under test
+        e = torch.randint(0, 256, (n, C.nbytes), dtype=torch.uint8, device="cuda", generator=g)
+        e[:16] = 0; e[16:32] = 255                    # corner scalars
+        hp = np.ascontiguousarray(P.cpu().numpy().view(np.uint64)).reshape(3 * C.N, n)
+        he = np.ascontiguousarray(e.cpu().numpy())
+        want = hp.copy()
+        o.lib.__getattr__("ecn_%s_batch_mul" % name.lower())(vp(he), vp(want), n, n)
+        got = C.mul(e, P.clone()).cpu().numpy().view(np.uint64).reshape(3 * C.N, n)
+        ok = bool(np.array_equal(got, want))
+        print("curve soak %-8s 2^16 scalar multiplications, projective limbs vs oracle: %s" % (name, "EQUAL" if ok else "MISMATCH"), flush=True)
+        rc |= 0 if ok else 1
+    return rc
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1] if len(sys.argv) > 1 else "field"
+    if mode == "field-child":
+        field_child(sys.argv[2])
+    elif mode == "field":
+        sys.exit(field())
+    else:
+        sys.exit(curves())
