@@ -175,17 +175,19 @@ MODARITH_AMD_DECLARE(X448)
 /* further primes of the generators' named lists (pseudo.py:1498-1548, monty.py:1966-2062) and the group orders
  * curve.py:324-329 feeds to monty.py; same functions, constants from modarith_amd/params.py:
  *   pseudo-Mersenne: NIST521 (9 x 58), PM266 (5 x 54), PM383 (7 x 55, non-EPM rows), NUMS256W (5 x 52)
- *   Montgomery     : NIST384 (7 x 56), NIST224 (4 x 56 + virtual limb), SECP256K1 (5 x 52), all full reduction
+ *   Montgomery     : NIST384 (7 x 56), NIST224 (4 x 56 + virtual limb), SECP256K1M (5 x 52), all full reduction
  *                    (ndash != 1); group orders NIST256Q, ED25519Q, ED448Q (general primes);
  *                    GM270 GM240 GM360 GM480 GM384 GM512 (generalised Mersenne trinomials), TWEEDLE, SIDH434, SIDH503
- *   pseudo-Mersenne: also C2065 (4 x 52), PM336 (6 x 56), PM512 (9 x 57, non-EPM rows) */
+ *   pseudo-Mersenne: also C2065 (4 x 52), PM336 (6 x 56), PM512 (9 x 57, non-EPM rows), and the split-high-part
+ *                    ("overflow") rows of pseudo.py:1640-1657: SECP256K1 (5 x 52, the field curve.py gives secp256k1 at
+ *                    64 bits) and C41417 (7 x 60).  SECP256K1M is monty.py's flavour of the secp256k1 prime. */
 MODARITH_AMD_DECLARE(NIST521)
 MODARITH_AMD_DECLARE(PM266)
 MODARITH_AMD_DECLARE(PM383)
 MODARITH_AMD_DECLARE(NUMS256W)
 MODARITH_AMD_DECLARE(NIST384)
 MODARITH_AMD_DECLARE(NIST224)
-MODARITH_AMD_DECLARE(SECP256K1)
+MODARITH_AMD_DECLARE(SECP256K1M)
 MODARITH_AMD_DECLARE(NIST256Q)
 MODARITH_AMD_DECLARE(ED25519Q)
 MODARITH_AMD_DECLARE(ED448Q)
@@ -201,6 +203,8 @@ MODARITH_AMD_DECLARE(GM512)
 MODARITH_AMD_DECLARE(TWEEDLE)
 MODARITH_AMD_DECLARE(SIDH434)
 MODARITH_AMD_DECLARE(SIDH503)
+MODARITH_AMD_DECLARE(SECP256K1)
+MODARITH_AMD_DECLARE(C41417)
 
 /* RFC 7748 ladder, bv = [bk] * bu (reference rfc7748.c:156 `void rfc7748(const char *bk,const char *bu,char *bv)`).
  * Scalar form: host pointers, Nbytes each (32 / 56), RFC little-endian.  Batched form: device pointers,

@@ -13,8 +13,9 @@ from ctypes import c_char_p, c_int, c_size_t, c_uint, c_void_p
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MA_LIB", os.path.join(HERE, "libmodarith_amd.so"))   # MA_LIB: a variant build under test
 PRIMES = ("X25519", "NIST256", "X448",
-          "NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1", "NIST256Q", "ED25519Q", "ED448Q",
-          "C2065", "PM336", "PM512", "GM270", "GM240", "GM360", "GM480", "GM384", "GM512", "TWEEDLE", "SIDH434", "SIDH503")
+          "NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1M", "NIST256Q", "ED25519Q", "ED448Q",
+          "C2065", "PM336", "PM512", "GM270", "GM240", "GM360", "GM480", "GM384", "GM512", "TWEEDLE", "SIDH434", "SIDH503",
+          "SECP256K1", "C41417")
 LADDERS = ("X25519", "X448")
 CURVES = {"ed25519": (5, 32), "ed448": (8, 56), "nist256": (5, 32), "nist384": (7, 48), "nist521": (9, 66)}       # curve -> (Nlimbs, Nbytes)
 ED_BATCH_FUNCS = ("mul", "mul2", "ran", "add", "sub", "cpy", "dbl", "neg", "inf", "gen", "cof", "affine", "cmp", "isinf", "set", "get")

@@ -242,9 +242,10 @@ struct Field {
 
     // Comba rows, high half folded by mm (pseudo.py:616-659, getZM 390-438; overflow=False only)
     static MA_DEV void pm_modmul(const spint* a, const spint* b, spint* c) {
-        static_assert(!P::OVERFLOW, "the overflow variants of pseudo.py are not built");
+        static_assert(!P::OVERFLOW || !FAST, "the split-high-part rows of pseudo.py's overflow form exist in exact form only");
         dpint t = 0;
         spint v[N];
+        spint hi_ov = 0;       // OVERFLOW form: high word of the previous row's folded sum (pseudo.py:407-420)
         Opd A[N], B[N], MA[N];
         static_for<0, N>([&](auto I) { A[I] = W::prep(a[I]); B[I] = W::prep(b[I]); });
         if constexpr (P::EPM) static_for<1, N>([&](auto I) { MA[I] = W::prep(a[I] * (spint)P::MM); });
@@ -263,14 +264,24 @@ struct Field {
                     hi.mac(A[k], B[N + row - k]);
                 });
                 dpint tt = hi.sum();
-                tt *= (dpint)P::MM;
-                t += tt;
+                if constexpr (P::OVERFLOW) {
+                    // mm times the folded sum would not fit 128 bits: its low limb is folded now, the rest with the
+                    // next row (bad_overflow_mul = False form; the driver refuses primes that need the other one)
+                    const spint lo = (spint)tt & MASK;
+                    if constexpr (row == 0) t += (dpint)lo * (dpint)P::MM;
+                    else t += (dpint)(spint)(lo + hi_ov) * (dpint)P::MM;
+                    hi_ov = (spint)(tt >> RADIX);
+                } else {
+                    tt *= (dpint)P::MM;
+                    t += tt;
+                }
             }
             static_for<0, row + 1>([&](auto K) {
                 constexpr int k = K;
                 col.mac(A[k], B[row - k]);
             });
             t += col.sum();
+            if constexpr (P::OVERFLOW && row == N - 1) t += (dpint)hi_ov * (dpint)P::MM;     // pseudo.py:435-436
             v[row] = (spint)t & MASK;
             t >>= RADIX;
         });
@@ -279,9 +290,10 @@ struct Field {
 
     // squaring rows (pseudo.py:663-702, getZS 441-554)
     static MA_DEV void pm_modsqr(const spint* a, spint* c) {
-        static_assert(!P::OVERFLOW, "the overflow variants of pseudo.py are not built");
+        static_assert(!P::OVERFLOW || !FAST, "the split-high-part rows of pseudo.py's overflow form exist in exact form only");
         dpint t = 0;
         spint v[N];
+        spint hi_ov = 0;       // OVERFLOW form (pseudo.py:492-493, 536-550)
         Opd A[N], TA[N], MA[N];
         static_for<0, N>([&](auto I) { A[I] = W::prep(a[I]); });
         if constexpr (P::EPM) {
@@ -315,8 +327,17 @@ struct Field {
                     sq.mac(A[k], A[k]);
                     tt += sq.sum();
                 }
-                tt *= (dpint)P::MM;
-                t += tt;
+                if constexpr (P::OVERFLOW) {
+                    const spint lo = (spint)tt & MASK;
+                    if constexpr (row == 0) t += (dpint)lo * (dpint)P::MM;
+                    else t += (dpint)(spint)(lo + hi_ov) * (dpint)P::MM;
+                    hi_ov = (spint)(tt >> RADIX);
+                } else {
+                    tt *= (dpint)P::MM;
+                    t += tt;
+                }
+            } else if constexpr (P::OVERFLOW) {
+                t += (dpint)hi_ov * (dpint)P::MM;          // row N-1 (pseudo.py:537-538)
             }
             // low part: pairs (k, l) with k + l = row
             constexpr int lpairs = (row + 1) / 2;

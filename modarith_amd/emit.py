@@ -21,8 +21,9 @@ from .params import FieldParams, derive
 HERE = os.path.dirname(os.path.abspath(__file__))
 GEN_DIR = os.path.join(HERE, "csrc", "generated")
 CORE_PRIMES = ("X25519", "NIST256", "X448")            # BASELINE.json configs; their capi_<P>.hip are hand-written
-EXTRA_PRIMES = ("NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1", "NIST256Q", "ED25519Q", "ED448Q",
-                "C2065", "PM336", "PM512", "GM270", "GM240", "GM360", "GM480", "GM384", "GM512", "TWEEDLE", "SIDH434", "SIDH503")
+EXTRA_PRIMES = ("NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1M", "NIST256Q", "ED25519Q", "ED448Q",
+                "C2065", "PM336", "PM512", "GM270", "GM240", "GM360", "GM480", "GM384", "GM512", "TWEEDLE", "SIDH434", "SIDH503",
+                "SECP256K1", "C41417")
 BUILT_PRIMES = CORE_PRIMES + EXTRA_PRIMES
 
 
@@ -184,6 +185,8 @@ def split_point(fp: FieldParams) -> int:
     Contract: every limb < 2^(radix+2) (tight limbs, [p,2p) with the top limb unmasked, generic=False sums);
     pre-multiplied operands (ma = mm*a, ta = 2a) are wider by bits(mm) / 1 bit.  n = most products per column."""
     W = fp.radix + 2
+    if fp.family == "pseudo" and fp.overflow:
+        return 0                               # the split-high-part rows exist in exact form only
     if fp.family == "pseudo":
         wa = W + (fp.mm.bit_length() if fp.epm else 0)
         wb = W + (1 if fp.epm else 0)

@@ -38,7 +38,11 @@ NAMED = {
     "PM383": (2**383 - 187, "pseudo"),
     "NUMS256W": (2**256 - 189, "pseudo"),
     "NIST521": (2**521 - 1, "pseudo"),
-    "SECP256K1": (2**256 - 2**32 - 977, "monty"),        # pseudo.py's overflow variant is not built
+    # secp256k1: curve.py:190-198 takes pseudo.py's field at 64 bits (the split-high-part "overflow" form,
+    # pseudo.py:1640-1657); monty.py's flavour of the same prime is kept under the key SECP256K1M
+    "SECP256K1": (2**256 - 2**32 - 977, "pseudo"),
+    "SECP256K1M": (2**256 - 2**32 - 977, "monty"),
+    "C41417": (2**414 - 17, "pseudo"),
     # further named moduli of monty.py's list (monty.py:1990-2075)
     "GM270": (2**270 - 2**162 - 1, "monty"),
     "GM240": (2**240 - 2**183 - 1, "monty"),
@@ -59,13 +63,16 @@ NAMED = {
 # per-name radix choices the generators hard-wire for 64-bit words (monty.py:2002-2037, `if WL==64: base=...`)
 RADIX_64 = {"GM240": 61, "GM360": 57, "GM480": 60, "GM384": 62, "GM512": 58}
 
+# keys of NAMED that are not the generators' own spelling
+REFERENCE_NAME = {"SECP256K1M": "SECP256K1"}
+
 # how each built name is spelled on the reference generators' command line (group orders: "00" + decimal)
 def reference_argv(name: str):
     p, fam = NAMED[name]
     script = "pseudo.py" if fam == "pseudo" else "monty.py"
     if name.endswith("Q"):
         return script, "00" + str(p)
-    return script, name
+    return script, REFERENCE_NAME.get(name, name)
 
 
 @dataclass
@@ -178,6 +185,8 @@ def derive_pseudo(name: str, p: int, radix: Optional[int] = None) -> FieldParams
         raise ValueError("excess too large for this radix")
     tw = b if n % radix == 0 else 1 << (n % radix)
     overflow = (b - 1) * (b - 1) * mm * N >= 1 << (2 * WL)
+    if overflow and (N - 1) * (b - 1) ** 2 >= 1 << (2 * WL - 3):
+        raise ValueError("pseudo.py's bad_overflow forms (pseudo.py:1646-1648) are not built")
     fred = _bits(N + 1) + radix + _bits(mm) < WL
     epm = (not overflow) and mm * (b - 1) < 1 << WL
     carry_on = m * ((1 << (2 * WL - radix + xcess)) + (1 << (radix - xcess))) >= 1 << (2 * radix)

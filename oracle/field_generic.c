@@ -99,7 +99,7 @@ static void pm_second_pass(const gparams *P, dpint t, spint *v, spint *c) {
 }
 static void pm_modmul(const gparams *P, const spint *a, const spint *b, spint *c) {
     dpint t = 0;
-    spint v[GMAXN], ma[GMAXN];
+    spint v[GMAXN], ma[GMAXN], hi = 0;
     if (P->epm) for (int i = 1; i < N; i++) ma[i] = a[i] * P->mm;
     for (int row = 0; row < N; row++) {
         if (P->epm) {
@@ -107,10 +107,18 @@ static void pm_modmul(const gparams *P, const spint *a, const spint *b, spint *c
         } else if (row < N - 1) {
             dpint tt = 0;
             for (int k = row + 1; k < N; k++) tt += (dpint)a[k] * (dpint)b[N + row - k];
-            tt *= (dpint)P->mm;
-            t += tt;
+            if (P->overflow) {                      /* getZM, pseudo.py:407-420 (bad_overflow_mul = False form) */
+                spint lo = (spint)tt & MASK;
+                if (row == 0) t += (dpint)lo * (dpint)P->mm;
+                else t += (dpint)(spint)(lo + hi) * (dpint)P->mm;
+                hi = (spint)(tt >> P->radix);
+            } else {
+                tt *= (dpint)P->mm;
+                t += tt;
+            }
         }
         for (int k = 0; k <= row; k++) t += (dpint)a[k] * (dpint)b[row - k];
+        if (row == N - 1 && P->overflow) t += (dpint)hi * (dpint)P->mm;          /* pseudo.py:435-436 */
         v[row] = (spint)t & MASK;
         t >>= P->radix;
     }
@@ -118,7 +126,7 @@ static void pm_modmul(const gparams *P, const spint *a, const spint *b, spint *c
 }
 static void pm_modsqr(const gparams *P, const spint *a, spint *c) {
     dpint t = 0;
-    spint v[GMAXN], ta[GMAXN], ma[GMAXN];
+    spint v[GMAXN], ta[GMAXN], ma[GMAXN], hi = 0;
     if (P->epm) for (int i = 1; i < N; i++) { ta[i] = a[i] * (spint)2; ma[i] = a[i] * P->mm; }
     for (int row = 0; row < N; row++) {
         int k = row + 1, l = N - 1;
@@ -131,8 +139,17 @@ static void pm_modsqr(const gparams *P, const spint *a, spint *c) {
             for (; k < l; k++, l--) tt += (dpint)a[k] * (dpint)a[l];
             if (dble) tt *= 2;
             if (k == l) tt += (dpint)a[k] * (dpint)a[k];
-            tt *= (dpint)P->mm;
-            t += tt;
+            if (P->overflow) {                      /* getZS, pseudo.py:492-493, 536-550 (bad_overflow_sqr = False form) */
+                spint lo = (spint)tt & MASK;
+                if (row == 0) t += (dpint)lo * (dpint)P->mm;
+                else t += (dpint)(spint)(lo + hi) * (dpint)P->mm;
+                hi = (spint)(tt >> P->radix);
+            } else {
+                tt *= (dpint)P->mm;
+                t += tt;
+            }
+        } else if (P->overflow) {
+            t += (dpint)hi * (dpint)P->mm;          /* row N-1: pseudo.py:537-538 */
         }
         k = 0; l = row;
         if (P->epm) {

@@ -25,6 +25,8 @@ typedef struct {
     int pe_words;
     spint pe[GMAXN];
     spint roi[GMAXN];
+    /* pseudo.py:1640-1657: column sums would overflow 128 bits, the folded high part is split (lo, hi) instead */
+    int overflow;
 } gparams;
 
 spint gen_flatten(const gparams *P, spint *n);
