@@ -269,13 +269,16 @@ int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void 
 
 MODARITH_AMD_DECLARE_EDWARDS(ed25519, 5)
 MODARITH_AMD_DECLARE_EDWARDS(ed448, 8)
-/* NIST P-256, P-384 and P-521 in short-Weierstrass form (weierstrass.c: complete add/dbl 68-281, setxy 366-410, mul
- * 494-543, mul2 545-569; constants curve.py:157-188) -- the same curve.h API and layouts; ecn_<c>_set needs x (y
- * optional), ecn_<c>_cof is a no-op.  Byte records whose length is a multiple of 8 must be 8-byte aligned; the 66-byte
+/* NIST P-256, P-384, P-521, secp256k1 (a = 0, CONSTANT_B = 7, over pseudo.py's SECP256K1 field as curve.py builds it at
+ * 64 bits) and NUMS256W (CONSTANT_B, CONSTANT_X) in short-Weierstrass form (weierstrass.c: complete add/dbl 68-281, setxy
+ * 366-410, mul 494-543, mul2 545-569; constants curve.py:147-198) -- the same curve.h API and layouts; ecn_<c>_set
+ * needs x (y optional), ecn_<c>_cof is a no-op.  Byte records whose length is a multiple of 8 must be 8-byte aligned; the 66-byte
  * P-521 records may sit anywhere. */
 MODARITH_AMD_DECLARE_EDWARDS(nist256, 5)
 MODARITH_AMD_DECLARE_EDWARDS(nist384, 7)
 MODARITH_AMD_DECLARE_EDWARDS(nist521, 9)
+MODARITH_AMD_DECLARE_EDWARDS(secp256k1, 5)
+MODARITH_AMD_DECLARE_EDWARDS(nums256w, 5)
 
 #ifdef __cplusplus
 }

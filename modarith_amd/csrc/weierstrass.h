@@ -2,7 +2,8 @@
 //
 // Device-side counterpart of the formulas in the reference's weierstrass.c: projective points (X:Y:Z) on
 // y^2 = x^3 + a*x + b with the complete addition / doubling of Renes-Costello-Batina (eprint 2015/1060) in the
-// operation order of weierstrass.c:68-281 (a = -3 and a = 0 branches, large-constant b), built from the
+// operation order of weierstrass.c:68-281 (a = -3 and a = 0 branches; b as a limb constant or, below 2^28 in magnitude,
+// as the C int CONSTANT_B multiplied in with modmli; small CONSTANT_X generators), built from the
 // bit-exact Field<P> functions.  Everything curve-independent is in curve.h.
 #pragma once
 #include "curve.h"
@@ -52,9 +53,17 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
         if constexpr (C::A == 0) {
             F::modadd(T0, T0, p.x);
             F::modadd(T0, p.x, T0);
-            const_b3(B);
-            F::modmul(T2, B, T2);
-            F::modmul(p.y, B, p.y);
+            if constexpr (C::SMALL_B > 0) {
+                F::modmli(T2, 3 * C::SMALL_B, T2);
+                F::modmli(p.y, 3 * C::SMALL_B, p.y);
+            } else if constexpr (C::SMALL_B < 0) {
+                F::modmli(T2, -3 * C::SMALL_B, T2); F::modneg(T2, T2);
+                F::modmli(p.y, -3 * C::SMALL_B, p.y); F::modneg(p.y, p.y);
+            } else {
+                const_b3(B);
+                F::modmul(T2, B, T2);
+                F::modmul(p.y, B, p.y);
+            }
             F::modadd(T1, T2, p.z);
             F::modsub(T1, T2, T1);
             F::modmul(p.y, T4, p.x);
@@ -68,10 +77,20 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
             F::modadd(p.z, T0, p.z);
         } else {
             static_assert(C::A == 0 || C::A == -3, "weierstrass.c handles a = 0 and a = -3");
-            const_b(B);
-            F::modmul(B, T2, p.z);
-            F::modsub(p.y, p.z, p.x);
-            F::modmul(p.y, B, p.y);
+            if constexpr (C::SMALL_B > 0) {
+                F::modmli(T2, C::SMALL_B, p.z);
+                F::modsub(p.y, p.z, p.x);
+                F::modmli(p.y, C::SMALL_B, p.y);
+            } else if constexpr (C::SMALL_B < 0) {
+                F::modmli(T2, -C::SMALL_B, p.z);
+                F::modadd(p.y, p.z, p.x);
+                F::modmli(p.y, -C::SMALL_B, p.y); F::modneg(p.y, p.y);
+            } else {
+                const_b(B);
+                F::modmul(B, T2, p.z);
+                F::modsub(p.y, p.z, p.x);
+                F::modmul(p.y, B, p.y);
+            }
             F::modadd(p.x, p.x, p.z);
             F::modadd(p.x, p.z, p.x);
             F::modsub(T1, p.x, p.z);
@@ -108,8 +127,14 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
             F::modmul(p.x, p.y, T4);
             F::modmul(p.y, p.z, T1);
             F::modsqr(p.z, T2);
-            const_b3(B);
-            F::modmul(T2, B, T2);
+            if constexpr (C::SMALL_B > 0) {
+                F::modmli(T2, 3 * C::SMALL_B, T2);
+            } else if constexpr (C::SMALL_B < 0) {
+                F::modmli(T2, -3 * C::SMALL_B, T2); F::modneg(T2, T2);
+            } else {
+                const_b3(B);
+                F::modmul(T2, B, T2);
+            }
             F::modmul(T2, T3, p.x);
             F::modadd(T0, T2, p.y);
             F::modmul(T3, T1, p.z);
@@ -129,10 +154,20 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
             F::modadd(T3, T3, T3);
             F::modmul(p.z, p.x, p.z);
             F::modadd(p.z, p.z, p.z);
-            const_b(B);
-            F::modmul(T2, B, p.y);
-            F::modsub(p.y, p.z, p.y);
-            F::modmul(p.z, B, p.z);
+            if constexpr (C::SMALL_B > 0) {
+                F::modmli(T2, C::SMALL_B, p.y);
+                F::modsub(p.y, p.z, p.y);
+                F::modmli(p.z, C::SMALL_B, p.z);
+            } else if constexpr (C::SMALL_B < 0) {
+                F::modmli(T2, -C::SMALL_B, p.y); F::modneg(p.y, p.y);
+                F::modsub(p.y, p.z, p.y);
+                F::modmli(p.z, -C::SMALL_B, p.z); F::modneg(p.z, p.z);
+            } else {
+                const_b(B);
+                F::modmul(T2, B, p.y);
+                F::modsub(p.y, p.z, p.y);
+                F::modmul(p.z, B, p.z);
+            }
             F::modadd(p.y, p.y, p.x);
             F::modadd(p.y, p.x, p.y);
             F::modsub(T1, p.y, p.x);
@@ -187,8 +222,16 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
             F::modsub(V, x, V);
             F::modsub(V, x, V);
         }
-        const_b(B);
-        F::modadd(V, B, V);
+        if constexpr (C::SMALL_B > 0) {
+            F::modint(C::SMALL_B, B);
+            F::modadd(V, B, V);
+        } else if constexpr (C::SMALL_B < 0) {
+            F::modint(-C::SMALL_B, B);
+            F::modsub(V, B, V);
+        } else {
+            const_b(B);
+            F::modadd(V, B, V);
+        }
         if constexpr (MODE == 0) {
             F::modsqr(y, T);
             const int ok = F::modcmp(T, V);
@@ -208,8 +251,13 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
     }
     static MA_DEV void gen(Point& p) {                                                  // weierstrass.c:431-440
         spint gx[N], gy[N];
-        static_for<0, N>([&](auto I) { gx[I] = C::gx(I); gy[I] = C::gy(I); });
-        setxy<0>(0, gx, gy, p);
+        if constexpr (C::SMALL_X != 0) {
+            F::modint(C::SMALL_X, gx);
+            setxy<1>(0, gx, nullptr, p);
+        } else {
+            static_for<0, N>([&](auto I) { gx[I] = C::gx(I); gy[I] = C::gy(I); });
+            setxy<0>(0, gx, gy, p);
+        }
     }
 };
 

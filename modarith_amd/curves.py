@@ -60,6 +60,14 @@ class WeierstrassCurve:
     gy: int
     fp: Optional[FieldParams] = None
 
+    @property
+    def small_b(self) -> bool:
+        return abs(self.b) < (1 << 28)      # curve.py:235-238: b stays the C int CONSTANT_B
+
+    @property
+    def small_x(self) -> bool:
+        return abs(self.gx) < (1 << 28)     # curve.py:239-240: generator decompressed from CONSTANT_X
+
     def internal(self, v: int) -> List[int]:
         fp = self.fp
         if fp.montgomery:
@@ -90,6 +98,17 @@ W_CURVES = {
         0x1fffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffa51868783bf2f966b7fcc0148f709a5d03bb5c9b8899c47aebb6fb71e91386409,
         0xC6858E06B70404E9CD9E3ECB662395B4429C648139053FB521F828AF606B4D3DBAA14B5E77EFE75928FE1DC127A2FFA8DE3348B3C1856A429BF97E7E31C2E5BD66,
         0x11839296A789A3BC0045C8A5FB42C7D1BD998F54449579B446817AFBD17273E662C97EE72995EF42640C550B9013FAD0761353C7086A272C24088BE94769FD16650),
+    # curve.py:190-198; at 64 bits over pseudo.py's field
+    "SECP256K1": WeierstrassCurve(
+        "SECP256K1", "SECP256K1", 0, 7,
+        0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141,
+        0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798,
+        0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8),
+    # curve.py:147-155: small b and small generator x (y is recovered, even sign)
+    "NUMS256W": WeierstrassCurve(
+        "NUMS256W", "NUMS256W", -3, 152961,
+        0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFE43C8275EA265C6020AB20294751A825,
+        2, 0),
 }
 
 

@@ -343,7 +343,7 @@ def _write(path: str, text: str) -> str:
     return path
 
 
-BUILT_WCURVES = ("NIST256", "NIST384", "NIST521")
+BUILT_WCURVES = ("NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W")
 
 
 def wcurve_header_text(name: str) -> str:
@@ -359,6 +359,8 @@ def wcurve_header_text(name: str) -> str:
          "struct C_%s {" % c.name,
          "    using FieldParams = P_%s;" % c.field,
          "    static constexpr int A = %d;" % c.a,
+         "    static constexpr int SMALL_B = %d;   // curve.py's CONSTANT_B when |b| < 2^28, else 0 (b, b3 below are used)" % (c.b if c.small_b else 0),
+         "    static constexpr int SMALL_X = %d;   // curve.py's CONSTANT_X when the generator is given by a small x, else 0" % (c.gx if c.small_x else 0),
          _switch("b", "unsigned long long", c.internal(c.b), _hexu),
          _switch("b3", "unsigned long long", c.internal(3 * c.b), _hexu),
          _switch("gx", "unsigned long long", c.internal(c.gx), _hexu),

@@ -747,6 +747,33 @@ class WsModel:
                            r2="12768d57b96e9be607d7462dbcb1b9a1eaf4263994c52c3d292e5c2e05843769f512dcdc59a860b3f8d411ac5b8b0a153787ddf88bd83352cdd9eef859eed86ea6c",
                            n1="e5386ecbe06b65a6a48b8148f6b38a088ca65ed389b74d0fb132e706298fadc1a606cb0fb39a1de644815ef6d13b8faa1837f8a88b17fc695a07a0ca6e0822e8f3",
                            n2="acc37459eef50bea63371ecd7b27cd813047229389571aa8766c307511b2b9437a28df6ec4ce4a2bbdc241330b01a9e71fde8a774bcf36d58b4737819096da1dac")
+        elif name == "SECP256K1":                     # curve.py:190-198
+            self.p = 2**256 - 2**32 - 977
+            self.a = 0
+            self.b = 7
+            self.q = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+            self.G = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798,
+                      0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
+            self.nbytes = 32
+            # testcurve.c:78-84
+            self.tc = dict(order="FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141",
+                           r1="166876CB6C86C76660666789A376F6790956A0D6A507657196D75D610E0C9D7B",
+                           r2="E9978934937938999F9998765C890985B1583C100A413ACA28FB012BC229A3C6",
+                           n1="120347457078878f77b707c070707077a07707b7b07070707223252357134272",
+                           n2="235279279432f249b298a876788d86294e02842092769136c086038b1812383a")
+        elif name == "NUMS256W":                      # curve.py:147-155: generator from x = 2, y of even sign
+            self.p = 2**256 - 189
+            self.a = -3
+            self.b = 152961
+            self.q = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFE43C8275EA265C6020AB20294751A825
+            self.nbytes = 32
+            self.G = (2, self.recover_y(2, 0))
+            # testcurve.c:71-77
+            self.tc = dict(order="FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFE43C8275EA265C6020AB20294751A825",
+                           r1="166876CB6C86C76660666789A376F6790956A0D6A507657196D75D610E0C9D7B",
+                           r2="E9978934937938999F9998765C890986DAE5E19F451EF6EE89D3C2C839450AAA",
+                           n1="120347457078878f77b707c070707077a07707b7b07070707223252357134272",
+                           n2="235279279432f249b298a876788d86294e02842092769136c086038b1812383a")
         else:
             raise ValueError(name)
         assert self.on_curve(self.G)
@@ -805,7 +832,7 @@ def weierstrass_fixture(name, seed, pairs=32):
     rng = random.Random(seed)
     M = WsModel(name)
     nb, p, q, G = M.nbytes, M.p, M.q, M.G
-    fx = {"curve": name, "source": "big-integer model (tests/golden/make_golden.py WsModel); constants curve.py:157-188",
+    fx = {"curve": name, "source": "big-integer model (tests/golden/make_golden.py WsModel); constants curve.py:147-198",
           "gen": M.xy_hex(G), "order": q.to_bytes(nb, "big").hex()}
     assert M.mul(q, G) is None
     recs = []
@@ -883,8 +910,8 @@ def main():
         extras()
         return
     if "--weierstrass-only" in sys.argv:
-        for k, wname in enumerate(("NIST256", "NIST384", "NIST521")):
-            json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else 24 - 4 * (k - 1)), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
+        for k, wname in enumerate(("NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W")):
+            json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else (24, 20, 28, 28)[k - 1]), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
         return
     if "--edwards-only" in sys.argv:
         for name, seed in (("ED25519", 5001), ("ED448", 5002)):
@@ -910,8 +937,8 @@ def main():
     for script, prime, seed in (("pseudo.py", "X25519", 4001), ("monty.py", "NIST256", 4002), ("monty.py", "X448", 4003)):
         json.dump(sqrt_fixture(script, prime, seed), open(os.path.join(HERE, "sqrt_%s.json" % prime), "w"), indent=0, separators=(",", ":"))
     extras()
-    for k, wname in enumerate(("NIST256", "NIST384", "NIST521")):
-        json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else 24 - 4 * (k - 1)), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
+    for k, wname in enumerate(("NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W")):
+        json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else (24, 20, 28, 28)[k - 1]), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
     for name, seed in (("ED25519", 5001), ("ED448", 5002)):
         json.dump(edwards_fixture(name, seed, pairs=40 if name == "ED25519" else 20), open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
     for curve, seed in (("X25519", 3001), ("X448", 3003)):

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 C = "nist256"
 
 
-@pytest.fixture(scope="module", params=["NIST256", "NIST384", "NIST521"])
+@pytest.fixture(scope="module", params=["NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W"])
 def cx(request):
     global C
     import torch

@@ -10,7 +10,7 @@ from tests.conftest import load_golden
 C = "nist256"
 
 
-@pytest.fixture(autouse=True, params=["nist256", "nist384", "nist521"])
+@pytest.fixture(autouse=True, params=["nist256", "nist384", "nist521", "secp256k1", "nums256w"])
 def _curve(request):
     global C
     C = request.param
