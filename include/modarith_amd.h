@@ -215,7 +215,8 @@ int rfc7748_X25519_batch(const char *bk, const char *bu, char *bv, size_t n, voi
 int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void *stream);
 
 /* ---- Curve layer on the field path: the API of curve.h:13-29 with XXX = _<curve>_
- * (curve.py:344-345), for ED25519 (over the X25519 field) and ED448 (over the X448 field).
+ * (curve.py:344-345), for ED25519 (over the X25519 field), ED448 (over the X448 field) and NUMS256E (over 2^256-189,
+ * CONSTANT_B and CONSTANT_X kept as C ints).
  * A point is projective (x:y:z), `struct xyz` of curve.py:304-309.  Scalar form: host `point`, one element
  * on the GPU.  Batched form: device SoA P[(c*Nlimbs + i)*ld + j], c = 0,1,2 for x,y,z -- a host point is
  * that layout with ld = 1.  Scalars e and coordinates x,y are big-endian Nbytes records, as in the
@@ -269,6 +270,7 @@ int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void 
 
 MODARITH_AMD_DECLARE_EDWARDS(ed25519, 5)
 MODARITH_AMD_DECLARE_EDWARDS(ed448, 8)
+MODARITH_AMD_DECLARE_EDWARDS(nums256e, 5)
 /* NIST P-256, P-384, P-521, secp256k1 (a = 0, CONSTANT_B = 7, over pseudo.py's SECP256K1 field as curve.py builds it at
  * 64 bits) and NUMS256W (CONSTANT_B, CONSTANT_X) in short-Weierstrass form (weierstrass.c: complete add/dbl 68-281, setxy
  * 366-410, mul 494-543, mul2 545-569; constants curve.py:147-198) -- the same curve.h API and layouts; ecn_<c>_set

@@ -149,8 +149,13 @@ struct Edwards : CurveOps<Edwards<C>, typename C::FieldParams> {
     }
     static MA_DEV void gen(Point& p) {                                                // edwards.c:369-378
         spint gx[N], gy[N];
-        static_for<0, N>([&](auto I) { gx[I] = C::gx(I); gy[I] = C::gy(I); });
-        setxy<0>(0, gx, gy, p);
+        if constexpr (C::SMALL_X != 0) {
+            F::modint(C::SMALL_X, gx);
+            setxy<1>(0, gx, nullptr, p);
+        } else {
+            static_for<0, N>([&](auto I) { gx[I] = C::gx(I); gy[I] = C::gy(I); });
+            setxy<0>(0, gx, gy, p);
+        }
     }
 
 };

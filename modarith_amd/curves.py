@@ -26,6 +26,10 @@ class EdwardsCurve:
     def small_b(self) -> bool:
         return abs(self.d) < (1 << 28)      # curve.py:235-240
 
+    @property
+    def small_x(self) -> bool:
+        return abs(self.gx) < (1 << 28)     # curve.py:239-240: generator decompressed from CONSTANT_X
+
     def internal(self, v: int) -> List[int]:
         """field element -> internal-form limbs (top limb masked: the value is canonical)"""
         fp = self.fp
@@ -46,6 +50,11 @@ CURVES = {
         (2**448 - 2**224 - 1 + 1 - 28312320572429821613362531907042076847709625476988141958474579766324) // 4,
         0x4f1970c66bed0ded221d15a622bf36da9e146570470f1767ea6de324a3d3a46412ae1af72ab66511433b80e18b00938e2626a82bc70cc05e,
         0x693f46716eb6bc248876203756c9c7624bea73736ca3984087789c1e05a0c2d73ad3ff1ce67c39c4fdbd132c4ed7c8ad9808795bf230fa14),
+    # curve.py:137-145: x^2 + y^2 = 1 - 15342 x^2 y^2 over 2^256-189, generator from CONSTANT_X = 34 (y of even sign)
+    "NUMS256E": EdwardsCurve(
+        "NUMS256E", "NUMS256W", 1, -15342, 2,
+        0x4000000000000000000000000000000041955AA52F59439B1A47B190EEDD4AF5,
+        34, 0),
 }
 
 

@@ -293,7 +293,7 @@ def header_text(fp: FieldParams) -> str:
     return "\n".join(L) + "\n"
 
 
-BUILT_CURVES = ("ED25519", "ED448")
+BUILT_CURVES = ("ED25519", "ED448", "NUMS256E")
 
 
 def curve_header_text(name: str) -> str:
@@ -311,7 +311,8 @@ def curve_header_text(name: str) -> str:
          "    using FieldParams = P_%s;" % c.field,
          "    static constexpr int A = %d, COF = %d;" % (c.a, c.cof),
          "    static constexpr bool B_SMALL = %s;" % ("true" if c.small_b else "false"),
-         "    static constexpr int B_INT = %d;       // CONSTANT_B when small (curve.py:256-257)" % (c.d if c.small_b else 0)]
+         "    static constexpr int B_INT = %d;       // CONSTANT_B when small (curve.py:256-257)" % (c.d if c.small_b else 0),
+         "    static constexpr int SMALL_X = %d;     // CONSTANT_X when the generator is given by a small x (curve.py:239-240), else 0" % (c.gx if c.small_x else 0)]
     bl = c.internal(c.d) if not c.small_b else [0] * N
     L.append(_switch("b", "unsigned long long", bl, _hexu))
     L.append(_switch("gx", "unsigned long long", c.internal(c.gx), _hexu))

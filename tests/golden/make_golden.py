@@ -526,6 +526,19 @@ class EdModel:
                            r2="9978934937938999F9998765C8909870B885907FDF03764C13B05B94EE93672",
                            n1="20347457078878f77b707c070707077a07707b7b07070707223252357134272",
                            n2="35279279432f249b298a876788d86294e02842092769136c086038b1812383a")
+        elif name == "NUMS256E":                      # curve.py:137-145: generator from x = 34, y of even sign
+            self.p = 2**256 - 189
+            self.a, self.cof = 1, 2
+            self.d = -15342 % self.p
+            self.q = 0x4000000000000000000000000000000041955AA52F59439B1A47B190EEDD4AF5
+            self.nbytes = 32
+            self.G = (34, self.recover_y(34, 0))
+            # testcurve.c:50-56
+            self.tc = dict(order="4000000000000000000000000000000041955AA52F59439B1A47B190EEDD4AF5",
+                           r1="166876CB6C86C76660666789A376F6790956A0D6A507657196D75D610E0C9D7B",
+                           r2="29978934937938999F9998765C890987383EB9CE8A51DE298370542FE0D0AD7A",
+                           n1="21347457078878f77b707c070707077a07707b7b070707072232523571342729",
+                           n2="35279279432f249b298a876788d86294e02842092769136c086038b1812383a5")
         else:
             self.p = 2**448 - 2**224 - 1
             self.a, self.cof = 1, 2
@@ -914,7 +927,7 @@ def main():
             json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else (24, 20, 28, 28)[k - 1]), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
         return
     if "--edwards-only" in sys.argv:
-        for name, seed in (("ED25519", 5001), ("ED448", 5002)):
+        for name, seed in (("ED25519", 5001), ("ED448", 5002), ("NUMS256E", 5003)):
             fx = edwards_fixture(name, seed, pairs=40 if name == "ED25519" else 20)
             json.dump(fx, open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
             if "testcurve" in fx:
@@ -939,7 +952,7 @@ def main():
     extras()
     for k, wname in enumerate(("NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W")):
         json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else (24, 20, 28, 28)[k - 1]), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
-    for name, seed in (("ED25519", 5001), ("ED448", 5002)):
+    for name, seed in (("ED25519", 5001), ("ED448", 5002), ("NUMS256E", 5003)):
         json.dump(edwards_fixture(name, seed, pairs=40 if name == "ED25519" else 20), open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
     for curve, seed in (("X25519", 3001), ("X448", 3003)):
         fx = ladder_fixture(curve, seed)
