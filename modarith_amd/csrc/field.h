@@ -242,7 +242,6 @@ struct Field {
 
     // Comba rows, high half folded by mm (pseudo.py:616-659, getZM 390-438; overflow=False only)
     static MA_DEV void pm_modmul(const spint* a, const spint* b, spint* c) {
-        static_assert(!P::OVERFLOW || !FAST, "the split-high-part rows of pseudo.py's overflow form exist in exact form only");
         dpint t = 0;
         spint v[N];
         spint hi_ov = 0;       // OVERFLOW form: high word of the previous row's folded sum (pseudo.py:407-420)
@@ -290,7 +289,6 @@ struct Field {
 
     // squaring rows (pseudo.py:663-702, getZS 441-554)
     static MA_DEV void pm_modsqr(const spint* a, spint* c) {
-        static_assert(!P::OVERFLOW || !FAST, "the split-high-part rows of pseudo.py's overflow form exist in exact form only");
         dpint t = 0;
         spint v[N];
         spint hi_ov = 0;       // OVERFLOW form (pseudo.py:492-493, 536-550)

@@ -185,8 +185,6 @@ def split_point(fp: FieldParams) -> int:
     Contract: every limb < 2^(radix+2) (tight limbs, [p,2p) with the top limb unmasked, generic=False sums);
     pre-multiplied operands (ma = mm*a, ta = 2a) are wider by bits(mm) / 1 bit.  n = most products per column."""
     W = fp.radix + 2
-    if fp.family == "pseudo" and fp.overflow:
-        return 0                               # the split-high-part rows exist in exact form only
     if fp.family == "pseudo":
         wa = W + (fp.mm.bit_length() if fp.epm else 0)
         wb = W + (1 if fp.epm else 0)
