@@ -221,10 +221,12 @@ int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void 
  * on the GPU.  Batched form: device SoA P[(c*Nlimbs + i)*ld + j], c = 0,1,2 for x,y,z -- a host point is
  * that layout with ld = 1.  Scalars e and coordinates x,y are big-endian Nbytes records, as in the
  * reference.  ecn_*_mul is the constant-time 4-bit fixed-window multiplication (edwards.c:435-482); its
- * 9-entry table lives in a caller-provided device workspace of ecn_*_mul_workspace_bytes(n) bytes.
+ * 9-entry table (two of them for mul2) lives in a caller-provided device workspace of
+ * ecn_*_mul_workspace_bytes(n) bytes.
  * Projective results equal the reference's limb for limb where it is deterministic (add, dbl, mul);
- * set/get/affine/cmp involve modpro and are comparable as affine coordinates.  ecnXXXmul2 (not constant
- * time in the reference) runs a fixed number of steps per lane here: same point, after affine.
+ * set/get/affine/cmp involve modpro and are comparable as affine coordinates.  ecnXXXmul2 (a joint sparse form
+ * with data-dependent branches in the reference, edwards.c:404-431, 486-510) is two interleaved fixed-window
+ * multiplications sharing their doublings here, constant-time: same point, another projective representative.
  * Input points must have limbs below 2^(Radix+2) -- true of every point these functions or the reference's
  * produce; the field-level functions above have no such condition. */
 #define MODARITH_AMD_DECLARE_EDWARDS(c, NL)                                                                             \

@@ -26,8 +26,14 @@ ARCH = "gfx950"
 # chains of C2065 (4 x 52-bit limbs; wrong for every lane, right at -O0, right with this switch: tools/diag_fast_chain.py);
 # the DAG-level mul24 selection stays on.  Measured cost on the VALU-bound kernels: see DESIGN.md.
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-codegenprepare-mul24=0"]
-UNITS = (["capi_common"] + ["capi_%s" % p for p in emit.CORE_PRIMES] + ["capi_%s" % c for c in emit.BUILT_CURVES] + ["capi_%sW" % c for c in emit.BUILT_WCURVES]
-         + ["generated/capi_%s" % p for p in emit.EXTRA_PRIMES])
+# (source unit, object name, extra flags).  Every curve unit is compiled three times (MA_CURVE_PART, capi_curve.inc):
+# its two scalar-multiplication kernels take minutes each for the 7- and 9-limb fields and go to separate jobs.
+_CURVE_UNITS = ["capi_%s" % c for c in emit.BUILT_CURVES] + ["capi_%sW" % c for c in emit.BUILT_WCURVES]
+UNITS = ([(u, u, []) for u in ["capi_common"] + ["capi_%s" % p for p in emit.CORE_PRIMES]]
+         + [(u, "%s_part%d" % (u, part), ["-DMA_CURVE_PART=%d" % part]) for u in _CURVE_UNITS for part in (1, 2, 3)]
+         + [("generated/capi_%s" % p, "capi_%s" % p, []) for p in emit.EXTRA_PRIMES])
+# longest first, so the pool does not finish on a long tail
+UNITS.sort(key=lambda t: 0 if "-DMA_CURVE_PART=1" in t[2] or "-DMA_CURVE_PART=2" in t[2] else 1)
 
 
 def _stamp() -> str:
@@ -41,10 +47,11 @@ def _stamp() -> str:
     return h.hexdigest()
 
 
-def _compile(unit: str) -> str:
-    src = os.path.join(CSRC, unit + ".hip")
-    obj = os.path.join(OBJ, os.path.basename(unit) + ".o")
-    subprocess.run([HIPCC] + FLAGS + ["-c", src, "-o", obj], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
+def _compile(unit) -> str:
+    src_unit, obj_name, extra = unit
+    src = os.path.join(CSRC, src_unit + ".hip")
+    obj = os.path.join(OBJ, obj_name + ".o")
+    subprocess.run([HIPCC] + FLAGS + extra + ["-c", src, "-o", obj], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
     return obj
 
 
@@ -57,7 +64,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     if verbose:
         print("[modarith_amd] compiling %d HIP units for %s ..." % (len(UNITS), ARCH), flush=True)
-    with cf.ThreadPoolExecutor(max_workers=min(int(os.environ.get('MA_BUILD_JOBS', '7')), len(UNITS))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(int(os.environ.get('MA_BUILD_JOBS', '8')), len(UNITS))) as ex:
         objs = list(ex.map(_compile, UNITS))
     subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
     with open(stamp_file, "w") as f:

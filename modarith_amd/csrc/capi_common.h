@@ -33,7 +33,7 @@ struct Staging {
     std::mutex mu;
     static constexpr int MAX_DEVICES = 64;
     unsigned char* dev[MAX_DEVICES] = {};         // one buffer per device of this process, made on first use
-    static constexpr size_t BYTES = 256 * 1024;   // holds the scalar ecn mul window table (64 lanes x 216 words)
+    static constexpr size_t BYTES = 512 * 1024;   // holds the scalar ecn mul2 window tables (64 lanes x up to 486 words)
     unsigned char* get();
 };
 Staging& staging();

@@ -58,7 +58,7 @@ struct CurveOps {
         return eq & F::modcmp(a, b);
     }
 
-    // ---- window table in the global workspace: slot of this lane, entry k
+    // ---- window tables in the global workspace: slot of this lane, entry k (mul: one 9-entry table; mul2: two)
     struct Table {
         spint* base;       // workspace + lane
         size_t stride;     // total lanes
@@ -77,7 +77,7 @@ struct CurveOps {
             });
         }
     };
-    static constexpr size_t TABLE_WORDS = 9 * 3 * N;   // per lane
+    static constexpr size_t TABLE_WORDS = 2 * 9 * 3 * N;   // per lane: room for the two tables of mul2
 
     // constant-time lookup of sign(b) * W[|b|] (edwards.c:381-401): every entry is read
     static MA_DEV void select(int b, const Table& W, Point& p) {
@@ -96,66 +96,65 @@ struct CurveOps {
         cmv(m & 1, mp, p);
     }
 
-    // P = e*P, signed 4-bit fixed window (edwards.c:435-482).  ew = the scalar as NW little-endian 64-bit
-    // words.  Window digits are produced top-down from a left-aligned copy of the scalar and the mask of
-    // recoding carries, so no per-lane digit array is needed.
-    static MA_DEV void mul(const spint* ew, Point& p, const Table& W) {
-        // table W[0..8] = 0, P, 2P, ..., 8P built exactly as edwards.c:441-449 orders it (even entries by
-        // doubling W[k/2], odd entries as W[k-1] + P), rolled into one loop so that the instruction stream
-        // holds a single copy of dbl and add
-        Point Q;
-        Crv::inf(Q);
-        {
-            Point T;
-            Crv::inf(T);
-            W.put(0, T);
-            W.put(1, p);
+    // table W[0..8] = 0, P, 2P, ..., 8P built exactly as edwards.c:441-449 orders it (even entries by doubling
+    // W[k/2], odd entries as W[k-1] + P), rolled into one loop so that the instruction stream holds a single
+    // copy of dbl and add
+    static MA_DEV void build_table(const Point& p, const Table& W) {
+        Point T;
+        Crv::inf(T);
+        W.put(0, T);
+        W.put(1, p);
 #pragma unroll 1
-            for (int k = 2; k <= 8; k++) {
-                if (k & 1) { W.get(k - 1, T); Crv::add(p, T); }
-                else       { W.get(k >> 1, T); Crv::dbl(T); }
-                W.put(k, T);
-            }
+        for (int k = 2; k <= 8; k++) {
+            if (k & 1) { W.get(k - 1, T); Crv::add(p, T); }
+            else       { W.get(k >> 1, T); Crv::dbl(T); }
+            W.put(k, T);
         }
+    }
 
-        // recoding carries: c_0 = 0, c_{j+1} = (nibble_j + c_j > 7)   (edwards.c:461-467)
-        // the scalar left-aligned in NW words (a no-op shift when Nbytes is a multiple of 8): the padding nibbles at
-        // the bottom are zero, produce no carry and are never reached by the 2*NB-digit loop
+    // Signed 4-bit recoding of a scalar (edwards.c:452-467), produced digit by digit from the top: the scalar stays
+    // left-aligned in NW words (nib), the carries c_0 = 0, c_{j+1} = (nibble_j + c_j > 7) are computed once into a bit
+    // mask (car), so no per-lane digit array is needed.  top() is the digit w[2*NB] (the final carry), next() then
+    // returns w[2*NB-1], ..., w[0].
+    struct Recoder {
         spint nib[NW], car[NW];
-        static_for<0, NW>([&](auto K) { nib[K] = ew[K]; car[K] = 0; });
-        shl_words<8 * PADB, NW>(nib);
-        unsigned c = 0;
-        static_for<0, NW>([&](auto K) {
-            spint word = nib[K], cw = 0;
+        unsigned cout;
+        int consumed;
+        MA_DEV int top(const spint* ew) {
+            // left-aligned (a no-op shift when Nbytes is a multiple of 8): the padding nibbles at the bottom are zero,
+            // produce no carry and are never reached by the 2*NB digits
+            static_for<0, NW>([&](auto K) { nib[K] = ew[K]; car[K] = 0; });
+            shl_words<8 * PADB, NW>(nib);
+            unsigned c = 0;
+            static_for<0, NW>([&](auto K) {
+                spint word = nib[K], cw = 0;
 #pragma unroll 1
-            for (int j = 0; j < 16; j++) {
-                cw |= (spint)c << j;
-                unsigned v = (unsigned)(word & 15) + c;
-                c = v > 7 ? 1u : 0u;
-                word >>= 4;
-            }
-            car[K] = cw;              // bit j = carry INTO nibble 16K + j
-        });
-        // top digit w[2*NB] = final carry
-        select((int)c, W, p);
-        // iterate nibbles from the top: keep nib left-aligned (top nibble in bits 63..60 of nib[NW-1])
-        // and car left-aligned (carry into the current nibble in bit 63 of car[NW-1]); the carry OUT of the
-        // current nibble is the carry into the one above, i.e. the bit we consumed in the previous step.
-        static_for<0, NW>([&](auto K) { car[K] <<= 48; });   // 16 carry bits per word -> top of the word
-        unsigned cout = c;
-#pragma unroll 1
-        for (int i = 2 * NB - 1; i >= 0; i--) {
+                for (int j = 0; j < 16; j++) {
+                    cw |= (spint)c << j;
+                    unsigned v = (unsigned)(word & 15) + c;
+                    c = v > 7 ? 1u : 0u;
+                    word >>= 4;
+                }
+                car[K] = cw;              // bit j = carry INTO nibble 16K + j
+            });
+            // car left-aligned: the carry into the current nibble in bit 63 of car[NW-1]; the carry OUT of the current
+            // nibble is the carry into the one above, i.e. the bit consumed in the previous step
+            static_for<0, NW>([&](auto K) { car[K] <<= 48; });   // 16 carry bits per word -> top of the word
+            cout = c;
+            consumed = 0;
+            return (int)c;
+        }
+        MA_DEV int next() {
             const unsigned nb4 = (unsigned)(nib[NW - 1] >> 60);
             const unsigned cin = (unsigned)(car[NW - 1] >> 63);
-            // shift the nibble registers left by 4 and the carry registers so that the next bit is on top
             static_for<0, NW>([&](auto KK) {
                 constexpr int k = NW - 1 - KK;
                 nib[k] <<= 4;
                 if constexpr (k > 0) nib[k] |= nib[k - 1] >> 60;
             });
-            // carries: 16 valid bits per word at the top; after consuming 16 of them move to the next word
             car[NW - 1] <<= 1;
-            if (((2 * NB - i) & 15) == 0) {          // 16 digits consumed: the next carry word moves up
+            consumed++;
+            if ((consumed & 15) == 0) {          // 16 digits consumed: the next carry word moves up
                 static_for<0, NW - 1>([&](auto KK) {
                     constexpr int k = NW - 1 - KK;
                     car[k] = car[k - 1];
@@ -163,65 +162,60 @@ struct CurveOps {
             }
             const int digit = (int)(nb4 + cin) - (int)(cout << 4);
             cout = cin;
-            select(digit, W, Q);
+            return digit;
+        }
+    };
+
+    // P = e*P, signed 4-bit fixed window (edwards.c:435-482).  ew = the scalar as NW little-endian 64-bit words.
+    static MA_DEV void mul(const spint* ew, Point& p, const Table& W) {
+        Point Q;
+        Crv::inf(Q);
+        build_table(p, W);
+        Recoder rc;
+        select(rc.top(ew), W, p);
+#pragma unroll 1
+        for (int i = 2 * NB - 1; i >= 0; i--) {
+            select(rc.next(), W, Q);
 #pragma unroll 1
             for (int r = 0; r < 4; r++) Crv::dbl(p);
             Crv::add(Q, p);
         }
     }
 
-    // R = e*P + f*Q (edwards.c:486-510).  The reference walks a joint sparse form (dnaf, 404-431) with
-    // data-dependent branches ("not constant time"); here every lane runs the same 8*NB+7 steps: digit
-    // w_i = bit_i(3e) - bit_i(e) + 3*(bit_i(3f) - bit_i(f)) in -4..4, table {O, P, Q-P, Q, Q+P} in the
-    // workspace, lookup by full scan + predicated negation, and an unconditional (complete) addition,
-    // adding O for a zero digit.  Same point, possibly another projective representative.
-    static constexpr int NW1 = NW + 1;
-    static MA_DEV void triple(const spint* x, spint* x3) {     // x3 = 3*x over NW+1 words
-        spint carry = 0;
-        static_for<0, NW>([&](auto K) {
-            dpint t = (dpint)x[K] * 3u + carry;
-            x3[K] = (spint)t;
-            carry = (spint)(t >> 64);
-        });
-        x3[NW] = carry;
-    }
+    // R = e*P + f*Q (edwards.c:486-510).  The reference walks a joint sparse form (dnaf, 404-431) with data-dependent
+    // branches ("not constant time"), which would diverge across lanes.  Here: two signed 4-bit fixed-window
+    // multiplications sharing their doublings -- tables {0..8}P and {0..8}Q in the workspace, per window four
+    // doublings and two complete additions -- so every lane runs the same 2*NB windows and the multiplication is
+    // constant-time as well.  Same point as the reference's, another projective representative.
     static MA_DEV void mul2(const spint* ew, const Point& p, const spint* fw, const Point& q, Point& r, const Table& W) {
-        {
-            Point t;
-            Crv::inf(t); W.put(0, t);
-            W.put(1, p);
-            W.put(3, q);
-            cpy(q, t); sub(p, t); W.put(2, t);       // Q - P
-            cpy(q, t); Crv::add(p, t); W.put(4, t);       // Q + P
+        // the two halves (table, lookup, addition) run through loops of two rolled iterations, so the instruction
+        // stream holds one copy of add / dbl / select, as in mul; t is wave-uniform
+        const size_t second = (size_t)9 * 3 * N * W.stride;
+        Point T;
+#pragma unroll 1
+        for (int t = 0; t < 2; t++) {
+            cpy(p, T);
+            if (t) cpy(q, T);
+            build_table(T, Table{W.base + (size_t)t * second, W.stride});
         }
-        // left-aligned copies of e, 3e, f, 3f over NW+1 words: bit 8*NB+7 goes to bit 63 of the top word, i.e. a left
-        // shift by 56 bits plus the record's padding bytes
-        spint e1[NW1], e3[NW1], f1[NW1], f3[NW1];
-        static_for<0, NW>([&](auto K) { e1[K] = ew[K]; f1[K] = fw[K]; });
-        e1[NW] = 0; f1[NW] = 0;
-        triple(ew, e3);
-        triple(fw, f3);
-        shl_words<56 + 8 * PADB, NW1>(e1); shl_words<56 + 8 * PADB, NW1>(e3);
-        shl_words<56 + 8 * PADB, NW1>(f1); shl_words<56 + 8 * PADB, NW1>(f3);
+        Recoder re, rf;
+        const int top_e = re.top(ew), top_f = rf.top(fw);
         Crv::inf(r);
 #pragma unroll 1
-        for (int i = 8 * NB + 7; i >= 1; i--) {
-            const int d = (int)(e3[NW] >> 63) - (int)(e1[NW] >> 63) + 3 * ((int)(f3[NW] >> 63) - (int)(f1[NW] >> 63));
-            shl_words<1, NW1>(e1); shl_words<1, NW1>(e3); shl_words<1, NW1>(f1); shl_words<1, NW1>(f3);
-            Crv::dbl(r);
-            const int m = d >> 31;
-            const int dabs = (d ^ m) - m;
-            Point t, sel;
-            Crv::inf(sel);
+        for (int t = 0; t < 2; t++) {
+            select(t ? top_f : top_e, Table{W.base + (size_t)t * second, W.stride}, T);
+            Crv::add(T, r);                      // first pass adds to the neutral element
+        }
 #pragma unroll 1
-            for (int k = 0; k <= 4; k++) {
-                W.get(k, t);
-                cmv((((dabs ^ k) - 1) >> 31) & 1, t, sel);
+        for (int i = 2 * NB - 1; i >= 0; i--) {
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) Crv::dbl(r);
+            const int de = re.next(), df = rf.next();
+#pragma unroll 1
+            for (int t = 0; t < 2; t++) {
+                select(t ? df : de, Table{W.base + (size_t)t * second, W.stride}, T);
+                Crv::add(T, r);
             }
-            cpy(sel, t);
-            Crv::neg(t);
-            cmv(m & 1, t, sel);
-            Crv::add(sel, r);
         }
     }
 
