@@ -180,7 +180,8 @@ MODARITH_AMD_DECLARE(X448)
  *                    GM270 GM240 GM360 GM480 GM384 GM512 (generalised Mersenne trinomials), TWEEDLE, SIDH434, SIDH503
  *   pseudo-Mersenne: also C2065 (4 x 52), PM336 (6 x 56), PM512 (9 x 57, non-EPM rows), and the split-high-part
  *                    ("overflow") rows of pseudo.py:1640-1657: SECP256K1 (5 x 52, the field curve.py gives secp256k1 at
- *                    64 bits) and C41417 (7 x 60).  SECP256K1M is monty.py's flavour of the secp256k1 prime. */
+ *                    64 bits) and C41417 (7 x 60).  SECP256K1M is monty.py's flavour of the secp256k1 prime.
+ *   Montgomery     : also the fields of curve.py's ED248, ED376, ED500 (5*2^248-1, 65*2^376-1, 27*2^500-1) */
 MODARITH_AMD_DECLARE(NIST521)
 MODARITH_AMD_DECLARE(PM266)
 MODARITH_AMD_DECLARE(PM383)
@@ -205,6 +206,9 @@ MODARITH_AMD_DECLARE(SIDH434)
 MODARITH_AMD_DECLARE(SIDH503)
 MODARITH_AMD_DECLARE(SECP256K1)
 MODARITH_AMD_DECLARE(C41417)
+MODARITH_AMD_DECLARE(ED248)
+MODARITH_AMD_DECLARE(ED376)
+MODARITH_AMD_DECLARE(ED500)
 
 /* RFC 7748 ladder, bv = [bk] * bu (reference rfc7748.c:156 `void rfc7748(const char *bk,const char *bu,char *bv)`).
  * Scalar form: host pointers, Nbytes each (32 / 56), RFC little-endian.  Batched form: device pointers,
@@ -215,8 +219,8 @@ int rfc7748_X25519_batch(const char *bk, const char *bu, char *bv, size_t n, voi
 int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void *stream);
 
 /* ---- Curve layer on the field path: the API of curve.h:13-29 with XXX = _<curve>_
- * (curve.py:344-345), for ED25519 (over the X25519 field), ED448 (over the X448 field) and NUMS256E (over 2^256-189,
- * CONSTANT_B and CONSTANT_X kept as C ints).
+ * (curve.py:344-345), for ED25519 (over the X25519 field), ED448 (over the X448 field), and NUMS256E (over 2^256-189), ED248,
+ * ED376, ED500 with CONSTANT_B and CONSTANT_X kept as C ints.
  * A point is projective (x:y:z), `struct xyz` of curve.py:304-309.  Scalar form: host `point`, one element
  * on the GPU.  Batched form: device SoA P[(c*Nlimbs + i)*ld + j], c = 0,1,2 for x,y,z -- a host point is
  * that layout with ld = 1.  Scalars e and coordinates x,y are big-endian Nbytes records, as in the
@@ -273,6 +277,9 @@ int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void 
 MODARITH_AMD_DECLARE_EDWARDS(ed25519, 5)
 MODARITH_AMD_DECLARE_EDWARDS(ed448, 8)
 MODARITH_AMD_DECLARE_EDWARDS(nums256e, 5)
+MODARITH_AMD_DECLARE_EDWARDS(ed248, 5)
+MODARITH_AMD_DECLARE_EDWARDS(ed376, 7)
+MODARITH_AMD_DECLARE_EDWARDS(ed500, 9)
 /* NIST P-256, P-384, P-521, secp256k1 (a = 0, CONSTANT_B = 7, over pseudo.py's SECP256K1 field as curve.py builds it at
  * 64 bits) and NUMS256W (CONSTANT_B, CONSTANT_X) in short-Weierstrass form (weierstrass.c: complete add/dbl 68-281, setxy
  * 366-410, mul 494-543, mul2 545-569; constants curve.py:147-198) -- the same curve.h API and layouts; ecn_<c>_set

@@ -55,6 +55,13 @@ CURVES = {
         "NUMS256E", "NUMS256W", 1, -15342, 2,
         0x4000000000000000000000000000000041955AA52F59439B1A47B190EEDD4AF5,
         34, 0),
+    # curve.py:107-135: x^2 + y^2 = 1 + d x^2 y^2 with small negative d and small generator x
+    "ED248": EdwardsCurve("ED248", "ED248", 1, -107431, 2,
+                          0x13FFFFFFFFFFFFFFFFFFFFFFFFFFFFFF098677E8D0D856DA332BA970DCFDEA1, 4, 0),
+    "ED376": EdwardsCurve("ED376", "ED376", 1, -66524, 2,
+                          0x104000000000000000000000000000000000000000000000303A69B3514879CD109A98F29F0D04F09F855D4F3C6A7037, 2, 0),
+    "ED500": EdwardsCurve("ED500", "ED500", 1, -105355, 2,
+                          0x6C00000000000000000000000000000000000000000000000000000000000002C8858DA0CB07C5ABCADABC1BEE86F8C9101174D8A115AD57E5F0228C2D0871, 6, 0),
 }
 
 

@@ -20,7 +20,7 @@ def _stream() -> int:
 
 class Edwards:
     """Batched curve API; despite the name it serves every built curve of the reference's curve layer:
-    Edwards ("ED25519", "ED448", "NUMS256E") and short Weierstrass ("NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W").  `Curve` is an alias."""
+    Edwards ("ED25519", "ED448", "NUMS256E", "ED248", "ED376", "ED500") and short Weierstrass ("NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W").  `Curve` is an alias."""
 
     def __init__(self, curve: str, device: Optional[torch.device] = None):
         self.name = curve.lower()

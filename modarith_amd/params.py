@@ -43,6 +43,10 @@ NAMED = {
     "SECP256K1": (2**256 - 2**32 - 977, "pseudo"),
     "SECP256K1M": (2**256 - 2**32 - 977, "monty"),
     "C41417": (2**414 - 17, "pseudo"),
+    # the fields of curve.py's ED248 / ED376 / ED500 (monty.py:2095-2102)
+    "ED248": (5 * 2**248 - 1, "monty"),
+    "ED376": (65 * 2**376 - 1, "monty"),
+    "ED500": (27 * 2**500 - 1, "monty"),
     # further named moduli of monty.py's list (monty.py:1990-2075)
     "GM270": (2**270 - 2**162 - 1, "monty"),
     "GM240": (2**240 - 2**183 - 1, "monty"),

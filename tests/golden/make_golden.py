@@ -539,6 +539,33 @@ class EdModel:
                            r2="29978934937938999F9998765C890987383EB9CE8A51DE298370542FE0D0AD7A",
                            n1="21347457078878f77b707c070707077a07707b7b070707072232523571342729",
                            n2="35279279432f249b298a876788d86294e02842092769136c086038b1812383a5")
+        elif name in ("ED248", "ED376", "ED500"):     # curve.py:107-135: generator from a small x, y of even sign
+            self.p, d, gx, self.q, self.nbytes, self.tc = {
+                # testcurve.c:85-105
+                "ED248": (5 * 2**248 - 1, -107431, 4, 0x13FFFFFFFFFFFFFFFFFFFFFFFFFFFFFF098677E8D0D856DA332BA970DCFDEA1, 32,
+                          dict(order="13FFFFFFFFFFFFFFFFFFFFFFFFFFFFFF098677E8D0D856DA332BA970DCFDEA1",
+                               r1="10876CB6C86C76660666789A376F6790956A0D6A507657196D75D610E0C9D7B",
+                               r2="378934937938999f9998765c890986e741c6a7e8061ffc0c5b5d35ffc34126",
+                               n1="7347457078878f77b707c070707077a07707b7b07070707223252357134272",
+                               n2="3279279432f249b298a876788d86294e02842092769136c086038b1812383a")),
+                "ED376": (65 * 2**376 - 1, -66524, 2,
+                          0x104000000000000000000000000000000000000000000000303A69B3514879CD109A98F29F0D04F09F855D4F3C6A7037, 48,
+                          dict(order="104000000000000000000000000000000000000000000000303A69B3514879CD109A98F29F0D04F09F855D4F3C6A7037",
+                               r1="6076CB6C86C76660666789A376F6790956A0D6A507657196D75D610E0C9D7B87508750F98765C890986DAE5E19F451E",
+                               r2="a38934937938999f9998765c890986f6a95f295af89a8e6c2c493a2707ea2149b9223e30696a86795fe82695acb2b19",
+                               n1="93347457078878f77b707c070707077a07707b7b070707072232523571342720986DAE5E19F451EF6EE89D3C2C0986D",
+                               n2="235279279432f249b298a876788d86294e02842092769136c086038b1812383a13427294582948924358f98985956A0")),
+                "ED500": (27 * 2**500 - 1, -105355, 6,
+                          0x6C00000000000000000000000000000000000000000000000000000000000002C8858DA0CB07C5ABCADABC1BEE86F8C9101174D8A115AD57E5F0228C2D0871, 64,
+                          dict(order="6C00000000000000000000000000000000000000000000000000000000000002C8858DA0CB07C5ABCADABC1BEE86F8C9101174D8A115AD57E5F0228C2D0871",
+                               r1="47235279279432f249b298a876788d86294e02842092769136c086038b1812383a8765C890985B1583C100A413ACA28FB0654735836726356262066876CB6C",
+                               r2="24dcad86d86bcd0db64d675789877279d6b1fd7bdf6d896ec93f79fc74e7edca8dfe27d83a6f6a964719bb77dada56395fac2da31dae8722838e1c23b63d05",
+                               n1="32120347457078878f77b707c070707077a07707b7b0707070722325235713427270707077a07707b7b07070707223252307707b7b070707072232523688A3",
+                               n2="19235279279432f249b298a876788d86294e02842092769136c086038b1812383a13427294582948924358f98985956A077b707c070707077a07707b7b0707")),
+            }[name]
+            self.a, self.cof = 1, 2
+            self.d = d % self.p
+            self.G = (gx, self.recover_y(gx, 0))
         else:
             self.p = 2**448 - 2**224 - 1
             self.a, self.cof = 1, 2
@@ -927,8 +954,8 @@ def main():
             json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else (24, 20, 28, 28)[k - 1]), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
         return
     if "--edwards-only" in sys.argv:
-        for name, seed in (("ED25519", 5001), ("ED448", 5002), ("NUMS256E", 5003)):
-            fx = edwards_fixture(name, seed, pairs=40 if name == "ED25519" else 20)
+        for name, seed in (("ED25519", 5001), ("ED448", 5002), ("NUMS256E", 5003), ("ED248", 5004), ("ED376", 5005), ("ED500", 5006)):
+            fx = edwards_fixture(name, seed, pairs={"ED25519": 40, "ED376": 16, "ED500": 12}.get(name, 20))
             json.dump(fx, open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
             if "testcurve" in fx:
                 print(name, "testcurve chain 10000:", fx["testcurve"]["mul_chain"]["10000"])
@@ -952,8 +979,8 @@ def main():
     extras()
     for k, wname in enumerate(("NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W")):
         json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else (24, 20, 28, 28)[k - 1]), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
-    for name, seed in (("ED25519", 5001), ("ED448", 5002), ("NUMS256E", 5003)):
-        json.dump(edwards_fixture(name, seed, pairs=40 if name == "ED25519" else 20), open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
+    for name, seed in (("ED25519", 5001), ("ED448", 5002), ("NUMS256E", 5003), ("ED248", 5004), ("ED376", 5005), ("ED500", 5006)):
+        json.dump(edwards_fixture(name, seed, pairs={"ED25519": 40, "ED376": 16, "ED500": 12}.get(name, 20)), open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
     for curve, seed in (("X25519", 3001), ("X448", 3003)):
         fx = ladder_fixture(curve, seed)
         json.dump(fx, open(os.path.join(HERE, "ladder_%s.json" % curve), "w"), indent=0, separators=(",", ":"))

@@ -15,9 +15,11 @@ INTP = POINTER(c_int)
 PRIMES = {"X25519": (5, 51, 255, 32), "NIST256": (5, 52, 256, 32), "X448": (8, 56, 448, 56)}
 # primes whose field.c function set is the generic oracle bound to the constants captured from the reference
 # (oracle/field_<P>.c with oracle_bind_<P>): they carry a curve-layer oracle
-BOUND_PRIMES = {"NIST384": (7, 56, 384, 48), "NIST521": (9, 58, 521, 66), "SECP256K1": (5, 52, 256, 32), "NUMS256W": (5, 52, 256, 32)}
+BOUND_PRIMES = {"NIST384": (7, 56, 384, 48), "NIST521": (9, 58, 521, 66), "SECP256K1": (5, 52, 256, 32), "NUMS256W": (5, 52, 256, 32),
+                "ED248": (5, 51, 251, 32), "ED376": (7, 55, 383, 48), "ED500": (9, 57, 505, 64)}
 ORACLE_CURVES = (("ed25519", "X25519"), ("ed448", "X448"), ("nist256", "NIST256"), ("nist384", "NIST384"), ("nist521", "NIST521"),
-                 ("secp256k1", "SECP256K1"), ("nums256w", "NUMS256W"), ("nums256e", "NUMS256W"))
+                 ("secp256k1", "SECP256K1"), ("nums256w", "NUMS256W"), ("nums256e", "NUMS256W"),
+                 ("ed248", "ED248"), ("ed376", "ED376"), ("ed500", "ED500"))
 
 
 def build_oracle():

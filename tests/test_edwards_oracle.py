@@ -8,7 +8,7 @@ import pytest
 
 from tests.conftest import load_golden
 
-CURVES = [("ed25519", "ED25519"), ("ed448", "ED448"), ("nums256e", "NUMS256E")]
+CURVES = [("ed25519", "ED25519"), ("ed448", "ED448"), ("nums256e", "NUMS256E"), ("ed248", "ED248"), ("ed376", "ED376"), ("ed500", "ED500")]
 
 
 @pytest.fixture(scope="module", params=CURVES)
@@ -92,7 +92,7 @@ def test_mul2(cx):
         assert o.ed_xy(C, R) == rec["R"]
 
 
-@pytest.mark.parametrize("C,name", [("ed25519", "ED25519"), ("nums256e", "NUMS256E")])
+@pytest.mark.parametrize("C,name", [("ed25519", "ED25519"), ("nums256e", "NUMS256E"), ("ed248", "ED248")])
 def test_testcurve_checks_and_chain(oracle, C, name):
     """testcurve.c:224-255: order*G = O, r1*G + r2*G = O, then P = n1*P chained; 1000 steps here (for ED25519 the
     10000-step value in the fixture equals the reference's own output)."""

@@ -9,7 +9,7 @@ import pytest
 from tests.conftest import load_golden
 
 pytestmark = pytest.mark.gpu
-CURVES = [("ed25519", "ED25519"), ("ed448", "ED448"), ("nums256e", "NUMS256E")]
+CURVES = [("ed25519", "ED25519"), ("ed448", "ED448"), ("nums256e", "NUMS256E"), ("ed248", "ED248"), ("ed376", "ED376"), ("ed500", "ED500")]
 
 
 @pytest.fixture(scope="module", params=CURVES)

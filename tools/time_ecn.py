@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from modarith_amd.edwards import Curve
 only = sys.argv[1:]
-for name, n in (("ED25519", 1 << 20), ("NIST256", 1 << 19), ("ED448", 1 << 18), ("NIST384", 1 << 18), ("NIST521", 1 << 17), ("SECP256K1", 1 << 19), ("NUMS256W", 1 << 19), ("NUMS256E", 1 << 19)):
+for name, n in (("ED25519", 1 << 20), ("NIST256", 1 << 19), ("ED448", 1 << 18), ("NIST384", 1 << 18), ("NIST521", 1 << 17), ("SECP256K1", 1 << 19), ("NUMS256W", 1 << 19), ("NUMS256E", 1 << 19), ("ED248", 1 << 19), ("ED376", 1 << 18), ("ED500", 1 << 17)):
     if only and name not in only:
         continue
     Ed = Curve(name)
