@@ -64,13 +64,27 @@ def addition_chain(e: int):
     """straight-line program computing x^e: list of steps
        ("dbl", dst, src, k): dst = src^(2^k) * src      ("inc", dst, src): dst = src^2 * x
        ("start", src): acc = src                         ("run", k, src): acc = acc^(2^k) * src
-       ("sqr", k): acc = acc^(2^k)
+       ("sqr", k): acc = acc^(2^k)                       ("mulx", dst, src): dst = src * x
     The leading run of ones is built by a doubling ladder (those squarings ARE the main chain); every
     later run is stitched from the ladder's by-products, largest first, so it costs multiplications
     only (e.g. NIST256: 253 squarings + 12 multiplications)."""
     runs = _runs(e)
     have = {1: "x"}
     steps: list = []
+    # e = A*2^r + (2^r - 1) with a short head A and a long trailing run (the c*2^k - 1 primes of ED248 / ED376 / ED500):
+    # with L = x^(2^r - 1) from the ladder, y = L*x = x^(2^r) and x^e = y^A * L -- the ladder's squarings are again the
+    # main chain (e.g. ED248: 247 squarings + 13 multiplications)
+    alt = None
+    if len(runs) >= 2 and runs[-1][1] == 0 and runs[-1][0] > runs[0][0]:
+        r = runs[-1][0]
+        have2, steps2 = {1: "x"}, []
+        L = _ones_plan(r, have2, steps2)
+        alt = list(steps2)
+        alt.append(("mulx", "y", L))                  # y = L * x
+        alt.append(("start", "y"))
+        for bit in bin(e >> r)[3:]:
+            alt.append(("run", 1, "y") if bit == "1" else ("sqr", 1))
+        alt.append(("run", 0, L))                     # acc = acc * L
     _ones_plan(runs[0][0], have, steps)
     prog = list(steps)
     prog.append(("start", have[runs[0][0]]))
@@ -85,6 +99,10 @@ def addition_chain(e: int):
         pending = zeros
     if pending:
         prog.append(("sqr", pending))
+    if alt is not None:
+        cost = lambda pr: chain_cost(pr)[0] + 1.4 * chain_cost(pr)[1]
+        if cost(alt) < cost(prog):
+            return alt
     return prog
 
 
@@ -95,6 +113,8 @@ def chain_cost(prog):
             s += st[3]; m += 1
         elif st[0] == "inc":
             s += 1; m += 1
+        elif st[0] == "mulx":
+            m += 1
         elif st[0] == "run":
             s += st[1]; m += 1
         elif st[0] == "sqr":
@@ -111,6 +131,8 @@ def eval_chain(prog, x: int, p: int) -> int:
             reg[st[1]] = pow(reg[st[2]], 1 << st[3], p) * reg[st[2]] % p
         elif st[0] == "inc":
             reg[st[1]] = reg[st[2]] ** 2 * reg["x"] % p
+        elif st[0] == "mulx":
+            reg[st[1]] = reg[st[2]] * reg["x"] % p
         elif st[0] == "start":
             acc = reg[st[1]]
         elif st[0] == "run":
@@ -148,7 +170,7 @@ def _chain_cpp(prog, N: int) -> str:
     lines = ["        spint x[%d], acc[%d];" % (N, N), "        F::modcpy(w, x);"]
     declared = set()
     for st in prog:
-        if st[0] in ("dbl", "inc"):
+        if st[0] in ("dbl", "inc", "mulx"):
             dst = st[1]
             if dst not in declared:
                 lines.append("        spint %s[%d];" % (dst, N))
@@ -159,6 +181,9 @@ def _chain_cpp(prog, N: int) -> str:
         elif st[0] == "inc":
             _, dst, src = st
             lines.append("        F::modsqr(%s, %s); F::modmul(%s, x, %s);" % (src, dst, dst, dst))
+        elif st[0] == "mulx":
+            _, dst, src = st
+            lines.append("        F::modmul(%s, x, %s);" % (src, dst))
         elif st[0] == "start":
             lines.append("        F::modcpy(%s, acc);" % st[1])
         elif st[0] == "run":
