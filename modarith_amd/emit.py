@@ -106,6 +106,45 @@ def addition_chain(e: int):
     return prog
 
 
+def trailing_plan(e: int):
+    """(r, A) if addition_chain(e) chose the trailing-run plan e = A*2^r + (2^r - 1), else None"""
+    prog = addition_chain(e)
+    if any(st[0] == "mulx" for st in prog):
+        r = _runs(e)[-1][0]
+        return r, e >> r
+    return None
+
+
+def _trailing_cpp(r: int, A: int, N: int) -> str:
+    """rolled form of the trailing-run plan: the doubling ladder for L = x^(2^r - 1) as a loop over the bits of r (one
+    copy of the multiplication and of the squaring loop in the instruction stream instead of one per ladder step),
+    then y = L*x, y^A by the binary method over the few bits of A, times L.  Same operation count as the chain."""
+    rb = r.bit_length()
+    ab = A.bit_length()
+    return "\n".join([
+        "        spint x[%d], L[%d], t[%d], acc[%d];" % (N, N, N, N),
+        "        F::modcpy(w, x);",
+        "        F::modcpy(x, L);",
+        "        int len = 1;",
+        "#pragma unroll 1",
+        "        for (int b = %d; b >= 0; b--) {                  // L = x^(2^len - 1), len -> %d" % (rb - 2, r),
+        "            F::modcpy(L, t); F::modnsqr(L, len); F::modmul(L, t, L);",
+        "            len *= 2;",
+        "            if ((%du >> b) & 1u) { F::modsqr(L, L); F::modmul(L, x, L); len += 1; }" % r,
+        "        }",
+        "        F::modmul(L, x, t);                              // y = x^(2^%d)" % r,
+        "        F::modcpy(t, acc);",
+        "#pragma unroll 1",
+        "        for (int b = %d; b >= 0; b--) {                  // y^A by the binary method, A = %s" % (ab - 2, hex(A)),
+        "            unsigned long long aw = 0;",
+        "            switch (b >> 6) { %s }" % " ".join("case %d: aw = 0x%xull; break;" % (i, (A >> (64 * i)) & ((1 << 64) - 1))
+                                                   for i in range((ab + 63) // 64)),
+        "            F::modsqr(acc, acc);",
+        "            if ((aw >> (b & 63)) & 1ull) F::modmul(acc, t, acc);",
+        "        }",
+        "        F::modmul(acc, L, z);"])
+
+
 def chain_cost(prog):
     s = m = 0
     for st in prog:
@@ -298,7 +337,15 @@ def header_text(fp: FieldParams) -> str:
     L.append(_switch("pp_sgn", "int", [t[1] for t in fp.pp], str))
     L.append(_switch("pp_val", "unsigned long long", [t[2] for t in fp.pp], _hexu))
     L.append(_switch("roi", "unsigned long long", fp.roi, _hexu))
-    if mu <= MAX_UNROLLED_MULS:
+    tp = trailing_plan(fp.pe)
+    if tp is not None:
+        L.append("    // progenitor for PE = %s = A*2^r + (2^r - 1), r = %d, A = %s: rolled doubling ladder, %d squarings + %d multiplications"
+                 % (hex(fp.pe), tp[0], hex(tp[1]), sq, mu))
+        L.append("    template <class F>")
+        L.append("    static __device__ __forceinline__ void modpro_chain(const spint* w, spint* z) {")
+        L.append(_trailing_cpp(tp[0], tp[1], N))
+        L.append("    }")
+    elif mu <= MAX_UNROLLED_MULS:
         L.append("    // progenitor chain for PE = %s: %d squarings + %d multiplications" % (hex(fp.pe), sq, mu))
         L.append("    template <class F>")
         L.append("    static __device__ __forceinline__ void modpro_chain(const spint* w, spint* z) {")
