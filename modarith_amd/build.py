@@ -12,6 +12,7 @@ import concurrent.futures as cf
 import hashlib
 import os
 import subprocess
+import time
 import sys
 
 from . import emit
@@ -47,11 +48,16 @@ def _stamp() -> str:
     return h.hexdigest()
 
 
+_TIMES = {}
+
+
 def _compile(unit) -> str:
     src_unit, obj_name, extra = unit
     src = os.path.join(CSRC, src_unit + ".hip")
     obj = os.path.join(OBJ, obj_name + ".o")
+    t0 = time.time()
     subprocess.run([HIPCC] + FLAGS + extra + ["-c", src, "-o", obj], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
+    _TIMES[obj_name] = time.time() - t0
     return obj
 
 
@@ -70,6 +76,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with open(stamp_file, "w") as f:
         f.write(stamp)
     if verbose:
+        slow = sorted(_TIMES.items(), key=lambda kv: -kv[1])[:6]
+        print("[modarith_amd] slowest units: " + ", ".join("%s %.0f s" % kv for kv in slow), flush=True)
         print("[modarith_amd] built", LIB, flush=True)
     return LIB
 
