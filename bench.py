@@ -199,6 +199,23 @@ def main():
                 others["%s_%s" % (P, op)] = {"ops_per_s_per_gpu": n / (ms * 1e-3), "GBps": nbytes / (ms * 1e-3) / 1e9,
                                              "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms}
             del xa, xb, xc
+        # the curve layer built on the path, one pass each: side figures (VALU-bound kernels)
+        from modarith_amd.edwards import Curve
+        for cname, m in (("ED25519", 1 << 19), ("SECP256K1", 1 << 18), ("NIST256", 1 << 18)):
+            Cv = Curve(cname, dev)
+            e = torch.randint(0, 256, (m, Cv.nbytes), dtype=torch.uint8, device=dev, generator=gen)
+            f = torch.randint(0, 256, (m, Cv.nbytes), dtype=torch.uint8, device=dev, generator=gen)
+            G = Cv.gen(m)
+            Pp = Cv.mul(e[:4096].contiguous(), Cv.gen(4096))          # warm-up (also loads the code objects)
+            del Pp
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            Q = Cv.mul(e, G.clone())
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            R = Cv.mul2(e, G, f, Q)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            others["%s_ecn_mul" % cname] = {"scalar_mults_per_s_per_gpu": m / (t1 - t0), "points": m, "bound": "VALU"}
+            others["%s_ecn_mul2" % cname] = {"double_mults_per_s_per_gpu": m / (t2 - t1), "pairs": m, "bound": "VALU"}
+            del e, f, G, Q, R
 
     ladder = None
     if not args.no_ladder:
