@@ -288,7 +288,7 @@ def main():
             "config": {"workload": "batched modmul 2^255-19, 5x51-bit limbs, 2^%d elements per GPU, limb-interleaved SoA" % LOG2_ELEMS,
                        "elements_per_gpu": n, "parallelism": "independent batches, %d rank(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_binary<P_X25519,OpMul,2>", "kernel_ms": kern_ms,
+                         "traffic": traffic, "kernel": "k_binary<P_X25519,OpMulAuto,2>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_MODMUL * n},
             "cpu_baseline": cpu,
             "x25519": ladder,

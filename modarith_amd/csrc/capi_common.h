@@ -16,6 +16,7 @@ int check_launch(const char* what);
 int max_blocks();          // grid cap for grid-stride streaming kernels (env MA_MAX_BLOCKS)
 int ladder_block();        // workgroup size of the ladder kernel (env MA_LADDER_BLOCK)
 bool force_fast();         // env MA_FORCE_FAST=1: element-wise modmul/modsqr/nres/redc/modinv on the FAST product path (tests)
+bool force_exact();        // env MA_FORCE_EXACT=1: element-wise modmul/modsqr on the exact 128-bit products only (tests)
 bool ladder_use_field();   // env MA_LADDER_IMPL=field: X25519 ladder on the 5x51 field.c-form arithmetic
 
 inline unsigned grid_for(size_t nthreads, int block = 256) {

@@ -42,6 +42,10 @@ bool force_fast() {
     static bool v = [] { const char* s = getenv("MA_FORCE_FAST"); return s && *s == '1'; }();
     return v;
 }
+bool force_exact() {
+    static bool v = [] { const char* s = getenv("MA_FORCE_EXACT"); return s && *s == '1'; }();
+    return v;
+}
 bool ladder_use_field() {
     static bool v = [] { const char* s = getenv("MA_LADDER_IMPL"); return s && strcmp(s, "field") == 0; }();
     return v;

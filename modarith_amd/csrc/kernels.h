@@ -70,6 +70,30 @@ template <class P> struct OpAdd { static MA_DEV void apply(const spint* a, const
 template <class P> struct OpSub { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P>::modsub(a, b, c); } };
 template <class P> struct OpAddLazy { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P>::modadd_lazy(a, b, c); } };
 template <class P> struct OpSubLazy { static MA_DEV void apply(const spint* a, const spint* b, spint* c) { Field<P>::modsub_lazy(a, b, c); } };
+// modmul / modsqr with a wave-uniform choice of product policy: the split products (Field<P,true>, fewer VALU
+// instructions) when every active lane's operands are inside their limb contract (< 2^(Radix+2), field.h), the exact
+// 128-bit products otherwise -- identical results either way, for every input
+template <class P> MA_DEV bool in_split_contract(const spint* a) {
+    spint m = 0;
+    static_for<0, P::N>([&](auto I) { m |= a[I]; });
+    return (m >> (P::RADIX + 2)) == 0;
+}
+template <class P> struct OpMulAuto {
+    static MA_DEV void apply(const spint* a, const spint* b, spint* c) {
+        if constexpr (P::SPLIT > 0) {
+            if (__all(in_split_contract<P>(a) && in_split_contract<P>(b))) { Field<P, true>::modmul(a, b, c); return; }
+        }
+        Field<P, false>::modmul(a, b, c);
+    }
+};
+template <class P> struct OpSqrAuto {
+    static MA_DEV void apply(const spint* a, spint* c) {
+        if constexpr (P::SPLIT > 0) {
+            if (__all(in_split_contract<P>(a))) { Field<P, true>::modsqr(a, c); return; }
+        }
+        Field<P, false>::modsqr(a, c);
+    }
+};
 template <class P, bool FAST = false> struct OpSqr { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::modsqr(a, c); } };
 template <class P> struct OpNeg { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modneg(a, c); } };
 template <class P> struct OpNegLazy { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modneg_lazy(a, c); } };

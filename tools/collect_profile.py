@@ -14,11 +14,11 @@ with open("profiles/%s_bench_kernel_stats.csv" % tag, "w", newline="") as f:
         w.writerow(r)
 def pmc(kind):
     f = glob.glob(src + "/pmc_%s/*/*_counter_collection.csv" % kind)[0]
-    return [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_binary<ma::P_X25519, ma::OpMul<ma::P_X25519" in r["Kernel_Name"]]
+    return [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_binary<ma::P_X25519, ma::OpMulAuto<ma::P_X25519" in r["Kernel_Name"]]
 fetch, write = pmc("fetch"), pmc("write")
 fk, wk = sum(fetch) / len(fetch), sum(write) / len(write)
-stat = [r for r in rows if r and "k_binary<ma::P_X25519, ma::OpMul<ma::P_X25519" in r[0]][0]
-doc = {"tag": tag, "kernel": "ma::k_binary<ma::P_X25519, ma::OpMul<ma::P_X25519>, 2>", "launches_sampled": len(fetch),
+stat = [r for r in rows if r and "k_binary<ma::P_X25519, ma::OpMulAuto<ma::P_X25519" in r[0]][0]
+doc = {"tag": tag, "kernel": "ma::k_binary<ma::P_X25519, ma::OpMulAuto<ma::P_X25519>, 2>", "launches_sampled": len(fetch),
        "rocprof_stats_avg_ns": float(stat[3]), "rocprof_stats_calls": int(stat[1]),
        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-ladder (two separate passes)",
        "FETCH_SIZE_KB_per_launch_raw": fk, "WRITE_SIZE_KB_per_launch_raw": wk,
