@@ -94,6 +94,22 @@ template <class P> struct OpSqrAuto {
         Field<P, false>::modsqr(a, c);
     }
 };
+template <class P> struct OpNresAuto {
+    static MA_DEV void apply(const spint* a, spint* c) {
+        if constexpr (P::SPLIT > 0 && P::MONTGOMERY) {
+            if (__all(in_split_contract<P>(a))) { Field<P, true>::nres(a, c); return; }
+        }
+        Field<P, false>::nres(a, c);
+    }
+};
+template <class P> struct OpRedcAuto {
+    static MA_DEV void apply(const spint* a, spint* c) {
+        if constexpr (P::SPLIT > 0 && P::MONTGOMERY) {
+            if (__all(in_split_contract<P>(a))) { Field<P, true>::redc(a, c); return; }
+        }
+        Field<P, false>::redc(a, c);
+    }
+};
 template <class P, bool FAST = false> struct OpSqr { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::modsqr(a, c); } };
 template <class P> struct OpNeg { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modneg(a, c); } };
 template <class P> struct OpNegLazy { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modneg_lazy(a, c); } };
