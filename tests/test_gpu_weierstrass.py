@@ -128,3 +128,21 @@ def test_projective_limbs_equal_oracle(oracle, cx):
         for c, nm in enumerate(("x", "y", "z")):
             assert [int(v) for v in qn[c, :, j]] == list(getattr(q, nm))
             assert [int(v) for v in sn[c, :, j]] == list(getattr(p, nm))
+
+
+def test_c_curve_api_example(tmp_path):
+    """examples/ecn_batch.c: curve.h's API under the reference's names in plain C -- testcurve.c's order / r1+r2 checks
+    through the scalar entry points, then a batched key generation compared with the scalar path."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ecn_batch")
+    subprocess.check_call(["gcc", "-O2", os.path.join(root, "examples", "ecn_batch.c"), "-I", os.path.join(root, "include"),
+                           "-L", os.path.join(root, "modarith_amd"), "-l:libmodarith_amd.so",
+                           "-Wl,-rpath," + os.path.join(root, "modarith_amd"), "-o", exe])
+    p = subprocess.run([exe, "2048"], capture_output=True, text=True, timeout=300)
+    out = p.stdout.splitlines()
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert out[1] == "79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798"
+    assert out[2].endswith("yes") and out[3].endswith("yes")
+    assert out[-1] == "batched == scalar: equal"
