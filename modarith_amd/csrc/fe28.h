@@ -89,6 +89,73 @@ struct Fe28 {
         reduce(c, r);
     }
 
+    // Karatsuba on the golden-ratio structure: with a = a0 + a1*phi, phi = 2^224, phi^2 = phi + 1,
+    //   a*b = (a0 b0 + a1 b1) + ((a0 + a1)(b0 + b1) - a0 b0) * phi
+    // three 8x8 products (192 v_mad_u64_u32 instead of 256).  Needs one operand tight and the other below 2^29 (or
+    // both tight for the squaring): the half sums are then below 2^29+2^10 and 2^30, a column of the middle product
+    // holds 8 products below 2^59 (< 2^62), and a folded limb L_m + H_{m-8} + H_m stays below 2^63.4.
+    static MA_DEV void fold_lh(const uint64_t* L, const uint64_t* H, uint32_t* r) {
+        uint64_t h[16];
+        static_for<0, 16>([&](auto MM) {
+            constexpr int m = MM;
+            uint64_t v = 0;
+            if constexpr (m <= 14) v = L[m];
+            if constexpr (m < 8) {
+                if constexpr (m + 8 <= 14) v += H[m + 8];
+            } else {
+                v += H[m - 8];
+                if constexpr (m <= 14) v += H[m];
+            }
+            h[m] = v;
+        });
+        carry(h, r);
+    }
+    static MA_DEV void mul_k(const uint32_t* f, const uint32_t* g, uint32_t* r) {
+        uint32_t fs[8], gs[8];
+        static_for<0, 8>([&](auto I) { fs[I] = f[I] + f[I + 8]; gs[I] = g[I] + g[I + 8]; });
+        uint64_t L[15], H[15];
+        static_for<0, 15>([&](auto KK) {
+            constexpr int k = KK;
+            constexpr int lo = k < 8 ? 0 : k - 7, hi = k < 8 ? k : 7;
+            uint64_t z0 = 0, z2 = 0, z1 = 0;
+            static_for<lo, hi + 1>([&](auto II) {
+                constexpr int i = II;
+                z0 += (uint64_t)f[i] * g[k - i];
+                z2 += (uint64_t)f[8 + i] * g[8 + k - i];
+                z1 += (uint64_t)fs[i] * gs[k - i];
+            });
+            L[k] = z0 + z2;
+            H[k] = z1 - z0;
+        });
+        fold_lh(L, H, r);
+    }
+    static MA_DEV void sqr_k(const uint32_t* f, uint32_t* r) {     // f tight
+        uint32_t fs[8], f2[16], fs2[8];
+        static_for<0, 8>([&](auto I) { fs[I] = f[I] + f[I + 8]; fs2[I] = 2u * fs[I]; });
+        static_for<0, 16>([&](auto I) { f2[I] = 2u * f[I]; });
+        uint64_t L[15], H[15];
+        static_for<0, 15>([&](auto KK) {
+            constexpr int k = KK;
+            constexpr int lo = k < 8 ? 0 : k - 7, hi = k < 8 ? k : 7;
+            uint64_t z0 = 0, z2 = 0, z1 = 0;
+            static_for<lo, hi + 1>([&](auto II) {
+                constexpr int i = II, j = k - i;
+                if constexpr (i < j) {
+                    z0 += (uint64_t)f2[i] * f[j];
+                    z2 += (uint64_t)f2[8 + i] * f[8 + j];
+                    z1 += (uint64_t)fs2[i] * fs[j];
+                } else if constexpr (i == j) {
+                    z0 += (uint64_t)f[i] * f[i];
+                    z2 += (uint64_t)f[8 + i] * f[8 + i];
+                    z1 += (uint64_t)fs[i] * fs[i];
+                }
+            });
+            L[k] = z0 + z2;
+            H[k] = z1 - z0;
+        });
+        fold_lh(L, H, r);
+    }
+
     template <uint32_t C>
     static MA_DEV void mul_small(const uint32_t* f, uint32_t* r) {
         uint64_t h[16];
@@ -118,9 +185,9 @@ struct Fe28 {
     }
     static MA_DEV void copy(const uint32_t* f, uint32_t* r) { static_for<0, 16>([&](auto I) { r[I] = f[I]; }); }
     static MA_DEV void set(uint32_t v, uint32_t* r) { static_for<0, 16>([&](auto I) { r[I] = (I == 0) ? v : 0u; }); }
-    static MA_DEV void sqn(uint32_t* f, int n) {
+    static MA_DEV void sqn(uint32_t* f, int n) {                    // f tight (results of mul / sqr)
 #pragma unroll 1
-        for (int i = 0; i < n; i++) sqr(f, f);
+        for (int i = 0; i < n; i++) sqr_k(f, f);
     }
 
     // z^(p-2), p-2 = 2^448 - 2^224 - 3 = [223 ones][0][222 ones][0][1]: 447 squarings + 13 multiplications
@@ -222,20 +289,20 @@ __global__ __launch_bounds__(256, 2) void k_x448_fe28(const uint64_t* bk, const 
             F::add(x3, z3, C);
             F::sub(x2, z2, B);
             F::sub(x3, z3, D);
-            F::sqr(A, AA);
-            F::sqr(B, BB);
-            F::mul(D, A, D);
-            F::mul(C, B, C);
+            F::sqr(A, AA);                      // A = x2 + z2 is not tight
+            F::sqr_k(B, BB);
+            F::mul_k(D, A, D);
+            F::mul_k(C, B, C);
             F::sub(D, C, z3);
             F::sub(AA, BB, E);
             F::mul_small<39081>(E, z2);
             F::add(D, C, x3);
             F::add(z2, AA, z2);
-            F::mul(z2, E, z2);
-            F::sqr(x3, x3);
-            F::sqr(z3, z3);
-            F::mul(z3, x1, z3);
-            F::mul(AA, BB, x2);
+            F::mul_k(z2, E, z2);
+            F::sqr(x3, x3);                     // x3 = D + C is not tight
+            F::sqr_k(z3, z3);
+            F::mul_k(z3, x1, z3);
+            F::mul_k(AA, BB, x2);
         }
         F::cswap(0u - swap, x2, x3);
         F::cswap(0u - swap, z2, z3);
