@@ -83,8 +83,9 @@ struct CurveOps {
     static MA_DEV void select(int b, const Table& W, Point& p) {
         const int m = b >> 31;
         const int babs = (b ^ m) - m;
+        Crv::inf(p);        // W[0] is the neutral element as inf() writes it: start from it and scan entries 1..8 only
 #pragma unroll 1    // rolled: unrolling 3x / 9x measured -2 % / -17 % (more live loads, same latency chain)
-        for (int k = 0; k <= 8; k++) {
+        for (int k = 1; k <= 8; k++) {
             Point w;
             W.get(k, w);
             const int eq = (((babs ^ k) - 1) >> 31) & 1;
