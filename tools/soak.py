@@ -4,7 +4,7 @@
   soak.py field   exact vs split/chain products on 2^22 elements per prime whose limbs are drawn from the contract's
                   edge classes (0, 1, 2^R-1, 2^R, 2^(R+1)-1, 2^(R+2)-1, random), plus 48-operation chains from
                   in-range values: the two product policies must agree bit for bit (checksums compared across two child processes, MA_FORCE_FAST=0/1)
-  soak.py curves  2^16 random scalars x random points per curve, fused ecn mul on the GPU against the CPU oracle,
+  soak.py curves  2^13 .. 2^16 random scalars x random points for each of the eleven curves, fused ecn mul on the GPU against the CPU oracle,
                   projective limbs compared
 """
 import os, subprocess, sys
@@ -73,8 +73,9 @@ def curves():
     from tests.util import vp
     o = load_oracle(build=not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")))
     rc = 0
-    n = 1 << 16
-    for name in ("ED25519", "NIST256", "ED448", "NIST384"):
+    for name, lg in (("ED25519", 16), ("NIST256", 16), ("ED448", 16), ("NIST384", 16), ("SECP256K1", 15), ("NUMS256W", 14), ("NUMS256E", 14),
+                     ("ED248", 14), ("ED376", 13), ("NIST521", 13), ("ED500", 13)):
+        n = 1 << lg
         C = Curve(name)
         g = torch.Generator(device="cuda").manual_seed(77)
         e0 = torch.randint(0, 256, (n, C.nbytes), dtype=torch.uint8, device="cuda", generator=g)
@@ -87,7 +88,7 @@ def curves():
         o.lib.__getattr__("ecn_%s_batch_mul" % name.lower())(vp(he), vp(want), n, n)
         got = C.mul(e, P.clone()).cpu().numpy().view(np.uint64).reshape(3 * C.N, n)
         ok = bool(np.array_equal(got, want))
-        print("curve soak %-8s 2^16 scalar multiplications, projective limbs vs oracle: %s" % (name, "EQUAL" if ok else "MISMATCH"), flush=True)
+        print("curve soak %-9s 2^%d scalar multiplications, projective limbs vs oracle: %s" % (name, lg, "EQUAL" if ok else "MISMATCH"), flush=True)
         rc |= 0 if ok else 1
     return rc
 
