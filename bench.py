@@ -93,6 +93,22 @@ def cpu_baseline(n_log2=LOG2_ELEMS, min_seconds=6.0):
     }
 
 
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, through
+    torch.distributed.run (the command the driver uses for N>1), relay their output and return their exit code.
+    This parent never imports torch.cuda nor touches HIP, and it does not replace itself: the ranks are children."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:             # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,13 +117,26 @@ def main():
     ap.add_argument("--no-ladder", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-others", action="store_true")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only check the rank launch: gloo group over the N ranks, no GPU work (tests/test_bench_launch.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        dist.init_process_group("gloo")
+        tt = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(tt)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": int(tt[0])}))
+        dist.destroy_process_group()
+        return
     # MA_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a box with fewer GPUs than ranks
     backend = os.environ.get("MA_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
@@ -127,11 +156,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
         else:
             dist.init_process_group(backend)
-    if args.gpus != world:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1" % (args.gpus, world), file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; reporting n_gpus = WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     cdev = dev if backend == "nccl" else torch.device("cpu")   # where collective payloads live
 
     def max_over_ranks(vals):

@@ -49,15 +49,41 @@ def _stamp() -> str:
 
 
 _TIMES = {}
+_ROOT = os.path.dirname(HERE)
+
+
+def _unit_hash(obj: str, cmd) -> str | None:
+    """hash of the command line and of every in-tree file the unit's last compile read (from its -MD depfile);
+    None when the depfile is missing or names a file that no longer exists"""
+    dep = obj[:-2] + ".d"
+    if not (os.path.exists(dep) and os.path.exists(obj)):
+        return None
+    h = hashlib.sha256(" ".join(cmd).encode())
+    text = open(dep).read().replace("\\\n", " ")
+    for f in sorted(set(text.split()[1:])):
+        if not os.path.abspath(f).startswith(_ROOT + os.sep):
+            continue                      # toolchain headers: covered by the hipcc path in the command line
+        if not os.path.exists(f):
+            return None
+        h.update(f.encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def _compile(unit) -> str:
+    """compile one unit unless its object is up to date (same command, same contents of every included in-tree file)"""
     src_unit, obj_name, extra = unit
     src = os.path.join(CSRC, src_unit + ".hip")
     obj = os.path.join(OBJ, obj_name + ".o")
+    cmd = [HIPCC] + FLAGS + extra + ["-c", src]
+    hfile = obj[:-2] + ".hash"
+    if os.path.exists(hfile) and open(hfile).read() == (_unit_hash(obj, cmd) or "-"):
+        return obj
     t0 = time.time()
-    subprocess.run([HIPCC] + FLAGS + extra + ["-c", src, "-o", obj], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
+    subprocess.run(cmd + ["-MD", "-MF", obj[:-2] + ".d", "-o", obj], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
     _TIMES[obj_name] = time.time() - t0
+    with open(hfile, "w") as f:
+        f.write(_unit_hash(obj, cmd) or "-")
     return obj
 
 
@@ -68,8 +94,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     stamp = _stamp()
     if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
         return LIB
+    if force:
+        for f in os.listdir(OBJ):
+            if f.endswith(".hash"):
+                os.remove(os.path.join(OBJ, f))
     if verbose:
-        print("[modarith_amd] compiling %d HIP units for %s ..." % (len(UNITS), ARCH), flush=True)
+        print("[modarith_amd] building %d HIP units for %s (unchanged units are reused) ..." % (len(UNITS), ARCH), flush=True)
     with cf.ThreadPoolExecutor(max_workers=min(int(os.environ.get('MA_BUILD_JOBS', '8')), len(UNITS))) as ex:
         objs = list(ex.map(_compile, UNITS))
     subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
@@ -77,7 +107,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         f.write(stamp)
     if verbose:
         slow = sorted(_TIMES.items(), key=lambda kv: -kv[1])[:6]
-        print("[modarith_amd] slowest units: " + ", ".join("%s %.0f s" % kv for kv in slow), flush=True)
+        print("[modarith_amd] compiled %d units; slowest: " % len(_TIMES) + ", ".join("%s %.0f s" % kv for kv in slow), flush=True)
         print("[modarith_amd] built", LIB, flush=True)
     return LIB
 

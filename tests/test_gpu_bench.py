@@ -38,3 +38,18 @@ def test_bench_line_contract():
 def test_bench_rccl_path_one_rank():
     d = _run(["--steps", "10", "--warmup", "3", "--no-cpu", "--no-others"], {"MA_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29533"})
     assert d["n_gpus"] == 1 and d["x25519"]["gather_ms"] is not None and d["x25519"]["gather_ms"] > 0
+
+
+def test_bench_self_launch_two_ranks_gloo():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts both ranks (they share the one GPU of
+    this box; gloo carries the collectives) and relays rank 0's single line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MA_BENCH_BACKEND="gloo", MA_BENCH_LOG2_ELEMS="22", MA_BENCH_LOG2_LADDER="18")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-cpu", "--no-others"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["elements_per_gpu"] == 1 << 22
+    assert d["x25519"]["scalars_per_gpu"] == 1 << 18 and d["x25519"]["gather_ms"] > 0 and d["x25519"]["value"] > 0
