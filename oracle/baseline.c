@@ -7,6 +7,15 @@
 void batch_modmul_X25519(const spint *, const spint *, spint *, size_t, size_t);
 void batch_modmul_NIST256(const spint *, const spint *, spint *, size_t, size_t);
 void batch_modmul_X448(const spint *, const spint *, spint *, size_t, size_t);
+void batch_modsqr_X25519(const spint *, spint *, size_t, size_t);
+void batch_modsqr_NIST256(const spint *, spint *, size_t, size_t);
+void batch_modsqr_X448(const spint *, spint *, size_t, size_t);
+void batch_nres_X25519(const spint *, spint *, size_t, size_t);
+void batch_nres_NIST256(const spint *, spint *, size_t, size_t);
+void batch_nres_X448(const spint *, spint *, size_t, size_t);
+void batch_redc_X25519(const spint *, spint *, size_t, size_t);
+void batch_redc_NIST256(const spint *, spint *, size_t, size_t);
+void batch_redc_X448(const spint *, spint *, size_t, size_t);
 void batch_rfc7748_X25519(const char *, const char *, char *, size_t);
 void batch_rfc7748_X448(const char *, const char *, char *, size_t);
 
@@ -27,11 +36,22 @@ static void *run(void *arg) {
     case 2: batch_modmul_X448(a, b, c, j->n, j->ld); break;
     case 3: batch_rfc7748_X25519((const char *)j->a + j->off * 32, (const char *)j->b + j->off * 32, (char *)j->c + j->off * 32, j->n); break;
     case 4: batch_rfc7748_X448((const char *)j->a + j->off * 56, (const char *)j->b + j->off * 56, (char *)j->c + j->off * 56, j->n); break;
+    /* unary ops over SoA: c = op(a), b unused */
+    case 5: batch_modsqr_X25519(a, c, j->n, j->ld); break;
+    case 6: batch_modsqr_NIST256(a, c, j->n, j->ld); break;
+    case 7: batch_modsqr_X448(a, c, j->n, j->ld); break;
+    case 8: batch_nres_X25519(a, c, j->n, j->ld); break;
+    case 9: batch_nres_NIST256(a, c, j->n, j->ld); break;
+    case 10: batch_nres_X448(a, c, j->n, j->ld); break;
+    case 11: batch_redc_X25519(a, c, j->n, j->ld); break;
+    case 12: batch_redc_NIST256(a, c, j->n, j->ld); break;
+    case 13: batch_redc_X448(a, c, j->n, j->ld); break;
     }
     return NULL;
 }
 
-/* kind: 0..2 = modmul X25519/NIST256/X448 over SoA (ld = limb stride), 3..4 = rfc7748 X25519/X448 */
+/* kind: 0..2 = modmul X25519/NIST256/X448 over SoA (ld = limb stride), 3..4 = rfc7748 X25519/X448,
+ * 5..7 = modsqr, 8..10 = nres, 11..13 = redc (X25519/NIST256/X448; b unused) */
 int oracle_parallel(int kind, const void *a, const void *b, void *c, size_t n, size_t ld, int threads) {
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;

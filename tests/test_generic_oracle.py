@@ -64,3 +64,24 @@ def test_agrees_with_per_prime_restatement(oracle, P):
         for op in ("modmul", "modadd", "modsub"):
             assert G.bi(op, a, b) == oracle.bi(op, P, a, b)
         assert G.un("modsqr", a) == oracle.un("modsqr", P, a)
+
+
+def test_round2_modnsqr_and_out_of_contract(gx):
+    """tests/golden/make_golden_r2.py: the reference's modnsqr (k squarings in place, pseudo.py:745-755) and its
+    answers on out-of-contract limbs (64-bit wrap-around), for every built prime"""
+    P, G, _ = gx
+    g2 = load_golden("field_%s_r2.json" % P)
+    for rec in g2["modnsqr"]:
+        z = limbs(rec["a"])
+        for _ in range(rec["k"]):
+            z = G.un("modsqr", z)
+        assert z == limbs(rec["out"]), (P, "modnsqr", rec["k"])
+    for i, rec in enumerate(g2["ooc"]):
+        a, b = limbs(rec["a"]), limbs(rec["b"])
+        for op in ("modmul", "modadd", "modsub"):
+            assert G.bi(op, a, b) == limbs(rec[op]), (P, op, i)
+        for op in ("modsqr", "nres", "redc", "modneg"):
+            assert G.un(op, a) == limbs(rec[op]), (P, op, i)
+        z = G.arr()
+        G.lib.gen_modmli(G.R, G.arr(a), 121665, z)
+        assert list(z) == limbs(rec["modmli_121665"]), (P, "modmli", i)

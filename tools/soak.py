@@ -3,7 +3,7 @@
 
   soak.py field   exact vs split/chain products on 2^22 elements per prime whose limbs are drawn from the contract's
                   edge classes (0, 1, 2^R-1, 2^R, 2^(R+1)-1, 2^(R+2)-1, random), plus 48-operation chains from
-                  in-range values: the two product policies must agree bit for bit (checksums compared across two child processes, MA_FORCE_FAST=0/1)
+                  in-range values: the product policies must agree bit for bit (checksums compared across three child processes: MA_FORCE_EXACT=1, MA_FORCE_FAST=1, default)
   soak.py curves  2^13 .. 2^16 random scalars x random points for each of the eleven curves, fused ecn mul on the GPU against the CPU oracle,
                   projective limbs compared
 """
@@ -51,18 +51,27 @@ def field_child(out):
 
 
 def field():
+    """three child processes, one per product policy (the switches are process-static): MA_FORCE_EXACT=1 (128-bit
+    products: the reference arithmetic), MA_FORCE_FAST=1 (split / chain products, unguarded) and the default per-wave
+    vote.  All edge classes are inside the split contract, so the default leg takes the split path too; the exact
+    leg is the one that differs in code.  (Against the CPU oracle: tests/test_gpu_round2.py, three primes.)"""
     import json
+    legs = (("exact", {"MA_FORCE_EXACT": "1"}), ("fast", {"MA_FORCE_FAST": "1"}), ("default", {}))
     outs = []
-    for fast in ("0", "1"):
-        f = "/tmp/soak_field_%s.json" % fast
-        subprocess.run([sys.executable, __file__, "field-child", f], env=dict(os.environ, MA_FORCE_FAST=fast), check=True)
+    for tag, extra in legs:
+        f = "/tmp/soak_field_%s.json" % tag
+        env = {k: v for k, v in os.environ.items() if k not in ("MA_FORCE_EXACT", "MA_FORCE_FAST")}
+        env.update(extra)
+        subprocess.run([sys.executable, __file__, "field-child", f], env=env, check=True)
         outs.append(json.load(open(f)))
     names = ["modmul(a,b)", "modsqr(a)", "modmul(b,b)", "nres(a)|chain", "redc(a)", "chain"]
+    bad = []
     for k in outs[0]:
-        if outs[0][k] != outs[1][k]:
-            print(k, "differs in:", [names[i] if len(outs[0][k]) == 6 or i < 3 else "chain" for i in range(len(outs[0][k])) if outs[0][k][i] != outs[1][k][i]])
-    bad = [k for k in outs[0] if outs[0][k] != outs[1][k]]
-    print("field soak: %d primes, 2^22 edge-class elements each, exact == split/chain: %s" % (len(outs[0]), "ALL EQUAL" if not bad else "MISMATCH " + str(bad)))
+        for leg, o in zip(legs[1:], outs[1:]):
+            if outs[0][k] != o[k]:
+                bad.append((k, leg[0]))
+                print(k, leg[0], "differs from exact in:", [names[i] if len(o[k]) == 6 or i < 3 else "chain" for i in range(len(o[k])) if outs[0][k][i] != o[k][i]])
+    print("field soak: %d primes, 2^22 edge-class elements each, exact == split/chain == default: %s" % (len(outs[0]), "ALL EQUAL" if not bad else "MISMATCH " + str(bad)))
     return 1 if bad else 0
 
 
