@@ -36,28 +36,54 @@ LOG2_ELEMS = int(os.environ.get("MA_BENCH_LOG2_ELEMS", "24"))
 LOG2_LADDER = int(os.environ.get("MA_BENCH_LOG2_LADDER", "23"))
 
 
-def cpu_baseline(n_log2=LOG2_ELEMS, min_seconds=6.0):
+def _native_baseline_lib():
+    """the cpu_baseline leg is timed on code built ON this machine with `gcc -O3 -march=native`:
+    oracle/Makefile target `native` (the three BASELINE fields, the ladder, the pthread driver; ~3 s).  The portable
+    liboracle.so that travels from the build container is the fallback, and the JSON says which one ran."""
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    flags = "-O3 -march=native -fPIC -fno-semantic-interposition -funroll-loops"
+    try:
+        subprocess.run(["make", "-s", "-B", "-C", odir, "native"], check=True, capture_output=True, timeout=300)
+        lib = ctypes.CDLL(os.path.join(odir, "libbaseline_native.so"))
+        built = "on this host"
+    except Exception as e:                                   # no compiler on the box: time the portable build
+        lib = ctypes.CDLL(os.path.join(odir, "liboracle.so"))
+        flags = "-O3 -march=x86-64-v3 -mtune=generic -fPIC -fno-semantic-interposition -funroll-loops"
+        built = "in the build container (native build failed: %s)" % type(e).__name__
+    try:
+        cc = subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    except Exception:
+        cc = "gcc (version unknown)"
+    lib.oracle_parallel.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]
+    lib.oracle_parallel.restype = ctypes.c_int
+    lib.time_modmul_X25519.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_long]
+    lib.time_modmul_X25519.restype = ctypes.c_uint
+    return lib, cc, flags, built
+
+
+def cpu_baseline(a_host, b_host, min_seconds=6.0):
     """oracle (kind "port": CPU restatement of the reference's generated field.c, limb-exact against the
     reference's golden vectors) timed on the host cores: all-core modmul throughput over the same
-    2^24-element workload, the reference's full time.c protocol on one core, and the ladder."""
+    2^24-element workload (the very arrays the GPU multiplied), the reference's full time.c protocol on one core,
+    and the ladder."""
     import numpy as np
-    from tests.oracle_binding import load_oracle
-    from tests.util import random_soa, vp
-    oracle = load_oracle(build=not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")))
+    from tests.util import vp
+    lib, cc, flags, built = _native_baseline_lib()
     cores = len(os.sched_getaffinity(0))
-    n = 1 << n_log2
-    a, b = random_soa("X25519", n, 101), random_soa("X25519", n, 102)
+    n = a_host.shape[1]
+    a, b = a_host, b_host
     c = np.empty_like(a)
-    oracle.lib.oracle_parallel(0, vp(a), vp(b), vp(c), n, n, cores)  # warm (page faults, thread start)
+    lib.oracle_parallel(0, vp(a), vp(b), vp(c), n, n, cores)  # warm (page faults, thread start)
     passes, t0 = 0, time.perf_counter()
     while True:
-        oracle.lib.oracle_parallel(0, vp(a), vp(b), vp(c), n, n, cores)
+        lib.oracle_parallel(0, vp(a), vp(b), vp(c), n, n, cores)
         passes += 1
         dt = time.perf_counter() - t0
         if dt >= min_seconds or passes >= 1024:
             break
     thr = passes * n / dt
-    del a, b, c
+    del c
     # reference-faithful latency: the full time.c protocol, 10^8 dependent modmuls on one core
     # (pseudo.py:1235-1250); the check word must be the reference's 0x116640
     U = ctypes.c_uint64 * 5
@@ -66,7 +92,7 @@ def cpu_baseline(n_log2=LOG2_ELEMS, min_seconds=6.0):
     rb = 0x4b95423416419f828b9d2434e465e150bd9c66b3ad3c2d6d1a3d1fa7bc8960a9
     x, y = mk(ra), mk(rb)
     t0 = time.perf_counter()
-    chk = oracle.fn("time_modmul", "X25519")(x, y, 100000)
+    chk = lib.time_modmul_X25519(x, y, 100000)
     lat = (time.perf_counter() - t0) / 1e8
     assert chk == 0x116640, "time.c check word mismatch: %#x" % chk
     # ladder on all cores, bounded sample
@@ -76,14 +102,15 @@ def cpu_baseline(n_log2=LOG2_ELEMS, min_seconds=6.0):
     u = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
     o = np.empty_like(u)
     t0 = time.perf_counter()
-    oracle.lib.oracle_parallel(3, vp(k), vp(u), vp(o), m, 0, cores)
+    lib.oracle_parallel(3, vp(k), vp(u), vp(o), m, 0, cores)
     ldt = time.perf_counter() - t0
     t0 = time.perf_counter()
-    oracle.lib.oracle_parallel(3, vp(k), vp(u), vp(o), 256, 0, 1)       # one thread, for the effective parallelism
+    lib.oracle_parallel(3, vp(k), vp(u), vp(o), 256, 0, 1)       # one thread, for the effective parallelism
     l1 = 256 / (time.perf_counter() - t0)
     return {
         "value": thr, "unit": "modmul/s", "cores": cores, "kind": "port",
-        "sample": "oracle modmul_X25519 over the 2^%d-element workload x %d passes, %d threads, %.1f s wall" % (n_log2, passes, cores, dt),
+        "sample": "oracle modmul_X25519 over the 2^%d-element workload (the GPU's own input arrays) x %d passes, %d threads, %.1f s wall" % (n.bit_length() - 1, passes, cores, dt),
+        "compiler": cc, "flags": flags, "built": built,
         "time_c_protocol": {"ns_per_modmul": lat * 1e9, "modmul_per_s": 1.0 / lat, "cores": 1, "dependent_modmuls": 10**8,
                             "check_word": hex(chk), "reference_check_word": "0x116640"},
         "x25519_scalar_mults_per_s": m / ldt, "x25519_sample": "%d ladders, %d threads, %.1f s wall" % (m, cores, ldt),
@@ -91,6 +118,34 @@ def cpu_baseline(n_log2=LOG2_ELEMS, min_seconds=6.0):
         "effective_parallelism": {"x25519": (m / ldt) / l1, "modmul": thr * lat,
                                   "note": "all-thread rate / one-thread rate; well below `cores` when the host is shared or the CPU quota is smaller than the visible core count (modmul over 2 GB of SoA arrays is also DRAM-bound)"},
     }
+
+
+def valu_roofline(scalars_per_s_per_gpu):
+    """VALU-issue roofline of the X25519 ladder kernel.  The instruction counts per scalar multiplication come from the
+    committed PMC summary (profiles/, SQ_INSTS_VALU of one pass / scalars); the rate is the one measured in THIS run.
+      achieved = scalars/s x wave-instructions per scalar (= per-lane instructions / 64 lanes)      [wave-instr/s]
+      peak     = 1024 SIMDs x 2.4 GHz / cost,  cost = (5.0 x mad + 2.5 x (instr - mad)) / instr     [wave-instr/s]
+    5.0 / 2.5 cycles per wave-instruction per SIMD: measured issue costs of v_mad_u64_u32 and of simple 32-bit ALU
+    instructions (profiles/r01_valubench.log); 2.4 GHz is the nominal peak clock, so frac is a lower bound when the
+    part clocks lower under this load (the PMC file records the clock seen during its pass)."""
+    for tag in ("r02", "r01g"):
+        path = os.path.join(ROOT, "profiles", "%s_valu_pmc.json" % tag)
+        if os.path.exists(path):
+            break
+    else:
+        return None
+    k = json.load(open(path)).get("k_x25519_fe26")
+    if not k:
+        return None
+    instr = k["SQ_INSTS_VALU"] * 64.0 / k["scalars"]          # per-lane VALU instructions per scalar multiplication
+    mad = k.get("mad_per_scalar", 739 * 255 + 11 * 100 + 254 * 55 + 100)
+    cost = (5.0 * mad + 2.5 * (instr - mad)) / instr
+    achieved = scalars_per_s_per_gpu * instr / 64.0
+    peak = 1024 * 2.4e9 / cost
+    return {"bound": "valu", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s", "frac": achieved / peak,
+            "instr_per_scalar": instr, "mad_per_scalar": mad, "issue_cost_of_mix_cycles": cost,
+            "cycles_per_instr": 1024 * 2.4e9 / achieved, "clock_GHz_assumed": 2.4, "source": "profiles/%s_valu_pmc.json" % tag,
+            "mad_only_ceiling_scalars_per_s": 1024 * 2.4e9 * 64 / (5.0 * mad)}
 
 
 def launch_ranks(n_ranks, argv):
@@ -169,8 +224,12 @@ def main():
     F = Field("X25519", dev)
     n = 1 << LOG2_ELEMS
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    a = torch.randint(0, 1 << 51, (5, n), dtype=torch.int64, device=dev, generator=gen)
-    b = torch.randint(0, 1 << 51, (5, n), dtype=torch.int64, device=dev, generator=gen)
+    # SURVEY 8(d) C2 input recipe: a[j], b[j] uniform in [0,p), element j of the splitmix64 stream keyed by
+    # (seed 42, array id) reduced mod p -- generated on the device (csrc/kernels.h k_uniform), regenerable on the host
+    # from (seed, array, j) alone (tests/util.py uniform_model).  Every rank draws its own arrays (ids 16*rank + ...).
+    SEED, AID = 42, 16 * rank
+    a = F.uniform(n, seed=SEED, array=AID + 0)
+    b = F.uniform(n, seed=SEED, array=AID + 1)
     c = torch.empty_like(a)
 
     def barrier():
@@ -200,30 +259,62 @@ def main():
     assert torch.equal(chk, c), "modmul is not commutative bit-for-bit: kernel bug"
     del chk
 
+    def rate(fn, reps=20, warm=3):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    # SURVEY 8(d) C2's second and third data sets (non-canonical limbs), short runs of the same kernel:
+    # values in [p,2p) with the top limb unmasked (what the reference's self-test feeds, pseudo.py:1763-1775), and
+    # the previous pass's outputs fed back in (what time.c and the ladders do, pseudo.py:1235-1242)
+    data_sets = {"uniform_mod_p": {"modmul_per_s_per_gpu": n / (kern_ms * 1e-3), "GBps": achieved, "kernel_ms": kern_ms,
+                                   "recipe": "splitmix64(seed 42, array id, j), %d words, mod p; canonical limbs" % 5}}
+    if not args.no_others:
+        a2 = F.uniform(n, seed=SEED, array=AID + 0, plus_p=True)
+        b2 = F.uniform(n, seed=SEED, array=AID + 1, plus_p=True)
+        c2 = torch.empty_like(a2)
+        ms = rate(lambda: F.modmul(a2, b2, out=c2))
+        data_sets["p_to_2p_top_limb_unmasked"] = {"modmul_per_s_per_gpu": n / (ms * 1e-3), "GBps": BYTES_PER_MODMUL * n / (ms * 1e-3) / 1e9, "kernel_ms": ms}
+        # same residues, other representative: the canonical results must agree
+        r1, r2 = F.redc(c), F.redc(c2)
+        assert torch.equal(r1, r2), "modmul of [p,2p) representatives disagrees with the canonical ones"
+        del a2, b2, r1, r2
+        F.modmul(c, a, out=c2)                       # fed back: operands are outputs of previous passes
+        fb = torch.empty_like(c2)
+        ms = rate(lambda: F.modmul(c2, c, out=fb))
+        data_sets["fed_back_outputs"] = {"modmul_per_s_per_gpu": n / (ms * 1e-3), "GBps": BYTES_PER_MODMUL * n / (ms * 1e-3) / 1e9, "kernel_ms": ms}
+        # shared multiplicand c[j] = a[j]*b0 (80 B per element)
+        b0 = [int(v) for v in b[:, 0].cpu().numpy().view("uint64")]
+        ms = rate(lambda: F.modmuls(a, b0, out=fb))
+        data_sets["shared_multiplicand"] = {"modmul_per_s_per_gpu": n / (ms * 1e-3), "GBps": 80 * n / (ms * 1e-3) / 1e9, "kernel_ms": ms, "bytes_per_element": 80}
+        del c2, fb
+
     # the other single-GPU configs of BASELINE.json (configs[2], configs[3]) with the same protocol, short runs:
     # parity for them is in tests/; these are side figures, not the headline
     others = {}
     if not args.no_others:
         for P, ops in (("NIST256", ("modmul",)), ("X448", ("modmul", "modsqr"))):
             Fp = Field(P, dev)
-            xa = torch.randint(0, 1 << Fp.radix, (Fp.N, n), dtype=torch.int64, device=dev, generator=gen)
-            xb = torch.randint(0, 1 << Fp.radix, (Fp.N, n), dtype=torch.int64, device=dev, generator=gen)
+            # uniform in [0,p) by the same recipe, then nres (Montgomery form)
+            xa = Fp.uniform(n, seed=SEED, array=AID + 2)
+            xb = Fp.uniform(n, seed=SEED, array=AID + 3)
+            Fp.nres(xa, out=xa)
+            Fp.nres(xb, out=xb)
             xc = torch.empty_like(xa)
             for op in ops:
                 fn = (lambda: Fp.modmul(xa, xb, out=xc)) if op == "modmul" else (lambda: Fp.modsqr(xa, out=xc))
-                for _ in range(3):
-                    fn()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize()
-                e0.record()
-                for _ in range(20):
-                    fn()
-                e1.record()
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / 20
+                ms = rate(fn)
                 nbytes = (3 if op == "modmul" else 2) * 8 * Fp.N * n
                 others["%s_%s" % (P, op)] = {"ops_per_s_per_gpu": n / (ms * 1e-3), "GBps": nbytes / (ms * 1e-3) / 1e9,
-                                             "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms}
+                                             "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms,
+                                             "inputs": "uniform mod p (splitmix64 recipe), nres'd"}
             del xa, xb, xc
         # the curve layer built on the path, one pass each: side figures (VALU-bound kernels)
         from modarith_amd.edwards import Curve
@@ -272,7 +363,8 @@ def main():
             lt, gather_ms = max_over_ranks([lt, gather_ms])
         ladder = {"value": world * m / lt, "unit": "X25519 scalar-mults/s", "scalars_per_gpu": m, "ms_per_pass": lt * 1e3,
                   "gather_ms": gather_ms, "io_bytes_per_scalar": 96,
-                  "bound": "VALU 32-bit integer multiply-add issue (not HBM)"}
+                  "bound": "VALU 32-bit integer multiply-add issue (not HBM)",
+                  "roofline": valu_roofline(m / lt)}
 
     verified = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -301,23 +393,31 @@ def main():
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu:
-            cpu = cpu_baseline()
-        traffic = None
+            import numpy as np
+            cpu = cpu_baseline(np.ascontiguousarray(a.cpu().numpy().view(np.uint64)), np.ascontiguousarray(b.cpu().numpy().view(np.uint64)))
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE, WRITE_SIZE; tools/gpu_profile.sh) of the same command on
+        # the same build: a property of the kernel and the batch size, so it is only quoted for the profiled size
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_modmul_X25519.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tdoc = json.load(open(tpath))
+            if tdoc.get("algorithmic_bytes_per_launch") == BYTES_PER_MODMUL * n:
+                traffic = tdoc.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/traffic_modmul_X25519.json (rocprofv3 --pmc passes, tag %s)" % tdoc.get("tag")
         out = {
             "metric": "256-bit modmul/s (2^255-19)", "value": value, "unit": "modmul/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": "batched modmul 2^255-19, 5x51-bit limbs, 2^%d elements per GPU, limb-interleaved SoA" % LOG2_ELEMS,
-                       "elements_per_gpu": n, "parallelism": "independent batches, %d rank(s), no data-path collective" % world},
+                       "elements_per_gpu": n, "inputs": "uniform mod p: splitmix64 stream (seed 42, array id, j) reduced mod p, generated on the device",
+                       "parallelism": "independent batches, %d rank(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_binary<P_X25519,OpMulAuto,2>", "kernel_ms": kern_ms,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "k_binary<P_X25519,OpMulAuto,2>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_MODMUL * n},
             "cpu_baseline": cpu,
             "x25519": ladder,
+            "data_sets": data_sets,
             "other_configs": others,
             "verified_against_oracle": verified,
         }

@@ -165,6 +165,12 @@ int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbi
        z[0][j] & 0xFFFFFF is the reference's check word */                                                            \
     int time_protocol_##P##_batch(int kind, const ma_spint *x, const ma_spint *y, ma_spint *z, long outer, size_t n,    \
                                   size_t ld, void *stream);                                                             \
+    /* synthetic inputs (SURVEY 8(d) recipe; not a reference function): out[j] = canonical limbs of a value uniform in  \
+       [0,p) -- the splitmix64 stream keyed by (seed, array) read at element first+j, ceil(Nbits/64)+1 words reduced     \
+       mod p; plus_p != 0 adds p and leaves the top limb unmasked (a representative in [p,2p)).  Plain values: apply     \
+       nres for Montgomery form.  Host model: tests/util.py uniform_model */                                            \
+    int moduniform_##P##_batch(unsigned long long seed, unsigned long long array, size_t first, int plus_p,             \
+                               ma_spint *out, size_t n, size_t ld, void *stream);                                       \
     /* byte records: device char[n*Nbytes], big-endian per record as modimp/modexp take them */                        \
     int modimp_##P##_batch(const char *b, ma_spint *a, int *flag, size_t n, size_t ld, void *stream);                   \
     int modexp_##P##_batch(const ma_spint *a, char *b, size_t n, size_t ld, void *stream);

@@ -63,6 +63,7 @@ _SIG = {
     "modimp": [_P, _P, _P, c_size_t, c_size_t, _P],
     "modexp": [_P, _P, c_size_t, c_size_t, _P],
     "time_protocol": [c_int, _P, _P, _P, ctypes.c_long, c_size_t, c_size_t, _P],
+    "moduniform": [ctypes.c_ulonglong, ctypes.c_ulonglong, c_size_t, c_int, _P, c_size_t, c_size_t, _P],
 }
 BATCH_FUNCS = tuple(_SIG)
 # scalar (_ct) names declared by the header, for the symbol-export test

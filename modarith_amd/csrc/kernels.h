@@ -347,6 +347,48 @@ __global__ __launch_bounds__(BLOCK) void k_exp(const spint* a, unsigned char* by
     }
 }
 
+// Synthetic field elements for benchmarks and full-size tests (SURVEY 8(d) input recipe): a splitmix64 stream keyed by
+// (seed, array id); element j takes the NWD = ceil(Nbits/64)+1 consecutive outputs number j*NWD+1 .. j*NWD+NWD as a
+// little-endian integer (bias below 2^-64) and reduces it mod p with field calls only -- Horner over the words with
+// modmul by nres(2^64) (keeps plain values plain) and modadd, then modfsb -- leaving the CANONICAL limbs of a value
+// uniform in [0,p) (plain, not nres'd).  plus_p: the same value + p, top limb unmasked: a representative in [p,2p).
+// Regenerable on the host from (seed, array, j) alone (tests/util.py uniform_model).
+MA_DEV spint splitmix64_at(spint s0, spint t) {
+    spint z = s0 + (t + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <class P>
+__global__ __launch_bounds__(BLOCK) void k_uniform(spint s0, size_t first, int plus_p, spint* out, size_t n, size_t ld) {
+    using F = Field<P>;
+    constexpr int NWD = (P::NBITS + 63) / 64 + 1;
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
+        const spint base = (spint)(first + t) * (spint)NWD;
+        spint c[P::N], e[P::N], acc[1][P::N];
+        F::mod2r(64, c);
+        auto word_elem = [&](int k, spint* x) {                     // one 64-bit word as plain limbs
+            spint w = splitmix64_at(s0, base + (spint)k);
+            x[0] = w & F::MASK;
+            x[1] = w >> P::RADIX;
+            static_for<2, P::N>([&](auto I) { x[I] = 0; });
+        };
+        word_elem(NWD - 1, acc[0]);
+#pragma unroll 1
+        for (int k = NWD - 2; k >= 0; k--) {
+            F::modmul(acc[0], c, acc[0]);
+            word_elem(k, e);
+            F::modadd(acc[0], e, acc[0]);
+        }
+        (void)F::modfsb(acc[0]);
+        if (plus_p) {
+            F::template addp<1>(acc[0], ~(spint)0);
+            (void)F::prop(acc[0]);
+        }
+        store_soa<P, 1>(out, ld, t, acc);
+    }
+}
+
 // The reference's timing protocol on the GPU (time.c: pseudo.py:1177-1386; its CUDA form
 // simd/pseudo_cuda.py:1163-1231 runs the same dependent chains inside one thread): every lane runs the
 // serially dependent chain on its own operands, entirely in registers, and leaves redc(z).

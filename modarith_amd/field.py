@@ -230,6 +230,16 @@ class Field:
         self._call("mod2r", int(r), a.data_ptr(), n, a.stride(0), _stream())
         return a
 
+    def uniform(self, n: int, seed: int = 42, array: int = 0, first: int = 0, plus_p: bool = False, out=None):
+        """synthetic batch (SURVEY 8(d) input recipe): canonical limbs of values uniform in [0,p), element j drawn from the
+        splitmix64 stream keyed by (seed, array) at position first+j; plus_p: the value + p with the top limb unmasked.
+        Plain values (apply nres for Montgomery form)."""
+        a = out if out is not None else self.empty(n)
+        if out is not None and self._chk(out) != n:
+            raise ValueError("out must hold n elements")
+        self._call("moduniform", int(seed), int(array), int(first), int(bool(plus_p)), a.data_ptr(), n, a.stride(0) if n else 1, _stream())
+        return a
+
     def _sel(self, d: torch.Tensor, n: int) -> torch.Tensor:
         if d.dtype != torch.int32 or d.numel() != n or not d.is_cuda or not d.is_contiguous():
             raise ValueError("selector must be a contiguous int32 device tensor with one 0/1 entry per element")

@@ -20,8 +20,9 @@ from make_golden import Ref, element_pool, hx  # noqa: E402
 
 
 def limb_classes(R, rng):
-    return [0, 1, (1 << R) - 1, 1 << R, (1 << (R + 1)) - 1, (1 << (R + 2)) - 1, 1 << (R + 2), (1 << (R + 3)) - 1,
-            1 << 63, (1 << 64) - 1, rng.getrandbits(64), rng.getrandbits(R)]
+    M = (1 << 64) - 1        # limbs are 64-bit words (radix 62 puts 2^(R+2) beyond them)
+    return [v & M for v in (0, 1, (1 << R) - 1, 1 << R, (1 << (R + 1)) - 1, (1 << (R + 2)) - 1, 1 << (R + 2), (1 << (R + 3)) - 1,
+                            1 << 63, (1 << 64) - 1, rng.getrandbits(64), rng.getrandbits(R))]
 
 
 def fixture(script, arg, seed, name, count=96):

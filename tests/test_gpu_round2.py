@@ -161,6 +161,29 @@ def test_contract_edge_classes_vs_oracle(oracle, torch_cuda, P):
     assert np.array_equal(to_np(F.redc(A)), oracle_un(oracle, "redc", P, a)), "redc"
 
 
+@pytest.mark.parametrize("P", CORE + ["NIST521", "GM384", "NIST224", "ED25519Q"])
+def test_uniform_inputs_match_host_model(torch_cuda, P):
+    """the benchmark's input recipe is regenerable on the host from (seed, array, j) alone"""
+    from modarith_amd.field import Field
+    from modarith_amd.params import derive
+    from tests.util import uniform_model
+    F, fp = Field(P), derive(P)
+    n = 1031
+    for seed, array, first in ((42, 0, 0), (42, 1, 0), (7, 3, (1 << 33) + 5)):
+        got = F.to_ints(F.uniform(n, seed=seed, array=array, first=first))
+        lim = F.to_limbs(F.uniform(n, seed=seed, array=array, first=first))
+        want = [uniform_model(fp.p, fp.n, seed, array, first + j) for j in range(n)]
+        assert got == want, (P, seed, array, first)
+        assert lim == [fp.to_limbs(v) for v in want]                       # canonical limbs, top limb included
+        shifted = F.to_limbs(F.uniform(n, seed=seed, array=array, first=first, plus_p=True))
+        assert shifted == [fp.to_limbs(v + fp.p) for v in want]            # [p,2p), top limb unmasked
+    # a window of a longer stream equals the same positions generated alone
+    a = F.uniform(4096, array=2)
+    b = F.uniform(100, array=2, first=1000)
+    assert torch_cuda.equal(a[:, 1000:1100], b)
+    assert len(set(F.to_ints(a))) > 4000
+
+
 # ---------------------------------------------------------------- BASELINE configs 2-4, full size, every element
 FULL = [("X25519", "modmul", 0), ("NIST256", "modmul", 1), ("X448", "modmul", 2), ("X448", "modsqr", 7)]
 

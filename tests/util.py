@@ -46,3 +46,22 @@ def to_dev(a: np.ndarray):
 
 def to_np(t) -> np.ndarray:
     return t.detach().cpu().numpy().view(np.uint64)
+
+
+# ---- host model of the synthetic-input recipe (device side: csrc/kernels.h k_uniform)
+_M64 = (1 << 64) - 1
+
+
+def splitmix64_at(s0: int, t: int) -> int:
+    z = (s0 + (t + 1) * 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def uniform_model(p: int, nbits: int, seed: int, array: int, j: int) -> int:
+    """the value of element j of stream (seed, array): ceil(nbits/64)+1 consecutive splitmix64 outputs, little-endian, mod p"""
+    s0 = (seed * 0x9E3779B97F4A7C15 + array * 0xD1342543DE82EF95) & _M64
+    nwd = (nbits + 63) // 64 + 1
+    v = sum(splitmix64_at(s0, j * nwd + k) << (64 * k) for k in range(nwd))
+    return v % p
