@@ -49,9 +49,17 @@ struct Fe26 {
         r[0] = (uint32_t)h0 & M26;
         r[1] += (uint32_t)(h0 >> 26);
     }
-    static MA_DEV void mul(const uint32_t* f, const uint32_t* g, uint32_t* r) {
-        uint32_t g19[10], f2[10];
+    static MA_DEV void pre19(const uint32_t* g, uint32_t* g19) {
         static_for<1, 10>([&](auto J) { g19[J] = 19u * g[J]; });
+    }
+    static MA_DEV void mul(const uint32_t* f, const uint32_t* g, uint32_t* r) {
+        uint32_t g19[10];
+        pre19(g, g19);
+        mul(f, g, g19, r);
+    }
+    // g19 = 19*g[1..9] supplied by the caller (the ladder's x1 is multiplied in every step: computed once)
+    static MA_DEV void mul(const uint32_t* f, const uint32_t* g, const uint32_t* g19, uint32_t* r) {
+        uint32_t f2[10];
         static_for<0, 5>([&](auto K) { f2[2 * K + 1] = 2u * f[2 * K + 1]; });
         uint64_t c = 0;
         uint32_t t[10];
@@ -66,6 +74,7 @@ struct Fe26 {
                 const uint32_t a = dbl ? f2[i] : f[i];
                 const uint32_t b = wrp ? g19[j] : g[j];
                 acc += (uint64_t)a * b;
+                MA_PIN(acc);
             });
             t[k] = (uint32_t)acc & ((k & 1) ? M25 : M26);
             c = acc >> bits(k);
@@ -99,6 +108,7 @@ struct Fe26 {
                         b = wrp ? (odd2 ? f38[j] : f19[j]) : (odd2 ? f2[j] : f[j]);
                     }
                     acc += (uint64_t)a * b;
+                    MA_PIN(acc);
                 }
             });
             t[k] = (uint32_t)acc & ((k & 1) ? M25 : M26);
@@ -114,6 +124,24 @@ struct Fe26 {
         uint64_t h[10];
         static_for<0, 10>([&](auto I) { h[I] = (uint64_t)f[I] * C; });
         carry(h, r);
+    }
+
+    // r = f * C + a, carried like mul(): the carry out of limb i is the accumulator start of limb i+1 (rides in its
+    // multiply-add), the addend joins the masked digit with one 32-bit add.  f < 1.5*2^27, C < 2^17: carries < 2^20;
+    // a tight -> r < 2^27 (even) / 2^26 (odd), r[1] a few units more: one add away from tight, as mul()/sqr() accept.
+    template <uint32_t C>
+    static MA_DEV void mul_small_add(const uint32_t* f, const uint32_t* a, uint32_t* r) {
+        uint64_t c = 0;
+        uint32_t t[10];
+        static_for<0, 10>([&](auto KK) {
+            constexpr int k = KK;
+            uint64_t acc = c + (uint64_t)f[k] * C;
+            MA_PIN(acc);
+            t[k] = (uint32_t)acc & ((k & 1) ? M25 : M26);
+            c = acc >> bits(k);
+        });
+        wrap(c, t);
+        static_for<0, 10>([&](auto I) { r[I] = t[I] + a[I]; });
     }
 
     static MA_DEV void add(const uint32_t* f, const uint32_t* g, uint32_t* r) {
@@ -133,6 +161,13 @@ struct Fe26 {
             uint32_t t = (f[I] ^ g[I]) & mask;
             f[I] ^= t;
             g[I] ^= t;
+        });
+    }
+    // r = s ? g : f per lane (v_cndmask; both values are read before the choice)
+    static MA_DEV void select(bool s, const uint32_t* f, const uint32_t* g, uint32_t* r) {
+        static_for<0, 10>([&](auto I) {
+            const uint32_t x = f[I], y = g[I];
+            r[I] = s ? y : x;
         });
     }
     static MA_DEV void copy(const uint32_t* f, uint32_t* r) { static_for<0, 10>([&](auto I) { r[I] = f[I]; }); }
@@ -204,67 +239,82 @@ struct Fe26 {
     }
 };
 
-// Batched X25519 (rfc7748.c:156-256 per element) on the fe26 representation.
-__global__ __launch_bounds__(256) void k_x25519_fe26(const uint64_t* bk, const uint64_t* bu, uint64_t* bv, size_t n) {
+// One X25519 scalar multiplication (rfc7748.c:156-256) on the fe26 representation: kw, uw = the 32-byte scalar and
+// u-coordinate records as four little-endian words; ow = the canonical result.
+//
+// Ladder step without data movement for the conditional swap.  With A = x2+z2, B = x2-z2, C = x3+z3, D = x3-z3 taken
+// from the UNSWAPPED pairs, exchanging (x2,z2) <-> (x3,z3) exchanges A <-> C and B <-> D, hence DA <-> CB: the
+// differential addition x3' = (DA+CB)^2, z3' = x1 (DA-CB)^2 does not see the swap at all (the difference only changes
+// sign under the square), and the doubling only needs A' = swap ? C : A and B' = swap ? D : B.  Two 10-limb selects
+// replace the two 10-limb swaps of rfc7748.c:190-191 (20 v_cndmask instead of 40 + mask arithmetic); the state after
+// every step is exactly the reference's ("2" = the doubled point, "3" = the sum), so the swap bit chains as there.
+MA_DEV void x25519_fe26_one(const uint64_t* kw_in, const uint64_t* uw_in, uint64_t* ow) {
     using F = Fe26;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        uint64_t kw[4], uw[4];
-        static_for<0, 4>([&](auto K) { kw[K] = bk[t * 4 + K]; });
-        static_for<0, 4>([&](auto K) { uw[K] = bu[t * 4 + K]; });
-        uw[3] &= 0x7fffffffffffffffull;                     // mask bit 255 of u (rfc7748.c:171-172)
-        kw[0] &= ~7ull;                                     // clamp (rfc7748.c:135-141)
-        kw[3] = (kw[3] & 0x7fffffffffffffffull) | 0x4000000000000000ull;
-        // left-align: bit 254 -> bit 63 of kw[3]
+    uint64_t kw[4], uw[4];
+    static_for<0, 4>([&](auto K) { kw[K] = kw_in[K]; uw[K] = uw_in[K]; });
+    uw[3] &= 0x7fffffffffffffffull;                     // mask bit 255 of u (rfc7748.c:171-172)
+    kw[0] &= ~7ull;                                     // clamp (rfc7748.c:135-141)
+    kw[3] = (kw[3] & 0x7fffffffffffffffull) | 0x4000000000000000ull;
+    // left-align: bit 254 -> bit 63 of kw[3]
+    kw[3] = (kw[3] << 1) | (kw[2] >> 63);
+    kw[2] = (kw[2] << 1) | (kw[1] >> 63);
+    kw[1] = (kw[1] << 1) | (kw[0] >> 63);
+    kw[0] <<= 1;
+
+    uint32_t x1[10], x1_19[10], x2[10], z2[10], x3[10], z3[10];
+    F::from_words(uw, x1);
+    F::pre19(x1, x1_19);
+    x1_19[0] = 0;
+    F::set(1, x2);
+    F::set(0, z2);
+    F::copy(x1, x3);
+    F::set(1, z3);
+
+    uint32_t swap = 0;
+#pragma unroll 1
+    for (int step = 0; step < 255; step++) {
+        const uint32_t kt = (uint32_t)(kw[3] >> 63);
         kw[3] = (kw[3] << 1) | (kw[2] >> 63);
         kw[2] = (kw[2] << 1) | (kw[1] >> 63);
         kw[1] = (kw[1] << 1) | (kw[0] >> 63);
         kw[0] <<= 1;
+        const bool sw = (swap ^ kt) != 0;
+        swap = kt;
+        uint32_t A[10], B[10], C[10], D[10], As[10], Bs[10], AA[10], BB[10], E[10];
+        F::add(x2, z2, A);
+        F::add(x3, z3, C);
+        F::sub(x2, z2, B);
+        F::sub(x3, z3, D);
+        F::select(sw, A, C, As);
+        F::select(sw, B, D, Bs);
+        F::mul(D, A, D);          // DA  (CB when swapped: the pair {DA, CB} is swap-invariant)
+        F::mul(C, B, C);          // CB
+        F::sqr(As, AA);
+        F::sqr(Bs, BB);
+        F::sub(D, C, z3);
+        F::add(D, C, x3);
+        F::sub(AA, BB, E);
+        F::mul_small_add<121665>(E, AA, z2);      // AA + a24*E
+        F::mul(z2, E, z2);
+        F::sqr(x3, x3);
+        F::sqr(z3, z3);
+        F::mul(z3, x1, x1_19, z3);
+        F::mul(AA, BB, x2);
+    }
+    F::select(swap != 0, x2, x3, x2);
+    F::select(swap != 0, z2, z3, z2);
+    F::invert(z2, z2);
+    F::mul(x2, z2, x2);
+    F::to_words(x2, ow);
+}
 
-        uint32_t x1[10], x2[10], z2[10], x3[10], z3[10];
-        F::from_words(uw, x1);
-        F::set(1, x2);
-        F::set(0, z2);
-        F::copy(x1, x3);
-        F::set(1, z3);
-
-        uint32_t swap = 0;
-#pragma unroll 1
-        for (int step = 0; step < 255; step++) {
-            const uint32_t kt = (uint32_t)(kw[3] >> 63);
-            kw[3] = (kw[3] << 1) | (kw[2] >> 63);
-            kw[2] = (kw[2] << 1) | (kw[1] >> 63);
-            kw[1] = (kw[1] << 1) | (kw[0] >> 63);
-            kw[0] <<= 1;
-            swap ^= kt;
-            F::cswap(0u - swap, x2, x3);
-            F::cswap(0u - swap, z2, z3);
-            swap = kt;
-            uint32_t A[10], B[10], C[10], D[10], AA[10], BB[10], E[10];
-            F::add(x2, z2, A);
-            F::add(x3, z3, C);
-            F::sub(x2, z2, B);
-            F::sub(x3, z3, D);
-            F::sqr(A, AA);
-            F::sqr(B, BB);
-            F::mul(D, A, D);          // DA
-            F::mul(C, B, C);          // CB
-            F::sub(D, C, z3);
-            F::sub(AA, BB, E);
-            F::mul_small<121665>(E, z2);
-            F::add(D, C, x3);
-            F::add(z2, AA, z2);
-            F::mul(z2, E, z2);
-            F::sqr(x3, x3);
-            F::sqr(z3, z3);
-            F::mul(z3, x1, z3);
-            F::mul(AA, BB, x2);
-        }
-        F::cswap(0u - swap, x2, x3);
-        F::cswap(0u - swap, z2, z3);
-        F::invert(z2, z2);
-        F::mul(x2, z2, x2);
-        uint64_t ow[4];
-        F::to_words(x2, ow);
+// Batched X25519 on the fe26 representation: contiguous 32-byte records (simd/rfc7748_simt.cu:165-168), one per lane.
+__global__ __launch_bounds__(256) void k_x25519_fe26(const uint64_t* bk, const uint64_t* bu, uint64_t* bv, size_t n) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        uint64_t kw[4], uw[4], ow[4];
+        static_for<0, 4>([&](auto K) { kw[K] = bk[t * 4 + K]; });
+        static_for<0, 4>([&](auto K) { uw[K] = bu[t * 4 + K]; });
+        x25519_fe26_one(kw, uw, ow);
         static_for<0, 4>([&](auto K) { bv[t * 4 + K] = ow[K]; });
     }
 }

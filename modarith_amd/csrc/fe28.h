@@ -162,19 +162,58 @@ struct Fe28 {
         static_for<0, 16>([&](auto I) { h[I] = (uint64_t)f[I] * C; });
         carry(h, r);
     }
+    // r = f * C + a with the carry of limb i riding in the multiply-add of limb i+1 (f tight, C < 2^16: carries < 2^16;
+    // a tight -> r < 2^29, r[1] / r[9] a few units more)
+    template <uint32_t C>
+    static MA_DEV void mul_small_add(const uint32_t* f, const uint32_t* a, uint32_t* r) {
+        uint64_t c = 0;
+        uint32_t t[16];
+        static_for<0, 16>([&](auto KK) {
+            constexpr int k = KK;
+            const uint64_t acc = c + (uint64_t)f[k] * C;
+            t[k] = (uint32_t)acc & M28;
+            c = acc >> 28;
+        });
+        const uint32_t top = (uint32_t)c;              // 2^448 = 2^224 + 1: re-enters at limbs 0 and 8
+        const uint32_t h0 = t[0] + top, h8 = t[8] + top;
+        t[0] = h0 & M28;
+        t[1] += h0 >> 28;
+        t[8] = h8 & M28;
+        t[9] += h8 >> 28;
+        static_for<0, 16>([&](auto I) { r[I] = t[I] + a[I]; });
+    }
 
     static MA_DEV void add(const uint32_t* f, const uint32_t* g, uint32_t* r) {
         static_for<0, 16>([&](auto I) { r[I] = f[I] + g[I]; });
     }
     // r = f - g + 2p, carried back to tight (limbs of 2p: 2^29-2, limb 8: 2^29-4)
+    // (f, g < 2^29 + small: every limb of f + 2p - g is below 2^31, so the carries run in 32-bit registers)
     static MA_DEV void sub(const uint32_t* f, const uint32_t* g, uint32_t* r) {
-        uint64_t h[16];
+        uint32_t h[16];
         static_for<0, 16>([&](auto I) {
             constexpr int i = I;
             constexpr uint32_t twop = (i == 8) ? 0x1ffffffcu : 0x1ffffffeu;
-            h[i] = (uint64_t)((f[i] + twop) - g[i]);
+            h[i] = (f[i] + twop) - g[i];
         });
-        carry(h, r);
+        static_for<0, 15>([&](auto I) {
+            constexpr int i = I;
+            h[i + 1] += h[i] >> 28;
+            r[i] = h[i] & M28;
+        });
+        const uint32_t top = h[15] >> 28;
+        r[15] = h[15] & M28;
+        const uint32_t h0 = r[0] + top, h8 = r[8] + top;
+        r[0] = h0 & M28;
+        r[1] += h0 >> 28;
+        r[8] = h8 & M28;
+        r[9] += h8 >> 28;
+    }
+    // r = s ? g : f per lane (v_cndmask; both values are read before the choice)
+    static MA_DEV void select(bool s, const uint32_t* f, const uint32_t* g, uint32_t* r) {
+        static_for<0, 16>([&](auto I) {
+            const uint32_t x = f[I], y = g[I];
+            r[I] = s ? y : x;
+        });
     }
     static MA_DEV void cswap(uint32_t mask, uint32_t* f, uint32_t* g) {
         static_for<0, 16>([&](auto I) {
@@ -254,62 +293,69 @@ struct Fe28 {
     }
 };
 
-// Batched X448 (rfc7748.c:156-256 per element, A24 = 39081, COF = 2) on the fe28 representation.
-__global__ __launch_bounds__(256, 2) void k_x448_fe28(const uint64_t* bk, const uint64_t* bu, uint64_t* bv, size_t n) {
+// One X448 scalar multiplication (rfc7748.c:156-256, A24 = 39081, COF = 2) on the fe28 representation; kw, uw = the
+// 56-byte records as seven little-endian words.  The conditional swap is folded into two selects exactly as in
+// fe26.h (x25519_fe26_one): {DA, CB} is invariant under the swap, only the doubling needs A' and B'.
+MA_DEV void x448_fe28_one(const uint64_t* kw_in, const uint64_t* uw_in, uint64_t* ow) {
     using F = Fe28;
+    uint64_t kw[7], uw[7];
+    static_for<0, 7>([&](auto K) { kw[K] = kw_in[K]; uw[K] = uw_in[K]; });
+    kw[0] &= ~3ull;                                       // clamp (rfc7748.c:135-141): Nbits % 8 == 0
+    kw[6] |= 0x8000000000000000ull;                       // bit 447 set; already left-aligned
+
+    uint32_t x1[16], x2[16], z2[16], x3[16], z3[16];
+    F::from_words(uw, x1);
+    F::set(1, x2);
+    F::set(0, z2);
+    F::copy(x1, x3);
+    F::set(1, z3);
+
+    uint32_t swap = 0;
+#pragma unroll 1
+    for (int step = 0; step < 448; step++) {
+        const uint32_t kt = (uint32_t)(kw[6] >> 63);
+        static_for<0, 7>([&](auto KK) {
+            constexpr int k = 6 - KK;
+            kw[k] <<= 1;
+            if constexpr (k > 0) kw[k] |= kw[k - 1] >> 63;
+        });
+        const bool sw = (swap ^ kt) != 0;
+        swap = kt;
+        uint32_t A[16], B[16], C[16], D[16], As[16], Bs[16], AA[16], BB[16], E[16];
+        F::add(x2, z2, A);
+        F::add(x3, z3, C);
+        F::sub(x2, z2, B);
+        F::sub(x3, z3, D);
+        F::select(sw, A, C, As);
+        F::select(sw, B, D, Bs);
+        F::mul_k(D, A, D);                  // D, B tight; A, C below 2^29
+        F::mul_k(C, B, C);
+        F::sqr(As, AA);                     // a sum of two tight values is not tight
+        F::sqr_k(Bs, BB);
+        F::sub(D, C, z3);
+        F::add(D, C, x3);
+        F::sub(AA, BB, E);
+        F::mul_small_add<39081>(E, AA, z2); // AA + a24*E
+        F::mul_k(z2, E, z2);
+        F::sqr(x3, x3);                     // x3 = D + C is not tight
+        F::sqr_k(z3, z3);
+        F::mul_k(z3, x1, z3);
+        F::mul_k(AA, BB, x2);
+    }
+    F::select(swap != 0, x2, x3, x2);
+    F::select(swap != 0, z2, z3, z2);
+    F::invert(z2, z2);
+    F::mul(x2, z2, x2);
+    F::to_words(x2, ow);
+}
+
+// Batched X448 on the fe28 representation: contiguous 56-byte records, one per lane.
+__global__ __launch_bounds__(256, 2) void k_x448_fe28(const uint64_t* bk, const uint64_t* bu, uint64_t* bv, size_t n) {
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        uint64_t kw[7], uw[7];
+        uint64_t kw[7], uw[7], ow[7];
         static_for<0, 7>([&](auto K) { kw[K] = bk[t * 7 + K]; });
         static_for<0, 7>([&](auto K) { uw[K] = bu[t * 7 + K]; });
-        kw[0] &= ~3ull;                                       // clamp (rfc7748.c:135-141): Nbits % 8 == 0
-        kw[6] |= 0x8000000000000000ull;                       // bit 447 set; already left-aligned
-
-        uint32_t x1[16], x2[16], z2[16], x3[16], z3[16];
-        F::from_words(uw, x1);
-        F::set(1, x2);
-        F::set(0, z2);
-        F::copy(x1, x3);
-        F::set(1, z3);
-
-        uint32_t swap = 0;
-#pragma unroll 1
-        for (int step = 0; step < 448; step++) {
-            const uint32_t kt = (uint32_t)(kw[6] >> 63);
-            static_for<0, 7>([&](auto KK) {
-                constexpr int k = 6 - KK;
-                kw[k] <<= 1;
-                if constexpr (k > 0) kw[k] |= kw[k - 1] >> 63;
-            });
-            swap ^= kt;
-            F::cswap(0u - swap, x2, x3);
-            F::cswap(0u - swap, z2, z3);
-            swap = kt;
-            uint32_t A[16], B[16], C[16], D[16], AA[16], BB[16], E[16];
-            F::add(x2, z2, A);
-            F::add(x3, z3, C);
-            F::sub(x2, z2, B);
-            F::sub(x3, z3, D);
-            F::sqr(A, AA);                      // A = x2 + z2 is not tight
-            F::sqr_k(B, BB);
-            F::mul_k(D, A, D);
-            F::mul_k(C, B, C);
-            F::sub(D, C, z3);
-            F::sub(AA, BB, E);
-            F::mul_small<39081>(E, z2);
-            F::add(D, C, x3);
-            F::add(z2, AA, z2);
-            F::mul_k(z2, E, z2);
-            F::sqr(x3, x3);                     // x3 = D + C is not tight
-            F::sqr_k(z3, z3);
-            F::mul_k(z3, x1, z3);
-            F::mul_k(AA, BB, x2);
-        }
-        F::cswap(0u - swap, x2, x3);
-        F::cswap(0u - swap, z2, z3);
-        F::invert(z2, z2);
-        F::mul(x2, z2, x2);
-        uint64_t ow[7];
-        F::to_words(x2, ow);
+        x448_fe28_one(kw, uw, ow);
         static_for<0, 7>([&](auto K) { bv[t * 7 + K] = ow[K]; });
     }
 }

@@ -22,7 +22,21 @@ using spint = uint64_t;
 using sspint = int64_t;
 using dpint = unsigned __int128;
 
+#ifndef MA_DEV          // tools/fe_host_check.hip defines it __host__ __device__ to run the same arithmetic on the CPU
 #define MA_DEV __device__ __forceinline__
+#endif
+
+// MA_PIN(x): an empty asm through which x passes in VGPRs.  The optimiser cannot see through it, so an accumulator
+// pinned after every `acc += a * b` keeps the SOURCE order of a multiply-add chain: each step stays one
+// v_mad_u64_u32 whose addend is the running value.  Without it LLVM's reassociation sorts the operands of a long sum
+// by the position of their definition, starts every column at zero and adds the (late) carry of the previous column
+// at the end with a separate 64-bit add (v_lshl_add_u64, same issue cost as a multiply-add) -- one extra instruction
+// per column.  No instruction is emitted for the pin itself.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MA_PIN(x) asm("" : "+v"(x))
+#else
+#define MA_PIN(x) ((void)0)
+#endif
 
 template <int I, int End, class Fn>
 MA_DEV void static_for(Fn&& fn) {
