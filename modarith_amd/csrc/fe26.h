@@ -135,7 +135,7 @@ struct Fe26 {
         uint32_t t[10];
         static_for<0, 10>([&](auto KK) {
             constexpr int k = KK;
-            uint64_t acc = c + (uint64_t)f[k] * C;
+            const uint64_t acc = c + (uint64_t)f[k] * C;
             MA_PIN(acc);
             t[k] = (uint32_t)acc & ((k & 1) ? M25 : M26);
             c = acc >> bits(k);

@@ -171,6 +171,7 @@ struct Fe28 {
         static_for<0, 16>([&](auto KK) {
             constexpr int k = KK;
             const uint64_t acc = c + (uint64_t)f[k] * C;
+            MA_PIN(acc);
             t[k] = (uint32_t)acc & M28;
             c = acc >> 28;
         });

@@ -26,14 +26,15 @@ using dpint = unsigned __int128;
 #define MA_DEV __device__ __forceinline__
 #endif
 
-// MA_PIN(x): an empty asm through which x passes in VGPRs.  The optimiser cannot see through it, so an accumulator
-// pinned after every `acc += a * b` keeps the SOURCE order of a multiply-add chain: each step stays one
-// v_mad_u64_u32 whose addend is the running value.  Without it LLVM's reassociation sorts the operands of a long sum
-// by the position of their definition, starts every column at zero and adds the (late) carry of the previous column
-// at the end with a separate 64-bit add (v_lshl_add_u64, same issue cost as a multiply-add) -- one extra instruction
-// per column.  No instruction is emitted for the pin itself.
+// MA_PIN(x): an empty, input-only asm that merely READS x.  A value with a second use is a leaf for LLVM's
+// reassociation, so an accumulator pinned after every `acc += a * b` keeps the SOURCE order of a multiply-add chain:
+// each step stays one v_mad_u64_u32 whose addend is the running value.  Without it the operands of a long sum are
+// sorted by rank, every column starts at zero and the (late) carry of the previous column is added at the end with
+// a separate 64-bit add (v_lshl_add_u64: the issue cost of a multiply-add) -- one extra instruction per column.
+// The asm defines no register, so it emits nothing and does not trigger the gfx950 hazard rule "a VALU reading a
+// register written by inline asm waits one state" (an `asm("" : "+v"(x))` pin costs an s_nop per step).
 #if defined(__HIP_DEVICE_COMPILE__)
-#define MA_PIN(x) asm("" : "+v"(x))
+#define MA_PIN(x) asm volatile("" ::"v"(x))
 #else
 #define MA_PIN(x) ((void)0)
 #endif

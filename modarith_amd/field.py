@@ -96,7 +96,8 @@ class Field:
         _lib.check(f(*args), "%s_%s_batch" % (fn, self.prime))
 
     def _out(self, like: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
-        return out if out is not None else torch.empty_like(like)
+        # a fresh result takes the operand's limb stride (views of wider batches keep theirs), as one call needs
+        return out if out is not None else torch.empty_strided(like.shape, like.stride(), dtype=like.dtype, device=like.device)
 
     def _bin(self, fn, a, b, out):
         out = self._out(a, out)

@@ -223,7 +223,7 @@ def test_full_size_vs_oracle(oracle, torch_cuda, P, op, kind):
     assert np.array_equal(hg, want), "%s %s differs from the oracle at full size" % (P, op)
     # fed back once more (outputs as inputs: what time.c and the ladder do), on the first 2^22 lanes
     m = 1 << 22
-    g2 = F.modmul(got[:, :m], A[:, :m])
+    g2 = F.modmul(got[:, :m], A[:, :m])                     # views of the wide batches: the result takes their limb stride
     w2 = np.empty((N, m), dtype=np.uint64)
     hgm, ham = np.ascontiguousarray(hg[:, :m]), np.ascontiguousarray(ha[:, :m])
     mulkind = {"X25519": 0, "NIST256": 1, "X448": 2}[P]

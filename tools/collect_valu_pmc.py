@@ -17,7 +17,7 @@ src = "gpurun_out/prof_%s" % tag
 want = {"k_x25519_fe26": ("k_x25519_fe26", 1 << 22), "k_x448_fe28": ("k_x448_fe28", 1 << 20)}
 for a in sys.argv[2:]:
     name, rest = a.split("=")
-    sub, units = rest.split(":")
+    sub, units = rest.rsplit(":", 1)
     want[name] = (sub, int(units))
 doc = {"command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE [...] --kernel-trace --output-format csv -- python3 tools/run_ladder.py (and tools/time_ecn.py for the curve kernels)",
        "note": "whole-GPU sums; GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs; SQ_INSTS_VALU counts wave-level instructions"}
