@@ -233,8 +233,10 @@ int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void 
  * reference.  ecn_*_mul is the constant-time 4-bit fixed-window multiplication (edwards.c:435-482); its
  * 9-entry table (two of them for mul2) lives in a caller-provided device workspace of
  * ecn_*_mul_workspace_bytes(n) bytes.
- * Projective results equal the reference's limb for limb where it is deterministic (add, dbl, mul);
- * set/get/affine/cmp involve modpro and are comparable as affine coordinates.  ecnXXXmul2 (a joint sparse form
+ * add, dbl and mul run the reference's formulas (edwards.c:73-145, weierstrass.c:68-281) from the bit-exact field calls
+ * in the reference's order; the reference-derived fixtures pin these results as AFFINE values (the curve templates
+ * cannot be built here without a stand-in for addchain), the projective limbs are checked against the restated
+ * templates in oracle/ ("affine-pinned").  set/get/affine/cmp involve modpro and are comparable as affine coordinates.  ecnXXXmul2 (a joint sparse form
  * with data-dependent branches in the reference, edwards.c:404-431, 486-510) is two interleaved fixed-window
  * multiplications sharing their doublings here, constant-time: same point, another projective representative.
  * Input points must have limbs below 2^(Radix+2) -- true of every point these functions or the reference's
@@ -296,6 +298,15 @@ MODARITH_AMD_DECLARE_EDWARDS(nist384, 7)
 MODARITH_AMD_DECLARE_EDWARDS(nist521, 9)
 MODARITH_AMD_DECLARE_EDWARDS(secp256k1, 5)
 MODARITH_AMD_DECLARE_EDWARDS(nums256w, 5)
+
+/* ---- Fused scalar multiplication + affine export: ecnXXXmul followed by ecnXXXget, the reference's own call
+ * pattern (ed448.c:182-184: `ecnXXXmul(e,&P); ecnXXXget(&P,x,y)`), in one kernel.  x, y (device, big-endian Nbytes
+ * records, either may be NULL) receive the affine coordinates of e*P, sign (device int[n] or NULL) the sign ecnXXXget
+ * returns (of y when y is NULL, of x when x is NULL, else 0).  P is NOT modified (the two-call form leaves e*P in it).
+ * Only canonical bytes leave the kernel, so it runs on 32-bit-limb internals with extended-coordinate formulas that are
+ * complete on the curve (csrc/ed26.h): the same bytes as ecn_<c>_mul_batch + ecn_<c>_get_batch for every input point
+ * on the curve, no workspace, constant-time fixed window like ecnXXXmul. */
+int ecn_ed25519_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,286 @@
+// modarith_amd/csrc/ed26.h -- fused ecnXXXmul + ecnXXXget for ED25519 on the fe26 representation (gfx950).
+//
+// The reference's callers end a scalar multiplication in ecnXXXget (ed448.c:182-184, nist256.c:155-161 pattern):
+// affine coordinates as canonical big-endian bytes (modexp does a full redc, pseudo.py:1115-1127).  Only those bytes
+// leave this kernel, so -- exactly as for rfc7748() in fe26.h -- the internal limb form AND the group-law formulas are
+// free: ten 25.5-bit limbs (every partial product one v_mad_u64_u32), extended twisted-Edwards coordinates
+// (X:Y:Z:T), a = -1, Hisil-Wong-Carter-Dawson doubling (4S + 3M, + 1M when T is needed) and mixed addition with a
+// cached affine operand (y+x, y-x, 2dxy; 6M).  These formulas are COMPLETE on -x^2 + y^2 = 1 + d x^2 y^2 (a = -1 is a
+// square and d a non-square mod 2^255-19): no exceptional cases for any pair of curve points, including the neutral
+// element and the points of small order, so the result is the affine point the reference's edwards.c:73-145 formulas
+// reach, for every input point ON the curve.  (For off-curve input neither side means anything; they may differ.)
+//
+// Scalar multiplication is fixed-window like edwards.c:435-482 -- every scalar takes the same instruction and address
+// sequence -- with 3-bit signed digits so that the whole table {1,2,3,4}P fits the register file: 12 field elements
+// held canonical and packed (4 x 64 bits each, 96 VGPRs); no workspace, no LDS, no table traffic.  A lookup scans
+// all four entries with lane-predicated selects (v_cndmask), the digit's sign swaps y+x / y-x and negates 2dxy.
+// Recoding without carries: e' = e + sum_{i<86} 4*8^i < 8^86, digit_i = window_i(e') - 4 in [-4, 3].
+// Work per scalar: 255 doublings + 86 additions + table (2 doublings, 1 general addition, one shared inversion)
+// + final inversion: about 2.37e5 multiply-adds, against 2.04e5 for the X25519 ladder.
+//
+// Limb bounds ("scale" 1 = 2^27 on even limbs / 2^26 on odd ones = twice tight): Fe26::mul(f, g) needs the
+// 19-premultiplied operand g below scale 1.68 (19 g < 2^32) and scale(f) * scale(g) <= 8 (column < 2^64); sqr needs
+// scale <= 1.68.  The comments give the scale of every intermediate; one weak carry per doubling keeps them there.
+#pragma once
+#include "fe26.h"
+
+namespace ma {
+
+template <class C>   // C: curve constants in the 5 x 51 field.c form (generated/curve_ED25519.h)
+struct Ed26 {
+    using F = Fe26;
+    static constexpr uint32_t M26 = F::M26, M25 = F::M25;
+    struct Ext { uint32_t X[10], Y[10], Z[10], T[10]; };
+
+    // limbs below 2^31 -> tight (r[1] may keep a few units above 2^25); 32-bit registers only
+    static MA_DEV void wc(uint32_t* f) {
+        static_for<0, 9>([&](auto I) {
+            constexpr int i = I;
+            f[i + 1] += f[i] >> F::bits(i);
+            f[i] &= (i & 1) ? M25 : M26;
+        });
+        const uint32_t c9 = f[9] >> 25;            // < 2^6
+        f[9] &= M25;
+        const uint32_t h0 = f[0] + 19u * c9;
+        f[0] = h0 & M26;
+        f[1] += h0 >> 26;
+    }
+    // r = f - g + 4p, for g up to scale 1.99 (limbs of 4p: 2^28-76, 2^27-4, 2^28-4, 2^27-4, ...)
+    static MA_DEV void sub4(const uint32_t* f, const uint32_t* g, uint32_t* r) {
+        static_for<0, 10>([&](auto I) {
+            constexpr int i = I;
+            constexpr uint32_t fourp = (i == 0) ? 0xfffffb4u : ((i & 1) ? 0x7fffffcu : 0xffffffcu);
+            r[i] = (f[i] + fourp) - g[i];
+        });
+    }
+    // 5 x 51-bit limbs (field.c form, limbs below 2^53: the contract of the curve layer) -> tight fe26
+    static MA_DEV void from51(const spint* x, uint32_t* r) {
+        static_for<0, 5>([&](auto K) {
+            constexpr int k = K;
+            r[2 * k] = (uint32_t)x[k] & M26;
+            r[2 * k + 1] = (uint32_t)(x[k] >> 26);
+        });
+        wc(r);
+    }
+    static MA_DEV void d2(uint32_t* r) {            // 2d, folded at compile time from the curve constant
+        spint d[5];
+        static_for<0, 5>([&](auto I) { d[I] = C::b(I); });
+        from51(d, r);
+        F::add(r, r, r);
+        wc(r);
+    }
+
+    // P = 2P, dbl-2008-hwcd with a = -1 (signs arranged so that no negation is needed):
+    //   A = X^2, B = Y^2, C = 2Z^2, H = A + B, E = H - (X+Y)^2, G = A - B, F = C + G
+    //   X3 = E F, Y3 = G H, Z3 = F G, T3 = E H.          Input X, Y, Z tight; T is not read.
+    template <bool WANT_T>
+    static MA_DEV void dbl(Ext& p) {
+        uint32_t A[10], B[10], Cc[10], S[10], H[10], E[10], G[10], Ff[10], H19[10], F19[10];
+        F::sqr(p.X, A);
+        F::sqr(p.Y, B);
+        F::sqr(p.Z, Cc);
+        F::add(p.X, p.Y, S);        // 1.0
+        F::sqr(S, S);
+        F::add(A, B, H);            // 1.0
+        F::sub(H, S, E);            // 2.0
+        F::sub(A, B, G);            // 1.5
+        F::add(Cc, Cc, Cc);         // 1.0
+        F::add(Cc, G, Ff);          // 2.5
+        wc(Ff);                     // tight
+        F::pre19(Ff, F19);
+        F::pre19(H, H19);
+        F::mul(E, Ff, F19, p.X);    // 2.0 x 0.5
+        F::mul(G, H, H19, p.Y);     // 1.5 x 1.0
+        F::mul(G, Ff, F19, p.Z);    // 1.5 x 0.5
+        if constexpr (WANT_T) F::mul(E, H, H19, p.T);
+    }
+
+    // the common tail of both additions: X3 = e f, Y3 = g h, Z3 = f g from a = (Y1-X1)(..), b = (Y1+X1)(..), c, d
+    static MA_DEV void add_tail(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, Ext& p) {
+        uint32_t e[10], f[10], g[10], h[10], g19[10];
+        F::sub(b, a, e);            // 1.5
+        F::sub(d, c, f);            // 2.0
+        F::add(d, c, g);            // 1.5
+        F::add(b, a, h);            // 1.0
+        F::pre19(g, g19);
+        F::mul(f, e, p.X);          // 2.0 x 1.5
+        F::mul(f, g, g19, p.Z);     // 2.0 x 1.5
+        F::mul(h, g, g19, p.Y);     // 1.0 x 1.5
+    }
+    // P += Q, Q affine and cached as (y+x, y-x, 2dxy) (madd-2008-hwcd-3, a = -1, Z2 = 1); yp, ym tight, t2d <= 1.5.
+    // Reads T of P; T of the sum is not produced (the next operation is a doubling, which does not read it).
+    static MA_DEV void add_cached(Ext& p, const uint32_t* yp, const uint32_t* ym, const uint32_t* t2d) {
+        uint32_t a[10], b[10], c[10], d[10];
+        F::sub(p.Y, p.X, a);        // 1.5
+        F::mul(a, ym, a);
+        F::add(p.Y, p.X, b);        // 1.0
+        F::mul(b, yp, b);
+        F::mul(p.T, t2d, c);
+        F::add(p.Z, p.Z, d);        // 1.0
+        add_tail(a, b, c, d, p);
+    }
+    // P += Q, both extended (add-2008-hwcd-3, a = -1); used once, to build 3P
+    static MA_DEV void add_ext(Ext& p, const Ext& q) {
+        uint32_t a[10], b[10], c[10], d[10], t[10], dd[10];
+        F::sub(p.Y, p.X, a);        // 1.5
+        F::sub(q.Y, q.X, t);        // 1.5
+        F::mul(a, t, a);
+        F::add(p.Y, p.X, b);        // 1.0
+        F::add(q.Y, q.X, t);        // 1.0
+        F::mul(b, t, b);
+        F::mul(p.T, q.T, c);
+        d2(dd);
+        F::mul(c, dd, c);
+        F::mul(p.Z, q.Z, d);
+        F::add(d, d, d);            // 1.0
+        add_tail(a, b, c, d, p);
+    }
+};
+
+// One fused ED25519 scalar multiplication + affine export.
+//   ew: the scalar as four little-endian 64-bit words (the caller has byte-swapped the big-endian record);
+//   X, Y, Z: the projective point, 5 x 51-bit limbs each (field.c form); xw, yw: canonical affine coordinates,
+//   four little-endian words each.
+template <class C>
+MA_DEV void ed25519_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* xw, uint64_t* yw) {
+    using E = Ed26<C>;
+    using F = Fe26;
+    typename E::Ext R, Q;
+    uint64_t tab[4][3][4];                  // {1,2,3,4}P as canonical packed (y+x, y-x, 2dxy)
+
+    {   // ---- table: projective P -> extended; 2P, 3P, 4P; one shared inversion; cached affine form
+        typename E::Ext P2, P3, P4;
+        uint32_t px[10], py[10], pz[10];
+        E::from51(X, px);
+        E::from51(Y, py);
+        E::from51(Z, pz);
+        F::mul(px, pz, Q.X);                // (XZ : YZ : Z^2 : XY)
+        F::mul(py, pz, Q.Y);
+        F::sqr(pz, Q.Z);
+        F::mul(px, py, Q.T);
+        P2 = Q;
+        E::template dbl<true>(P2);
+        P3 = P2;
+        E::add_ext(P3, Q);
+        P4 = P2;
+        E::template dbl<false>(P4);
+        // Montgomery's trick: the four Z inverted with one inversion
+        uint32_t z12[10], z123[10], inv[10], i1[10], i2[10], i3[10], i4[10];
+        F::mul(Q.Z, P2.Z, z12);
+        F::mul(z12, P3.Z, z123);
+        F::mul(z123, P4.Z, inv);
+        F::invert(inv, inv);
+        F::mul(inv, z123, i4);
+        F::mul(inv, P4.Z, inv);             // 1 / (Z1 Z2 Z3)
+        F::mul(inv, z12, i3);
+        F::mul(inv, P3.Z, inv);             // 1 / (Z1 Z2)
+        F::mul(inv, Q.Z, i2);
+        F::mul(inv, P2.Z, i1);
+        uint32_t dd[10];
+        E::d2(dd);
+        auto cache = [&](const typename E::Ext& p, const uint32_t* zi, uint64_t (*out)[4]) {
+            uint32_t x[10], y[10], s[10];
+            F::mul(p.X, zi, x);
+            F::mul(p.Y, zi, y);
+            F::add(y, x, s);
+            F::to_words(s, out[0]);
+            F::sub(y, x, s);
+            F::to_words(s, out[1]);
+            F::mul(x, y, s);
+            F::mul(s, dd, s);
+            F::to_words(s, out[2]);
+        };
+        cache(Q, i1, tab[0]);
+        cache(P2, i2, tab[1]);
+        cache(P3, i3, tab[2]);
+        cache(P4, i4, tab[3]);
+    }
+
+    // ---- recoding: e' = e + sum_{i<86} 4*8^i, left-aligned so that window 85 (bits 255..257) is the top of w[4]
+    uint64_t w[5];
+    {
+        constexpr auto cw = [](int k) {
+            uint64_t v = 0;
+            for (int b = 0; b < 64; b++) {
+                const int pos = 64 * k + b;
+                if (pos < 258 && pos % 3 == 2) v |= (uint64_t)1 << b;
+            }
+            return v;
+        };
+        unsigned __int128 acc = 0;
+        uint64_t s[5];
+        static_for<0, 5>([&](auto K) {
+            constexpr int k = K;
+            acc += (unsigned __int128)(k < 4 ? ew[k < 4 ? k : 0] : 0) + cw(k);
+            s[k] = (uint64_t)acc;
+            acc >>= 64;
+        });
+        w[4] = (s[4] << 62) | (s[3] >> 2);
+        w[3] = (s[3] << 62) | (s[2] >> 2);
+        w[2] = (s[2] << 62) | (s[1] >> 2);
+        w[1] = (s[1] << 62) | (s[0] >> 2);
+        w[0] = s[0] << 62;
+    }
+
+    // R = neutral element (0 : 1 : 1 : 0)
+    F::set(0, R.X);
+    F::set(1, R.Y);
+    F::set(1, R.Z);
+    F::set(0, R.T);
+
+#pragma unroll 1
+    for (int i = 0; i < 86; i++) {
+        const uint32_t win = (uint32_t)(w[4] >> 61);
+        w[4] = (w[4] << 3) | (w[3] >> 61);
+        w[3] = (w[3] << 3) | (w[2] >> 61);
+        w[2] = (w[2] << 3) | (w[1] >> 61);
+        w[1] = (w[1] << 3) | (w[0] >> 61);
+        w[0] <<= 3;
+        const int dgt = (int)win - 4;                       // [-4, 3]
+        const bool neg = dgt < 0;
+        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);    // 0..4
+        if (i != 0) {
+            E::template dbl<false>(R);
+            E::template dbl<false>(R);
+            E::template dbl<true>(R);
+        }
+        // constant-time lookup: scan all entries, start from the neutral element (y+x, y-x, 2dxy) = (1, 1, 0)
+        uint64_t sel[3][4];
+        static_for<0, 3>([&](auto CI) { static_for<0, 4>([&](auto K) { sel[CI][K] = (CI < 2 && K == 0) ? 1u : 0u; }); });
+        static_for<0, 4>([&](auto EI) {
+            constexpr int e = EI;
+            const bool hit = (m == (uint32_t)(e + 1));
+            static_for<0, 3>([&](auto CI) {
+                static_for<0, 4>([&](auto K) {
+                    const uint64_t a = tab[e][CI][K], b = sel[CI][K];
+                    sel[CI][K] = hit ? a : b;
+                });
+            });
+        });
+        // -Q = (y-x, y+x, -2dxy)
+        uint32_t yp[10], ym[10], t2[10], nt[10];
+        uint64_t sp[4], sm[4];
+        static_for<0, 4>([&](auto K) {
+            const uint64_t a = sel[0][K], b = sel[1][K];
+            sp[K] = neg ? b : a;
+            sm[K] = neg ? a : b;
+        });
+        F::from_words(sp, yp);
+        F::from_words(sm, ym);
+        F::from_words(sel[2], t2);
+        F::set(0, nt);
+        F::sub(nt, t2, nt);                                 // 2p - t: 1.0 .. 1.5
+        F::select(neg, t2, nt, t2);
+        E::add_cached(R, yp, ym, t2);
+    }
+
+    // ---- affine, canonical (ecnXXXget: edwards.c:221-239)
+    uint32_t zi[10], ax[10], ay[10];
+    F::invert(R.Z, zi);
+    F::mul(R.X, zi, ax);
+    F::mul(R.Y, zi, ay);
+    F::to_words(ax, xw);
+    F::to_words(ay, yw);
+}
+
+}  // namespace ma

@@ -308,6 +308,7 @@ MA_DEV void x25519_fe26_one(const uint64_t* kw_in, const uint64_t* uw_in, uint64
     F::to_words(x2, ow);
 }
 
+#ifdef MA_LADDER_FE26   // the kernel is emitted by the unit that owns the ladder entry point (capi_prime.inc)
 // Batched X25519 on the fe26 representation: contiguous 32-byte records (simd/rfc7748_simt.cu:165-168), one per lane.
 __global__ __launch_bounds__(256) void k_x25519_fe26(const uint64_t* bk, const uint64_t* bu, uint64_t* bv, size_t n) {
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
@@ -318,5 +319,7 @@ __global__ __launch_bounds__(256) void k_x25519_fe26(const uint64_t* bk, const u
         static_for<0, 4>([&](auto K) { bv[t * 4 + K] = ow[K]; });
     }
 }
+
+#endif
 
 }  // namespace ma

@@ -350,6 +350,7 @@ MA_DEV void x448_fe28_one(const uint64_t* kw_in, const uint64_t* uw_in, uint64_t
     F::to_words(x2, ow);
 }
 
+#ifdef MA_LADDER_FE28   // the kernel is emitted by the unit that owns the ladder entry point (capi_prime.inc)
 // Batched X448 on the fe28 representation: contiguous 56-byte records, one per lane.
 __global__ __launch_bounds__(256, 2) void k_x448_fe28(const uint64_t* bk, const uint64_t* bu, uint64_t* bv, size_t n) {
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
@@ -360,5 +361,7 @@ __global__ __launch_bounds__(256, 2) void k_x448_fe28(const uint64_t* bk, const 
         static_for<0, 7>([&](auto K) { bv[t * 7 + K] = ow[K]; });
     }
 }
+
+#endif
 
 }  // namespace ma

@@ -32,6 +32,7 @@ def _declared_symbols():
     for fn in re.findall(r"\becn_##c##_(\w+)\s*\(", emacro):
         for c in re.findall(r"^MODARITH_AMD_DECLARE_EDWARDS\((\w+),", text, flags=re.M):
             names.add("ecn_%s_%s" % (c, fn))
+    names.update(re.findall(r"\b(ecn_\w+_mul_get_batch)\s*\(", text))
     return sorted(names), primes
 
 
@@ -52,6 +53,7 @@ def test_binding_tables_cover_header(lib):
     bound |= set(_lib.UTIL_FUNCS) | {"rfc7748_X25519", "rfc7748_X448", "rfc7748_X25519_batch", "rfc7748_X448_batch"}
     bound |= {"ecn_%s_%s_batch" % (c, f) for c in _lib.CURVES for f in _lib.ED_BATCH_FUNCS}
     bound |= {"ecn_%s_%s" % (c, f) for c in _lib.CURVES for f in _lib.ED_SCALAR_FUNCS}
+    bound |= set(_lib.FUSED_FUNCS)
     assert bound == set(names)
 
 

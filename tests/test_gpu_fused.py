@@ -1,0 +1,126 @@
+"""GPU parity of the fused scalar multiplication + affine export (csrc/ed26.h, ecn_<c>_mul_get_batch): byte-equal to
+ecn_<c>_mul_batch followed by ecn_<c>_get_batch, to the reference-derived fixtures, and to the CPU oracle's ecn mul +
+ecn get -- on random projective points, the special points of the curve and corner scalars."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+FUSED = [("ed25519", "ED25519")]
+
+
+@pytest.fixture(scope="module", params=FUSED)
+def fx(request):
+    import torch
+    assert torch.cuda.is_available()
+    from modarith_amd.edwards import Edwards
+    C, name = request.param
+    return C, Edwards(name), load_golden("edwards_%s.json" % name), torch
+
+
+def dev_bytes(torch, hexes):
+    return torch.tensor([list(bytes.fromhex(h)) for h in hexes], dtype=torch.uint8, device="cuda")
+
+
+def hexrows(t):
+    return [bytes(r).hex() for r in t.cpu().numpy()]
+
+
+def test_fused_mul_get_fixture(fx):
+    """the reference-derived records of edwards_<C>.json (tests/golden/make_golden.py): e, P -> affine e*P"""
+    C, Ed, g, torch = fx
+    recs = g["mul"]
+    P = Ed.set(None, dev_bytes(torch, [r["P"][0] for r in recs]), dev_bytes(torch, [r["P"][1] for r in recs]))
+    keep = P.clone()
+    x, y, sign = Ed.mul_get(dev_bytes(torch, [r["e"] for r in recs]), P)
+    assert torch.equal(P, keep)                                              # the point batch is not modified
+    assert [[a, b] for a, b in zip(hexrows(x), hexrows(y))] == [r["eP"] for r in recs]
+    assert sign.cpu().tolist() == [0] * len(recs)                            # both coordinates requested
+    # the reference main()'s chain P = n1*P (testcurve.c:247-255) through the fused kernel: steps 1 and 10
+    if "testcurve" in g:
+        t = g["testcurve"]
+        n1 = dev_bytes(torch, [t["n1"]])
+        Pp = Ed.gen(1)
+        for i in range(10):
+            x, y, _ = Ed.mul_get(n1, Pp)
+            if str(i + 1) in t["mul_chain"]:
+                assert [hexrows(x)[0], hexrows(y)[0]] == t["mul_chain"][str(i + 1)]
+            Pp = Ed.set(None, x, y)
+
+
+def test_fused_equals_two_call_form_random(fx, oracle):
+    """2^16 random (scalar, projective point) pairs: fused == mul + get on the GPU == the oracle's mul + get"""
+    C, Ed, g, torch = fx
+    n = 1 << 16
+    gen = torch.Generator(device="cuda").manual_seed(91)
+    k0 = torch.randint(0, 256, (n, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=gen)
+    e = torch.randint(0, 256, (n, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=gen)
+    base = Ed.mul(k0, Ed.gen(n))                                             # random points, projective (Z != 1)
+    x, y, _ = Ed.mul_get(e, base)
+    want = Ed.mul(e, base.clone())
+    wx, wy, _ = Ed.get(want)
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+    # the oracle on a sample (scalar functions, element by element)
+    Pt, nb = oracle.ed[C]
+    soa = base.cpu().numpy().view(np.uint64)
+    he, hx, hy = e.cpu().numpy(), x.cpu().numpy(), y.cpu().numpy()
+    for j in list(range(0, n, 997)) + [n - 1]:
+        p = Pt()
+        for c, nm in enumerate(("x", "y", "z")):
+            for i in range(Ed.N):
+                getattr(p, nm)[i] = int(soa[c, i, j])
+        oracle.ecn(C, "mul")(bytes(he[j]), ctypes.byref(p))
+        ox, oy = ctypes.create_string_buffer(nb), ctypes.create_string_buffer(nb)
+        oracle.ecn(C, "get")(ctypes.byref(p), ox, oy)
+        assert bytes(hx[j]) == ox.raw and bytes(hy[j]) == oy.raw, j
+    # one coordinate + sign (point compression, edwards.c:219-239)
+    xo, none, sy = Ed.mul_get(e[:4099], base[:, :, :4099].contiguous(), want_y=False)
+    assert none is None and torch.equal(xo, x[:4099]) and torch.equal(sy, (y[:4099, -1] & 1).to(torch.int32))
+    none, yo, sx = Ed.mul_get(e[:4099], base[:, :, :4099].contiguous(), want_x=False)
+    assert none is None and torch.equal(yo, y[:4099]) and torch.equal(sx, (x[:4099, -1] & 1).to(torch.int32))
+
+
+def test_fused_special_points_and_scalars(fx):
+    """the complete addition law at work: neutral element, points of order 2, 4 and 8, scalars 0, 1, 8, the group order,
+    order +- 1 and all ones -- every (point, scalar) pair against the two-call form"""
+    C, Ed, g, torch = fx
+    p = (1 << 255) - 19
+    order = int(g["testcurve"]["order"], 16)
+    be = lambda v: v.to_bytes(Ed.nbytes, "big").hex()
+    G = Ed.gen(1)
+    lowy = [0, p - 1, 1]                                                     # y = 0 (order 4), y = -1 (order 2), y = 1 (neutral)
+    pts = [G, Ed.inf(1)]
+    for yv in lowy:
+        for s in (0, 1):
+            pts.append(Ed.set(torch.tensor([s], dtype=torch.int32, device="cuda"), None, dev_bytes(torch, [be(yv)])))
+    # a point of order 8: (order * k) * (random point of the full group); decompress y values until one has order 8
+    for yv in range(2, 40):
+        Q = Ed.set(torch.tensor([0], dtype=torch.int32, device="cuda"), None, dev_bytes(torch, [be(yv)]))
+        if Ed.isinf(Q).item():
+            continue
+        T = Ed.mul(dev_bytes(torch, [be(order)]), Q.clone())                 # kills the prime-order part
+        if not Ed.isinf(Ed.mul(dev_bytes(torch, [be(4)]), T.clone())).item():
+            pts.append(T)                                                    # 4T != O: order 8
+            break
+    assert len(pts) >= 9
+    scalars = [0, 1, 2, 7, 8, order - 1, order, order + 1, 8 * order, (1 << 256) - 1, 1 << 255, (1 << 255) - 1]
+    P = torch.cat([q for q in pts for _ in scalars], dim=2).contiguous()
+    e = dev_bytes(torch, [be(s) for _ in pts for s in scalars])
+    x, y, _ = Ed.mul_get(e, P)
+    wx, wy, _ = Ed.get(Ed.mul(e, P.clone()))
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+    # order * G is the neutral element: affine (0, 1)
+    i = scalars.index(order)
+    assert hexrows(x)[i] == be(0) and hexrows(y)[i] == be(1)
+
+
+def test_fused_rejects_bad_arguments(fx):
+    C, Ed, g, torch = fx
+    from modarith_amd.edwards import Edwards
+    with pytest.raises(ValueError):
+        Edwards("NIST256").mul_get(torch.zeros((1, 32), dtype=torch.uint8, device="cuda"), Edwards("NIST256").gen(1))
+    x, y, s = Ed.mul_get(torch.zeros((0, Ed.nbytes), dtype=torch.uint8, device="cuda"), Ed.empty(0))
+    assert x.shape[0] == 0

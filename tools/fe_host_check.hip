@@ -6,6 +6,8 @@
 #define MA_DEV __host__ __device__ inline
 #include "../modarith_amd/csrc/fe26.h"
 #include "../modarith_amd/csrc/fe28.h"
+#include "../modarith_amd/csrc/generated/curve_ED25519.h"
+#include "../modarith_amd/csrc/ed26.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -19,6 +21,54 @@ static uint64_t sm() {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
+}
+
+struct pt25519 { uint64_t x[5], y[5], z[5]; };
+extern "C" void ecn_ed25519_gen(pt25519*);
+extern "C" void ecn_ed25519_inf(pt25519*);
+extern "C" void ecn_ed25519_mul(const char* e, pt25519*);
+extern "C" void ecn_ed25519_dbl(pt25519*);
+extern "C" int ecn_ed25519_get(pt25519*, char* x, char* y);
+extern "C" void ecn_ed25519_set(int s, const char* x, const char* y, pt25519*);
+
+// fused ED25519 mul+get (csrc/ed26.h) against the oracle's ecn mul followed by ecn get, on random projective points
+// (random multiples of the generator, NOT normalised) and on the special points: neutral element, the point of order 2,
+// points of order 4 and 8 (decompressed from y = 0 and from a small-order y), scalars 0 / 1 / group order / all ones
+static int run_ed25519(int n) {
+    int bad = 0;
+    pt25519 base;
+    for (int it = 0; it < n; it++) {
+        pt25519 P;
+        unsigned char e[32], k[32];
+        for (int i = 0; i < 32; i++) { e[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
+        ecn_ed25519_gen(&P);
+        ecn_ed25519_mul((const char*)k, &P);             // random projective point
+        if (it % 16 == 1) ecn_ed25519_inf(&P);            // neutral element
+        if (it % 16 == 2) { char y[32]; memset(y, 0, 32); ecn_ed25519_set(0, nullptr, y, &P); }            // y = 0: order 4
+        if (it % 16 == 3) { char y[32]; memset(y, 0xff, 32); y[0] = 0x7f; y[31] = 0xec; ecn_ed25519_set(0, nullptr, y, &P); }  // y = -1: order 2
+        if (it % 16 == 4) ecn_ed25519_gen(&P);            // affine generator
+        if (it == 5) memset(e, 0, 32);
+        if (it == 6) { memset(e, 0, 32); e[31] = 1; }
+        if (it == 7) memset(e, 0xff, 32);
+        if (it == 8) { const unsigned char q[32] = {0x10,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0x14,0xde,0xf9,0xde,0xa2,0xf7,0x9c,0xd6,0x58,0x12,0x63,0x1a,0x5c,0xf5,0xd3,0xed}; memcpy(e, q, 32); }
+        if (it == 9) { memset(e, 0, 32); e[31] = 8; }
+        pt25519 Q = P;
+        uint64_t ew[4], xw[4], yw[4];
+        for (int w = 0; w < 4; w++) { uint64_t v = 0; for (int b = 0; b < 8; b++) v |= (uint64_t)e[31 - (8 * w + b)] << (8 * b); ew[w] = v; }
+        ma::ed25519_mul_get_one<ma::C_ED25519>(ew, P.x, P.y, P.z, xw, yw);
+        char wx[32], wy[32];
+        ecn_ed25519_mul((const char*)e, &Q);
+        ecn_ed25519_get(&Q, wx, wy);
+        unsigned char gx[32], gy[32];
+        for (int i = 0; i < 32; i++) { gx[i] = (unsigned char)(xw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); gy[i] = (unsigned char)(yw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); }
+        if (memcmp(gx, wx, 32) != 0 || memcmp(gy, wy, 32) != 0) {
+            if (bad < 6) printf("ed25519_mul_get_one: record %d differs\n", it);
+            bad++;
+        }
+    }
+    printf("ed25519_mul_get_one: %d records, %d differ from the oracle's ecn mul + get\n", n, bad);
+    (void)base;
+    return bad;
 }
 
 template <int NW, class Fn, class Ref>
@@ -51,5 +101,6 @@ int main(int argc, char** argv) {
     int n = argc > 1 ? atoi(argv[1]) : 2000;
     int bad = run<4>("x25519_fe26_one", n, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x25519_fe26_one(k, u, o); }, rfc7748_X25519);
     bad += run<7>("x448_fe28_one", n / 4 + 8, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x448_fe28_one(k, u, o); }, rfc7748_X448);
+    bad += run_ed25519(n / 4 + 16);
     return bad ? 1 : 0;
 }

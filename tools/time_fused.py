@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""fused ecn mul_get against the two-call form (ecn mul + ecn get) on the GPU box: rate of both, best of 3"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from modarith_amd.edwards import Curve
+for name, n in (("ED25519", 1 << 21),):
+    Ed = Curve(name)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    e = torch.randint(0, 256, (n, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=g)
+    k = torch.randint(0, 256, (n, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=g)
+    P = Ed.mul(k, Ed.gen(n))
+    Ed.mul_get(e[:4096].contiguous(), P[:, :, :4096].contiguous()); torch.cuda.synchronize()
+    bf = bt = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter(); x, y, s = Ed.mul_get(e, P); torch.cuda.synchronize(); bf = min(bf, time.perf_counter() - t0)
+    for _ in range(3):
+        Q = P.clone(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); Ed.mul(e, Q); wx, wy, _ = Ed.get(Q); torch.cuda.synchronize(); bt = min(bt, time.perf_counter() - t0)
+    print("%s 2^%d: fused mul_get %.3e/s (%.1f ms)   mul + get %.3e/s (%.1f ms)   ratio %.2f   equal: %s" % (
+        name, n.bit_length() - 1, n / bf, bf * 1e3, n / bt, bt * 1e3, bt / bf, bool(torch.equal(x, wx) and torch.equal(y, wy))), flush=True)
