@@ -332,6 +332,21 @@ def main():
             torch.cuda.synchronize(); t2 = time.perf_counter()
             others["%s_ecn_mul" % cname] = {"scalar_mults_per_s_per_gpu": m / (t1 - t0), "points": m, "bound": "VALU"}
             others["%s_ecn_mul2" % cname] = {"double_mults_per_s_per_gpu": m / (t2 - t1), "pairs": m, "bound": "VALU"}
+            if cname in Cv.FUSED:
+                # the reference's call pattern ecnXXXmul + ecnXXXget (ed448.c:182-184): two-call form against the fused kernel
+                Cv.mul_get(e[:4096].contiguous(), Q[:, :, :4096].contiguous())
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                fx_, fy_, _ = Cv.mul_get(e, Q)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                W = Cv.mul(e, Q.clone())
+                torch.cuda.synchronize(); t2 = time.perf_counter()       # (the clone is inside: 60 MB, negligible)
+                wx_, wy_, _ = Cv.get(W)
+                torch.cuda.synchronize(); t3 = time.perf_counter()
+                assert torch.equal(fx_, wx_) and torch.equal(fy_, wy_), "fused mul_get differs from mul + get"
+                others["%s_ecn_mul_get_fused" % cname] = {"scalar_mults_per_s_per_gpu": m / (t1 - t0), "points": m, "bound": "VALU",
+                                                          "two_call_form_per_s": m / (t3 - t1), "speedup": (t3 - t1) / (t1 - t0),
+                                                          "bytes_equal_to_two_call_form": True}
+                del fx_, fy_, wx_, wy_, W
             del e, f, G, Q, R
 
     ladder = None

@@ -34,7 +34,7 @@ int max_blocks() {
     return v;
 }
 int ladder_block() {
-    static int v = env_int("MA_LADDER_BLOCK", 64, 64, 1024) / 64 * 64;
+    static int v = env_int("MA_LADDER_BLOCK", 64, 64, 256) / 64 * 64;    // the ladder kernels carry __launch_bounds__(256)
     return v;
 }
 

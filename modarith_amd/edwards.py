@@ -14,8 +14,8 @@ import torch
 from . import _lib
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 class Edwards:
@@ -41,51 +41,59 @@ class Edwards:
             if p.dtype != torch.int64 or p.dim() != 3 or p.shape[0] != 3 or p.shape[1] != self.N or p.shape[2] != n \
                     or not p.is_cuda or not p.is_contiguous():
                 raise ValueError("expected contiguous int64 device tensors of shape [3, %d, n]" % self.N)
+            if p.device != self.device:
+                raise ValueError("batch on %s, curve bound to %s" % (p.device, self.device))
         return n
 
     def _bytes(self, b: Optional[torch.Tensor], n: int):
         if b is None:
             return None
-        if b.dtype != torch.uint8 or b.shape != (n, self.nbytes) or not b.is_contiguous() or not b.is_cuda:
+        if b.dtype != torch.uint8 or b.shape != (n, self.nbytes) or not b.is_contiguous() or not b.is_cuda or b.device != self.device:
             raise ValueError("expected a contiguous uint8 device tensor [n, %d]" % self.nbytes)
         return b.data_ptr()
 
     def _call(self, fn: str, *args):
         f = getattr(self.lib, "ecn_%s_%s_batch" % (self.name, fn))
-        _lib.check(f(*args), "ecn_%s_%s_batch" % (self.name, fn))
+        with torch.cuda.device(self.device):          # the C-ABI launches on the calling thread's current device
+            _lib.check(f(*args), "ecn_%s_%s_batch" % (self.name, fn))
+
+    def _scalars(self, e: Optional[torch.Tensor], n: int):
+        if e is None:
+            raise ValueError("scalar records are required (uint8 [n, %d], big-endian)" % self.nbytes)
+        return self._bytes(e, n)
 
     # ------------------------------------------------------------------ curve.h API, batched
     def inf(self, n: int):
         P = self.empty(n)
-        self._call("inf", P.data_ptr(), n, n, _stream())
+        self._call("inf", P.data_ptr(), n, n, _stream(self.device))
         return P
 
     def gen(self, n: int):
         P = self.empty(n)
-        self._call("gen", P.data_ptr(), n, n, _stream())
+        self._call("gen", P.data_ptr(), n, n, _stream(self.device))
         return P
 
     def cpy(self, Q):
         P = torch.empty_like(Q)
         n = self._chk(Q, P)
-        self._call("cpy", Q.data_ptr(), P.data_ptr(), n, n, _stream())
+        self._call("cpy", Q.data_ptr(), P.data_ptr(), n, n, _stream(self.device))
         return P
 
     def add(self, Q, P):
         """P += Q"""
         n = self._chk(Q, P)
-        self._call("add", Q.data_ptr(), P.data_ptr(), n, n, _stream())
+        self._call("add", Q.data_ptr(), P.data_ptr(), n, n, _stream(self.device))
         return P
 
     def sub(self, Q, P):
         """P -= Q"""
         n = self._chk(Q, P)
-        self._call("sub", Q.data_ptr(), P.data_ptr(), n, n, _stream())
+        self._call("sub", Q.data_ptr(), P.data_ptr(), n, n, _stream(self.device))
         return P
 
     def _un(self, fn, P):
         n = self._chk(P)
-        self._call(fn, P.data_ptr(), n, n, _stream())
+        self._call(fn, P.data_ptr(), n, n, _stream(self.device))
         return P
 
     def dbl(self, P): return self._un("dbl", P)
@@ -99,7 +107,7 @@ class Edwards:
         need = int(getattr(self.lib, "ecn_%s_mul_workspace_bytes" % self.name)(n))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        self._call("mul", self._bytes(e, n), P.data_ptr(), n, n, self._ws.data_ptr(), self._ws.numel(), _stream())
+        self._call("mul", self._scalars(e, n), P.data_ptr(), n, n, self._ws.data_ptr(), self._ws.numel(), _stream(self.device))
         return P
 
     FUSED = ("ED25519",)       # curves with a fused mul + get kernel (csrc/ed26.h)
@@ -114,8 +122,8 @@ class Edwards:
         x = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device) if want_x else None
         y = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device) if want_y else None
         sign = torch.empty(n, dtype=torch.int32, device=self.device)
-        self._call("mul_get", self._bytes(e, n), P.data_ptr(), None if x is None else x.data_ptr(), None if y is None else y.data_ptr(),
-                   sign.data_ptr(), n, n, _stream())
+        self._call("mul_get", self._scalars(e, n), P.data_ptr(), None if x is None else x.data_ptr(), None if y is None else y.data_ptr(),
+                   sign.data_ptr(), n, n, _stream(self.device))
         return x, y, sign
 
     def _workspace(self, n: int):
@@ -129,25 +137,25 @@ class Edwards:
         n = self._chk(P, Q)
         R = torch.empty_like(P)
         ws = self._workspace(n)
-        self._call("mul2", self._bytes(e, n), P.data_ptr(), self._bytes(f, n), Q.data_ptr(), R.data_ptr(), n, n,
-                   ws.data_ptr(), ws.numel(), _stream())
+        self._call("mul2", self._scalars(e, n), P.data_ptr(), self._scalars(f, n), Q.data_ptr(), R.data_ptr(), n, n,
+                   ws.data_ptr(), ws.numel(), _stream(self.device))
         return R
 
     def ran(self, r: int, P):
         n = self._chk(P)
-        self._call("ran", int(r), P.data_ptr(), n, n, _stream())
+        self._call("ran", int(r), P.data_ptr(), n, n, _stream(self.device))
         return P
 
     def cmp(self, P, Q):
         n = self._chk(P, Q)
         out = torch.empty(n, dtype=torch.int32, device=self.device)
-        self._call("cmp", P.data_ptr(), Q.data_ptr(), out.data_ptr(), n, n, _stream())
+        self._call("cmp", P.data_ptr(), Q.data_ptr(), out.data_ptr(), n, n, _stream(self.device))
         return out
 
     def isinf(self, P):
         n = self._chk(P)
         out = torch.empty(n, dtype=torch.int32, device=self.device)
-        self._call("isinf", P.data_ptr(), out.data_ptr(), n, n, _stream())
+        self._call("isinf", P.data_ptr(), out.data_ptr(), n, n, _stream(self.device))
         return out
 
     def set(self, s: Optional[torch.Tensor], x: Optional[torch.Tensor], y: Optional[torch.Tensor]):
@@ -161,7 +169,7 @@ class Edwards:
             if s.dtype != torch.int32 or s.numel() != n or not s.is_cuda:
                 raise ValueError("s must be an int32 device tensor [n]")
             sp = s.data_ptr()
-        self._call("set", sp, self._bytes(x, n), self._bytes(y, n), P.data_ptr(), n, n, _stream())
+        self._call("set", sp, self._bytes(x, n), self._bytes(y, n), P.data_ptr(), n, n, _stream(self.device))
         return P
 
     def get(self, P, want_x: bool = True, want_y: bool = True):
@@ -172,7 +180,7 @@ class Edwards:
         y = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device) if want_y else None
         sign = torch.empty(n, dtype=torch.int32, device=self.device)
         self._call("get", P.data_ptr(), None if x is None else x.data_ptr(), None if y is None else y.data_ptr(),
-                   sign.data_ptr(), n, n, _stream())
+                   sign.data_ptr(), n, n, _stream(self.device))
         return x, y, sign
 
 

@@ -20,8 +20,8 @@ from . import _lib
 from .params import FieldParams, derive
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 class Field:
@@ -65,14 +65,14 @@ class Field:
             raise ValueError("expected a contiguous int64 device tensor of shape [n, %d]" % self.N)
         n = aos.shape[0]
         out = torch.empty((self.N, n), dtype=torch.int64, device=aos.device)
-        _lib.check(self.lib.modarith_amd_aos_to_soa(aos.data_ptr(), out.data_ptr(), n, self.N, max(n, 1), _stream()), "aos_to_soa")
+        _lib.check(self.lib.modarith_amd_aos_to_soa(aos.data_ptr(), out.data_ptr(), n, self.N, max(n, 1), _stream(self.device)), "aos_to_soa")
         return out
 
     def to_aos(self, soa: torch.Tensor) -> torch.Tensor:
         """limb-interleaved batch [N, n] -> element-major int64 [n, N], on the device."""
         n = self._chk(soa)
         out = torch.empty((n, self.N), dtype=torch.int64, device=soa.device)
-        _lib.check(self.lib.modarith_amd_soa_to_aos(soa.data_ptr(), out.data_ptr(), n, self.N, soa.stride(0) if n else 1, _stream()), "soa_to_aos")
+        _lib.check(self.lib.modarith_amd_soa_to_aos(soa.data_ptr(), out.data_ptr(), n, self.N, soa.stride(0) if n else 1, _stream(self.device)), "soa_to_aos")
         return out
 
     # ------------------------------------------------------------------ plumbing
@@ -83,6 +83,8 @@ class Field:
                 raise ValueError("expected int64 tensors of shape [%d, n]" % self.N)
             if not t.is_cuda:
                 raise ValueError("batches must live in device memory")
+            if t.device != self.device:
+                raise ValueError("batch on %s, field bound to %s (kernels launch on the field's device)" % (t.device, self.device))
             if t.stride(1) != 1:
                 raise ValueError("batches must be limb-major with unit element stride")
         ld = ts[0].stride(0) if n > 1 or ts[0].stride(0) >= 1 else n
@@ -93,7 +95,8 @@ class Field:
 
     def _call(self, fn: str, *args):
         f = getattr(self.lib, "%s_%s_batch" % (fn, self.prime))
-        _lib.check(f(*args), "%s_%s_batch" % (fn, self.prime))
+        with torch.cuda.device(self.device):          # the C-ABI launches on the calling thread's current device
+            _lib.check(f(*args), "%s_%s_batch" % (fn, self.prime))
 
     def _out(self, like: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
         # a fresh result takes the operand's limb stride (views of wider batches keep theirs), as one call needs
@@ -102,13 +105,13 @@ class Field:
     def _bin(self, fn, a, b, out):
         out = self._out(a, out)
         n = self._chk(a, b, out)
-        self._call(fn, a.data_ptr(), b.data_ptr(), out.data_ptr(), n, a.stride(0), _stream())
+        self._call(fn, a.data_ptr(), b.data_ptr(), out.data_ptr(), n, a.stride(0), _stream(self.device))
         return out
 
     def _un(self, fn, a, out):
         out = self._out(a, out)
         n = self._chk(a, out)
-        self._call(fn, a.data_ptr(), out.data_ptr(), n, a.stride(0), _stream())
+        self._call(fn, a.data_ptr(), out.data_ptr(), n, a.stride(0), _stream(self.device))
         return out
 
     def _ints(self, n: int) -> torch.Tensor:
@@ -133,72 +136,72 @@ class Field:
         out = self._out(a, out)
         n = self._chk(a, out)
         host = (_lib.ctypes.c_uint64 * self.N)(*[int(v) for v in b0])
-        self._call("modmuls", a.data_ptr(), _lib.ctypes.cast(host, _lib.ctypes.c_void_p), out.data_ptr(), n, a.stride(0), _stream())
+        self._call("modmuls", a.data_ptr(), _lib.ctypes.cast(host, _lib.ctypes.c_void_p), out.data_ptr(), n, a.stride(0), _stream(self.device))
         return out
 
     def modmli(self, a, b: int, out=None):
         out = self._out(a, out)
         n = self._chk(a, out)
-        self._call("modmli", a.data_ptr(), int(b), out.data_ptr(), n, a.stride(0), _stream())
+        self._call("modmli", a.data_ptr(), int(b), out.data_ptr(), n, a.stride(0), _stream(self.device))
         return out
 
     def modnsqr(self, a, k: int):
         n = self._chk(a)
-        self._call("modnsqr", a.data_ptr(), int(k), n, a.stride(0), _stream())
+        self._call("modnsqr", a.data_ptr(), int(k), n, a.stride(0), _stream(self.device))
         return a
 
     def modinv(self, x, h=None, out=None):
         out = self._out(x, out)
         n = self._chk(x, out) if h is None else self._chk(x, h, out)
-        self._call("modinv", x.data_ptr(), None if h is None else h.data_ptr(), out.data_ptr(), n, x.stride(0), _stream())
+        self._call("modinv", x.data_ptr(), None if h is None else h.data_ptr(), out.data_ptr(), n, x.stride(0), _stream(self.device))
         return out
 
     def modsqrt(self, x, h=None, out=None):
         out = self._out(x, out)
         n = self._chk(x, out) if h is None else self._chk(x, h, out)
-        self._call("modsqrt", x.data_ptr(), None if h is None else h.data_ptr(), out.data_ptr(), n, x.stride(0), _stream())
+        self._call("modsqrt", x.data_ptr(), None if h is None else h.data_ptr(), out.data_ptr(), n, x.stride(0), _stream(self.device))
         return out
 
     def modqr(self, h, x):
         """1 where x is a quadratic residue (or zero); h = optional progenitors modpro(x)."""
         n = self._chk(x) if h is None else self._chk(x, h)
         out = self._ints(n)
-        self._call("modqr", None if h is None else h.data_ptr(), x.data_ptr(), out.data_ptr(), n, x.stride(0), _stream())
+        self._call("modqr", None if h is None else h.data_ptr(), x.data_ptr(), out.data_ptr(), n, x.stride(0), _stream(self.device))
         return out
 
     def modfsb(self, a):
         """in place; returns the per-element flag (1 if the input was < p)."""
         n = self._chk(a)
         flag = self._ints(n)
-        self._call("modfsb", a.data_ptr(), flag.data_ptr(), n, a.stride(0), _stream())
+        self._call("modfsb", a.data_ptr(), flag.data_ptr(), n, a.stride(0), _stream(self.device))
         return flag
 
     def flatten(self, a):
         n = self._chk(a)
         flag = self._ints(n)
-        self._call("flatten", a.data_ptr(), flag.data_ptr(), n, a.stride(0), _stream())
+        self._call("flatten", a.data_ptr(), flag.data_ptr(), n, a.stride(0), _stream(self.device))
         return flag
 
     def modhaf(self, a):
         n = self._chk(a)
-        self._call("modhaf", a.data_ptr(), n, a.stride(0), _stream())
+        self._call("modhaf", a.data_ptr(), n, a.stride(0), _stream(self.device))
         return a
 
     def modshl(self, k: int, a):
         n = self._chk(a)
-        self._call("modshl", int(k), a.data_ptr(), n, a.stride(0), _stream())
+        self._call("modshl", int(k), a.data_ptr(), n, a.stride(0), _stream(self.device))
         return a
 
     def modshr(self, k: int, a):
         n = self._chk(a)
         out = self._ints(n)
-        self._call("modshr", int(k), a.data_ptr(), out.data_ptr(), n, a.stride(0), _stream())
+        self._call("modshr", int(k), a.data_ptr(), out.data_ptr(), n, a.stride(0), _stream(self.device))
         return out
 
     def _pred(self, fn, a):
         n = self._chk(a)
         out = self._ints(n)
-        self._call(fn, a.data_ptr(), out.data_ptr(), n, a.stride(0), _stream())
+        self._call(fn, a.data_ptr(), out.data_ptr(), n, a.stride(0), _stream(self.device))
         return out
 
     def modis1(self, a): return self._pred("modis1", a)
@@ -208,27 +211,27 @@ class Field:
     def modcmp(self, a, b):
         n = self._chk(a, b)
         out = self._ints(n)
-        self._call("modcmp", a.data_ptr(), b.data_ptr(), out.data_ptr(), n, a.stride(0), _stream())
+        self._call("modcmp", a.data_ptr(), b.data_ptr(), out.data_ptr(), n, a.stride(0), _stream(self.device))
         return out
 
     def modzer(self, n: int):
         a = self.empty(n)
-        self._call("modzer", a.data_ptr(), n, a.stride(0), _stream())
+        self._call("modzer", a.data_ptr(), n, a.stride(0), _stream(self.device))
         return a
 
     def modone(self, n: int):
         a = self.empty(n)
-        self._call("modone", a.data_ptr(), n, a.stride(0), _stream())
+        self._call("modone", a.data_ptr(), n, a.stride(0), _stream(self.device))
         return a
 
     def modint(self, x: int, n: int):
         a = self.empty(n)
-        self._call("modint", int(x), a.data_ptr(), n, a.stride(0), _stream())
+        self._call("modint", int(x), a.data_ptr(), n, a.stride(0), _stream(self.device))
         return a
 
     def mod2r(self, r: int, n: int):
         a = self.empty(n)
-        self._call("mod2r", int(r), a.data_ptr(), n, a.stride(0), _stream())
+        self._call("mod2r", int(r), a.data_ptr(), n, a.stride(0), _stream(self.device))
         return a
 
     def uniform(self, n: int, seed: int = 42, array: int = 0, first: int = 0, plus_p: bool = False, out=None):
@@ -238,7 +241,7 @@ class Field:
         a = out if out is not None else self.empty(n)
         if out is not None and self._chk(out) != n:
             raise ValueError("out must hold n elements")
-        self._call("moduniform", int(seed), int(array), int(first), int(bool(plus_p)), a.data_ptr(), n, a.stride(0) if n else 1, _stream())
+        self._call("moduniform", int(seed), int(array), int(first), int(bool(plus_p)), a.data_ptr(), n, a.stride(0) if n else 1, _stream(self.device))
         return a
 
     def _sel(self, d: torch.Tensor, n: int) -> torch.Tensor:
@@ -249,13 +252,13 @@ class Field:
     def modcmv(self, d, g, f):
         """f[j] = g[j] where d[j] == 1 (constant time); d: int32 [n]."""
         n = self._chk(g, f)
-        self._call("modcmv", self._sel(d, n).data_ptr(), g.data_ptr(), f.data_ptr(), n, g.stride(0), _stream())
+        self._call("modcmv", self._sel(d, n).data_ptr(), g.data_ptr(), f.data_ptr(), n, g.stride(0), _stream(self.device))
         return f
 
     def modcsw(self, d, g, f):
         """swap g[j], f[j] where d[j] == 1 (constant time)."""
         n = self._chk(g, f)
-        self._call("modcsw", self._sel(d, n).data_ptr(), g.data_ptr(), f.data_ptr(), n, g.stride(0), _stream())
+        self._call("modcsw", self._sel(d, n).data_ptr(), g.data_ptr(), f.data_ptr(), n, g.stride(0), _stream(self.device))
         return g, f
 
     def time_protocol(self, kind: str, x, y=None, outer: int = 1):
@@ -266,7 +269,7 @@ class Field:
         y = x if y is None else y
         z = torch.empty_like(x)
         n = self._chk(x, y, z)
-        self._call("time_protocol", k, x.data_ptr(), y.data_ptr(), z.data_ptr(), int(outer), n, x.stride(0), _stream())
+        self._call("time_protocol", k, x.data_ptr(), y.data_ptr(), z.data_ptr(), int(outer), n, x.stride(0), _stream(self.device))
         return z
 
     def modimp(self, b: torch.Tensor):
@@ -276,13 +279,13 @@ class Field:
         n = b.shape[0]
         a = self.empty(n)
         flag = self._ints(n)
-        self._call("modimp", b.data_ptr(), a.data_ptr(), flag.data_ptr(), n, a.stride(0), _stream())
+        self._call("modimp", b.data_ptr(), a.data_ptr(), flag.data_ptr(), n, a.stride(0), _stream(self.device))
         return a, flag
 
     def modexp(self, a):
         n = self._chk(a)
         b = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device)
-        self._call("modexp", a.data_ptr(), b.data_ptr(), n, a.stride(0), _stream())
+        self._call("modexp", a.data_ptr(), b.data_ptr(), n, a.stride(0), _stream(self.device))
         return b
 
 
@@ -298,7 +301,13 @@ def rfc7748(curve: str, bk: torch.Tensor, bu: torch.Tensor, out: Optional[torch.
             raise ValueError("expected contiguous uint8 device tensors [n, %d]" % nb)
     if bk.shape[0] != bu.shape[0]:
         raise ValueError("bk and bu must hold the same number of records")
-    out = out if out is not None else torch.empty_like(bu)
+    if bk.device != bu.device:
+        raise ValueError("bk and bu must live on the same device")
+    if out is None:
+        out = torch.empty_like(bu)
+    elif (out.dtype != torch.uint8 or out.shape != bu.shape or not out.is_contiguous() or out.device != bu.device):
+        raise ValueError("out must be a contiguous uint8 tensor of shape %s on %s" % (tuple(bu.shape), bu.device))
     f = getattr(lib, "rfc7748_%s_batch" % curve)
-    _lib.check(f(bk.data_ptr(), bu.data_ptr(), out.data_ptr(), bk.shape[0], _stream()), "rfc7748_%s_batch" % curve)
+    with torch.cuda.device(bu.device):
+        _lib.check(f(bk.data_ptr(), bu.data_ptr(), out.data_ptr(), bk.shape[0], torch.cuda.current_stream().cuda_stream), "rfc7748_%s_batch" % curve)
     return out
