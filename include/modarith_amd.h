@@ -305,8 +305,15 @@ MODARITH_AMD_DECLARE_EDWARDS(nums256w, 5)
  * returns (of y when y is NULL, of x when x is NULL, else 0).  P is NOT modified (the two-call form leaves e*P in it).
  * Only canonical bytes leave the kernel, so it runs on 32-bit-limb internals with extended-coordinate formulas that are
  * complete on the curve (csrc/ed26.h): the same bytes as ecn_<c>_mul_batch + ecn_<c>_get_batch for every input point
- * on the curve, no workspace, constant-time fixed window like ecnXXXmul. */
-int ecn_ed25519_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld, void *stream);
+ * on the curve, constant-time fixed window like ecnXXXmul.  workspace: a device buffer of
+ * ecn_<c>_mul_get_workspace_bytes(n) bytes for the per-lane window tables (0 for ed25519, whose table lives in
+ * registers: workspace may then be NULL; ed448: 672 bytes per resident lane, at most 88 MB). */
+size_t ecn_ed25519_mul_get_workspace_bytes(size_t n);
+int ecn_ed25519_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
+                              void *workspace, size_t workspace_bytes, void *stream);
+size_t ecn_ed448_mul_get_workspace_bytes(size_t n);
+int ecn_ed448_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

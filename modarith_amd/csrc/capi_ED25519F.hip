@@ -31,7 +31,10 @@ void k_ed25519_mul_get(const unsigned char* e, const spint* Pb, unsigned char* x
 
 using namespace ma;
 
-extern "C" int ecn_ed25519_mul_get_batch(const char* e, const ma_spint* P, char* x, char* y, int* sign, size_t n, size_t ld, void* st) {
+extern "C" size_t ecn_ed25519_mul_get_workspace_bytes(size_t) { return 0; }      // the table lives in registers
+
+extern "C" int ecn_ed25519_mul_get_batch(const char* e, const ma_spint* P, char* x, char* y, int* sign, size_t n, size_t ld,
+                                         void* /*workspace*/, size_t /*workspace_bytes*/, void* st) {
     if (n == 0) return 0;
     if ((reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 7u) {
         set_error("ecn mul_get: byte records must be 8-byte aligned");

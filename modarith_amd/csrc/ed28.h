@@ -1,0 +1,259 @@
+// modarith_amd/csrc/ed28.h -- fused ecnXXXmul + ecnXXXget for ED448 on the fe28 representation (gfx950).
+//
+// Same construction as ed26.h (which see): only canonical affine bytes leave the kernel, so the arithmetic runs on
+// sixteen 28-bit limbs (fe28.h: golden-ratio Karatsuba products) and on extended coordinates (X:Y:Z:T) with the
+// Hisil-Wong-Carter-Dawson formulas for a = 1, which are complete on x^2 + y^2 = 1 - 39081 x^2 y^2 (a = 1 is a square,
+// d = -39081 a non-square mod 2^448 - 2^224 - 1): the affine point the reference's edwards.c formulas reach, for every
+// input point on the curve.  The coordinates arrive in Montgomery form (monty.py, R = 2^504): a projective point whose
+// three coordinates carry the same factor R is the same point, so the limbs are simply read as integers mod p.
+//
+// 3-bit signed fixed windows like ed26.h: e' = e + sum_{i<150} 4*8^i < 8^150, digit_i = window_i(e') - 4.  The table
+// {1,2,3,4}P -- affine, cached as canonical packed (x, y, 39081 x y), 4 x 3 x 56 bytes per lane -- does not fit the
+// register file next to a 64-register point, so it lives in a caller-provided device workspace laid out
+// [entry][word][lane] (8-byte coalesced accesses; 88 MB for the resident grid, inside the Infinity Cache); every lookup
+// reads all four entries and selects with v_cndmask.
+//
+// Limb bounds (fe28.h): "tight" = below 2^28 (+2^9 on limbs 1, 9); add() of tight values stays below 2^29; sub() carries
+// back to tight; mul_k / sqr_k (Karatsuba) want one tight operand and one below 2^29 / a tight operand; mul / sqr take
+// anything below 2^29 (one operand up to 1.5 * 2^29: a folded column holds 38 products, 57 * 2^58 < 2^64).
+#pragma once
+#include "fe28.h"
+
+namespace ma {
+
+struct Ed28 {
+    using F = Fe28;
+    static constexpr uint32_t M28 = F::M28;
+    static constexpr uint32_t D_ABS = 39081;       // d = -39081 (curve.py: CONSTANT_B of ED448)
+    struct Ext { uint32_t X[16], Y[16], Z[16], T[16]; };
+
+    // limbs below 2^31 -> tight, 32-bit registers only (the carry out of limb 15 re-enters at limbs 0 and 8)
+    static MA_DEV void wc(uint32_t* f) {
+        static_for<0, 15>([&](auto I) {
+            constexpr int i = I;
+            f[i + 1] += f[i] >> 28;
+            f[i] &= M28;
+        });
+        const uint32_t top = f[15] >> 28;
+        f[15] &= M28;
+        const uint32_t h0 = f[0] + top, h8 = f[8] + top;
+        f[0] = h0 & M28;
+        f[1] += h0 >> 28;
+        f[8] = h8 & M28;
+        f[9] += h8 >> 28;
+    }
+    // r = 2p - f for tight f: below 2^29, not carried (limbs of 2p: 2^29-2, limb 8: 2^29-4)
+    static MA_DEV void neg2p(const uint32_t* f, uint32_t* r) {
+        static_for<0, 16>([&](auto I) {
+            constexpr int i = I;
+            constexpr uint32_t twop = (i == 8) ? 0x1ffffffcu : 0x1ffffffeu;
+            r[i] = twop - f[i];
+        });
+    }
+    // 8 x 56-bit limbs (field.c form, limbs below 2^58: the contract of the curve layer) -> tight fe28
+    static MA_DEV void from56(const spint* x, uint32_t* r) {
+        static_for<0, 8>([&](auto K) {
+            constexpr int k = K;
+            r[2 * k] = (uint32_t)x[k] & M28;
+            r[2 * k + 1] = (uint32_t)(x[k] >> 28);
+        });
+        wc(r);
+    }
+
+    // P = 2P, dbl-2008-hwcd with a = 1: A = X^2, B = Y^2, C = 2Z^2, G = A + B, E = (X+Y)^2 - G, F = G - C, H = A - B;
+    // X3 = E F, Y3 = G H, Z3 = F G, T3 = E H.  Input X, Y, Z tight; T is not read.
+    template <bool WANT_T>
+    static MA_DEV void dbl(Ext& p) {
+        uint32_t A[16], B[16], Cc[16], S[16], G[16], E[16], Ff[16], H[16];
+        F::sqr_k(p.X, A);
+        F::sqr_k(p.Y, B);
+        F::sqr_k(p.Z, Cc);
+        F::add(p.X, p.Y, S);        // < 2^29
+        F::sqr(S, S);
+        F::add(A, B, G);            // < 2^29
+        F::sub(S, G, E);            // tight
+        F::add(Cc, Cc, Cc);         // < 2^29
+        F::sub(G, Cc, Ff);          // tight
+        F::sub(A, B, H);            // tight
+        F::mul_k(E, Ff, p.X);
+        F::mul_k(H, G, p.Y);
+        F::mul_k(Ff, G, p.Z);
+        if constexpr (WANT_T) F::mul_k(E, H, p.T);
+    }
+    // common tail of the additions (a = 1, d = -39081): with A = X1 X2, B = Y1 Y2, Cc = 39081 T1 T2 (= -C), D = Z1 Z2,
+    // M = (X1+Y1)(X2+Y2):  E = M - A - B, F = D - C = D + Cc, G = D + C = D - Cc, H = B - A;  X3 = E F, Y3 = G H, Z3 = F G
+    static MA_DEV void add_tail(const uint32_t* A, const uint32_t* B, const uint32_t* Cc, const uint32_t* D, const uint32_t* M, Ext& p) {
+        uint32_t E[16], Ff[16], G[16], H[16], AB[16];
+        F::add(A, B, AB);           // < 2^29
+        F::sub(M, AB, E);           // tight
+        F::add(D, Cc, Ff);          // < 2^29
+        F::sub(D, Cc, G);           // tight
+        F::sub(B, A, H);            // tight
+        F::mul_k(E, Ff, p.X);
+        F::mul_k(G, H, p.Y);
+        F::mul_k(G, Ff, p.Z);
+    }
+    // P += Q, Q affine and cached as (x, y, td = 39081 x y), already sign-adjusted: xs, tds below 2^29, y tight.
+    // Reads T of P; T of the sum is not produced (a doubling follows).
+    static MA_DEV void add_cached(Ext& p, const uint32_t* xs, const uint32_t* y, const uint32_t* tds) {
+        uint32_t A[16], B[16], Cc[16], M[16], s1[16], s2[16];
+        F::mul_k(p.X, xs, A);
+        F::mul_k(p.Y, y, B);
+        F::mul_k(p.T, tds, Cc);
+        F::add(p.X, p.Y, s1);       // < 2^29
+        F::add(xs, y, s2);          // < 1.5 * 2^29
+        F::mul(s1, s2, M);
+        add_tail(A, B, Cc, p.Z, M, p);
+    }
+    // P += Q, both extended; used once, to build 3P
+    static MA_DEV void add_ext(Ext& p, const Ext& q) {
+        uint32_t A[16], B[16], Cc[16], D[16], M[16], s1[16], s2[16];
+        F::mul_k(p.X, q.X, A);
+        F::mul_k(p.Y, q.Y, B);
+        F::mul_k(p.T, q.T, Cc);
+        F::mul_small<D_ABS>(Cc, Cc);
+        F::mul_k(p.Z, q.Z, D);
+        F::add(p.X, p.Y, s1);
+        F::add(q.X, q.Y, s2);
+        F::mul(s1, s2, M);
+        add_tail(A, B, Cc, D, M, p);
+    }
+};
+
+constexpr int ED448_TABLE_WORDS = 4 * 3 * 7;       // 64-bit words per lane in the workspace
+
+// One fused ED448 scalar multiplication + affine export.  ew: the scalar as seven little-endian words; X, Y, Z: 8 x 56-bit
+// limbs each; tab: this lane's table slots, word k at tab[k * tstride]; xw, yw: canonical affine coordinates, seven words.
+MA_DEV void ed448_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
+                              uint64_t* xw, uint64_t* yw) {
+    using E = Ed28;
+    using F = Fe28;
+    E::Ext R;
+
+    {   // ---- table: projective P -> extended; 2P, 3P, 4P; one shared inversion; cached affine form
+        E::Ext Q, P2, P3, P4;
+        uint32_t px[16], py[16], pz[16];
+        E::from56(X, px);
+        E::from56(Y, py);
+        E::from56(Z, pz);
+        F::mul_k(px, pz, Q.X);              // (XZ : YZ : Z^2 : XY)
+        F::mul_k(py, pz, Q.Y);
+        F::sqr_k(pz, Q.Z);
+        F::mul_k(px, py, Q.T);
+        P2 = Q;
+        E::dbl<true>(P2);
+        P3 = P2;
+        E::add_ext(P3, Q);
+        P4 = P2;
+        E::dbl<false>(P4);
+        uint32_t z12[16], z123[16], inv[16], i1[16], i2[16], i3[16], i4[16];
+        F::mul_k(Q.Z, P2.Z, z12);
+        F::mul_k(z12, P3.Z, z123);
+        F::mul_k(z123, P4.Z, inv);
+        F::invert(inv, inv);
+        F::mul_k(inv, z123, i4);
+        F::mul_k(inv, P4.Z, inv);
+        F::mul_k(inv, z12, i3);
+        F::mul_k(inv, P3.Z, inv);
+        F::mul_k(inv, Q.Z, i2);
+        F::mul_k(inv, P2.Z, i1);
+        auto cache = [&](const E::Ext& p, const uint32_t* zi, int entry) {
+            uint32_t x[16], y[16], s[16];
+            uint64_t w[7];
+            F::mul_k(p.X, zi, x);
+            F::mul_k(p.Y, zi, y);
+            F::to_words(x, w);
+            static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + K) * tstride] = w[K]; });
+            F::to_words(y, w);
+            static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + 7 + K) * tstride] = w[K]; });
+            F::mul_k(x, y, s);
+            F::mul_small<E::D_ABS>(s, s);
+            F::to_words(s, w);
+            static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + 14 + K) * tstride] = w[K]; });
+        };
+        cache(Q, i1, 0);
+        cache(P2, i2, 1);
+        cache(P3, i3, 2);
+        cache(P4, i4, 3);
+    }
+
+    // ---- recoding: e' = e + sum_{i<150} 4*8^i (450 bits), left-aligned so that window 149 is the top of w[7]
+    uint64_t w[8];
+    {
+        constexpr auto cw = [](int k) {
+            uint64_t v = 0;
+            for (int b = 0; b < 64; b++) {
+                const int pos = 64 * k + b;
+                if (pos < 450 && pos % 3 == 2) v |= (uint64_t)1 << b;
+            }
+            return v;
+        };
+        unsigned __int128 acc = 0;
+        uint64_t s[8];
+        static_for<0, 8>([&](auto K) {
+            constexpr int k = K;
+            acc += (unsigned __int128)(k < 7 ? ew[k < 7 ? k : 0] : 0) + cw(k);
+            s[k] = (uint64_t)acc;
+            acc >>= 64;
+        });
+        static_for<0, 8>([&](auto KK) {
+            constexpr int k = 7 - KK;
+            w[k] = s[k] << 62;
+            if constexpr (k > 0) w[k] |= s[k - 1] >> 2;
+        });
+    }
+
+    F::set(0, R.X);
+    F::set(1, R.Y);
+    F::set(1, R.Z);
+    F::set(0, R.T);
+
+#pragma unroll 1
+    for (int i = 0; i < 150; i++) {
+        const uint32_t win = (uint32_t)(w[7] >> 61);
+        static_for<0, 8>([&](auto KK) {
+            constexpr int k = 7 - KK;
+            w[k] <<= 3;
+            if constexpr (k > 0) w[k] |= w[k - 1] >> 61;
+        });
+        const int dgt = (int)win - 4;                       // [-4, 3]
+        const bool neg = dgt < 0;
+        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);    // 0..4
+        if (i != 0) {
+            E::dbl<false>(R);
+            E::dbl<false>(R);
+            E::dbl<true>(R);
+        }
+        // constant-time lookup: every entry is read; start from the neutral element (x, y, td) = (0, 1, 0)
+        uint64_t sel[21];
+        static_for<0, 21>([&](auto K) { sel[K] = (K == 7) ? 1u : 0u; });
+#pragma unroll 1
+        for (int e = 0; e < 4; e++) {
+            const bool hit = (m == (uint32_t)(e + 1));
+            static_for<0, 21>([&](auto K) {
+                const uint64_t a = tab[(size_t)(e * 21 + K) * tstride], b = sel[K];
+                sel[K] = hit ? a : b;
+            });
+        }
+        // -Q = (-x, y, -td)
+        uint32_t xs[16], ys[16], ts[16], nx[16], nt[16];
+        F::from_words(sel, xs);
+        F::from_words(sel + 7, ys);
+        F::from_words(sel + 14, ts);
+        E::neg2p(xs, nx);
+        E::neg2p(ts, nt);
+        F::select(neg, xs, nx, xs);
+        F::select(neg, ts, nt, ts);
+        E::add_cached(R, xs, ys, ts);
+    }
+
+    // ---- affine, canonical (ecnXXXget: edwards.c:221-239)
+    uint32_t zi[16], ax[16], ay[16];
+    F::invert(R.Z, zi);
+    F::mul_k(R.X, zi, ax);
+    F::mul_k(R.Y, zi, ay);
+    F::to_words(ax, xw);
+    F::to_words(ay, yw);
+}
+
+}  // namespace ma

@@ -30,6 +30,7 @@ class Edwards:
         self.N, self.nbytes = _lib.CURVES[self.name]
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self._ws = None
+        self._fws = None          # window tables of the fused mul_get kernel (ED448)
 
     # ------------------------------------------------------------------ plumbing
     def empty(self, n: int) -> torch.Tensor:
@@ -110,20 +111,23 @@ class Edwards:
         self._call("mul", self._scalars(e, n), P.data_ptr(), n, n, self._ws.data_ptr(), self._ws.numel(), _stream(self.device))
         return P
 
-    FUSED = ("ED25519",)       # curves with a fused mul + get kernel (csrc/ed26.h)
+    FUSED = ("ED25519", "ED448")       # curves with a fused mul + get kernel (csrc/ed26.h, csrc/ed28.h)
 
     def mul_get(self, e: torch.Tensor, P: torch.Tensor, want_x: bool = True, want_y: bool = True):
         """ecnXXXmul followed by ecnXXXget (the reference's call pattern, ed448.c:182-184) in ONE kernel: the affine
         coordinates of e*P as canonical big-endian byte records, and the sign of the omitted coordinate.  P is not
-        modified.  Same bytes as mul() + get() for every point on the curve; several times faster, no workspace."""
+        modified.  Same bytes as mul() + get() for every point on the curve, about twice as fast."""
         if self.name.upper() not in self.FUSED:
             raise ValueError("no fused mul_get kernel for %s (available: %s)" % (self.name, ", ".join(self.FUSED)))
         n = self._chk(P)
         x = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device) if want_x else None
         y = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device) if want_y else None
         sign = torch.empty(n, dtype=torch.int32, device=self.device)
+        need = int(getattr(self.lib, "ecn_%s_mul_get_workspace_bytes" % self.name)(n))
+        if need and (self._fws is None or self._fws.numel() < need):
+            self._fws = torch.empty(need, dtype=torch.uint8, device=self.device)
         self._call("mul_get", self._scalars(e, n), P.data_ptr(), None if x is None else x.data_ptr(), None if y is None else y.data_ptr(),
-                   sign.data_ptr(), n, n, _stream(self.device))
+                   sign.data_ptr(), n, n, self._fws.data_ptr() if need else None, need, _stream(self.device))
         return x, y, sign
 
     def _workspace(self, n: int):

@@ -9,7 +9,7 @@ import pytest
 from tests.conftest import load_golden
 
 pytestmark = pytest.mark.gpu
-FUSED = [("ed25519", "ED25519")]
+FUSED = [("ed25519", "ED25519"), ("ed448", "ED448")]
 
 
 @pytest.fixture(scope="module", params=FUSED)
@@ -54,7 +54,7 @@ def test_fused_mul_get_fixture(fx):
 def test_fused_equals_two_call_form_random(fx, oracle):
     """2^16 random (scalar, projective point) pairs: fused == mul + get on the GPU == the oracle's mul + get"""
     C, Ed, g, torch = fx
-    n = 1 << 16
+    n = 1 << (16 if C == "ed25519" else 14)
     gen = torch.Generator(device="cuda").manual_seed(91)
     k0 = torch.randint(0, 256, (n, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=gen)
     e = torch.randint(0, 256, (n, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=gen)
@@ -87,7 +87,7 @@ def test_fused_special_points_and_scalars(fx):
     """the complete addition law at work: neutral element, points of order 2, 4 and 8, scalars 0, 1, 8, the group order,
     order +- 1 and all ones -- every (point, scalar) pair against the two-call form"""
     C, Ed, g, torch = fx
-    p = (1 << 255) - 19
+    p = (1 << 255) - 19 if C == "ed25519" else (1 << 448) - (1 << 224) - 1
     order = int(g["testcurve"]["order"], 16)
     be = lambda v: v.to_bytes(Ed.nbytes, "big").hex()
     G = Ed.gen(1)
@@ -105,8 +105,9 @@ def test_fused_special_points_and_scalars(fx):
         if not Ed.isinf(Ed.mul(dev_bytes(torch, [be(4)]), T.clone())).item():
             pts.append(T)                                                    # 4T != O: order 8
             break
-    assert len(pts) >= 9
-    scalars = [0, 1, 2, 7, 8, order - 1, order, order + 1, 8 * order, (1 << 256) - 1, 1 << 255, (1 << 255) - 1]
+    assert len(pts) >= (9 if C == "ed25519" else 8)          # (ED448 has cofactor 4: no point of order 8)
+    nbits = 8 * Ed.nbytes
+    scalars = [0, 1, 2, 7, 8, order - 1, order, order + 1, 4 * order - 1, (1 << nbits) - 1, 1 << (nbits - 1), (1 << (nbits - 1)) - 1]
     P = torch.cat([q for q in pts for _ in scalars], dim=2).contiguous()
     e = dev_bytes(torch, [be(s) for _ in pts for s in scalars])
     x, y, _ = Ed.mul_get(e, P)

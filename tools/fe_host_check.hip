@@ -8,6 +8,7 @@
 #include "../modarith_amd/csrc/fe28.h"
 #include "../modarith_amd/csrc/generated/curve_ED25519.h"
 #include "../modarith_amd/csrc/ed26.h"
+#include "../modarith_amd/csrc/ed28.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -71,6 +72,47 @@ static int run_ed25519(int n) {
     return bad;
 }
 
+struct pt448 { uint64_t x[8], y[8], z[8]; };
+extern "C" void ecn_ed448_gen(pt448*);
+extern "C" void ecn_ed448_inf(pt448*);
+extern "C" void ecn_ed448_mul(const char* e, pt448*);
+extern "C" int ecn_ed448_get(pt448*, char* x, char* y);
+extern "C" void ecn_ed448_set(int s, const char* x, const char* y, pt448*);
+
+static int run_ed448(int n) {
+    int bad = 0;
+    for (int it = 0; it < n; it++) {
+        pt448 P;
+        unsigned char e[56], k[56];
+        for (int i = 0; i < 56; i++) { e[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
+        ecn_ed448_gen(&P);
+        ecn_ed448_mul((const char*)k, &P);
+        if (it % 16 == 1) ecn_ed448_inf(&P);
+        if (it % 16 == 2) { char y[56]; memset(y, 0, 56); ecn_ed448_set(0, nullptr, y, &P); }            // y = 0: order 4
+        if (it % 16 == 3) { char y[56]; memset(y, 0xff, 56); y[27] = (char)0xfe; y[55] = (char)0xfe; ecn_ed448_set(0, nullptr, y, &P); }  // y = p - 1: order 2
+        if (it % 16 == 4) ecn_ed448_gen(&P);
+        if (it == 5) memset(e, 0, 56);
+        if (it == 6) { memset(e, 0, 56); e[55] = 1; }
+        if (it == 7) memset(e, 0xff, 56);
+        if (it == 9) { memset(e, 0, 56); e[55] = 4; }
+        pt448 Q = P;
+        uint64_t ew[7], xw[7], yw[7], tab[ma::ED448_TABLE_WORDS];
+        for (int w = 0; w < 7; w++) { uint64_t v = 0; for (int b = 0; b < 8; b++) v |= (uint64_t)e[55 - (8 * w + b)] << (8 * b); ew[w] = v; }
+        ma::ed448_mul_get_one(ew, P.x, P.y, P.z, tab, 1, xw, yw);
+        char wx[56], wy[56];
+        ecn_ed448_mul((const char*)e, &Q);
+        ecn_ed448_get(&Q, wx, wy);
+        unsigned char gx[56], gy[56];
+        for (int i = 0; i < 56; i++) { gx[i] = (unsigned char)(xw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); gy[i] = (unsigned char)(yw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); }
+        if (memcmp(gx, wx, 56) != 0 || memcmp(gy, wy, 56) != 0) {
+            if (bad < 6) printf("ed448_mul_get_one: record %d differs\n", it);
+            bad++;
+        }
+    }
+    printf("ed448_mul_get_one: %d records, %d differ from the oracle's ecn mul + get\n", n, bad);
+    return bad;
+}
+
 template <int NW, class Fn, class Ref>
 static int run(const char* name, int n, Fn fn, Ref ref) {
     int bad = 0;
@@ -102,5 +144,6 @@ int main(int argc, char** argv) {
     int bad = run<4>("x25519_fe26_one", n, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x25519_fe26_one(k, u, o); }, rfc7748_X25519);
     bad += run<7>("x448_fe28_one", n / 4 + 8, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x448_fe28_one(k, u, o); }, rfc7748_X448);
     bad += run_ed25519(n / 4 + 16);
+    bad += run_ed448(n / 16 + 16);
     return bad ? 1 : 0;
 }

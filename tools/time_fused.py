@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from modarith_amd.edwards import Curve
-for name, n in (("ED25519", 1 << 21),):
+for name, n in (("ED25519", 1 << 21), ("ED448", 1 << 19)):
     Ed = Curve(name)
     g = torch.Generator(device="cuda").manual_seed(3)
     e = torch.randint(0, 256, (n, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=g)
