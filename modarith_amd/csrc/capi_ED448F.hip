@@ -8,13 +8,19 @@
 
 namespace ma {
 
+constexpr size_t ED448_ROW_SKEW = 32 + 4;   // words added to the row pitch (288 bytes)
+
 // one scalar multiplication per lane; the window table of lane slot s = blockIdx.x * 64 + threadIdx.x sits in the
 // workspace at word k -> ws[k * slots + s] (every access of a wave is one coalesced 512-byte row)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#ifndef MA_ED448F_WAVES
+#define MA_ED448F_WAVES 2
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MA_ED448F_WAVES, MA_ED448F_WAVES)))
 void k_ed448_mul_get(const unsigned char* e, const spint* Pb, unsigned char* xb, unsigned char* yb, int* sign, size_t n, size_t ld,
                      uint64_t* ws) {
     using P = P_X448;
     const size_t slots = (size_t)gridDim.x * blockDim.x;
+    const size_t tstride = slots + ED448_ROW_SKEW;          // rows 2^k bytes apart would all fall on one memory channel
     uint64_t* tab = ws + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += slots) {
         spint ew[7], X[8], Y[8], Z[8], xw[7], yw[7];
@@ -24,7 +30,7 @@ void k_ed448_mul_get(const unsigned char* e, const spint* Pb, unsigned char* xb,
             Y[I] = Pb[(size_t)(8 + I) * ld + t];
             Z[I] = Pb[(size_t)(16 + I) * ld + t];
         });
-        ed448_mul_get_one(ew, X, Y, Z, tab, slots, xw, yw);
+        ed448_mul_get_one(ew, X, Y, Z, tab, tstride, xw, yw);
         if (xb) store_be_record<P>(xb, t, xw);
         if (yb) store_be_record<P>(yb, t, yw);
         if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
@@ -38,12 +44,12 @@ using namespace ma;
 namespace {
 // resident grid: 2 waves on each of the 1024 SIMDs, grid-stride over the batch
 size_t fused_lanes(size_t n) {
-    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
+    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)MA_ED448F_WAVES * 1024 * 64;
     return lanes < cap ? lanes : cap;
 }
 }  // namespace
 
-extern "C" size_t ecn_ed448_mul_get_workspace_bytes(size_t n) { return fused_lanes(n) * ED448_TABLE_WORDS * sizeof(uint64_t); }
+extern "C" size_t ecn_ed448_mul_get_workspace_bytes(size_t n) { return (fused_lanes(n) + ED448_ROW_SKEW) * ED448_TABLE_WORDS * sizeof(uint64_t); }
 
 extern "C" int ecn_ed448_mul_get_batch(const char* e, const ma_spint* P, char* x, char* y, int* sign, size_t n, size_t ld,
                                        void* workspace, size_t workspace_bytes, void* st) {
@@ -53,7 +59,7 @@ extern "C" int ecn_ed448_mul_get_batch(const char* e, const ma_spint* P, char* x
         return (int)hipErrorInvalidValue;
     }
     const size_t lanes = fused_lanes(n);
-    if (workspace == nullptr || workspace_bytes < lanes * ED448_TABLE_WORDS * sizeof(uint64_t)) {
+    if (workspace == nullptr || workspace_bytes < (lanes + ED448_ROW_SKEW) * ED448_TABLE_WORDS * sizeof(uint64_t)) {
         set_error("ecn mul_get: workspace too small (see ecn_ed448_mul_get_workspace_bytes)");
         return (int)hipErrorInvalidValue;
     }

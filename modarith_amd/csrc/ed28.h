@@ -63,7 +63,11 @@ struct Ed28 {
     // P = 2P, dbl-2008-hwcd with a = 1: A = X^2, B = Y^2, C = 2Z^2, G = A + B, E = (X+Y)^2 - G, F = G - C, H = A - B;
     // X3 = E F, Y3 = G H, Z3 = F G, T3 = E H.  Input X, Y, Z tight; T is not read.
     template <bool WANT_T>
-    static MA_DEV void dbl(Ext& p) {
+    static MA_DEV void dbl(Ext& p) { dbl(p, WANT_T); }
+    // want_t is wave-uniform (a loop counter, never data): the window loop keeps ONE copy of the doubling in the
+    // instruction stream -- three unrolled copies plus the addition are about 80 KB of code, more than the 64 KB
+    // instruction cache, and the kernel then waits on instruction fetch for 40 % of its time (SQ_WAIT_ANY)
+    static MA_DEV void dbl(Ext& p, bool want_t) {
         uint32_t A[16], B[16], Cc[16], S[16], G[16], E[16], Ff[16], H[16];
         F::sqr_k(p.X, A);
         F::sqr_k(p.Y, B);
@@ -78,7 +82,7 @@ struct Ed28 {
         F::mul_k(E, Ff, p.X);
         F::mul_k(H, G, p.Y);
         F::mul_k(Ff, G, p.Z);
-        if constexpr (WANT_T) F::mul_k(E, H, p.T);
+        if (want_t) F::mul_k(E, H, p.T);
     }
     // common tail of the additions (a = 1, d = -39081): with A = X1 X2, B = Y1 Y2, Cc = 39081 T1 T2 (= -C), D = Z1 Z2,
     // M = (X1+Y1)(X2+Y2):  E = M - A - B, F = D - C = D + Cc, G = D + C = D - Cc, H = B - A;  X3 = E F, Y3 = G H, Z3 = F G
@@ -220,20 +224,37 @@ MA_DEV void ed448_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y
         const bool neg = dgt < 0;
         const uint32_t m = (uint32_t)(neg ? -dgt : dgt);    // 0..4
         if (i != 0) {
-            E::dbl<false>(R);
-            E::dbl<false>(R);
-            E::dbl<true>(R);
+#pragma unroll 1
+            for (int j = 0; j < 3; j++) E::dbl(R, j == 2);
         }
         // constant-time lookup: every entry is read; start from the neutral element (x, y, td) = (0, 1, 0)
         uint64_t sel[21];
         static_for<0, 21>([&](auto K) { sel[K] = (K == 7) ? 1u : 0u; });
+        // (all 84 loads are issued before the first select: one memory latency per window, and the doublings' temporaries
+        // are dead here, so the 168 landing registers are free)
+        // The memory clobber keeps the (loop-invariant) loads inside the iteration: hoisted out of the loop they would
+        // occupy 168 registers across the doublings, i.e. be spilled and reloaded from scratch one by one, each with
+        // its own s_waitcnt vmcnt(0) -- measured as 40 % of the kernel's time in SQ_WAIT_ANY.
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::: "memory");
+#endif
+        // two entries (84 landing registers) per round: four at once do not fit next to the point
 #pragma unroll 1
-        for (int e = 0; e < 4; e++) {
-            const bool hit = (m == (uint32_t)(e + 1));
-            static_for<0, 21>([&](auto K) {
-                const uint64_t a = tab[(size_t)(e * 21 + K) * tstride], b = sel[K];
-                sel[K] = hit ? a : b;
+        for (int e = 0; e < 4; e += 2) {
+            uint64_t ent[2][21];
+            static_for<0, 2>([&](auto EI) {
+                static_for<0, 21>([&](auto K) { ent[EI][K] = tab[(size_t)((e + EI) * 21 + K) * tstride]; });
             });
+            static_for<0, 2>([&](auto EI) {
+                const bool hit = (m == (uint32_t)(e + EI + 1));
+                static_for<0, 21>([&](auto K) {
+                    const uint64_t a = ent[EI][K], b = sel[K];
+                    sel[K] = hit ? a : b;
+                });
+            });
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::: "memory");
+#endif
         }
         // -Q = (-x, y, -td)
         uint32_t xs[16], ys[16], ts[16], nx[16], nt[16];

@@ -88,7 +88,7 @@ def test_fused_special_points_and_scalars(fx):
     order +- 1 and all ones -- every (point, scalar) pair against the two-call form"""
     C, Ed, g, torch = fx
     p = (1 << 255) - 19 if C == "ed25519" else (1 << 448) - (1 << 224) - 1
-    order = int(g["testcurve"]["order"], 16)
+    order = int(g["order"], 16)
     be = lambda v: v.to_bytes(Ed.nbytes, "big").hex()
     G = Ed.gen(1)
     lowy = [0, p - 1, 1]                                                     # y = 0 (order 4), y = -1 (order 2), y = 1 (neutral)

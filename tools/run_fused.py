@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""one fused ecn mul_get pass per curve (for profiling): ED25519 2^21, ED448 2^19 scalars"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from modarith_amd.edwards import Curve
+for name, n in (("ED25519", 1 << 21), ("ED448", 1 << 19)):
+    if sys.argv[1:] and name not in sys.argv[1:]:
+        continue
+    Ed = Curve(name)
+    e = torch.randint(0, 256, (n, Ed.nbytes), dtype=torch.uint8, device="cuda")
+    k = torch.randint(0, 256, (n, Ed.nbytes), dtype=torch.uint8, device="cuda")
+    P = Ed.mul(k, Ed.gen(n))
+    Ed.mul_get(e[:4096].contiguous(), P[:, :, :4096].contiguous())
+    x, y, s = Ed.mul_get(e, P)
+    torch.cuda.synchronize()
+print("done")
