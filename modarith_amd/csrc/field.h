@@ -433,6 +433,119 @@ struct Field {
         pm_second_pass((dpint)t.c, v, c);
     }
 
+    // ---------------------------------------------------------------- half-limb columns (2^255-19 shape)
+    // For an odd radix R = 2H - 1 and p = 2^(N R) - MM the product loops above compute the integer
+    //     T = sum_{k,j} a_k b_j w(k+j),   w(m) = 2^(R m) for m < N,  MM 2^(R (m-N)) for m >= N,
+    // emit its base-2^R digits v_0 .. v_{N-1} and hand T >> (N R) to the second pass.  T is bilinear in the limbs, so
+    // it can be accumulated from HALF limbs a_k = lo_k + 2^H hi_k (lo < 2^H, hi < 2^(R+2-H)) just as well: half-limb
+    // i sits at bit R (i/2) + H (i%2), two odd halves meet one bit above a column boundary (factor 2), and the 2N
+    // column sums h_i are exactly the columns of the 2N x (H or H-1)-bit mixed radix -- what csrc/fe26.h does for the
+    // ladder.  Every partial product is ONE v_mad_u64_u32 into a 64-bit column (100 per modmul instead of 100 + the
+    // three-accumulator digit() assembly; 174 instead of 273 instructions), the carry chain yields the 2N half digits,
+    // v_r = t_{2r} + 2^H t_{2r+1} are the reference's digits and the last carry is its T >> (N R): the SAME limbs as
+    // pm_modmul for every input inside the limb contract (limbs < 2^(R+2)).
+    // One family of terms needs care: two ODD halves with i + j = 2N exactly (limbs k + j = N - 1) weigh
+    // 2^(2H) 2^(R (N-1)) = 2 * 2^(N R) -- congruent to 2 MM, but the reference keeps a_k b_j whole in row N-1, so in
+    // its T they sit ABOVE bit N R.  Wrapping them into column 0 would give T - 2 p X: the same residue, but a
+    // different integer, hence (whenever the low part borrows) other digits.  They are accumulated on top of the last
+    // carry instead, so that the value handed to the second pass is the reference's t.
+    // Bounds for R = 51, H = 26, N = 5, MM = 19, limbs < 2^53: lo < 2^26, hi < 2^27, 19 hi < 2^31.3; the largest
+    // column (k = 2: four wrapped odd-odd terms 2 * 19 * hi hi, three wrapped even-even ones, three plain) stays below
+    // 4 * 2^59.3 + 2^59 < 2^61.6, carries below 2^36, the value handed to the second pass below 2^36 + 5 * 2^55.
+    static constexpr bool HALF = FAST && !P::MONTGOMERY && P::EPM && !P::OVERFLOW && P::FRED && RADIX == 51 && N == 5 && P::MM == 19;
+    static constexpr int HH = (RADIX + 1) / 2;                      // 26
+    static constexpr int hbits(int i) { return (i & 1) ? RADIX - HH : HH; }
+    static MA_DEV void half_split(const spint* a, uint32_t* f) {
+        static_for<0, N>([&](auto K) {
+            constexpr int k = K;
+            f[2 * k] = (uint32_t)a[k] & ((1u << HH) - 1u);
+            f[2 * k + 1] = (uint32_t)(a[k] >> HH);
+        });
+    }
+    // half digits t[0..2N) and the final carry -> the reference's limbs (second pass included)
+    static MA_DEV void half_finish(const uint32_t* t, uint64_t carry, spint* c) {
+        spint v[N];
+        static_for<0, N>([&](auto K) {
+            constexpr int k = K;
+            v[k] = (spint)t[2 * k] | ((spint)t[2 * k + 1] << HH);
+        });
+        pm_second_pass((dpint)carry, v, c);
+    }
+    static MA_DEV void pm_modmul_half(const spint* a, const spint* b, spint* c) {
+        constexpr int M = 2 * N;
+        uint32_t f[M], g[M], g19[M], f2[M], t[M];
+        half_split(a, f);
+        half_split(b, g);
+        static_for<1, M>([&](auto J) { g19[J] = (uint32_t)P::MM * g[J]; });
+        static_for<0, N>([&](auto K) { f2[2 * K + 1] = 2u * f[2 * K + 1]; });
+        uint64_t cy = 0;
+        static_for<0, M>([&](auto KK) {
+            constexpr int k = KK;
+            uint64_t acc = cy;
+            static_for<0, M>([&](auto II) {
+                constexpr int i = II;
+                constexpr int j = (k - i + M) % M;
+                constexpr bool wrp = (i + j) >= M;
+                constexpr bool dbl = (i & 1) && (j & 1);
+                if constexpr (!(dbl && i + j == M)) {             // (those go on top of the last carry, below)
+                    const uint32_t x = dbl ? f2[i] : f[i];
+                    const uint32_t y = wrp ? g19[j] : g[j];
+                    acc += (uint64_t)x * y;
+                    MA_PIN(acc);
+                }
+            });
+            t[k] = (uint32_t)acc & ((1u << hbits(k)) - 1u);
+            cy = acc >> hbits(k);
+        });
+        static_for<0, N>([&](auto K) {
+            constexpr int i = 2 * K + 1;
+            cy += (uint64_t)f2[i] * g[M - i];
+            MA_PIN(cy);
+        });
+        half_finish(t, cy, c);
+    }
+    static MA_DEV void pm_modsqr_half(const spint* a, spint* c) {
+        constexpr int M = 2 * N;
+        uint32_t f[M], f2[M], f4[M], f19[M], t[M];
+        half_split(a, f);
+        static_for<0, M>([&](auto I) { f2[I] = 2u * f[I]; });
+        static_for<0, N>([&](auto K) { f4[2 * K + 1] = 4u * f[2 * K + 1]; });
+        static_for<1, M>([&](auto J) { f19[J] = (uint32_t)P::MM * f[J]; });
+        uint64_t cy = 0;
+        static_for<0, M>([&](auto KK) {
+            constexpr int k = KK;
+            uint64_t acc = cy;
+            static_for<0, M>([&](auto II) {
+                constexpr int i = II;
+                constexpr int j = (k - i + M) % M;
+                if constexpr (i <= j) {
+                    constexpr bool wrp = (i + j) >= M;
+                    constexpr bool odd2 = (i & 1) && (j & 1);
+                    uint32_t x, y;
+                    if constexpr (i == j) {                       // f_i^2, times 2 if odd, times MM if wrapped
+                        x = odd2 ? f2[i] : f[i];
+                        y = wrp ? f19[j] : f[j];
+                    } else {                                      // 2 f_i f_j, times 2 if both odd, times MM if wrapped
+                        x = odd2 ? f4[i] : f2[i];
+                        y = wrp ? f19[j] : f[j];
+                    }
+                    if constexpr (!(odd2 && i + j == M)) {
+                        acc += (uint64_t)x * y;
+                        MA_PIN(acc);
+                    }
+                }
+            });
+            t[k] = (uint32_t)acc & ((1u << hbits(k)) - 1u);
+            cy = acc >> hbits(k);
+        });
+        static_for<0, N>([&](auto K) {                            // odd i + j = 2N: on top of the last carry
+            constexpr int i = 2 * K + 1, j = M - i;
+            if constexpr (i < j) { cy += (uint64_t)f4[i] * f[j]; MA_PIN(cy); }
+            else if constexpr (i == j) { cy += (uint64_t)f2[i] * f[j]; MA_PIN(cy); }
+        });
+        half_finish(t, cy, c);
+    }
+
     // pseudo.py:705-728; (dpint)b sign-extends a negative int exactly as the emitted C does
     static MA_DEV void pm_modmli(const spint* a, int b, spint* c) {
         dpint t = 0;
@@ -702,14 +815,18 @@ struct Field {
         if constexpr (P::MONTGOMERY) {
             if constexpr (CHAINED) monty_mul_chain<false>(a, b, c); else monty_mul<false>(a, b, c);
         } else {
-            if constexpr (CHAINED) pm_modmul_chain(a, b, c); else pm_modmul(a, b, c);
+            if constexpr (HALF) pm_modmul_half(a, b, c);
+            else if constexpr (CHAINED) pm_modmul_chain(a, b, c);
+            else pm_modmul(a, b, c);
         }
     }
     static MA_DEV void modsqr(const spint* a, spint* c) {
         if constexpr (P::MONTGOMERY) {
             if constexpr (CHAINED) monty_mul_chain<true>(a, a, c); else monty_mul<true>(a, a, c);
         } else {
-            if constexpr (CHAINED) pm_modsqr_chain(a, c); else pm_modsqr(a, c);
+            if constexpr (HALF) pm_modsqr_half(a, c);
+            else if constexpr (CHAINED) pm_modsqr_chain(a, c);
+            else pm_modsqr(a, c);
         }
     }
     static MA_DEV void modmli(const spint* a, int b, spint* c) {
