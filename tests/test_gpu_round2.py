@@ -247,3 +247,30 @@ def test_parity_suite_under_forced_policy(knob):
     assert p.returncode == 0, tail
     last = [l for l in p.stdout.splitlines() if " passed" in l][-1]
     assert int(last.split(" passed")[0].split()[-1]) > 300, tail
+
+
+# ---------------------------------------------------------------- curve soak as a test (tools/soak.py curves, 2^13 scalars)
+ALL_CURVES = ["ED25519", "NIST256", "ED448", "NIST384", "SECP256K1", "NUMS256W", "NUMS256E", "ED248", "ED376", "NIST521", "ED500"]
+
+
+@pytest.mark.skipif(os.environ.get("MA_POLICY_CHILD") == "1", reason="curve kernels do not read the product-policy switches")
+@pytest.mark.parametrize("name", ALL_CURVES)
+def test_curve_soak_projective_limbs(oracle, torch_cuda, name):
+    """2^13 random scalars x random projective points per curve: the fused bit-exact `ecn mul` against the restated
+    edwards.c / weierstrass.c on the CPU, projective limbs compared (for ED25519 this runs the half-limb products)"""
+    torch = torch_cuda
+    from modarith_amd.edwards import Curve
+    n = 1 << 13
+    C = Curve(name)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    e0 = torch.randint(0, 256, (n, C.nbytes), dtype=torch.uint8, device="cuda", generator=g)
+    P = C.mul(e0, C.gen(n))
+    e = torch.randint(0, 256, (n, C.nbytes), dtype=torch.uint8, device="cuda", generator=g)
+    e[:16] = 0
+    e[16:32] = 255
+    hp = np.ascontiguousarray(P.cpu().numpy().view(np.uint64)).reshape(3 * C.N, n)
+    he = np.ascontiguousarray(e.cpu().numpy())
+    want = hp.copy()
+    getattr(oracle.lib, "ecn_%s_batch_mul" % name.lower())(vp(he), vp(want), n, n)
+    got = C.mul(e, P.clone()).cpu().numpy().view(np.uint64).reshape(3 * C.N, n)
+    assert np.array_equal(got, want), name
