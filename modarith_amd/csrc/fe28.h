@@ -110,51 +110,77 @@ struct Fe28 {
         });
         carry(h, r);
     }
-    static MA_DEV void mul_k(const uint32_t* f, const uint32_t* g, uint32_t* r) {
-        uint32_t fs[8], gs[8];
-        static_for<0, 8>([&](auto I) { fs[I] = f[I] + f[I + 8]; gs[I] = g[I] + g[I + 8]; });
-        uint64_t L[15], H[15];
-        static_for<0, 15>([&](auto KK) {
+    // Column form of the Karatsuba product: with Z0 = a0 b0, Z2 = a1 b1, Z1 = (a0+a1)(b0+b1) (8 x 8 limbs each, 15 columns),
+    //   h[m] = Z0[m] + Z2[m] + Z1[m+8] - Z0[m+8]          (m <= 6)       h[7]  = Z0[7] + Z2[7]
+    //   h[m] = Z1[m-8] - Z0[m-8] + Z2[m] + Z1[m]           (8 <= m <= 14) h[15] = Z1[7] - Z0[7]
+    // (Z0[m] cancels for m >= 8).  Only Z0[0..7] and Z1[8..14] occur twice; they are summed once (64 multiply-adds) and
+    // added with 64-bit adds.  Every other product goes straight into the accumulator of its column, which starts from
+    // the carry of the previous column (MA_PIN keeps that order), Z0[m+8] through a signed multiply-add with -a0: about
+    // 38 64-bit add/sub instructions per product instead of 83 for "sum three 15-column products, fold, carry".
+    // Same 192 multiply-adds, same bounds (the column values are the ones of the fold); the running value may be
+    // negative in between (two's complement), each finished column is >= 0 because Z1 >= Z0 + Z2 column by column.
+    template <bool SQR>
+    static MA_DEV void karatsuba(const uint32_t* f, const uint32_t* g, uint32_t* r) {
+        uint32_t fs[8], gs[8], nf[8];
+        static_for<0, 8>([&](auto I) { fs[I] = f[I] + f[I + 8]; nf[I] = 0u - f[I]; });
+        if constexpr (!SQR) static_for<0, 8>([&](auto I) { gs[I] = g[I] + g[I + 8]; });
+        const uint32_t* gg = SQR ? f : g;
+        const uint32_t* gss = SQR ? fs : gs;
+        // one column of an 8 x 8 product a*b (b = a for the squaring: symmetric terms once, doubled operand)
+        auto col = [&](auto KK, const uint32_t* a, const uint32_t* b, uint64_t acc, bool neg_a) -> uint64_t {
             constexpr int k = KK;
             constexpr int lo = k < 8 ? 0 : k - 7, hi = k < 8 ? k : 7;
-            uint64_t z0 = 0, z2 = 0, z1 = 0;
-            static_for<lo, hi + 1>([&](auto II) {
-                constexpr int i = II;
-                z0 += (uint64_t)f[i] * g[k - i];
-                z2 += (uint64_t)f[8 + i] * g[8 + k - i];
-                z1 += (uint64_t)fs[i] * gs[k - i];
-            });
-            L[k] = z0 + z2;
-            H[k] = z1 - z0;
-        });
-        fold_lh(L, H, r);
-    }
-    static MA_DEV void sqr_k(const uint32_t* f, uint32_t* r) {     // f tight
-        uint32_t fs[8], f2[16], fs2[8];
-        static_for<0, 8>([&](auto I) { fs[I] = f[I] + f[I + 8]; fs2[I] = 2u * fs[I]; });
-        static_for<0, 16>([&](auto I) { f2[I] = 2u * f[I]; });
-        uint64_t L[15], H[15];
-        static_for<0, 15>([&](auto KK) {
-            constexpr int k = KK;
-            constexpr int lo = k < 8 ? 0 : k - 7, hi = k < 8 ? k : 7;
-            uint64_t z0 = 0, z2 = 0, z1 = 0;
             static_for<lo, hi + 1>([&](auto II) {
                 constexpr int i = II, j = k - i;
-                if constexpr (i < j) {
-                    z0 += (uint64_t)f2[i] * f[j];
-                    z2 += (uint64_t)f2[8 + i] * f[8 + j];
-                    z1 += (uint64_t)fs2[i] * fs[j];
-                } else if constexpr (i == j) {
-                    z0 += (uint64_t)f[i] * f[i];
-                    z2 += (uint64_t)f[8 + i] * f[8 + i];
-                    z1 += (uint64_t)fs[i] * fs[i];
+                if constexpr (!SQR) {
+                    if (neg_a) acc += (uint64_t)((int64_t)(int32_t)a[i] * (int64_t)(int32_t)b[j]);
+                    else acc += (uint64_t)a[i] * b[j];
+                    MA_PIN(acc);
+                } else if constexpr (i <= j) {
+                    const uint32_t bj = (i < j) ? 2u * b[j] : b[j];
+                    if (neg_a) acc += (uint64_t)((int64_t)(int32_t)a[i] * (int64_t)(int32_t)bj);
+                    else acc += (uint64_t)a[i] * bj;
+                    MA_PIN(acc);
                 }
             });
-            L[k] = z0 + z2;
-            H[k] = z1 - z0;
+            return acc;
+        };
+        uint64_t S0[8], S1[15];
+        static_for<0, 8>([&](auto K) { S0[K] = col(K, f, gg, 0, false); });
+        static_for<8, 15>([&](auto K) { S1[K] = col(K, fs, gss, 0, false); });
+        uint64_t cy = 0;
+        uint32_t t[16];
+        static_for<0, 16>([&](auto MM) {
+            constexpr int m = MM;
+            uint64_t acc = cy;
+            if constexpr (m <= 7) {
+                acc = col(std::integral_constant<int, m>{}, f + 8, gg + 8, acc, false);                    // Z2[m]
+                if constexpr (m <= 6) {
+                    acc = col(std::integral_constant<int, m + 8>{}, nf, gg, acc, true);                    // -Z0[m+8]
+                    acc += S1[m + 8];
+                }
+                acc += S0[m];
+            } else {
+                acc = col(std::integral_constant<int, m - 8>{}, fs, gss, acc, false);                      // Z1[m-8]
+                if constexpr (m <= 14) {
+                    acc = col(std::integral_constant<int, m>{}, f + 8, gg + 8, acc, false);                // Z2[m]
+                    acc += S1[m];
+                }
+                acc -= S0[m - 8];
+            }
+            t[m] = (uint32_t)acc & M28;
+            cy = acc >> 28;
         });
-        fold_lh(L, H, r);
+        // the carry out of limb 15 re-enters at limbs 0 and 8 (2^448 = 2^224 + 1)
+        const uint64_t h0 = (uint64_t)t[0] + cy, h8 = (uint64_t)t[8] + cy;
+        t[0] = (uint32_t)h0 & M28;
+        t[1] += (uint32_t)(h0 >> 28);
+        t[8] = (uint32_t)h8 & M28;
+        t[9] += (uint32_t)(h8 >> 28);
+        static_for<0, 16>([&](auto I) { r[I] = t[I]; });
     }
+    static MA_DEV void mul_k(const uint32_t* f, const uint32_t* g, uint32_t* r) { karatsuba<false>(f, g, r); }
+    static MA_DEV void sqr_k(const uint32_t* f, uint32_t* r) { karatsuba<true>(f, f, r); }     // f tight
 
     template <uint32_t C>
     static MA_DEV void mul_small(const uint32_t* f, uint32_t* r) {

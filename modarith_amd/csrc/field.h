@@ -668,6 +668,92 @@ struct Field {
         c[N - 1] = (spint)t;
     }
 
+    // ---------------------------------------------------------------- half-limb columns, Montgomery shape (P-256)
+    // The same idea as pm_modmul_half for an EVEN radix R = 2H with "Montgomery-friendly" digits (ndash == 1,
+    // p = -1 mod 2^R, no virtual limb, no negative limb above limb 0): the reference's column loop is
+    //     t += column C of a*b + sum_l v_{C-l} ppw(l);   v_C = t mod 2^R (C <= JMAX) or c_{C-N} = t mod 2^R;   t >>= R
+    // and ends with c_{N-1} = t.  Everything is an integer sum in which each term has a definite weight, so it can be
+    // accumulated from half limbs in radix 2^H: a_k = lo + 2^H hi puts lo lo' / cross / hi hi' at half columns
+    // 2(k+j), +1, +2 (2H = R: no doubling factors), a digit v_j = u_2j + 2^H u_2j+1 times a prime limb 2^e goes to half
+    // column 2(j+l) + e/H as (u << e%H), times a general limb d = d_lo + 2^H d_hi as four multiply-adds, and the low
+    // limb -1 is the digit extraction itself.  Nothing wraps, so -- unlike the pseudo-Mersenne form -- there is no
+    // early-fold subtlety: the half digits, two by two, ARE the reference's digits, and the running value after half
+    // column 4N-3 is its last limb.  100 multiply-adds + 20 reduction multiply-adds and 20 shift-adds per modmul of
+    // P-256 (about 210 instructions instead of 355).
+    // Bounds for R = 52, N = 5, limbs < 2^54: lo < 2^26, hi < 2^28; a half column holds at most 10 products below 2^56,
+    // digit terms below 2^49 and a carry below 2^38: < 2^60.
+    static constexpr bool MHALF = FAST && P::MONTGOMERY && P::NDASH == 1 && !P::E && P::NEG_LIMB == 0 && RADIX == 52 && N == 5 &&
+                                  P::ppw(0) == -1;
+    template <bool SQR>
+    static MA_DEV void monty_mul_half(const spint* a, const spint* b, spint* c) {
+        constexpr int H = RADIX / 2, M = 2 * N;             // 26-bit halves, 10 of them per operand
+        constexpr uint32_t HM = (1u << H) - 1u;
+        uint32_t f[M], g[M], u[2 * M];
+        static_for<0, N>([&](auto K) {
+            constexpr int k = K;
+            f[2 * k] = (uint32_t)a[k] & HM;
+            f[2 * k + 1] = (uint32_t)(a[k] >> H);
+            if constexpr (!SQR) {
+                g[2 * k] = (uint32_t)b[k] & HM;
+                g[2 * k + 1] = (uint32_t)(b[k] >> H);
+            }
+        });
+        uint32_t f2[M];
+        if constexpr (SQR) static_for<0, M>([&](auto I) { f2[I] = 2u * f[I]; });
+        uint64_t cy = 0;
+        // half columns 0 .. 2M-2 carry products; digits are produced up to half column 2N-1 (JMAX = N-1 limbs), the limbs
+        // c_0 .. c_{N-2} are half columns 2N .. 4N-3, and what is left afterwards is c_{N-1}
+        static_for<0, 4 * N - 1>([&](auto KK) {
+            constexpr int k = KK;                            // half column; k = 4N-2 is the remainder (not masked)
+            uint64_t acc = cy;
+            constexpr int lo = k < M ? 0 : k - (M - 1), hi = k < M ? k : M - 1;
+            static_for<lo, hi + 1>([&](auto II) {
+                constexpr int i = II, j = k - i;
+                if constexpr (!SQR) {
+                    acc += (uint64_t)f[i] * g[j];
+                    MA_PIN(acc);
+                } else if constexpr (i <= j) {
+                    acc += (uint64_t)((i < j) ? f2[i] : f[i]) * f[j];
+                    MA_PIN(acc);
+                }
+            });
+            // reduction terms: digit halves u[2j], u[2j+1] times prime limb l >= 1 land at bit R (j + l) + (bits of the limb)
+            static_for<1, N>([&](auto L) {
+                constexpr int l = L;
+                constexpr long long d = P::ppw(l);
+                static_assert(d >= 0, "only the low prime limb may be negative here");
+                if constexpr (d > 0) {
+                    if constexpr ((d & (d - 1)) == 0) {
+                        constexpr int e = __builtin_ctzll((unsigned long long)d);
+                        constexpr int q = e / H, sh = e % H;                 // u << sh at half column 2(j+l) + q + (half index)
+                        static_for<0, M>([&](auto JJ) {                       // JJ = index of the digit half
+                            constexpr int jh = JJ;
+                            if constexpr (2 * l + q + jh == k && jh < k) { acc += (uint64_t)u[jh] << sh; MA_PIN(acc); }
+                        });
+                    } else {
+                        constexpr uint32_t dlo = (uint32_t)((unsigned long long)d & HM), dhi = (uint32_t)((unsigned long long)d >> H);
+                        static_assert(((unsigned long long)d >> (2 * H)) == 0, "prime limb wider than the radix");
+                        static_for<0, M>([&](auto JJ) {
+                            constexpr int jh = JJ;
+                            if constexpr (2 * l + jh == k && jh < k && dlo != 0) { acc += (uint64_t)u[jh] * dlo; MA_PIN(acc); }
+                            if constexpr (2 * l + jh + 1 == k && jh < k && dhi != 0) { acc += (uint64_t)u[jh] * dhi; MA_PIN(acc); }
+                        });
+                    }
+                }
+            });
+            if constexpr (k < 4 * N - 2) {
+                u[k] = (uint32_t)acc & HM;
+                cy = acc >> H;
+            } else {
+                c[N - 1] = acc;                                               // the last limb is not masked (monty.py:830-838)
+            }
+        });
+        static_for<0, N - 1>([&](auto I) {
+            constexpr int i = I;
+            c[i] = (spint)u[M + 2 * i] | ((spint)u[M + 2 * i + 1] << H);
+        });
+    }
+
     // the same columns on the 64-bit column chain (see Wide::Acc): shifts of a digit become products with a
     // constant power of two (one half of which is zero), one-word terms go to the carry word
     template <int C, class AccT>
@@ -813,7 +899,9 @@ struct Field {
     // ================================================================ family dispatch
     static MA_DEV void modmul(const spint* a, const spint* b, spint* c) {
         if constexpr (P::MONTGOMERY) {
-            if constexpr (CHAINED) monty_mul_chain<false>(a, b, c); else monty_mul<false>(a, b, c);
+            if constexpr (MHALF) monty_mul_half<false>(a, b, c);
+            else if constexpr (CHAINED) monty_mul_chain<false>(a, b, c);
+            else monty_mul<false>(a, b, c);
         } else {
             if constexpr (HALF) pm_modmul_half(a, b, c);
             else if constexpr (CHAINED) pm_modmul_chain(a, b, c);
@@ -822,7 +910,9 @@ struct Field {
     }
     static MA_DEV void modsqr(const spint* a, spint* c) {
         if constexpr (P::MONTGOMERY) {
-            if constexpr (CHAINED) monty_mul_chain<true>(a, a, c); else monty_mul<true>(a, a, c);
+            if constexpr (MHALF) monty_mul_half<true>(a, a, c);
+            else if constexpr (CHAINED) monty_mul_chain<true>(a, a, c);
+            else monty_mul<true>(a, a, c);
         } else {
             if constexpr (HALF) pm_modsqr_half(a, c);
             else if constexpr (CHAINED) pm_modsqr_chain(a, c);

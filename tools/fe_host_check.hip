@@ -7,6 +7,7 @@
 #include "../modarith_amd/csrc/fe26.h"
 #include "../modarith_amd/csrc/fe28.h"
 #include "../modarith_amd/csrc/generated/curve_ED25519.h"
+#include "../modarith_amd/csrc/generated/params_NIST256.h"
 #include "../modarith_amd/csrc/ed26.h"
 #include "../modarith_amd/csrc/ed28.h"
 #include <stdio.h>
@@ -143,6 +144,37 @@ static int run_half(int n) {
     return bad;
 }
 
+extern "C" void modmul_NIST256(const uint64_t*, const uint64_t*, uint64_t*);
+extern "C" void modsqr_NIST256(const uint64_t*, uint64_t*);
+extern "C" void nres_NIST256(const uint64_t*, uint64_t*);
+extern "C" void redc_NIST256(const uint64_t*, uint64_t*);
+
+// Field<P_NIST256, true>'s Montgomery half-limb products (csrc/field.h monty_mul_half) against the oracle, limb for limb
+static int run_mhalf(int n) {
+    using F = ma::Field<ma::P_NIST256, true>;
+    static_assert(F::MHALF, "half-limb Montgomery products are expected for NIST256");
+    int bad = 0;
+    const uint64_t edge[] = {0, 1, (1ull << 52) - 1, 1ull << 52, (1ull << 53) - 1, (1ull << 54) - 1, (1ull << 26) - 1, 1ull << 26, 0xffffffff0000ull};
+    for (int it = 0; it < n; it++) {
+        uint64_t a[5], b[5], got[5], want[5];
+        for (int i = 0; i < 5; i++) {
+            uint64_t r = sm();
+            a[i] = (r % 10 < 9 && it % 3) ? edge[r % 9] : (sm() & ((1ull << 54) - 1));
+            r = sm();
+            b[i] = (r % 10 < 9 && it % 3 == 1) ? edge[r % 9] : (sm() & ((1ull << 54) - 1));
+        }
+        if (it == 0) for (int i = 0; i < 5; i++) a[i] = b[i] = (1ull << 54) - 1;
+        int d = 0;
+        F::modmul(a, b, got); modmul_NIST256(a, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::modsqr(a, got); modsqr_NIST256(a, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::nres(a, got); nres_NIST256(a, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::redc(a, got); redc_NIST256(a, want); d |= memcmp(got, want, sizeof got) != 0;
+        if (d) { if (bad < 4) printf("NIST256 half-limb: record %d differs\n", it); bad++; }
+    }
+    printf("Field<P_NIST256,true> half-limb modmul/modsqr/nres/redc: %d records, %d differ from the oracle\n", n, bad);
+    return bad;
+}
+
 template <int NW, class Fn, class Ref>
 static int run(const char* name, int n, Fn fn, Ref ref) {
     int bad = 0;
@@ -174,6 +206,7 @@ int main(int argc, char** argv) {
     int bad = run<4>("x25519_fe26_one", n, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x25519_fe26_one(k, u, o); }, rfc7748_X25519);
     bad += run<7>("x448_fe28_one", n / 4 + 8, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x448_fe28_one(k, u, o); }, rfc7748_X448);
     bad += run_half(n * 50);
+    bad += run_mhalf(n * 50);
     bad += run_ed25519(n / 4 + 16);
     bad += run_ed448(n / 16 + 16);
     return bad ? 1 : 0;
