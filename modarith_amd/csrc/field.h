@@ -754,6 +754,70 @@ struct Field {
         });
     }
 
+    // The trinomial shape with a virtual limb (2^448 - 2^224 - 1: ppw = [-1, 0.., -1 at limb NEG, 0.., +1 at limb N]):
+    // the reference carries the negative middle limb with its borrow convention -- column NEG adds Q - v_0, every later
+    // column adds the scratch word s = mask - v_{C-NEG} + v_{C-N}, and the last limb adds v_N - 1 (monty.py:597-627,
+    // 717-738, 830-838; monty_reduce above).  Each of these is an explicit integer added at the weight of limb column
+    // C, so in radix 2^H (R = 2H) it splits exactly: Q - v = (2^H - u_a) + 2^H (2^H - 1 - u_b) and
+    // s = (m - u_a + u'_a) + 2^H (m - u_b + u'_b), m = 2^H - 1, all halves non-negative: they go to half columns 2C and
+    // 2C + 1 as 32-bit values.  256 multiply-adds into 31 half columns with one carry chain instead of 64 limb products
+    // on three accumulators each.
+    static constexpr bool MHALF_TRI = FAST && P::MONTGOMERY && P::NDASH == 1 && P::E && RADIX == 56 && N == 8 && P::NEG_LIMB == 4 &&
+                                      P::ppw(0) == -1 && P::ppw(4) == -1 && P::ppw(8) == 1 && P::ppw(1) == 0 && P::ppw(2) == 0 &&
+                                      P::ppw(3) == 0 && P::ppw(5) == 0 && P::ppw(6) == 0 && P::ppw(7) == 0;
+    template <bool SQR>
+    static MA_DEV void monty_mul_half_tri(const spint* a, const spint* b, spint* c) {
+        constexpr int H = RADIX / 2, M = 2 * N, NEG = P::NEG_LIMB;
+        constexpr uint32_t HM = (1u << H) - 1u;
+        uint32_t f[M], g[M], u[4 * N];
+        static_for<0, N>([&](auto K) {
+            constexpr int k = K;
+            f[2 * k] = (uint32_t)a[k] & HM;
+            f[2 * k + 1] = (uint32_t)(a[k] >> H);
+            if constexpr (!SQR) {
+                g[2 * k] = (uint32_t)b[k] & HM;
+                g[2 * k + 1] = (uint32_t)(b[k] >> H);
+            }
+        });
+        uint32_t f2[M];
+        if constexpr (SQR) static_for<0, M>([&](auto I) { f2[I] = 2u * f[I]; });
+        uint64_t cy = 0;
+        // limb columns 0 .. 2N-1 = half columns 0 .. 4N-1; digits v_0 .. v_N are half digits u_0 .. u_{2N+1}
+        static_for<0, 4 * N>([&](auto KK) {
+            constexpr int k = KK, C = k / 2, h = k % 2;
+            uint64_t acc = cy;
+            constexpr int lo = k < M ? 0 : k - (M - 1), hi = k < M ? k : M - 1;
+            if constexpr (lo <= hi) {
+                static_for<lo, hi + 1>([&](auto II) {
+                    constexpr int i = II, j = k - i;
+                    if constexpr (!SQR) {
+                        acc += (uint64_t)f[i] * g[j];
+                        MA_PIN(acc);
+                    } else if constexpr (i <= j) {
+                        acc += (uint64_t)((i < j) ? f2[i] : f[i]) * f[j];
+                        MA_PIN(acc);
+                    }
+                });
+            }
+            if constexpr (C == NEG) {                                  // Q - v_0
+                acc += (uint64_t)(h == 0 ? (HM + 1u) - u[0] : HM - u[1]);
+            } else if constexpr (C > NEG) {                            // s = mask - v_{C-NEG} + v_{C-N}
+                uint32_t sh = HM;
+                if constexpr (C - NEG <= N) sh -= u[2 * (C - NEG) + h];
+                if constexpr (C >= N) sh += u[2 * (C - N) + h];
+                acc += (uint64_t)sh;
+            }
+            u[k] = (uint32_t)acc & HM;
+            cy = acc >> H;
+        });
+        const spint vN = (spint)u[2 * N] | ((spint)u[2 * N + 1] << H);
+        static_for<0, N - 1>([&](auto I) {
+            constexpr int i = I;
+            c[i] = (spint)u[2 * (N + 1) + 2 * i] | ((spint)u[2 * (N + 1) + 2 * i + 1] << H);
+        });
+        c[N - 1] = cy + vN - (spint)1;                                 // monty.py:830-838
+    }
+
     // the same columns on the 64-bit column chain (see Wide::Acc): shifts of a digit become products with a
     // constant power of two (one half of which is zero), one-word terms go to the carry word
     template <int C, class AccT>
@@ -899,7 +963,8 @@ struct Field {
     // ================================================================ family dispatch
     static MA_DEV void modmul(const spint* a, const spint* b, spint* c) {
         if constexpr (P::MONTGOMERY) {
-            if constexpr (MHALF) monty_mul_half<false>(a, b, c);
+            if constexpr (MHALF_TRI) monty_mul_half_tri<false>(a, b, c);
+            else if constexpr (MHALF) monty_mul_half<false>(a, b, c);
             else if constexpr (CHAINED) monty_mul_chain<false>(a, b, c);
             else monty_mul<false>(a, b, c);
         } else {
@@ -910,7 +975,8 @@ struct Field {
     }
     static MA_DEV void modsqr(const spint* a, spint* c) {
         if constexpr (P::MONTGOMERY) {
-            if constexpr (MHALF) monty_mul_half<true>(a, a, c);
+            if constexpr (MHALF_TRI) monty_mul_half_tri<true>(a, a, c);
+            else if constexpr (MHALF) monty_mul_half<true>(a, a, c);
             else if constexpr (CHAINED) monty_mul_chain<true>(a, a, c);
             else monty_mul<true>(a, a, c);
         } else {

@@ -8,6 +8,7 @@
 #include "../modarith_amd/csrc/fe28.h"
 #include "../modarith_amd/csrc/generated/curve_ED25519.h"
 #include "../modarith_amd/csrc/generated/params_NIST256.h"
+#include "../modarith_amd/csrc/generated/params_X448.h"
 #include "../modarith_amd/csrc/ed26.h"
 #include "../modarith_amd/csrc/ed28.h"
 #include <stdio.h>
@@ -175,6 +176,38 @@ static int run_mhalf(int n) {
     return bad;
 }
 
+extern "C" void modmul_X448(const uint64_t*, const uint64_t*, uint64_t*);
+extern "C" void modsqr_X448(const uint64_t*, uint64_t*);
+extern "C" void nres_X448(const uint64_t*, uint64_t*);
+extern "C" void redc_X448(const uint64_t*, uint64_t*);
+
+// Field<P_X448, true>'s trinomial half-limb products (csrc/field.h monty_mul_half_tri) against the oracle, limb for limb
+static int run_mhalf448(int n) {
+    using F = ma::Field<ma::P_X448, true>;
+    static_assert(F::MHALF_TRI, "half-limb trinomial products are expected for X448");
+    int bad = 0;
+    const uint64_t edge[] = {0, 1, (1ull << 56) - 1, 1ull << 56, (1ull << 57) - 1, (1ull << 58) - 1, (1ull << 28) - 1, 1ull << 28, (1ull << 56) - 2};
+    for (int it = 0; it < n; it++) {
+        uint64_t a[8], b[8], got[8], want[8];
+        for (int i = 0; i < 8; i++) {
+            uint64_t r = sm();
+            a[i] = (r % 10 < 9 && it % 3) ? edge[r % 9] : (sm() & ((1ull << 58) - 1));
+            r = sm();
+            b[i] = (r % 10 < 9 && it % 3 == 1) ? edge[r % 9] : (sm() & ((1ull << 58) - 1));
+        }
+        if (it == 0) for (int i = 0; i < 8; i++) a[i] = b[i] = (1ull << 58) - 1;
+        if (it == 1) for (int i = 0; i < 8; i++) a[i] = b[i] = 0;
+        int d = 0;
+        F::modmul(a, b, got); modmul_X448(a, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::modsqr(a, got); modsqr_X448(a, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::nres(a, got); nres_X448(a, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::redc(a, got); redc_X448(a, want); d |= memcmp(got, want, sizeof got) != 0;
+        if (d) { if (bad < 4) printf("X448 half-limb: record %d differs\n", it); bad++; }
+    }
+    printf("Field<P_X448,true> half-limb modmul/modsqr/nres/redc: %d records, %d differ from the oracle\n", n, bad);
+    return bad;
+}
+
 template <int NW, class Fn, class Ref>
 static int run(const char* name, int n, Fn fn, Ref ref) {
     int bad = 0;
@@ -207,6 +240,7 @@ int main(int argc, char** argv) {
     bad += run<7>("x448_fe28_one", n / 4 + 8, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x448_fe28_one(k, u, o); }, rfc7748_X448);
     bad += run_half(n * 50);
     bad += run_mhalf(n * 50);
+    bad += run_mhalf448(n * 25);
     bad += run_ed25519(n / 4 + 16);
     bad += run_ed448(n / 16 + 16);
     return bad ? 1 : 0;
