@@ -117,8 +117,19 @@ template <class P, bool FAST = false> struct OpNres { static MA_DEV void apply(c
 template <class P, bool FAST = false> struct OpRedc { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::redc(a, c); } };
 template <class P> struct OpCpy { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modcpy(a, c); } };
 template <class P, bool FAST = false> struct OpInv { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::modinv(a, nullptr, c); } };
-template <class P> struct OpSqrt { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modsqrt(a, nullptr, c); } };
-template <class P> struct OpPro { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modpro(a, c); } };
+template <class P, bool FAST = false> struct OpSqrt { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::modsqrt(a, nullptr, c); } };
+template <class P, bool FAST = false> struct OpPro { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::modpro(a, c); } };
+// the long chains (x^PE and what hangs on it: ~250-450 squarings + multiplications per element) with the same wave-uniform
+// choice as OpMulAuto: split / half-limb products when every lane's input is inside the limb contract (the chain then stays
+// inside it by closure), exact ones otherwise -- the same limbs either way
+template <class P, template <class, bool> class Op> struct OpAutoUnary {
+    static MA_DEV void apply(const spint* a, spint* c) {
+        if constexpr (P::SPLIT > 0) {
+            if (__all(in_split_contract<P>(a))) { Op<P, true>::apply(a, c); return; }
+        }
+        Op<P, false>::apply(a, c);
+    }
+};
 
 // c[j] = op(a[j], b[j])
 template <class P, class Op, int EPT>
@@ -209,7 +220,9 @@ __global__ __launch_bounds__(BLOCK) void k_nsqr(spint* a, int k, size_t n, size_
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N];
         load_soa<P, 1>(a, ld, t, x);
-        Field<P>::modnsqr(x[0], k);
+        bool fast = false;
+        if constexpr (P::SPLIT > 0) fast = __all(in_split_contract<P>(x[0]));
+        if (fast) Field<P, true>::modnsqr(x[0], k); else Field<P, false>::modnsqr(x[0], k);
         store_soa<P, 1>(a, ld, t, x);
     }
 }
@@ -222,7 +235,9 @@ __global__ __launch_bounds__(BLOCK) void k_inv_h(const spint* xs, const spint* h
         spint x[1][P::N], h[1][P::N], z[1][P::N];
         load_soa<P, 1>(xs, ldx, t, x);
         load_soa<P, 1>(hs, ldh, t, h);
-        Field<P>::modinv(x[0], h[0], z[0]);
+        bool fast = false;
+        if constexpr (P::SPLIT > 0) fast = __all(in_split_contract<P>(x[0]) && in_split_contract<P>(h[0]));
+        if (fast) Field<P, true>::modinv(x[0], h[0], z[0]); else Field<P, false>::modinv(x[0], h[0], z[0]);
         store_soa<P, 1>(zs, ldz, t, z);
     }
 }
@@ -234,10 +249,12 @@ __global__ __launch_bounds__(BLOCK) void k_sqrt_h(const spint* xs, const spint* 
         spint x[1][P::N], h[1][P::N], r[1][P::N];
         load_soa<P, 1>(xs, ld, t, x);
         load_soa<P, 1>(hs, ld, t, h);
+        bool fast = false;
+        if constexpr (P::SPLIT > 0) fast = __all(in_split_contract<P>(x[0]) && in_split_contract<P>(h[0]));
         if constexpr (QR) {
-            out[t] = Field<P>::modqr(h[0], x[0]);
+            out[t] = fast ? Field<P, true>::modqr(h[0], x[0]) : Field<P, false>::modqr(h[0], x[0]);
         } else {
-            Field<P>::modsqrt(x[0], h[0], r[0]);
+            if (fast) Field<P, true>::modsqrt(x[0], h[0], r[0]); else Field<P, false>::modsqrt(x[0], h[0], r[0]);
             store_soa<P, 1>(rs, ld, t, r);
         }
     }
@@ -278,7 +295,11 @@ __global__ __launch_bounds__(BLOCK) void k_inplace(spint* a, int* out, size_t n,
         if constexpr (KIND == K_MODIS0) r = Field<P>::modis0(x[0]);
         if constexpr (KIND == K_MODSIGN) r = Field<P>::modsign(x[0]);
         if constexpr (KIND == K_MODHAF) { Field<P>::modhaf(x[0]); wr = true; }
-        if constexpr (KIND == K_MODQR) r = Field<P>::modqr(nullptr, x[0]);
+        if constexpr (KIND == K_MODQR) {
+            bool fast = false;
+            if constexpr (P::SPLIT > 0) fast = __all(in_split_contract<P>(x[0]));
+            r = fast ? Field<P, true>::modqr(nullptr, x[0]) : Field<P, false>::modqr(nullptr, x[0]);
+        }
         if (wr) store_soa<P, 1>(a, ld, t, x);
         if (out) out[t] = r;
     }
