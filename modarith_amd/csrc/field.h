@@ -111,8 +111,13 @@ struct Wide<true, H> {
     };
 };
 
-template <class P, bool FAST_ = false>
+// PIN_: keep the multiply-add chains of the half-limb products pinned (MA_PIN).  On by default; the progenitor chain
+// x^PE -- a separate, non-inlined function, for which no launch bound caps the register allocation -- is built from
+// the unpinned variant: with pins that one function takes 248 VGPRs (the whole kernel then runs at one wave per
+// SIMD), without them 132, and the extra 64-bit add per column costs less than the lost occupancy.
+template <class P, bool FAST_ = false, bool PIN_ = true>
 struct Field {
+    template <class T> static MA_DEV void pin(T& x) { if constexpr (PIN_) MA_PIN(x); }
     static constexpr int N = P::N;
     static constexpr int RADIX = P::RADIX;
     static constexpr spint Q = (spint)1 << RADIX;
@@ -491,7 +496,7 @@ struct Field {
                     const uint32_t x = dbl ? f2[i] : f[i];
                     const uint32_t y = wrp ? g19[j] : g[j];
                     acc += (uint64_t)x * y;
-                    MA_PIN(acc);
+                    pin(acc);
                 }
             });
             t[k] = (uint32_t)acc & ((1u << hbits(k)) - 1u);
@@ -500,7 +505,7 @@ struct Field {
         static_for<0, N>([&](auto K) {
             constexpr int i = 2 * K + 1;
             cy += (uint64_t)f2[i] * g[M - i];
-            MA_PIN(cy);
+            pin(cy);
         });
         half_finish(t, cy, c);
     }
@@ -531,7 +536,7 @@ struct Field {
                     }
                     if constexpr (!(odd2 && i + j == M)) {
                         acc += (uint64_t)x * y;
-                        MA_PIN(acc);
+                        pin(acc);
                     }
                 }
             });
@@ -540,8 +545,8 @@ struct Field {
         });
         static_for<0, N>([&](auto K) {                            // odd i + j = 2N: on top of the last carry
             constexpr int i = 2 * K + 1, j = M - i;
-            if constexpr (i < j) { cy += (uint64_t)f4[i] * f[j]; MA_PIN(cy); }
-            else if constexpr (i == j) { cy += (uint64_t)f2[i] * f[j]; MA_PIN(cy); }
+            if constexpr (i < j) { cy += (uint64_t)f4[i] * f[j]; pin(cy); }
+            else if constexpr (i == j) { cy += (uint64_t)f2[i] * f[j]; pin(cy); }
         });
         half_finish(t, cy, c);
     }
@@ -711,10 +716,10 @@ struct Field {
                 constexpr int i = II, j = k - i;
                 if constexpr (!SQR) {
                     acc += (uint64_t)f[i] * g[j];
-                    MA_PIN(acc);
+                    pin(acc);
                 } else if constexpr (i <= j) {
                     acc += (uint64_t)((i < j) ? f2[i] : f[i]) * f[j];
-                    MA_PIN(acc);
+                    pin(acc);
                 }
             });
             // reduction terms: digit halves u[2j], u[2j+1] times prime limb l >= 1 land at bit R (j + l) + (bits of the limb)
@@ -728,15 +733,15 @@ struct Field {
                         constexpr int q = e / H, sh = e % H;                 // u << sh at half column 2(j+l) + q + (half index)
                         static_for<0, M>([&](auto JJ) {                       // JJ = index of the digit half
                             constexpr int jh = JJ;
-                            if constexpr (2 * l + q + jh == k && jh < k) { acc += (uint64_t)u[jh] << sh; MA_PIN(acc); }
+                            if constexpr (2 * l + q + jh == k && jh < k) { acc += (uint64_t)u[jh] << sh; pin(acc); }
                         });
                     } else {
                         constexpr uint32_t dlo = (uint32_t)((unsigned long long)d & HM), dhi = (uint32_t)((unsigned long long)d >> H);
                         static_assert(((unsigned long long)d >> (2 * H)) == 0, "prime limb wider than the radix");
                         static_for<0, M>([&](auto JJ) {
                             constexpr int jh = JJ;
-                            if constexpr (2 * l + jh == k && jh < k && dlo != 0) { acc += (uint64_t)u[jh] * dlo; MA_PIN(acc); }
-                            if constexpr (2 * l + jh + 1 == k && jh < k && dhi != 0) { acc += (uint64_t)u[jh] * dhi; MA_PIN(acc); }
+                            if constexpr (2 * l + jh == k && jh < k && dlo != 0) { acc += (uint64_t)u[jh] * dlo; pin(acc); }
+                            if constexpr (2 * l + jh + 1 == k && jh < k && dhi != 0) { acc += (uint64_t)u[jh] * dhi; pin(acc); }
                         });
                     }
                 }
@@ -792,10 +797,10 @@ struct Field {
                     constexpr int i = II, j = k - i;
                     if constexpr (!SQR) {
                         acc += (uint64_t)f[i] * g[j];
-                        MA_PIN(acc);
+                        pin(acc);
                     } else if constexpr (i <= j) {
                         acc += (uint64_t)((i < j) ? f2[i] : f[i]) * f[j];
-                        MA_PIN(acc);
+                        pin(acc);
                     }
                 });
             }
@@ -1025,7 +1030,7 @@ struct Field {
     static __device__ __attribute__((noinline)) void modpro(const spint* w, spint* z) {
         spint x[N], r[N];
         modcpy(w, x);
-        P::template modpro_chain<Field<P, FAST_>>(x, r);
+        P::template modpro_chain<Field<P, FAST_, false>>(x, r);
         modcpy(r, z);
     }
 

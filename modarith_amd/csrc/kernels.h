@@ -174,6 +174,20 @@ __global__ __launch_bounds__(BLOCK) void k_binary_pipe(const spint* a, const spi
     }
 }
 
+// c[j] = op(a[j]) for the long chains (modinv, modsqrt, modpro): same body as k_unary below, but compiled for at least
+// three waves per SIMD on the small fields -- with only __launch_bounds__(256) the register allocator may take 512
+// VGPRs, and it does (400 for the pinned half-limb products of modinv): one wave per SIMD on a latency-bound chain
+template <class P, class Op>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(P::N <= 5 ? 3 : 1)))
+void k_unary_heavy(const spint* a, spint* c, size_t nthreads, size_t lda, size_t ldc) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
+        spint x[1][P::N], z[1][P::N];
+        load_soa<P, 1>(a, lda, t, x);
+        Op::apply(x[0], z[0]);
+        store_soa<P, 1>(c, ldc, t, z);
+    }
+}
+
 // c[j] = op(a[j])
 template <class P, class Op, int EPT>
 __global__ __launch_bounds__(BLOCK) void k_unary(const spint* a, spint* c, size_t nthreads,
