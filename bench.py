@@ -347,6 +347,21 @@ def main():
                                                           "two_call_form_per_s": m / (t3 - t1), "speedup": (t3 - t1) / (t1 - t0),
                                                           "bytes_equal_to_two_call_form": True}
                 del fx_, fy_, wx_, wy_, W
+            if cname in getattr(Cv, "FUSED2", ()):
+                # verification pattern ecnXXXmul2 + ecnXXXget (ed448.c:305): fused against the two calls
+                mq = m // 2
+                e2, f2, G2, Q2 = e[:mq].contiguous(), f[:mq].contiguous(), G[:, :, :mq].contiguous(), Q[:, :, :mq].contiguous()
+                Cv.mul2_get(e2[:4096].contiguous(), G2[:, :, :4096].contiguous(), f2[:4096].contiguous(), Q2[:, :, :4096].contiguous())
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                fx_, fy_, _ = Cv.mul2_get(e2, G2, f2, Q2)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                wx_, wy_, _ = Cv.get(Cv.mul2(e2, G2, f2, Q2))
+                torch.cuda.synchronize(); t2 = time.perf_counter()
+                assert torch.equal(fx_, wx_) and torch.equal(fy_, wy_), "fused mul2_get differs from mul2 + get"
+                others["%s_ecn_mul2_get_fused" % cname] = {"double_mults_per_s_per_gpu": mq / (t1 - t0), "pairs": mq, "bound": "VALU",
+                                                           "two_call_form_per_s": mq / (t2 - t1), "speedup": (t2 - t1) / (t1 - t0),
+                                                           "bytes_equal_to_two_call_form": True}
+                del fx_, fy_, wx_, wy_, e2, f2, G2, Q2
             del e, f, G, Q, R
 
     ladder = None

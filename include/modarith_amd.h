@@ -311,6 +311,11 @@ MODARITH_AMD_DECLARE_EDWARDS(nums256w, 5)
 size_t ecn_ed25519_mul_get_workspace_bytes(size_t n);
 int ecn_ed25519_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
                               void *workspace, size_t workspace_bytes, void *stream);
+/* R = e*P + f*Q and its affine export in one kernel: ecnXXXmul2 followed by ecnXXXget, the verification pattern
+ * (ed448.c:305, nist256.c:251-254); same conventions as mul_get, P and Q are not modified */
+size_t ecn_ed25519_mul2_get_workspace_bytes(size_t n);
+int ecn_ed25519_mul2_get_batch(const char *e, const ma_spint *P, const char *f, const ma_spint *Q, char *x, char *y, int *sign,
+                               size_t n, size_t ld, void *workspace, size_t workspace_bytes, void *stream);
 size_t ecn_ed448_mul_get_workspace_bytes(size_t n);
 int ecn_ed448_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
                             void *workspace, size_t workspace_bytes, void *stream);

@@ -96,19 +96,23 @@ struct Ed26 {
     }
 
     // the common tail of both additions: X3 = e f, Y3 = g h, Z3 = f g from a = (Y1-X1)(..), b = (Y1+X1)(..), c, d
+    template <bool WANT_T = false>
     static MA_DEV void add_tail(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, Ext& p) {
-        uint32_t e[10], f[10], g[10], h[10], g19[10];
+        uint32_t e[10], f[10], g[10], h[10], g19[10], e19[10];
         F::sub(b, a, e);            // 1.5
         F::sub(d, c, f);            // 2.0
         F::add(d, c, g);            // 1.5
         F::add(b, a, h);            // 1.0
         F::pre19(g, g19);
-        F::mul(f, e, p.X);          // 2.0 x 1.5
+        F::pre19(e, e19);
+        F::mul(f, e, e19, p.X);     // 2.0 x 1.5
         F::mul(f, g, g19, p.Z);     // 2.0 x 1.5
         F::mul(h, g, g19, p.Y);     // 1.0 x 1.5
+        if constexpr (WANT_T) F::mul(h, e, e19, p.T);   // 1.0 x 1.5
     }
     // P += Q, Q affine and cached as (y+x, y-x, 2dxy) (madd-2008-hwcd-3, a = -1, Z2 = 1); yp, ym tight, t2d <= 1.5.
     // Reads T of P; T of the sum is not produced (the next operation is a doubling, which does not read it).
+    template <bool WANT_T = false>
     static MA_DEV void add_cached(Ext& p, const uint32_t* yp, const uint32_t* ym, const uint32_t* t2d) {
         uint32_t a[10], b[10], c[10], d[10];
         F::sub(p.Y, p.X, a);        // 1.5
@@ -117,7 +121,7 @@ struct Ed26 {
         F::mul(b, yp, b);
         F::mul(p.T, t2d, c);
         F::add(p.Z, p.Z, d);        // 1.0
-        add_tail(a, b, c, d, p);
+        add_tail<WANT_T>(a, b, c, d, p);
     }
     // P += Q, both extended (add-2008-hwcd-3, a = -1); used once, to build 3P
     static MA_DEV void add_ext(Ext& p, const Ext& q) {
@@ -275,6 +279,155 @@ MA_DEV void ed25519_mul_get_one(const uint64_t* ew, const spint* X, const spint*
     }
 
     // ---- affine, canonical (ecnXXXget: edwards.c:221-239)
+    uint32_t zi[10], ax[10], ay[10];
+    F::invert(R.Z, zi);
+    F::mul(R.X, zi, ax);
+    F::mul(R.Y, zi, ay);
+    F::to_words(ax, xw);
+    F::to_words(ay, yw);
+}
+
+// Fused double multiplication + affine export: the affine coordinates of e*P + f*Q (ecnXXXmul2 followed by ecnXXXget,
+// the verification pattern ed448.c:305 / nist256.c:251-254).  Same arithmetic as ed25519_mul_get_one; both scalars are
+// recoded into 129 signed 2-bit digits (e' = e + sum 2*4^i, digit = window - 2 in [-2, 1]) so that the two tables
+// {P, 2P} and {Q, 2Q} fit the register file together (4 x 24 VGPRs); per window two doublings and two additions, all
+// lookups scan their table.  (The reference's mul2 is a joint sparse form with data-dependent branches; any
+// evaluation reaches the same affine point.)
+template <class C>
+MA_DEV void ed25519_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
+                                 const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ, uint64_t* xw, uint64_t* yw) {
+    using E = Ed26<C>;
+    using F = Fe26;
+    typename E::Ext R;
+    uint64_t tab[4][3][4];                  // P, 2P, Q, 2Q as canonical packed (y+x, y-x, 2dxy)
+    {
+        typename E::Ext A1, A2, B1, B2;
+        uint32_t px[10], py[10], pz[10];
+        auto ext = [&](const spint* X, const spint* Y, const spint* Z, typename E::Ext& o) {
+            E::from51(X, px);
+            E::from51(Y, py);
+            E::from51(Z, pz);
+            F::mul(px, pz, o.X);
+            F::mul(py, pz, o.Y);
+            F::sqr(pz, o.Z);
+            F::mul(px, py, o.T);
+        };
+        ext(PX, PY, PZ, A1);
+        A2 = A1;
+        E::template dbl<false>(A2);
+        ext(QX, QY, QZ, B1);
+        B2 = B1;
+        E::template dbl<false>(B2);
+        uint32_t z12[10], z123[10], inv[10], i1[10], i2[10], i3[10], i4[10];
+        F::mul(A1.Z, A2.Z, z12);
+        F::mul(z12, B1.Z, z123);
+        F::mul(z123, B2.Z, inv);
+        F::invert(inv, inv);
+        F::mul(inv, z123, i4);
+        F::mul(inv, B2.Z, inv);
+        F::mul(inv, z12, i3);
+        F::mul(inv, B1.Z, inv);
+        F::mul(inv, A1.Z, i2);
+        F::mul(inv, A2.Z, i1);
+        uint32_t dd[10];
+        E::d2(dd);
+        auto cache = [&](const typename E::Ext& p, const uint32_t* zi, uint64_t (*out)[4]) {
+            uint32_t x[10], y[10], s[10];
+            F::mul(p.X, zi, x);
+            F::mul(p.Y, zi, y);
+            F::add(y, x, s);
+            F::to_words(s, out[0]);
+            F::sub(y, x, s);
+            F::to_words(s, out[1]);
+            F::mul(x, y, s);
+            F::mul(s, dd, s);
+            F::to_words(s, out[2]);
+        };
+        cache(A1, i1, tab[0]);
+        cache(A2, i2, tab[1]);
+        cache(B1, i3, tab[2]);
+        cache(B2, i4, tab[3]);
+    }
+    // e' = e + sum_{i<129} 2*4^i (258 bits), left-aligned
+    uint64_t we[5], wf[5];
+    auto recode = [&](const uint64_t* in, uint64_t* w) {
+        constexpr auto cw = [](int k) {
+            uint64_t v = 0;
+            for (int b = 0; b < 64; b++) {
+                const int pos = 64 * k + b;
+                if (pos < 258 && pos % 2 == 1) v |= (uint64_t)1 << b;
+            }
+            return v;
+        };
+        unsigned __int128 acc = 0;
+        uint64_t s[5];
+        static_for<0, 5>([&](auto K) {
+            constexpr int k = K;
+            acc += (unsigned __int128)(k < 4 ? in[k < 4 ? k : 0] : 0) + cw(k);
+            s[k] = (uint64_t)acc;
+            acc >>= 64;
+        });
+        w[4] = (s[4] << 62) | (s[3] >> 2);
+        w[3] = (s[3] << 62) | (s[2] >> 2);
+        w[2] = (s[2] << 62) | (s[1] >> 2);
+        w[1] = (s[1] << 62) | (s[0] >> 2);
+        w[0] = s[0] << 62;
+    };
+    recode(ew, we);
+    recode(fw, wf);
+    F::set(0, R.X);
+    F::set(1, R.Y);
+    F::set(1, R.Z);
+    F::set(0, R.T);
+    auto take = [&](uint64_t* w) -> int {
+        const int d = (int)(uint32_t)(w[4] >> 62) - 2;
+        w[4] = (w[4] << 2) | (w[3] >> 62);
+        w[3] = (w[3] << 2) | (w[2] >> 62);
+        w[2] = (w[2] << 2) | (w[1] >> 62);
+        w[1] = (w[1] << 2) | (w[0] >> 62);
+        w[0] <<= 2;
+        return d;
+    };
+    // sign * table[|d|] (|d| in 0..2), scanned, then added to R
+    auto lookup_add = [&](int dgt, int base, auto want_t) {
+        const bool neg = dgt < 0;
+        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);
+        uint64_t sel[3][4];
+        static_for<0, 3>([&](auto CI) { static_for<0, 4>([&](auto K) { sel[CI][K] = (CI < 2 && K == 0) ? 1u : 0u; }); });
+        static_for<0, 2>([&](auto EI) {
+            const bool hit = (m == (uint32_t)(EI + 1));
+            static_for<0, 3>([&](auto CI) {
+                static_for<0, 4>([&](auto K) {
+                    const uint64_t a = tab[base + EI][CI][K], b = sel[CI][K];
+                    sel[CI][K] = hit ? a : b;
+                });
+            });
+        });
+        uint32_t yp[10], ym[10], t2[10], nt[10];
+        uint64_t sp[4], sm[4];
+        static_for<0, 4>([&](auto K) {
+            const uint64_t a = sel[0][K], b = sel[1][K];
+            sp[K] = neg ? b : a;
+            sm[K] = neg ? a : b;
+        });
+        F::from_words(sp, yp);
+        F::from_words(sm, ym);
+        F::from_words(sel[2], t2);
+        F::set(0, nt);
+        F::sub(nt, t2, nt);
+        F::select(neg, t2, nt, t2);
+        E::template add_cached<decltype(want_t)::value>(R, yp, ym, t2);
+    };
+#pragma unroll 1
+    for (int i = 0; i < 129; i++) {
+        const int de = take(we), df = take(wf);
+        if (i != 0) {
+            E::template dbl<false>(R);
+            E::template dbl<true>(R);
+        }
+        lookup_add(de, 0, std::true_type{});
+        lookup_add(df, 2, std::false_type{});
+    }
     uint32_t zi[10], ax[10], ay[10];
     F::invert(R.Z, zi);
     F::mul(R.X, zi, ax);

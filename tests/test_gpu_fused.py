@@ -125,3 +125,46 @@ def test_fused_rejects_bad_arguments(fx):
         Edwards("NIST256").mul_get(torch.zeros((1, 32), dtype=torch.uint8, device="cuda"), Edwards("NIST256").gen(1))
     x, y, s = Ed.mul_get(torch.zeros((0, Ed.nbytes), dtype=torch.uint8, device="cuda"), Ed.empty(0))
     assert x.shape[0] == 0
+
+
+def test_fused_mul2_get(oracle):
+    """e*P + f*Q and its affine export in one kernel (ED25519): against mul2 + get on the GPU (2^14 random pairs) and the
+    oracle's ecn mul2 + ecn get on a sample; special operands: neutral element, P = Q, zero scalars, small order"""
+    import torch
+    from modarith_amd.edwards import Edwards
+    Ed = Edwards("ED25519")
+    C = "ed25519"
+    n = 1 << 14
+    gen = torch.Generator(device="cuda").manual_seed(92)
+    rnd = lambda: torch.randint(0, 256, (n, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=gen)
+    P, Q = Ed.mul(rnd(), Ed.gen(n)), Ed.mul(rnd(), Ed.gen(n))
+    e, f = rnd(), rnd()
+    P[:, :, 0:8] = Ed.inf(8)                        # neutral element as P
+    Q[:, :, 8:16] = Ed.inf(8)                       # ... as Q
+    Q[:, :, 16:24] = P[:, :, 16:24]                 # P = Q
+    low = Ed.set(torch.zeros(8, dtype=torch.int32, device="cuda"), None, torch.zeros((8, Ed.nbytes), dtype=torch.uint8, device="cuda"))
+    Q[:, :, 24:32] = low                            # y = 0: order 4
+    e[32:40] = 0
+    f[40:48] = 0
+    e[48:56] = 255
+    f[48:56] = 255
+    keepP, keepQ = P.clone(), Q.clone()
+    x, y, _ = Ed.mul2_get(e, P, f, Q)
+    assert torch.equal(P, keepP) and torch.equal(Q, keepQ)
+    wx, wy, _ = Ed.get(Ed.mul2(e, P, f, Q))
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+    Pt, nb = oracle.ed[C]
+    sp, sq = P.cpu().numpy().view(np.uint64), Q.cpu().numpy().view(np.uint64)
+    he, hf, hx, hy = e.cpu().numpy(), f.cpu().numpy(), x.cpu().numpy(), y.cpu().numpy()
+    for j in list(range(0, 64, 3)) + list(range(64, n, 1999)):
+        p, q, r = Pt(), Pt(), Pt()
+        for c, nm in enumerate(("x", "y", "z")):
+            for i in range(Ed.N):
+                getattr(p, nm)[i] = int(sp[c, i, j])
+                getattr(q, nm)[i] = int(sq[c, i, j])
+        oracle.ecn(C, "mul2")(bytes(he[j]), ctypes.byref(p), bytes(hf[j]), ctypes.byref(q), ctypes.byref(r))
+        ox, oy = ctypes.create_string_buffer(nb), ctypes.create_string_buffer(nb)
+        oracle.ecn(C, "get")(ctypes.byref(r), ox, oy)
+        assert bytes(hx[j]) == ox.raw and bytes(hy[j]) == oy.raw, j
+    none, yo, sx = Ed.mul2_get(e[:100], P[:, :, :100].contiguous(), f[:100], Q[:, :, :100].contiguous(), want_x=False)
+    assert none is None and torch.equal(yo, y[:100]) and torch.equal(sx, (x[:100, -1] & 1).to(torch.int32))

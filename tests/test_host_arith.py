@@ -1,6 +1,6 @@
 """The device arithmetic of the fused kernels, compiled for the HOST and run against the CPU oracle (no GPU needed):
 tools/fe_host_check.hip instantiates the very functions the kernels wrap -- x25519_fe26_one, x448_fe28_one (ladders),
-ed25519_mul_get_one, ed448_mul_get_one (fused scalar multiplication + affine export) and the half-limb column products of
+ed25519_mul_get_one, ed25519_mul2_get_one, ed448_mul_get_one (fused scalar / double multiplication + affine export) and the half-limb column products of
 Field<P_X25519,true>, Field<P_NIST256,true> and Field<P_X448,true> -- with MA_DEV = __host__ __device__, and compares every output with the oracle
 (rfc7748, ecn mul + ecn get, modmul / modsqr), including special points, corner scalars and the limb contract's edge
 classes.  This checks the limb arithmetic and the group-law logic; code generation for gfx950 is checked on the GPU box."""
@@ -24,4 +24,4 @@ def test_device_arithmetic_on_host_against_oracle(oracle, tmp_path):
     p = subprocess.run([exe, "400"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:]
     lines = [l for l in p.stdout.splitlines() if "records" in l]
-    assert len(lines) == 7 and all(" 0 differ" in l for l in lines), p.stdout
+    assert len(lines) == 8 and all(" 0 differ" in l for l in lines), p.stdout

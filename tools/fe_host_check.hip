@@ -74,6 +74,40 @@ static int run_ed25519(int n) {
     return bad;
 }
 
+extern "C" void ecn_ed25519_mul2(const char* e, pt25519* P, const char* f, pt25519* Q, pt25519* R);
+
+// fused double multiplication + get against the oracle's ecn mul2 + ecn get
+static int run_ed25519_mul2(int n) {
+    int bad = 0;
+    for (int it = 0; it < n; it++) {
+        pt25519 P, Q, R;
+        unsigned char e[32], f[32], k[32];
+        for (int i = 0; i < 32; i++) { e[i] = (unsigned char)sm(); f[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
+        ecn_ed25519_gen(&P); ecn_ed25519_mul((const char*)k, &P);
+        for (int i = 0; i < 32; i++) k[i] = (unsigned char)sm();
+        ecn_ed25519_gen(&Q); ecn_ed25519_mul((const char*)k, &Q);
+        if (it % 8 == 1) ecn_ed25519_inf(&P);
+        if (it % 8 == 2) ecn_ed25519_inf(&Q);
+        if (it % 8 == 3) Q = P;                                    // eP + fP
+        if (it % 8 == 4) { char y[32]; memset(y, 0, 32); ecn_ed25519_set(0, nullptr, y, &Q); }   // order 4
+        if (it == 5) memset(e, 0, 32);
+        if (it == 6) memset(f, 0, 32);
+        if (it == 7) { memset(e, 0xff, 32); memset(f, 0xff, 32); }
+        if (it == 13) { memset(e, 0, 32); memset(f, 0, 32); }
+        uint64_t ew[4], fw[4], xw[4], yw[4];
+        for (int w = 0; w < 4; w++) { uint64_t v = 0, u = 0; for (int b = 0; b < 8; b++) { v |= (uint64_t)e[31 - (8 * w + b)] << (8 * b); u |= (uint64_t)f[31 - (8 * w + b)] << (8 * b); } ew[w] = v; fw[w] = u; }
+        ma::ed25519_mul2_get_one<ma::C_ED25519>(ew, P.x, P.y, P.z, fw, Q.x, Q.y, Q.z, xw, yw);
+        char wx[32], wy[32];
+        ecn_ed25519_mul2((const char*)e, &P, (const char*)f, &Q, &R);
+        ecn_ed25519_get(&R, wx, wy);
+        unsigned char gx[32], gy[32];
+        for (int i = 0; i < 32; i++) { gx[i] = (unsigned char)(xw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); gy[i] = (unsigned char)(yw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); }
+        if (memcmp(gx, wx, 32) != 0 || memcmp(gy, wy, 32) != 0) { if (bad < 6) printf("ed25519_mul2_get_one: record %d differs\n", it); bad++; }
+    }
+    printf("ed25519_mul2_get_one: %d records, %d differ from the oracle's ecn mul2 + get\n", n, bad);
+    return bad;
+}
+
 struct pt448 { uint64_t x[8], y[8], z[8]; };
 extern "C" void ecn_ed448_gen(pt448*);
 extern "C" void ecn_ed448_inf(pt448*);
@@ -242,6 +276,7 @@ int main(int argc, char** argv) {
     bad += run_mhalf(n * 50);
     bad += run_mhalf448(n * 25);
     bad += run_ed25519(n / 4 + 16);
+    bad += run_ed25519_mul2(n / 8 + 16);
     bad += run_ed448(n / 16 + 16);
     return bad ? 1 : 0;
 }
