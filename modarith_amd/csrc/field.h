@@ -551,6 +551,83 @@ struct Field {
         half_finish(t, cy, c);
     }
 
+    // The "overflow" pseudo-Mersenne form (secp256k1 as pseudo.py builds it at 64 bits: R = 52 = 2*26, N = 5, 2^260 = mm with
+    // mm = 2^36 + 0x3d10): the reference folds the high rows by lo/hi_ov pieces (pm_modmul above), which sums to exactly
+    // T = L + mm * HI with L / HI the low / high halves of the limb product.  In radix 2^26: the high half columns
+    // 10..18 (without the odd-odd pairs of column 10, which belong to limb row N-1 and stay above bit N R, cf.
+    // pm_modmul_half) are carried into 26-bit digits d_m, each digit folds into column m as d_m * 0x3d10 and into column
+    // m+1 as d_m << 10, columns >= 10 are the value handed to the second pass.  100 + 11 multiply-adds.
+    // Bounds (limbs < 2^54: lo < 2^26, hi < 2^28): a half column holds at most 10 products below 2^56 and fold terms
+    // below 2^41: < 2^60; the second-pass value stays below 2^46.
+    static constexpr bool HALF_OV = FAST && !P::MONTGOMERY && !P::EPM && P::OVERFLOW && RADIX == 52 && N == 5 &&
+                                    (P::MM >> 36) == 1 && (P::MM & 0xfffffffffull) < (1ull << 16);
+    template <bool SQR>
+    static MA_DEV void pm_mul_half_ov(const spint* a, const spint* b, spint* c) {
+        constexpr int H = 26, M = 2 * N;
+        constexpr uint32_t HM = (1u << H) - 1u;
+        constexpr uint32_t MLO = (uint32_t)(P::MM & 0xfffffffffull);         // mm = 2^36 + MLO
+        uint32_t f[M], g[M], f2[M], u[M], d[M + 1];
+        static_for<0, N>([&](auto K) {
+            constexpr int k = K;
+            f[2 * k] = (uint32_t)a[k] & HM;
+            f[2 * k + 1] = (uint32_t)(a[k] >> H);
+            if constexpr (!SQR) {
+                g[2 * k] = (uint32_t)b[k] & HM;
+                g[2 * k + 1] = (uint32_t)(b[k] >> H);
+            }
+        });
+        if constexpr (SQR) static_for<0, M>([&](auto I) { f2[I] = 2u * f[I]; });
+        // one half column of the product; TOP selects the odd-odd pairs of column M (limb row N-1), WRAP the others
+        auto column = [&](auto KK, uint64_t acc, auto only_top, auto skip_top) -> uint64_t {
+            constexpr int k = KK;
+            constexpr int lo = k < M ? 0 : k - (M - 1), hi = k < M ? k : M - 1;
+            static_for<lo, hi + 1>([&](auto II) {
+                constexpr int i = II, j = k - i;
+                constexpr bool top = (k == M) && (i & 1) && (j & 1);
+                if constexpr ((!decltype(only_top)::value || top) && !(decltype(skip_top)::value && top)) {
+                    if constexpr (!SQR) {
+                        acc += (uint64_t)f[i] * g[j];
+                        pin(acc);
+                    } else if constexpr (i <= j) {
+                        acc += (uint64_t)((i < j) ? f2[i] : f[i]) * f[j];
+                        pin(acc);
+                    }
+                }
+            });
+            return acc;
+        };
+        // high part: half columns M .. 2M-2 -> digits d_0 .. d_8, then the rest d_9, d_10
+        uint64_t hcy = 0;
+        static_for<0, M - 1>([&](auto MM_) {
+            constexpr int m = MM_;
+            const uint64_t acc = column(std::integral_constant<int, M + m>{}, hcy, std::false_type{}, std::true_type{});
+            d[m] = (uint32_t)acc & HM;
+            hcy = acc >> H;
+        });
+        d[M - 1] = (uint32_t)hcy & HM;
+        d[M] = (uint32_t)(hcy >> H);
+        // low part + folded digits
+        uint64_t cy = 0;
+        static_for<0, M>([&](auto KK) {
+            constexpr int k = KK;
+            uint64_t acc = column(KK, cy, std::false_type{}, std::false_type{});
+            acc += (uint64_t)d[k] * MLO;
+            pin(acc);
+            if constexpr (k > 0) { acc += (uint64_t)d[k - 1] << 10; pin(acc); }
+            u[k] = (uint32_t)acc & HM;
+            cy = acc >> H;
+        });
+        // what lies at or above bit N R: the running carry, the folds of d_9 / d_10 and the odd-odd pairs of column M
+        uint64_t t = column(std::integral_constant<int, M>{}, cy, std::true_type{}, std::false_type{});
+        t += (uint64_t)d[M] * MLO + ((uint64_t)d[M - 1] << 10) + ((uint64_t)d[M] << (10 + H));
+        spint v[N];
+        static_for<0, N>([&](auto K) {
+            constexpr int k = K;
+            v[k] = (spint)u[2 * k] | ((spint)u[2 * k + 1] << H);
+        });
+        pm_second_pass((dpint)t, v, c);
+    }
+
     // pseudo.py:705-728; (dpint)b sign-extends a negative int exactly as the emitted C does
     static MA_DEV void pm_modmli(const spint* a, int b, spint* c) {
         dpint t = 0;
@@ -973,7 +1050,8 @@ struct Field {
             else if constexpr (CHAINED) monty_mul_chain<false>(a, b, c);
             else monty_mul<false>(a, b, c);
         } else {
-            if constexpr (HALF) pm_modmul_half(a, b, c);
+            if constexpr (HALF_OV) pm_mul_half_ov<false>(a, b, c);
+            else if constexpr (HALF) pm_modmul_half(a, b, c);
             else if constexpr (CHAINED) pm_modmul_chain(a, b, c);
             else pm_modmul(a, b, c);
         }
@@ -985,7 +1063,8 @@ struct Field {
             else if constexpr (CHAINED) monty_mul_chain<true>(a, a, c);
             else monty_mul<true>(a, a, c);
         } else {
-            if constexpr (HALF) pm_modsqr_half(a, c);
+            if constexpr (HALF_OV) pm_mul_half_ov<true>(a, a, c);
+            else if constexpr (HALF) pm_modsqr_half(a, c);
             else if constexpr (CHAINED) pm_modsqr_chain(a, c);
             else pm_modsqr(a, c);
         }

@@ -9,6 +9,7 @@
 #include "../modarith_amd/csrc/generated/curve_ED25519.h"
 #include "../modarith_amd/csrc/generated/params_NIST256.h"
 #include "../modarith_amd/csrc/generated/params_X448.h"
+#include "../modarith_amd/csrc/generated/params_SECP256K1.h"
 #include "../modarith_amd/csrc/ed26.h"
 #include "../modarith_amd/csrc/ed28.h"
 #include <stdio.h>
@@ -242,6 +243,32 @@ static int run_mhalf448(int n) {
     return bad;
 }
 
+// Field<P_SECP256K1, true>'s half-limb products of the "overflow" pseudo-Mersenne form against the exact 128-bit restatement
+// compiled from the same header (Field<P_SECP256K1, false>, which the GPU suite pins to the reference's golden vectors)
+static int run_half_ov(int n) {
+    using F = ma::Field<ma::P_SECP256K1, true>;
+    using X = ma::Field<ma::P_SECP256K1, false>;
+    static_assert(F::HALF_OV, "half-limb overflow-form products are expected for SECP256K1");
+    int bad = 0;
+    const uint64_t edge[] = {0, 1, (1ull << 52) - 1, 1ull << 52, (1ull << 53) - 1, (1ull << 54) - 1, (1ull << 26) - 1, 1ull << 26, 0xffffefffffc2full};
+    for (int it = 0; it < n; it++) {
+        uint64_t a[5], b[5], got[5], want[5];
+        for (int i = 0; i < 5; i++) {
+            uint64_t r = sm();
+            a[i] = (r % 10 < 9 && it % 3) ? edge[r % 9] : (sm() & ((1ull << 54) - 1));
+            r = sm();
+            b[i] = (r % 10 < 9 && it % 3 == 1) ? edge[r % 9] : (sm() & ((1ull << 54) - 1));
+        }
+        if (it == 0) for (int i = 0; i < 5; i++) a[i] = b[i] = (1ull << 54) - 1;
+        int d = 0;
+        F::modmul(a, b, got); X::modmul(a, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::modsqr(a, got); X::modsqr(a, want); d |= memcmp(got, want, sizeof got) != 0;
+        if (d) { if (bad < 4) printf("SECP256K1 half-limb: record %d differs\n", it); bad++; }
+    }
+    printf("Field<P_SECP256K1,true> half-limb modmul/modsqr: %d records, %d differ from the exact products\n", n, bad);
+    return bad;
+}
+
 template <int NW, class Fn, class Ref>
 static int run(const char* name, int n, Fn fn, Ref ref) {
     int bad = 0;
@@ -275,6 +302,7 @@ int main(int argc, char** argv) {
     bad += run_half(n * 50);
     bad += run_mhalf(n * 50);
     bad += run_mhalf448(n * 25);
+    bad += run_half_ov(n * 50);
     bad += run_ed25519(n / 4 + 16);
     bad += run_ed25519_mul2(n / 8 + 16);
     bad += run_ed448(n / 16 + 16);
