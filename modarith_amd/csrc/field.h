@@ -122,7 +122,10 @@ struct Field {
     static constexpr int RADIX = P::RADIX;
     static constexpr spint Q = (spint)1 << RADIX;
     static constexpr spint MASK = Q - 1;
-    static constexpr bool FAST = FAST_ && (P::SPLIT > 0);
+    // (FOLD52: the 5 x 52 pseudo-Mersenne primes with a small mm -- 2^256-189 -- have no provable split form, mm * a does not
+    // fit the three-accumulator scheme, but the half-limb columns with digit folding below do: pm_mul_half_ov)
+    static constexpr bool FOLD52 = FAST_ && !P::MONTGOMERY && P::EPM && !P::OVERFLOW && P::RADIX == 52 && P::N == 5 && P::MM < (1ull << 16);
+    static constexpr bool FAST = FAST_ && (P::SPLIT > 0 || FOLD52);
     using W = Wide<FAST, (P::SPLIT > 0 ? P::SPLIT : 32)>;
     using Opd = typename W::Opd;
     using Col = typename W::Col;
@@ -559,13 +562,18 @@ struct Field {
     // m+1 as d_m << 10, columns >= 10 are the value handed to the second pass.  100 + 11 multiply-adds.
     // Bounds (limbs < 2^54: lo < 2^26, hi < 2^28): a half column holds at most 10 products below 2^56 and fold terms
     // below 2^41: < 2^60; the second-pass value stays below 2^46.
-    static constexpr bool HALF_OV = FAST && !P::MONTGOMERY && !P::EPM && P::OVERFLOW && RADIX == 52 && N == 5 &&
-                                    (P::MM >> 36) == 1 && (P::MM & 0xfffffffffull) < (1ull << 16);
+    // The same routine serves FOLD52 (mm < 2^16, EPM form: mm * a_k times b_j sums to the same T = L + mm * HI), with the
+    // 2^36 part absent.  There the reference itself wraps mm * a_k at 64 bits, so "inside the contract" means limbs below
+    // 2^64 / mm (2^52.4 for mm = 0xbd0) -- true of everything the field functions return (masked digits plus a small
+    // carry), which is all the curve layer ever multiplies.
+    static constexpr bool HALF_OV = FAST && !P::MONTGOMERY && RADIX == 52 && N == 5 &&
+                                    ((!P::EPM && P::OVERFLOW && (P::MM >> 36) == 1 && (P::MM & 0xfffffffffull) < (1ull << 16)) || FOLD52);
     template <bool SQR>
     static MA_DEV void pm_mul_half_ov(const spint* a, const spint* b, spint* c) {
         constexpr int H = 26, M = 2 * N;
         constexpr uint32_t HM = (1u << H) - 1u;
-        constexpr uint32_t MLO = (uint32_t)(P::MM & 0xfffffffffull);         // mm = 2^36 + MLO
+        constexpr uint32_t MLO = (uint32_t)(P::MM & 0xfffffffffull);         // mm = MHI * 2^36 + MLO
+        constexpr bool MHI = (P::MM >> 36) != 0;
         uint32_t f[M], g[M], f2[M], u[M], d[M + 1];
         static_for<0, N>([&](auto K) {
             constexpr int k = K;
@@ -613,13 +621,14 @@ struct Field {
             uint64_t acc = column(KK, cy, std::false_type{}, std::false_type{});
             acc += (uint64_t)d[k] * MLO;
             pin(acc);
-            if constexpr (k > 0) { acc += (uint64_t)d[k - 1] << 10; pin(acc); }
+            if constexpr (k > 0 && MHI) { acc += (uint64_t)d[k - 1] << 10; pin(acc); }
             u[k] = (uint32_t)acc & HM;
             cy = acc >> H;
         });
         // what lies at or above bit N R: the running carry, the folds of d_9 / d_10 and the odd-odd pairs of column M
         uint64_t t = column(std::integral_constant<int, M>{}, cy, std::true_type{}, std::false_type{});
-        t += (uint64_t)d[M] * MLO + ((uint64_t)d[M - 1] << 10) + ((uint64_t)d[M] << (10 + H));
+        t += (uint64_t)d[M] * MLO;
+        if constexpr (MHI) t += ((uint64_t)d[M - 1] << 10) + ((uint64_t)d[M] << (10 + H));
         spint v[N];
         static_for<0, N>([&](auto K) {
             constexpr int k = K;

@@ -10,6 +10,7 @@
 #include "../modarith_amd/csrc/generated/params_NIST256.h"
 #include "../modarith_amd/csrc/generated/params_X448.h"
 #include "../modarith_amd/csrc/generated/params_SECP256K1.h"
+#include "../modarith_amd/csrc/generated/params_NUMS256W.h"
 #include "../modarith_amd/csrc/ed26.h"
 #include "../modarith_amd/csrc/ed28.h"
 #include <stdio.h>
@@ -269,6 +270,33 @@ static int run_half_ov(int n) {
     return bad;
 }
 
+// Field<P_NUMS256W, true> (half-limb columns with digit folding, mm = 0xbd0) against the exact products of the same header;
+// limbs below 2^52.3: beyond 2^64 / mm the reference's own mm * a wraps and there is nothing to agree with
+static int run_fold52(int n) {
+    using F = ma::Field<ma::P_NUMS256W, true>;
+    using X = ma::Field<ma::P_NUMS256W, false>;
+    static_assert(F::FOLD52 && F::HALF_OV, "digit-folding half-limb products are expected for NUMS256W");
+    int bad = 0;
+    const uint64_t top = 5ull << 50;      // 2^52.32
+    const uint64_t edge[] = {0, 1, (1ull << 52) - 1, 1ull << 52, top - 1, (1ull << 52) + 12345, (1ull << 26) - 1, 1ull << 26, (1ull << 52) - 189};
+    for (int it = 0; it < n; it++) {
+        uint64_t a[5], b[5], got[5], want[5];
+        for (int i = 0; i < 5; i++) {
+            uint64_t r = sm();
+            a[i] = (r % 10 < 9 && it % 3) ? edge[r % 9] : (sm() % top);
+            r = sm();
+            b[i] = (r % 10 < 9 && it % 3 == 1) ? edge[r % 9] : (sm() % top);
+        }
+        if (it == 0) for (int i = 0; i < 5; i++) a[i] = b[i] = top - 1;
+        int d = 0;
+        F::modmul(a, b, got); X::modmul(a, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::modsqr(a, got); X::modsqr(a, want); d |= memcmp(got, want, sizeof got) != 0;
+        if (d) { if (bad < 4) printf("NUMS256W half-limb: record %d differs\n", it); bad++; }
+    }
+    printf("Field<P_NUMS256W,true> half-limb modmul/modsqr: %d records, %d differ from the exact products\n", n, bad);
+    return bad;
+}
+
 template <int NW, class Fn, class Ref>
 static int run(const char* name, int n, Fn fn, Ref ref) {
     int bad = 0;
@@ -303,6 +331,7 @@ int main(int argc, char** argv) {
     bad += run_mhalf(n * 50);
     bad += run_mhalf448(n * 25);
     bad += run_half_ov(n * 50);
+    bad += run_fold52(n * 50);
     bad += run_ed25519(n / 4 + 16);
     bad += run_ed25519_mul2(n / 8 + 16);
     bad += run_ed448(n / 16 + 16);
