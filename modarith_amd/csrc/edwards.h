@@ -19,6 +19,7 @@ struct Edwards : CurveOps<Edwards<C>, typename C::FieldParams> {
     using Base::cpy;
     static constexpr int N = P::N;
     static constexpr bool HAS_Y_ONLY_SET = true;    // ecnXXXset accepts y + sign of x (edwards.c:362-365)
+    static constexpr bool SELECT_FROM_NEUTRAL = true;    // curve.h select(): start the table scan from the neutral element
 
     // e <- d*e  with the sign handling of edwards.c:81-98
     static MA_DEV void bterm(spint* e) {

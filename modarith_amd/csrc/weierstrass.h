@@ -20,6 +20,7 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
     using Base::cpy;
     static constexpr int N = P::N;
     static constexpr bool HAS_Y_ONLY_SET = false;   // weierstrass.c:417-428: x is mandatory
+    static constexpr bool SELECT_FROM_NEUTRAL = (P::N < 9);    // curve.h select(): start the table scan from the neutral element
 
     static MA_DEV void const_b(spint* b) { static_for<0, N>([&](auto I) { b[I] = C::b(I); }); }
     static MA_DEV void const_b3(spint* b) { static_for<0, N>([&](auto I) { b[I] = C::b3(I); }); }
