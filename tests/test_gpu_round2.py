@@ -274,3 +274,35 @@ def test_curve_soak_projective_limbs(oracle, torch_cuda, name):
     getattr(oracle.lib, "ecn_%s_batch_mul" % name.lower())(vp(he), vp(want), n, n)
     got = C.mul(e, P.clone()).cpu().numpy().view(np.uint64).reshape(3 * C.N, n)
     assert np.array_equal(got, want), name
+
+
+# ---------------------------------------------------------------- coarse rate floors (catch codegen regressions, not tuning)
+RATE_FLOORS = {"ED25519": 2.0e7, "NIST256": 9e6, "ED448": 5e6, "NIST384": 3e6, "SECP256K1": 1.2e7, "NUMS256W": 1.0e7, "NUMS256E": 1.8e7,
+               "ED248": 1.7e7, "ED376": 7e6, "NIST521": 1.2e6, "ED500": 2.2e6}
+
+
+@pytest.mark.skipif(os.environ.get("MA_POLICY_CHILD") == "1", reason="timing belongs to the parent suite")
+@pytest.mark.parametrize("name", ALL_CURVES)
+def test_curve_mul_rate_floor(torch_cuda, name):
+    """`ecn mul` on one resident grid (2^17 points) must reach 40 % of the documented rate: a register-allocation accident in
+    one of these 250-VGPR kernels (spills inside the window loop) costs a factor, not per cents -- NIST P-521 ran 8x
+    slower for a round without any test noticing"""
+    import time
+    torch = torch_cuda
+    from modarith_amd.edwards import Curve
+    C = Curve(name)
+    n = 1 << 17
+    g = torch.Generator(device="cuda").manual_seed(5)
+    e = torch.randint(0, 256, (n, C.nbytes), dtype=torch.uint8, device="cuda", generator=g)
+    P = C.gen(n)
+    C.mul(e[:4096].contiguous(), C.gen(4096))
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(2):
+        Q = P.clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        C.mul(e, Q)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    assert n / best >= RATE_FLOORS[name], "%s ecn mul %.3g/s, floor %.3g/s" % (name, n / best, RATE_FLOORS[name])
