@@ -110,11 +110,21 @@ template <class P> struct OpRedcAuto {
         Field<P, false>::redc(a, c);
     }
 };
+// The 8-byte-per-lane kernels (EPT = 1: unaligned buffers, odd limb strides, the last element of an odd batch) run the exact
+// products instead of the per-wave choice: compiled with EPT = 1 the two-path functors were allocated 217 (5 limbs) to 512
+// (8 limbs: 256 VGPRs + 256 AGPRs, a v_accvgpr copy around every multiply-add) registers, and unaligned X448 batches
+// streamed at 2.0 TB/s.  The exact path is right for every input, needs 66-100 VGPRs, and at 8 bytes per lane the kernel
+// is not faster than its arithmetic anyway.
+template <class Op> struct ScalarOp { using type = Op; };
+template <class P> struct ScalarOp<OpMulAuto<P>> { using type = OpMul<P, false>; };
 template <class P, bool FAST = false> struct OpSqr { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::modsqr(a, c); } };
+template <class P> struct ScalarOp<OpSqrAuto<P>> { using type = OpSqr<P, false>; };
 template <class P> struct OpNeg { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modneg(a, c); } };
 template <class P> struct OpNegLazy { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modneg_lazy(a, c); } };
 template <class P, bool FAST = false> struct OpNres { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::nres(a, c); } };
 template <class P, bool FAST = false> struct OpRedc { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::redc(a, c); } };
+template <class P> struct ScalarOp<OpNresAuto<P>> { using type = OpNres<P, false>; };
+template <class P> struct ScalarOp<OpRedcAuto<P>> { using type = OpRedc<P, false>; };
 template <class P> struct OpCpy { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modcpy(a, c); } };
 template <class P, bool FAST = false> struct OpInv { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::modinv(a, nullptr, c); } };
 template <class P, bool FAST = false> struct OpSqrt { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::modsqrt(a, nullptr, c); } };
