@@ -155,35 +155,6 @@ __global__ __launch_bounds__(BLOCK) void k_binary(const spint* a, const spint* b
     }
 }
 
-// the same with the NEXT iteration's operand rows requested before the current product is computed and stored: the
-// loads of iteration i+1 are in flight while iteration i does its arithmetic (two-stage software pipeline)
-template <class P, class Op, int EPT>
-__global__ __launch_bounds__(BLOCK) void k_binary_pipe(const spint* a, const spint* b,
-                                                       spint* c, size_t nthreads, size_t lda, size_t ldb, size_t ldc) {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= nthreads) return;
-    const size_t stride = (size_t)gridDim.x * BLOCK;
-    spint x[EPT][P::N], y[EPT][P::N];
-    load_soa<P, EPT>(a, lda, t, x);
-    load_soa<P, EPT>(b, ldb, t, y);
-    for (;;) {
-        const size_t tn = t + stride;
-        const bool more = tn < nthreads;
-        spint xn[EPT][P::N], yn[EPT][P::N], z[EPT][P::N];
-        if (more) {
-            load_soa<P, EPT>(a, lda, tn, xn);
-            load_soa<P, EPT>(b, ldb, tn, yn);
-        }
-#pragma unroll
-        for (int e = 0; e < EPT; e++) Op::apply(x[e], y[e], z[e]);
-        store_soa<P, EPT>(c, ldc, t, z);
-        if (!more) break;
-#pragma unroll
-        for (int e = 0; e < EPT; e++) static_for<0, P::N>([&](auto I) { x[e][I] = xn[e][I]; y[e][I] = yn[e][I]; });
-        t = tn;
-    }
-}
-
 // c[j] = op(a[j]) for the long chains (modinv, modsqrt, modpro): same body as k_unary below, but compiled for at least
 // three waves per SIMD on the small fields -- with only __launch_bounds__(256) the register allocator may take 512
 // VGPRs, and it does (400 for the pinned half-limb products of modinv): one wave per SIMD on a latency-bound chain

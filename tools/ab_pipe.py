@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""A/B on one box, one process: plain grid-stride k_binary against the two-stage pipelined k_binary_pipe (MA_BINARY_PIPE=1),
-modcpy as the streaming control; X25519 / NIST256 / X448 at 2^24 elements, interleaved rounds, median of 7."""
+"""One box, one process: modmul against its streaming controls modadd (same three streams, no multiplication) and modcpy;
+X25519 / NIST256 / X448 at 2^24 elements, interleaved rounds, median of 7.  (Round 2 also ran a two-stage software-pipelined
+variant of the binary kernel through this script -- next iteration's row loads in flight during the product, 148 VGPRs --
+and measured no difference: X25519 5 564 vs 5 564 GB/s, NIST256 5 625 vs 5 613, X448 5 252 vs 5 309; the variant was
+removed again)"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,11 +18,10 @@ for P in sys.argv[1:] or ["X25519", "NIST256", "X448"]:
         for _ in range(reps): fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
-    res = {"plain": [], "pipe": [], "modcpy": [], "modadd": []}
+    res = {"modmul": [], "modcpy": [], "modadd": []}
     for _ in range(7):
-        os.environ["MA_BINARY_PIPE"] = "0"; res["plain"].append(rate(lambda: F.modmul(a, b, out=c)))
-        os.environ["MA_BINARY_PIPE"] = "1"; res["pipe"].append(rate(lambda: F.modmul(a, b, out=c)))
-        os.environ["MA_BINARY_PIPE"] = "0"; res["modadd"].append(rate(lambda: F.modadd(a, b, out=c)))
+        res["modmul"].append(rate(lambda: F.modmul(a, b, out=c)))
+        res["modadd"].append(rate(lambda: F.modadd(a, b, out=c)))
         res["modcpy"].append(rate(lambda: F.modcpy(a, out=c)))
     for k, v in res.items():
         ms = statistics.median(v)
