@@ -316,6 +316,9 @@ int ecn_ed25519_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y
 size_t ecn_ed25519_mul2_get_workspace_bytes(size_t n);
 int ecn_ed25519_mul2_get_batch(const char *e, const ma_spint *P, const char *f, const ma_spint *Q, char *x, char *y, int *sign,
                                size_t n, size_t ld, void *workspace, size_t workspace_bytes, void *stream);
+size_t ecn_ed448_mul2_get_workspace_bytes(size_t n);
+int ecn_ed448_mul2_get_batch(const char *e, const ma_spint *P, const char *f, const ma_spint *Q, char *x, char *y, int *sign,
+                             size_t n, size_t ld, void *workspace, size_t workspace_bytes, void *stream);
 size_t ecn_ed448_mul_get_workspace_bytes(size_t n);
 int ecn_ed448_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
                             void *workspace, size_t workspace_bytes, void *stream);

@@ -86,7 +86,8 @@ struct Ed28 {
     }
     // common tail of the additions (a = 1, d = -39081): with A = X1 X2, B = Y1 Y2, Cc = 39081 T1 T2 (= -C), D = Z1 Z2,
     // M = (X1+Y1)(X2+Y2):  E = M - A - B, F = D - C = D + Cc, G = D + C = D - Cc, H = B - A;  X3 = E F, Y3 = G H, Z3 = F G
-    static MA_DEV void add_tail(const uint32_t* A, const uint32_t* B, const uint32_t* Cc, const uint32_t* D, const uint32_t* M, Ext& p) {
+    static MA_DEV void add_tail(const uint32_t* A, const uint32_t* B, const uint32_t* Cc, const uint32_t* D, const uint32_t* M, Ext& p,
+                                bool want_t = false) {
         uint32_t E[16], Ff[16], G[16], H[16], AB[16];
         F::add(A, B, AB);           // < 2^29
         F::sub(M, AB, E);           // tight
@@ -96,10 +97,11 @@ struct Ed28 {
         F::mul_k(E, Ff, p.X);
         F::mul_k(G, H, p.Y);
         F::mul_k(G, Ff, p.Z);
+        if (want_t) F::mul_k(E, H, p.T);    // (wave-uniform flag: one copy of the addition serves both uses)
     }
     // P += Q, Q affine and cached as (x, y, td = 39081 x y), already sign-adjusted: xs, tds below 2^29, y tight.
     // Reads T of P; T of the sum is not produced (a doubling follows).
-    static MA_DEV void add_cached(Ext& p, const uint32_t* xs, const uint32_t* y, const uint32_t* tds) {
+    static MA_DEV void add_cached(Ext& p, const uint32_t* xs, const uint32_t* y, const uint32_t* tds, bool want_t = false) {
         uint32_t A[16], B[16], Cc[16], M[16], s1[16], s2[16];
         F::mul_k(p.X, xs, A);
         F::mul_k(p.Y, y, B);
@@ -107,7 +109,7 @@ struct Ed28 {
         F::add(p.X, p.Y, s1);       // < 2^29
         F::add(xs, y, s2);          // < 1.5 * 2^29
         F::mul(s1, s2, M);
-        add_tail(A, B, Cc, p.Z, M, p);
+        add_tail(A, B, Cc, p.Z, M, p, want_t);
     }
     // P += Q, both extended; used once, to build 3P
     static MA_DEV void add_ext(Ext& p, const Ext& q) {
@@ -269,6 +271,151 @@ MA_DEV void ed448_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y
     }
 
     // ---- affine, canonical (ecnXXXget: edwards.c:221-239)
+    uint32_t zi[16], ax[16], ay[16];
+    F::invert(R.Z, zi);
+    F::mul_k(R.X, zi, ax);
+    F::mul_k(R.Y, zi, ay);
+    F::to_words(ax, xw);
+    F::to_words(ay, yw);
+}
+
+// Fused double multiplication + affine export for ED448: the affine coordinates of e*P + f*Q (ecnXXXmul2 followed by
+// ecnXXXget, the verification pattern ed448.c:305).  Both scalars in 225 signed 2-bit digits (e' = e + sum 2*4^i,
+// digit = window - 2 in [-2, 1]); the tables {P, 2P}, {Q, 2Q} take the four entry slots of the same per-lane workspace
+// as ed448_mul_get_one; per window two doublings and two additions (one rolled copy of each in the instruction stream).
+MA_DEV void ed448_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
+                               const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
+                               uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
+    using E = Ed28;
+    using F = Fe28;
+    E::Ext R;
+    {
+        E::Ext A1, A2, B1, B2;
+        uint32_t px[16], py[16], pz[16];
+        auto ext = [&](const spint* X, const spint* Y, const spint* Z, E::Ext& o) {
+            E::from56(X, px);
+            E::from56(Y, py);
+            E::from56(Z, pz);
+            F::mul_k(px, pz, o.X);
+            F::mul_k(py, pz, o.Y);
+            F::sqr_k(pz, o.Z);
+            F::mul_k(px, py, o.T);
+        };
+        ext(PX, PY, PZ, A1);
+        A2 = A1;
+        E::dbl<false>(A2);
+        ext(QX, QY, QZ, B1);
+        B2 = B1;
+        E::dbl<false>(B2);
+        uint32_t z12[16], z123[16], inv[16], i1[16], i2[16], i3[16], i4[16];
+        F::mul_k(A1.Z, A2.Z, z12);
+        F::mul_k(z12, B1.Z, z123);
+        F::mul_k(z123, B2.Z, inv);
+        F::invert(inv, inv);
+        F::mul_k(inv, z123, i4);
+        F::mul_k(inv, B2.Z, inv);
+        F::mul_k(inv, z12, i3);
+        F::mul_k(inv, B1.Z, inv);
+        F::mul_k(inv, A1.Z, i2);
+        F::mul_k(inv, A2.Z, i1);
+        auto cache = [&](const E::Ext& p, const uint32_t* zi, int entry) {
+            uint32_t x[16], y[16], s[16];
+            uint64_t w[7];
+            F::mul_k(p.X, zi, x);
+            F::mul_k(p.Y, zi, y);
+            F::to_words(x, w);
+            static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + K) * tstride] = w[K]; });
+            F::to_words(y, w);
+            static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + 7 + K) * tstride] = w[K]; });
+            F::mul_k(x, y, s);
+            F::mul_small<E::D_ABS>(s, s);
+            F::to_words(s, w);
+            static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + 14 + K) * tstride] = w[K]; });
+        };
+        cache(A1, i1, 0);
+        cache(A2, i2, 1);
+        cache(B1, i3, 2);
+        cache(B2, i4, 3);
+    }
+    // e' = e + sum_{i<225} 2*4^i (450 bits), left-aligned in 8 words
+    uint64_t we[8], wf[8];
+    auto recode = [&](const uint64_t* in, uint64_t* w) {
+        constexpr auto cw = [](int k) {
+            uint64_t v = 0;
+            for (int b = 0; b < 64; b++) {
+                const int pos = 64 * k + b;
+                if (pos < 450 && pos % 2 == 1) v |= (uint64_t)1 << b;
+            }
+            return v;
+        };
+        unsigned __int128 acc = 0;
+        uint64_t s[8];
+        static_for<0, 8>([&](auto K) {
+            constexpr int k = K;
+            acc += (unsigned __int128)(k < 7 ? in[k < 7 ? k : 0] : 0) + cw(k);
+            s[k] = (uint64_t)acc;
+            acc >>= 64;
+        });
+        static_for<0, 8>([&](auto KK) {
+            constexpr int k = 7 - KK;
+            w[k] = s[k] << 62;
+            if constexpr (k > 0) w[k] |= s[k - 1] >> 2;
+        });
+    };
+    recode(ew, we);
+    recode(fw, wf);
+    F::set(0, R.X);
+    F::set(1, R.Y);
+    F::set(1, R.Z);
+    F::set(0, R.T);
+#pragma unroll 1
+    for (int i = 0; i < 225; i++) {
+        if (i != 0) {
+#pragma unroll 1
+            for (int j = 0; j < 2; j++) E::dbl(R, j == 1);
+        }
+        auto take = [&](uint64_t* w) -> int {                   // (static register indices only)
+            const int d = (int)(uint32_t)(w[7] >> 62) - 2;      // [-2, 1]
+            static_for<0, 8>([&](auto KK) {
+                constexpr int k = 7 - KK;
+                w[k] <<= 2;
+                if constexpr (k > 0) w[k] |= w[k - 1] >> 62;
+            });
+            return d;
+        };
+        const int de = take(we), df = take(wf);
+#pragma unroll 1
+        for (int which = 0; which < 2; which++) {               // 0: digit of e, table {P, 2P};  1: digit of f, table {Q, 2Q}
+            const int dgt = which ? df : de;
+            const bool neg = dgt < 0;
+            const uint32_t m = (uint32_t)(neg ? -dgt : dgt);
+            uint64_t sel[21];
+            static_for<0, 21>([&](auto K) { sel[K] = (K == 7) ? 1u : 0u; });
+            uint64_t ent[2][21];
+            static_for<0, 2>([&](auto EI) {
+                static_for<0, 21>([&](auto K) { ent[EI][K] = tab[(size_t)((2 * which + EI) * 21 + K) * tstride]; });
+            });
+            static_for<0, 2>([&](auto EI) {
+                const bool hit = (m == (uint32_t)(EI + 1));
+                static_for<0, 21>([&](auto K) {
+                    const uint64_t a = ent[EI][K], b = sel[K];
+                    sel[K] = hit ? a : b;
+                });
+            });
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::: "memory");
+#endif
+            uint32_t xs[16], ys[16], ts[16], nx[16], nt[16];
+            F::from_words(sel, xs);
+            F::from_words(sel + 7, ys);
+            F::from_words(sel + 14, ts);
+            E::neg2p(xs, nx);
+            E::neg2p(ts, nt);
+            F::select(neg, xs, nx, xs);
+            F::select(neg, ts, nt, ts);
+            E::add_cached(R, xs, ys, ts, which == 0);
+        }
+    }
     uint32_t zi[16], ax[16], ay[16];
     F::invert(R.Z, zi);
     F::mul_k(R.X, zi, ax);

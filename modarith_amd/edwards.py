@@ -130,7 +130,7 @@ class Edwards:
                    sign.data_ptr(), n, n, self._fws.data_ptr() if need else None, need, _stream(self.device))
         return x, y, sign
 
-    FUSED2 = ("ED25519",)      # curves with a fused mul2 + get kernel
+    FUSED2 = ("ED25519", "ED448")      # curves with a fused mul2 + get kernel
 
     def mul2_get(self, e, P, f, Q, want_x: bool = True, want_y: bool = True):
         """ecnXXXmul2 followed by ecnXXXget (the verification pattern, ed448.c:305) in ONE kernel: the affine coordinates of
@@ -141,9 +141,12 @@ class Edwards:
         x = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device) if want_x else None
         y = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device) if want_y else None
         sign = torch.empty(n, dtype=torch.int32, device=self.device)
+        need = int(getattr(self.lib, "ecn_%s_mul2_get_workspace_bytes" % self.name)(n))
+        if need and (self._fws is None or self._fws.numel() < need):
+            self._fws = torch.empty(need, dtype=torch.uint8, device=self.device)
         self._call("mul2_get", self._scalars(e, n), P.data_ptr(), self._scalars(f, n), Q.data_ptr(),
-                   None if x is None else x.data_ptr(), None if y is None else y.data_ptr(), sign.data_ptr(), n, n, None, 0,
-                   _stream(self.device))
+                   None if x is None else x.data_ptr(), None if y is None else y.data_ptr(), sign.data_ptr(), n, n,
+                   self._fws.data_ptr() if need else None, need, _stream(self.device))
         return x, y, sign
 
     def _workspace(self, n: int):

@@ -297,6 +297,38 @@ static int run_fold52(int n) {
     return bad;
 }
 
+extern "C" void ecn_ed448_mul2(const char* e, pt448* P, const char* f, pt448* Q, pt448* R);
+
+static int run_ed448_mul2(int n) {
+    int bad = 0;
+    for (int it = 0; it < n; it++) {
+        pt448 P, Q, R;
+        unsigned char e[56], f[56], k[56];
+        for (int i = 0; i < 56; i++) { e[i] = (unsigned char)sm(); f[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
+        ecn_ed448_gen(&P); ecn_ed448_mul((const char*)k, &P);
+        for (int i = 0; i < 56; i++) k[i] = (unsigned char)sm();
+        ecn_ed448_gen(&Q); ecn_ed448_mul((const char*)k, &Q);
+        if (it % 8 == 1) ecn_ed448_inf(&P);
+        if (it % 8 == 2) ecn_ed448_inf(&Q);
+        if (it % 8 == 3) Q = P;
+        if (it % 8 == 4) { char y[56]; memset(y, 0, 56); ecn_ed448_set(0, nullptr, y, &Q); }
+        if (it == 5) memset(e, 0, 56);
+        if (it == 6) memset(f, 0, 56);
+        if (it == 7) { memset(e, 0xff, 56); memset(f, 0xff, 56); }
+        uint64_t ew[7], fw[7], xw[7], yw[7], tab[ma::ED448_TABLE_WORDS];
+        for (int w = 0; w < 7; w++) { uint64_t v = 0, u = 0; for (int b = 0; b < 8; b++) { v |= (uint64_t)e[55 - (8 * w + b)] << (8 * b); u |= (uint64_t)f[55 - (8 * w + b)] << (8 * b); } ew[w] = v; fw[w] = u; }
+        ma::ed448_mul2_get_one(ew, P.x, P.y, P.z, fw, Q.x, Q.y, Q.z, tab, 1, xw, yw);
+        char wx[56], wy[56];
+        ecn_ed448_mul2((const char*)e, &P, (const char*)f, &Q, &R);
+        ecn_ed448_get(&R, wx, wy);
+        unsigned char gx[56], gy[56];
+        for (int i = 0; i < 56; i++) { gx[i] = (unsigned char)(xw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); gy[i] = (unsigned char)(yw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); }
+        if (memcmp(gx, wx, 56) != 0 || memcmp(gy, wy, 56) != 0) { if (bad < 6) printf("ed448_mul2_get_one: record %d differs\n", it); bad++; }
+    }
+    printf("ed448_mul2_get_one: %d records, %d differ from the oracle's ecn mul2 + get\n", n, bad);
+    return bad;
+}
+
 template <int NW, class Fn, class Ref>
 static int run(const char* name, int n, Fn fn, Ref ref) {
     int bad = 0;
@@ -335,5 +367,6 @@ int main(int argc, char** argv) {
     bad += run_ed25519(n / 4 + 16);
     bad += run_ed25519_mul2(n / 8 + 16);
     bad += run_ed448(n / 16 + 16);
+    bad += run_ed448_mul2(n / 32 + 16);
     return bad ? 1 : 0;
 }
