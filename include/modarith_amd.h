@@ -150,6 +150,9 @@ int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbi
     int modis1_##P##_batch(const ma_spint *a, int *out, size_t n, size_t ld, void *stream);                             \
     int modis0_##P##_batch(const ma_spint *a, int *out, size_t n, size_t ld, void *stream);                             \
     int modsign_##P##_batch(const ma_spint *a, int *out, size_t n, size_t ld, void *stream);                            \
+    /* not in field.c: out[j] = 1 when every limb of element j is below 2^(Radix+2), the limb budget the generators'  */ \
+    /* functions keep (SURVEY 8b "Errors") and the curve-layer kernels rely on; 0 flags a fabricated operand             */ \
+    int modlimbs_##P##_batch(const ma_spint *a, int *out, size_t n, size_t ld, void *stream);                           \
     int modcmp_##P##_batch(const ma_spint *a, const ma_spint *b, int *out, size_t n, size_t ld, void *stream);          \
     /* fills */                                                                                                         \
     int modzer_##P##_batch(ma_spint *a, size_t n, size_t ld, void *stream);                                             \

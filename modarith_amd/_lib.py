@@ -57,6 +57,7 @@ _SIG = {
     "modis1": [_P, _P, c_size_t, c_size_t, _P],
     "modis0": [_P, _P, c_size_t, c_size_t, _P],
     "modsign": [_P, _P, c_size_t, c_size_t, _P],
+    "modlimbs": [_P, _P, c_size_t, c_size_t, _P],
     "modcmp": [_P, _P, _P, c_size_t, c_size_t, _P],
     "modzer": [_P, c_size_t, c_size_t, _P],
     "modone": [_P, c_size_t, c_size_t, _P],

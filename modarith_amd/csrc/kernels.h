@@ -276,7 +276,7 @@ __global__ __launch_bounds__(BLOCK) void k_cond(const int* d, spint* g, spint* f
 }
 
 // in-place normalisers / predicates; KIND selects the function, optional int result per element
-enum { K_MODFSB = 0, K_FLATTEN, K_MODIS1, K_MODIS0, K_MODSIGN, K_MODHAF, K_MODQR };
+enum { K_MODFSB = 0, K_FLATTEN, K_MODIS1, K_MODIS0, K_MODSIGN, K_MODHAF, K_MODQR, K_MODLIMBS };
 template <class P, int KIND>
 __global__ __launch_bounds__(BLOCK) void k_inplace(spint* a, int* out, size_t n, size_t ld) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(BLOCK) void k_inplace(spint* a, int* out, size_t n,
         if constexpr (KIND == K_MODIS1) r = Field<P>::modis1(x[0]);
         if constexpr (KIND == K_MODIS0) r = Field<P>::modis0(x[0]);
         if constexpr (KIND == K_MODSIGN) r = Field<P>::modsign(x[0]);
+        if constexpr (KIND == K_MODLIMBS) r = in_split_contract<P>(x[0]) ? 1 : 0;   // every limb < 2^(Radix+2)
         if constexpr (KIND == K_MODHAF) { Field<P>::modhaf(x[0]); wr = true; }
         if constexpr (KIND == K_MODQR) {
             bool fast = false;

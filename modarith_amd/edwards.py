@@ -97,6 +97,18 @@ class Edwards:
         self._call(fn, P.data_ptr(), n, n, _stream(self.device))
         return P
 
+    def limbs_ok(self, P: torch.Tensor) -> torch.Tensor:
+        """int32 [n]: 1 where all three coordinates of the point keep the limb budget (every limb < 2^(Radix+2)) that the
+        outputs of every function of this library keep and the scalar-multiplication kernels rely on; a 0 marks limbs
+        fabricated outside the API (the reference's functions "silently overflow" there too, SURVEY 8b, but differently)."""
+        from . import curves
+        from .field import Field
+        self._chk(P)
+        up = self.name.upper()
+        fname = (curves.CURVES[up] if up in curves.CURVES else curves.W_CURVES[up]).field
+        F = Field(fname, device=self.device)
+        return F.modlimbs(P[0]) & F.modlimbs(P[1]) & F.modlimbs(P[2])
+
     def dbl(self, P): return self._un("dbl", P)
     def neg(self, P): return self._un("neg", P)
     def cof(self, P): return self._un("cof", P)

@@ -208,6 +208,10 @@ class Field:
     def modis0(self, a): return self._pred("modis0", a)
     def modsign(self, a): return self._pred("modsign", a)
 
+    def modlimbs(self, a):
+        """1 per element whose limbs are all below 2^(Radix+2) (the limb budget of the generated functions), else 0"""
+        return self._pred("modlimbs", a)
+
     def modcmp(self, a, b):
         n = self._chk(a, b)
         out = self._ints(n)

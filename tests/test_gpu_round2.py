@@ -276,6 +276,38 @@ def test_curve_soak_projective_limbs(oracle, torch_cuda, name):
     assert np.array_equal(got, want), name
 
 
+@pytest.mark.skipif(os.environ.get("MA_POLICY_CHILD") == "1", reason="no product policy involved")
+@pytest.mark.parametrize("name", ["ED25519", "ED448", "NIST256", "NIST521", "SECP256K1"])
+def test_limb_budget_predicate(torch_cuda, name):
+    """modlimbs / Curve.limbs_ok: every output of the library keeps the limb budget (< 2^(Radix+2)) the curve kernels
+    rely on, and a fabricated limb at or above it is flagged, lane by lane"""
+    torch = torch_cuda
+    from modarith_amd.edwards import Curve
+    from modarith_amd.field import Field
+    from modarith_amd import curves
+    n = 1000
+    C = Curve(name)
+    up = name.upper()
+    F = Field((curves.CURVES[up] if up in curves.CURVES else curves.W_CURVES[up]).field)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    e = torch.randint(0, 256, (n, C.nbytes), dtype=torch.uint8, device="cuda", generator=g)
+    P = C.mul(e, C.gen(n))
+    assert bool(C.limbs_ok(P).all())
+    assert bool(C.limbs_ok(C.add(P.clone(), C.dbl(P.clone()))).all())
+    bad = P.clone()
+    lanes = [0, 63, 64, 500, n - 1]
+    for k, j in enumerate(lanes):
+        bad[k % 3, (k * 2) % C.N, j] = (1 << (F.radix + 2)) + k          # one limb exactly at / just above the bound
+    bad[1, 0, 7] = -1                                                    # all-ones limb
+    ok = C.limbs_ok(bad).cpu().numpy()
+    want = np.ones(n, dtype=np.int32)
+    want[lanes + [7]] = 0
+    assert np.array_equal(ok, want)
+    a = F.uniform(n, seed=3)
+    a[F.N - 1, 5] = (1 << (F.radix + 2)) - 1                             # the largest limb inside the budget
+    assert bool(F.modlimbs(a).all())
+
+
 # ---------------------------------------------------------------- coarse rate floors (catch codegen regressions, not tuning)
 RATE_FLOORS = {"ED25519": 2.0e7, "NIST256": 9e6, "ED448": 5e6, "NIST384": 3e6, "SECP256K1": 1.2e7, "NUMS256W": 1.0e7, "NUMS256E": 1.8e7,
                "ED248": 1.7e7, "ED376": 7e6, "NIST521": 1.2e6, "ED500": 2.2e6}
