@@ -325,6 +325,16 @@ int ecn_ed448_mul2_get_batch(const char *e, const ma_spint *P, const char *f, co
 size_t ecn_ed448_mul_get_workspace_bytes(size_t n);
 int ecn_ed448_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
                             void *workspace, size_t workspace_bytes, void *stream);
+/* NIST P-256 (csrc/wn26.h): the ECDSA patterns nist256.c:155-161, 219-222 (ecnXXXmul + ecnXXXget) and nist256.c:251-256
+ * (ecnXXXmul2 + ecnXXXget).  Ten signed 26-bit limbs, Montgomery form with R' = 2^286, the same complete a = -3 formulas
+ * as weierstrass.c:68-281; 960 bytes of window table per resident lane (at most 126 MB).  A result at infinity leaves
+ * as x = 0, y = 1, the bytes ecnXXXget produces for it (weierstrass.c:299-310). */
+size_t ecn_nist256_mul_get_workspace_bytes(size_t n);
+int ecn_nist256_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
+                              void *workspace, size_t workspace_bytes, void *stream);
+size_t ecn_nist256_mul2_get_workspace_bytes(size_t n);
+int ecn_nist256_mul2_get_batch(const char *e, const ma_spint *P, const char *f, const ma_spint *Q, char *x, char *y, int *sign,
+                               size_t n, size_t ld, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

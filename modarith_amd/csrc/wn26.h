@@ -1,0 +1,327 @@
+// modarith_amd/csrc/wn26.h -- fused ecnXXXmul + ecnXXXget (and ecnXXXmul2 + ecnXXXget) for NIST P-256 on the fm26
+// representation (gfx950).
+//
+// The reference's ECDSA code ends every scalar multiplication in ecnXXXget: key generation and signing
+// (nist256.c:155-161, 219-222: ecnXXXmul then ecnXXXget), verification (nist256.c:251-256: ecnXXXmul2, ecnXXXisinf,
+// ecnXXXget).  Only canonical big-endian coordinate bytes leave, so -- exactly as for ED25519 in ed26.h -- the limb form
+// and the window width are free; the group law is kept: the COMPLETE projective formulas of Renes-Costello-Batina for
+// a = -3 (eprint 2015/1060 algorithms 4 and 6, the ones weierstrass.c:68-281 implements), which have no exceptional
+// cases on a curve of prime order, so the affine point reached is the reference's for every input point ON the curve,
+// the point at infinity included (it leaves as x = 0, y = 1, the bytes ecnXXXget gives after weierstrass.c:299-310).
+// (For off-curve input neither side means anything; they may differ.)
+//
+// Scalar multiplication is fixed-window as weierstrass.c:494-543 -- the same instruction and address sequence for every
+// scalar -- with signed 4-bit digits from a carry-free recoding: e' = e + sum_{i<65} 8*16^i < 16^65, digit_i =
+// window_i(e') - 8 in [-8, 7].  The table {1..8}P (projective, fm26 limbs as computed, 15 words per entry) lives in a
+// per-lane slot of a global workspace [entry][word][lane] and every lookup reads all eight entries with lane-predicated
+// selects; the digit's sign negates Y.  Work per scalar: 256 doublings + 65 additions + table (4 + 3) + one inversion.
+//
+// K (fm26.h) is given in the comments: |limb| <= K 2^26.  Point coordinates entering add / dbl have K <= 4.
+#pragma once
+#include "fm26.h"
+
+namespace ma {
+
+constexpr int NIST256_TABLE_WORDS = 8 * 15;     // 64-bit words per lane slot: eight entries of (X, Y, Z), two limbs per word
+
+template <class C>   // C: curve constants in the 5 x 52 field.c form (generated/curve_NIST256.h)
+struct Wn26 {
+    using F = Fm26;
+    struct Pt { int32_t X[10], Y[10], Z[10]; };
+
+    // b 2^286 mod p
+    static constexpr int32_t bhat(int i) {
+        constexpr int32_t v[10] = {0x30c0187, 0x4bddfd, 0x37d88a7, 0x274d89c, 0x327150a, 0x2cf005c, 0x84bb5a, 0x21a8ff7, 0x394025c, 0x1e0b74};
+        return v[i];
+    }
+    static MA_DEV void mulb(const int32_t* f, int32_t* r) {
+        int32_t b[10];
+        static_for<0, 10>([&](auto I) { b[I] = bhat(I); });
+        F::mul(f, b, r);
+    }
+    static MA_DEV void inf(Pt& p) { F::zero(p.X); F::set_one(p.Y); F::zero(p.Z); }
+
+    // P += Q (RCB algorithm 4, a = -3; operation order of weierstrass.c:68-175)
+    static MA_DEV void add(const Pt& q, Pt& p) {
+        int32_t B[10], T0[10], T1[10], T2[10], T3[10], T4[10];
+        F::mul(p.X, q.X, T0);
+        F::mul(p.Y, q.Y, T1);
+        F::mul(p.Z, q.Z, T2);
+        F::add(p.X, p.Y, T3);       // 8
+        F::add(q.X, q.Y, T4);       // 8
+        F::mul(T3, T4, T3);
+        F::add(T0, T1, T4);         // 2
+        F::sub(T3, T4, T3);         // 3
+        F::add(p.Y, p.Z, T4);       // 8
+        F::add(q.Y, q.Z, B);        // 8
+        F::mul(T4, B, T4);
+        F::add(T1, T2, B);          // 2
+        F::sub(T4, B, T4);          // 3
+        F::add(p.X, p.Z, p.X);      // 8
+        F::add(q.Z, q.X, p.Y);      // 8
+        F::mul(p.X, p.Y, p.X);
+        F::add(T0, T2, p.Y);        // 2
+        F::sub(p.X, p.Y, p.Y);      // 3
+        mulb(T2, p.Z);
+        F::sub(p.Y, p.Z, p.X);      // 4
+        F::add(p.X, p.X, p.Z);      // 8
+        F::add(p.X, p.Z, p.X);      // 12
+        F::sub(T1, p.X, p.Z);       // 13
+        F::add(p.X, T1, p.X);       // 13
+        mulb(p.Y, p.Y);
+        F::add(T2, T2, T1);         // 2
+        F::add(T2, T1, T2);         // 3
+        F::sub(p.Y, T2, p.Y);       // 4
+        F::sub(p.Y, T0, p.Y);       // 5
+        F::add(p.Y, p.Y, T1);       // 10
+        F::add(p.Y, T1, p.Y);       // 15
+        F::add(T0, T0, T1);         // 2
+        F::add(T0, T1, T0);         // 3
+        F::sub(T0, T2, T0);         // 6
+        // the three outputs are sums of two products each; X3 and Z3 take one Montgomery reduction for both products
+        // (weierstrass.c:158-174 reduces each product and adds), Y3 = 13 x 13 + 6 x 15 would overflow a column
+        F::mul(T0, p.Y, T2);        // 6 x 15
+        F::neg(p.Y, T1);            // 15
+        F::mul(p.X, p.Z, p.Y);      // 13 x 13
+        F::add(p.Y, T2, p.Y);       // 2
+        F::mul2(p.X, T3, T4, T1, p.X);   // X3 = X T3 - T4 Y:  13 x 3 + 3 x 15
+        F::mul2(p.Z, T4, T3, T0, p.Z);   // Z3 = Z T4 + T3 T0: 13 x 3 + 3 x 6
+    }
+
+    // P = 2P (RCB algorithm 6, a = -3; weierstrass.c:187-281)
+    static MA_DEV void dbl(Pt& p) {
+        int32_t T0[10], T1[10], T2[10], T3[10], T4[10];
+        F::sqr(p.X, T0);
+        F::sqr(p.Y, T1);
+        F::sqr(p.Z, T2);
+        F::mul(p.X, p.Y, T3);
+        F::mul(p.Y, p.Z, T4);
+        F::add(T3, T3, T3);         // 2
+        F::mul(p.Z, p.X, p.Z);
+        F::add(p.Z, p.Z, p.Z);      // 2
+        mulb(T2, p.Y);
+        F::sub(p.Y, p.Z, p.Y);      // 3
+        mulb(p.Z, p.Z);
+        F::add(p.Y, p.Y, p.X);      // 6
+        F::add(p.Y, p.X, p.Y);      // 9
+        F::sub(T1, p.Y, p.X);       // 10
+        F::add(p.Y, T1, p.Y);       // 10
+        int32_t U[10];
+        F::add(T2, T2, U);          // 2
+        F::add(T2, U, T2);          // 3
+        F::sub(p.Z, T2, p.Z);       // 4
+        F::sub(p.Z, T0, p.Z);       // 5
+        F::add(p.Z, p.Z, U);        // 10
+        F::add(p.Z, U, p.Z);        // 15
+        F::add(T0, T0, U);          // 2
+        F::add(T0, U, T0);          // 3
+        F::sub(T0, T2, T0);         // 6
+        F::add(T4, T4, T4);         // 2
+        // Y3 = Y X + T0 Z and X3 = X T3 - Z T4, each under one Montgomery reduction (weierstrass.c:249-275 reduces the four
+        // products separately): 10 x 10 + 6 x 15 = 190 and 10 x 2 + 15 x 2
+        F::mul2(p.Y, p.X, T0, p.Z, p.Y);
+        F::neg(p.Z, U);             // 15
+        F::mul2(p.X, T3, U, T4, p.X);
+        F::mul(T4, T1, p.Z);
+        F::add(p.Z, p.Z, p.Z);      // 2
+        F::add(p.Z, p.Z, p.Z);      // 4
+    }
+
+    static MA_DEV void load_point(const spint* X, const spint* Y, const spint* Z, Pt& p) {
+        F::from52(X, p.X);
+        F::from52(Y, p.Y);
+        F::from52(Z, p.Z);
+    }
+    static MA_DEV void put(uint64_t* tab, size_t tstride, int entry, const Pt& p) {
+        uint64_t w[5];
+        F::pack(p.X, w);
+        static_for<0, 5>([&](auto K) { tab[(size_t)(entry * 15 + K) * tstride] = w[K]; });
+        F::pack(p.Y, w);
+        static_for<0, 5>([&](auto K) { tab[(size_t)(entry * 15 + 5 + K) * tstride] = w[K]; });
+        F::pack(p.Z, w);
+        static_for<0, 5>([&](auto K) { tab[(size_t)(entry * 15 + 10 + K) * tstride] = w[K]; });
+    }
+    static MA_DEV void get(const uint64_t* tab, size_t tstride, int entry, Pt& p) {
+        uint64_t w[15];
+        static_for<0, 15>([&](auto K) { w[K] = tab[(size_t)(entry * 15 + K) * tstride]; });
+        F::unpack(w, p.X);
+        F::unpack(w + 5, p.Y);
+        F::unpack(w + 10, p.Z);
+    }
+    // entries base .. base + COUNT - 1 = P, 2P, ..., COUNT P: even multiples by doubling, odd ones as (k-1)P + P, rolled
+    // into one loop so that the instruction stream holds a single copy of dbl and add for the table
+    template <int COUNT>
+    static MA_DEV void build_table(const Pt& p, uint64_t* tab, size_t tstride, int base) {
+        put(tab, tstride, base, p);
+#pragma unroll 1
+        for (int k = 2; k <= COUNT; k++) {
+            Pt t;
+            get(tab, tstride, base + ((k & 1) ? k - 2 : (k >> 1) - 1), t);
+            if (k & 1) add(p, t);
+            else dbl(t);
+            put(tab, tstride, base + k - 1, t);
+        }
+    }
+    // sign * table[base + m - 1] (m = 0: the point at infinity), every entry read; COUNT entries scanned two per round
+    template <int COUNT>
+    static MA_DEV void lookup(const uint64_t* tab, size_t tstride, int base, uint32_t m, bool neg, Pt& q) {
+        uint64_t sel[15];
+        {
+            int32_t o[10];
+            uint64_t w[5];
+            F::set_one(o);
+            F::pack(o, w);
+            static_for<0, 15>([&](auto K) { sel[K] = (K >= 5 && K < 10) ? w[K - 5] : 0u; });
+        }
+        // the memory clobbers keep the (loop-invariant) table loads inside the iteration (see ed28.h)
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::: "memory");
+#endif
+#pragma unroll 1
+        for (int e = 0; e < COUNT; e += 2) {
+            uint64_t ent[2][15];
+            static_for<0, 2>([&](auto EI) {
+                static_for<0, 15>([&](auto K) { ent[EI][K] = tab[(size_t)((base + e + EI) * 15 + K) * tstride]; });
+            });
+            static_for<0, 2>([&](auto EI) {
+                const bool hit = (m == (uint32_t)(e + EI + 1));
+                static_for<0, 15>([&](auto K) {
+                    const uint64_t a = ent[EI][K], b = sel[K];
+                    sel[K] = hit ? a : b;
+                });
+            });
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::: "memory");
+#endif
+        }
+        int32_t ny[10];
+        F::unpack(sel, q.X);
+        F::unpack(sel + 5, q.Y);
+        F::unpack(sel + 10, q.Z);
+        F::neg(q.Y, ny);
+        F::select(neg, q.Y, ny, q.Y);
+    }
+    // ecnXXXget of a projective point: canonical affine words; Z = 0 leaves as (0, 1) (weierstrass.c:299-310)
+    static MA_DEV void affine_words(const Pt& p, uint64_t* xw, uint64_t* yw) {
+        int32_t zi[10], ax[10], ay[10];
+        uint64_t zw[4];
+        F::to_words(p.Z, zw);
+        const bool z0 = (zw[0] | zw[1] | zw[2] | zw[3]) == 0;
+        F::invert(p.Z, zi);
+        F::mul(p.X, zi, ax);
+        F::mul(p.Y, zi, ay);
+        F::to_words(ax, xw);
+        F::to_words(ay, yw);
+        static_for<0, 4>([&](auto K) {
+            xw[K] = z0 ? 0u : xw[K];
+            yw[K] = z0 ? (K == 0 ? 1u : 0u) : yw[K];
+        });
+    }
+};
+
+// s = e + bias (bias: a 1 in bit positions b < BITS with b % W == W - 1), then left-aligned so that the top window
+// (bits BITS-W .. BITS-1 of s) is the top of w[4]
+template <int W, int BITS>
+MA_DEV void wn26_recode(const uint64_t* ew, uint64_t* w) {
+    constexpr auto cw = [](int k) {
+        uint64_t v = 0;
+        for (int b = 0; b < 64; b++) {
+            const int pos = 64 * k + b;
+            if (pos < BITS && pos % W == W - 1) v |= (uint64_t)1 << b;
+        }
+        return v;
+    };
+    unsigned __int128 acc = 0;
+    uint64_t s[5];
+    static_for<0, 5>([&](auto K) {
+        constexpr int k = K;
+        acc += (unsigned __int128)(k < 4 ? ew[k < 4 ? k : 0] : 0) + cw(k);
+        s[k] = (uint64_t)acc;
+        acc >>= 64;
+    });
+    constexpr int SH = 320 - BITS;           // 60 for 260 bits, 62 for 258
+    static_for<0, 5>([&](auto KK) {
+        constexpr int k = 4 - KK;
+        w[k] = s[k] << SH;
+        if constexpr (k > 0) w[k] |= s[k - 1] >> (64 - SH);
+    });
+}
+template <int W>
+MA_DEV uint32_t wn26_take(uint64_t* w) {
+    const uint32_t win = (uint32_t)(w[4] >> (64 - W));
+    static_for<0, 5>([&](auto KK) {
+        constexpr int k = 4 - KK;
+        w[k] <<= W;
+        if constexpr (k > 0) w[k] |= w[k - 1] >> (64 - W);
+    });
+    return win;
+}
+
+// One fused P-256 scalar multiplication + affine export.
+//   ew: the scalar as four little-endian 64-bit words (the caller has byte-swapped the big-endian record);
+//   X, Y, Z: the projective point, 5 x 52-bit limbs each (field.c form); tab: this lane's table slot (NIST256_TABLE_WORDS
+//   words, tstride apart); xw, yw: canonical affine coordinates, four little-endian words each.
+template <class C>
+MA_DEV void nist256_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
+                                uint64_t* xw, uint64_t* yw) {
+    using E = Wn26<C>;
+    typename E::Pt R, Q;
+    E::load_point(X, Y, Z, Q);
+    E::template build_table<8>(Q, tab, tstride, 0);
+    uint64_t w[5];
+    wn26_recode<4, 260>(ew, w);
+    E::inf(R);
+#pragma unroll 1
+    for (int i = 0; i < 65; i++) {
+        const int dgt = (int)wn26_take<4>(w) - 8;               // [-8, 7]
+        const bool neg = dgt < 0;
+        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0..8
+        if (i != 0) {
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) E::dbl(R);
+        }
+        E::template lookup<8>(tab, tstride, 0, m, neg, Q);
+        E::add(Q, R);
+    }
+    E::affine_words(R, xw, yw);
+}
+
+// Fused double multiplication + affine export: the affine coordinates of e*P + f*Q (ecnXXXmul2 followed by ecnXXXget,
+// the verification pattern nist256.c:251-256).  Signed 3-bit digits (e' = e + sum_{i<86} 4*8^i, digit = window - 4 in
+// [-4, 3]) so that the two tables {1..4}P and {1..4}Q share the eight entry slots of the same per-lane workspace; per
+// window three doublings and two additions, all lookups scan their table.  (The reference's mul2 is a joint sparse form
+// with data-dependent branches; any evaluation reaches the same affine point.)  An infinite result leaves as (0, 1).
+template <class C>
+MA_DEV void nist256_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
+                                 const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
+                                 uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
+    using E = Wn26<C>;
+    typename E::Pt R, Q;
+    E::load_point(PX, PY, PZ, Q);
+    E::template build_table<4>(Q, tab, tstride, 0);
+    E::load_point(QX, QY, QZ, Q);
+    E::template build_table<4>(Q, tab, tstride, 4);
+    uint64_t we[5], wf[5];
+    wn26_recode<3, 258>(ew, we);
+    wn26_recode<3, 258>(fw, wf);
+    E::inf(R);
+#pragma unroll 1
+    for (int i = 0; i < 86; i++) {
+        const int de = (int)wn26_take<3>(we) - 4, df = (int)wn26_take<3>(wf) - 4;   // [-4, 3]
+        if (i != 0) {
+#pragma unroll 1
+            for (int j = 0; j < 3; j++) E::dbl(R);
+        }
+#pragma unroll 1
+        for (int which = 0; which < 2; which++) {
+            const int dgt = which ? df : de;
+            const bool neg = dgt < 0;
+            const uint32_t m = (uint32_t)(neg ? -dgt : dgt);    // 0..4
+            E::template lookup<4>(tab, tstride, 4 * which, m, neg, Q);
+            E::add(Q, R);
+        }
+    }
+    E::affine_words(R, xw, yw);
+}
+
+}  // namespace ma

@@ -1,4 +1,4 @@
-"""GPU parity of the fused scalar multiplication + affine export (csrc/ed26.h, ecn_<c>_mul_get_batch): byte-equal to
+"""GPU parity of the fused scalar multiplication + affine export (csrc/ed26.h, ed28.h, wn26.h; ecn_<c>_mul_get_batch): byte-equal to
 ecn_<c>_mul_batch followed by ecn_<c>_get_batch, to the reference-derived fixtures, and to the CPU oracle's ecn mul +
 ecn get -- on random projective points, the special points of the curve and corner scalars."""
 import ctypes
@@ -9,7 +9,8 @@ import pytest
 from tests.conftest import load_golden
 
 pytestmark = pytest.mark.gpu
-FUSED = [("ed25519", "ED25519"), ("ed448", "ED448")]
+FUSED = [("ed25519", "ED25519"), ("ed448", "ED448"), ("nist256", "NIST256")]
+WEIER = ("nist256",)
 
 
 @pytest.fixture(scope="module", params=FUSED)
@@ -18,7 +19,7 @@ def fx(request):
     assert torch.cuda.is_available()
     from modarith_amd.edwards import Edwards
     C, name = request.param
-    return C, Edwards(name), load_golden("edwards_%s.json" % name), torch
+    return C, Edwards(name), load_golden(("weierstrass_%s.json" if C in WEIER else "edwards_%s.json") % name), torch
 
 
 def dev_bytes(torch, hexes):
@@ -87,6 +88,8 @@ def test_fused_special_points_and_scalars(fx):
     """the complete addition law at work: neutral element, points of order 2, 4 and 8, scalars 0, 1, 8, the group order,
     order +- 1 and all ones -- every (point, scalar) pair against the two-call form"""
     C, Ed, g, torch = fx
+    if C in WEIER:
+        pytest.skip("Edwards special points; see test_fused_weierstrass_special_points_and_scalars")
     p = (1 << 255) - 19 if C == "ed25519" else (1 << 448) - (1 << 224) - 1
     order = int(g["order"], 16)
     be = lambda v: v.to_bytes(Ed.nbytes, "big").hex()
@@ -118,16 +121,50 @@ def test_fused_special_points_and_scalars(fx):
     assert hexrows(x)[i] == be(0) and hexrows(y)[i] == be(1)
 
 
+def test_fused_weierstrass_special_points_and_scalars(fx):
+    """prime-order curve, complete formulas: the point at infinity, G, -G, a random point and its negative against scalars
+    0, 1, 2, 8, 15, 16, the group order q, q +- 1, 2q - 1, all ones, single high bits -- against the two-call form; an
+    infinite result leaves as (0, 1), what ecnXXXget gives (weierstrass.c:299-310)"""
+    C, Ed, g, torch = fx
+    if C not in WEIER:
+        pytest.skip("Weierstrass curves")
+    order = int(g["order"], 16)
+    be = lambda v: v.to_bytes(Ed.nbytes, "big").hex()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    G = Ed.gen(1)
+    Rn = Ed.mul(torch.randint(0, 256, (1, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=gen), Ed.gen(1))
+    pts = [G, Ed.inf(1), Ed.neg(G.clone()), Rn, Ed.neg(Rn.clone())]
+    nbits = 8 * Ed.nbytes
+    scalars = [0, 1, 2, 7, 8, 9, 15, 16, 17, 0x88, order - 1, order, order + 1, (1 << nbits) - 1, 1 << (nbits - 1), (1 << (nbits - 1)) - 1,
+               (1 << nbits) - order, 0x8888888888888888888888888888888888888888888888888888888888888888 % (1 << nbits), (1 << nbits) - 8]
+    P = torch.cat([q for q in pts for _ in scalars], dim=2).contiguous()
+    e = dev_bytes(torch, [be(s) for _ in pts for s in scalars])
+    x, y, _ = Ed.mul_get(e, P)
+    wx, wy, _ = Ed.get(Ed.mul(e, P.clone()))
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+    i = scalars.index(order)
+    assert hexrows(x)[i] == be(0) and hexrows(y)[i] == be(1)                 # q * G = infinity -> (0, 1)
+    # mul2: e*P + f*Q = infinity (Q = -P, f = e), P = Q, infinite operands
+    n = len(scalars)
+    Pm = torch.cat([Rn] * n, dim=2).contiguous()
+    Qm = torch.cat([Ed.neg(Rn.clone())] * n, dim=2).contiguous()
+    em = dev_bytes(torch, [be(s) for s in scalars])
+    x2, y2, _ = Ed.mul2_get(em, Pm, em, Qm)
+    assert hexrows(x2) == [be(0)] * n and hexrows(y2) == [be(1)] * n
+    w2x, w2y, _ = Ed.get(Ed.mul2(em, Pm, em, Qm))
+    assert torch.equal(x2, w2x) and torch.equal(y2, w2y)
+
+
 def test_fused_rejects_bad_arguments(fx):
     C, Ed, g, torch = fx
     from modarith_amd.edwards import Edwards
     with pytest.raises(ValueError):
-        Edwards("NIST256").mul_get(torch.zeros((1, 32), dtype=torch.uint8, device="cuda"), Edwards("NIST256").gen(1))
+        Edwards("SECP256K1").mul_get(torch.zeros((1, 32), dtype=torch.uint8, device="cuda"), Edwards("SECP256K1").gen(1))
     x, y, s = Ed.mul_get(torch.zeros((0, Ed.nbytes), dtype=torch.uint8, device="cuda"), Ed.empty(0))
     assert x.shape[0] == 0
 
 
-@pytest.mark.parametrize("C,name,lg", [("ed25519", "ED25519", 14), ("ed448", "ED448", 12)])
+@pytest.mark.parametrize("C,name,lg", [("ed25519", "ED25519", 14), ("ed448", "ED448", 12), ("nist256", "NIST256", 14)])
 def test_fused_mul2_get(oracle, C, name, lg):
     """e*P + f*Q and its affine export in one kernel: against mul2 + get on the GPU (2^14 / 2^12 random pairs) and the
     oracle's ecn mul2 + ecn get on a sample; special operands: neutral element, P = Q, zero scalars, small order"""
@@ -142,8 +179,12 @@ def test_fused_mul2_get(oracle, C, name, lg):
     P[:, :, 0:8] = Ed.inf(8)                        # neutral element as P
     Q[:, :, 8:16] = Ed.inf(8)                       # ... as Q
     Q[:, :, 16:24] = P[:, :, 16:24]                 # P = Q
-    low = Ed.set(torch.zeros(8, dtype=torch.int32, device="cuda"), None, torch.zeros((8, Ed.nbytes), dtype=torch.uint8, device="cuda"))
-    Q[:, :, 24:32] = low                            # y = 0: order 4
+    if C in WEIER:
+        Q[:, :, 24:32] = Ed.neg(P[:, :, 24:32].contiguous())            # Q = -P
+        f[24:28] = e[24:28]                                              # ... with f = e: the sum is the point at infinity
+    else:
+        low = Ed.set(torch.zeros(8, dtype=torch.int32, device="cuda"), None, torch.zeros((8, Ed.nbytes), dtype=torch.uint8, device="cuda"))
+        Q[:, :, 24:32] = low                        # y = 0: order 4
     e[32:40] = 0
     f[40:48] = 0
     e[48:56] = 255

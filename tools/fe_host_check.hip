@@ -13,6 +13,8 @@
 #include "../modarith_amd/csrc/generated/params_NUMS256W.h"
 #include "../modarith_amd/csrc/ed26.h"
 #include "../modarith_amd/csrc/ed28.h"
+#include "../modarith_amd/csrc/generated/curve_NIST256.h"
+#include "../modarith_amd/csrc/wn26.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -355,6 +357,99 @@ static int run(const char* name, int n, Fn fn, Ref ref) {
     return bad;
 }
 
+struct pt256 { uint64_t x[5], y[5], z[5]; };
+extern "C" void ecn_nist256_gen(pt256*);
+extern "C" void ecn_nist256_inf(pt256*);
+extern "C" void ecn_nist256_neg(pt256*);
+extern "C" void ecn_nist256_mul(const char* e, pt256*);
+extern "C" void ecn_nist256_mul2(const char* e, pt256* P, const char* f, pt256* Q, pt256* R);
+extern "C" int ecn_nist256_get(pt256*, char* x, char* y);
+
+static void be_words4(const unsigned char* e, uint64_t* w) {
+    for (int k = 0; k < 4; k++) { uint64_t v = 0; for (int b = 0; b < 8; b++) v |= (uint64_t)e[31 - (8 * k + b)] << (8 * b); w[k] = v; }
+}
+static void words4_be(const uint64_t* w, unsigned char* o) {
+    for (int i = 0; i < 32; i++) o[i] = (unsigned char)(w[(31 - i) / 8] >> (8 * ((31 - i) % 8)));
+}
+static const unsigned char NIST256_ORDER[32] = {0xff,0xff,0xff,0xff,0,0,0,0,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xbc,0xe6,0xfa,0xad,0xa7,0x17,0x9e,0x84,0xf3,0xb9,0xca,0xc2,0xfc,0x63,0x25,0x51};
+
+// fused P-256 mul+get (csrc/wn26.h) against the oracle's ecn mul followed by ecn get: random projective points (random
+// multiples of the generator, NOT normalised), the point at infinity, the affine generator; scalars 0, 1, 2, the group
+// order q, q - 1, q + 1, all ones, single-window values
+static int run_nist256(int n) {
+    int bad = 0;
+    for (int it = 0; it < n; it++) {
+        pt256 P;
+        unsigned char e[32], k[32];
+        for (int i = 0; i < 32; i++) { e[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
+        ecn_nist256_gen(&P);
+        ecn_nist256_mul((const char*)k, &P);
+        if (it % 16 == 1) ecn_nist256_inf(&P);
+        if (it % 16 == 4) ecn_nist256_gen(&P);
+        if (it == 5 || it == 17) memset(e, 0, 32);
+        if (it == 6) { memset(e, 0, 32); e[31] = 1; }
+        if (it == 7) memset(e, 0xff, 32);
+        if (it == 8) memcpy(e, NIST256_ORDER, 32);
+        if (it == 9) { memcpy(e, NIST256_ORDER, 32); e[31] -= 1; }
+        if (it == 10) { memcpy(e, NIST256_ORDER, 32); e[31] += 1; }
+        if (it == 11) { memset(e, 0, 32); e[31] = 2; }
+        if (it == 12) { memset(e, 0, 32); e[31] = 8; }
+        if (it == 13) { memset(e, 0, 32); e[31] = 0x88; }
+        if (it == 14) { memset(e, 0, 32); e[0] = 0x80; }
+        pt256 Q = P;
+        uint64_t ew[4], xw[4], yw[4], tab[ma::NIST256_TABLE_WORDS];
+        be_words4(e, ew);
+        ma::nist256_mul_get_one<ma::C_NIST256>(ew, P.x, P.y, P.z, tab, 1, xw, yw);
+        char wx[32], wy[32];
+        ecn_nist256_mul((const char*)e, &Q);
+        ecn_nist256_get(&Q, wx, wy);
+        unsigned char gx[32], gy[32];
+        words4_be(xw, gx);
+        words4_be(yw, gy);
+        if (memcmp(gx, wx, 32) != 0 || memcmp(gy, wy, 32) != 0) {
+            if (bad < 6) printf("nist256_mul_get_one: record %d differs\n", it);
+            bad++;
+        }
+    }
+    printf("nist256_mul_get_one: %d records, %d differ from the oracle's ecn mul + get\n", n, bad);
+    return bad;
+}
+
+// fused P-256 mul2+get against the oracle's ecn mul2 + get; includes e*P + f*Q = infinity (Q = -P, f = e), P = Q, infinite inputs
+static int run_nist256_mul2(int n) {
+    int bad = 0;
+    for (int it = 0; it < n; it++) {
+        pt256 P, Q, R;
+        unsigned char e[32], f[32], k[32];
+        for (int i = 0; i < 32; i++) { e[i] = (unsigned char)sm(); f[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
+        ecn_nist256_gen(&P); ecn_nist256_mul((const char*)k, &P);
+        for (int i = 0; i < 32; i++) k[i] = (unsigned char)sm();
+        ecn_nist256_gen(&Q); ecn_nist256_mul((const char*)k, &Q);
+        if (it % 16 == 1) ecn_nist256_inf(&P);
+        if (it % 16 == 2) ecn_nist256_inf(&Q);
+        if (it % 16 == 3) { Q = P; ecn_nist256_neg(&Q); memcpy(f, e, 32); }     // e P + e (-P) = infinity
+        if (it % 16 == 4) Q = P;
+        if (it % 16 == 5) { Q = P; ecn_nist256_neg(&Q); }
+        if (it == 6) { memset(e, 0, 32); memset(f, 0, 32); }
+        if (it == 7) { memset(e, 0xff, 32); memset(f, 0xff, 32); }
+        if (it == 8) { memcpy(e, NIST256_ORDER, 32); memset(f, 0, 32); f[31] = 1; }
+        pt256 P0 = P, Q0 = Q;
+        uint64_t ew[4], fw[4], xw[4], yw[4], tab[ma::NIST256_TABLE_WORDS];
+        be_words4(e, ew);
+        be_words4(f, fw);
+        ma::nist256_mul2_get_one<ma::C_NIST256>(ew, P.x, P.y, P.z, fw, Q.x, Q.y, Q.z, tab, 1, xw, yw);
+        char wx[32], wy[32];
+        ecn_nist256_mul2((const char*)e, &P0, (const char*)f, &Q0, &R);
+        ecn_nist256_get(&R, wx, wy);
+        unsigned char gx[32], gy[32];
+        words4_be(xw, gx);
+        words4_be(yw, gy);
+        if (memcmp(gx, wx, 32) != 0 || memcmp(gy, wy, 32) != 0) { if (bad < 6) printf("nist256_mul2_get_one: record %d differs\n", it); bad++; }
+    }
+    printf("nist256_mul2_get_one: %d records, %d differ from the oracle's ecn mul2 + get\n", n, bad);
+    return bad;
+}
+
 int main(int argc, char** argv) {
     int n = argc > 1 ? atoi(argv[1]) : 2000;
     int bad = run<4>("x25519_fe26_one", n, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x25519_fe26_one(k, u, o); }, rfc7748_X25519);
@@ -368,5 +463,7 @@ int main(int argc, char** argv) {
     bad += run_ed25519_mul2(n / 8 + 16);
     bad += run_ed448(n / 16 + 16);
     bad += run_ed448_mul2(n / 32 + 16);
+    bad += run_nist256(n / 8 + 16);
+    bad += run_nist256_mul2(n / 16 + 16);
     return bad ? 1 : 0;
 }

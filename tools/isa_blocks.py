@@ -27,7 +27,7 @@ for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\s*s_endpgm", t, re.S | re.M):
         for k in ("scratch", "flat", "global", "ds"):
             if op.startswith(k):
                 s[k] += 1
-        s["mad"] += op == "v_mad_u64_u32"
+        s["mad"] += op in ("v_mad_u64_u32", "v_mad_i64_i32")
         s["nop"] += op == "s_nop"
         if op.startswith("s_cbranch") or op == "s_branch":
             br[blk].append(l.split()[-1])

@@ -4,7 +4,10 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from modarith_amd.edwards import Curve
-for name, n in (("ED25519", 1 << 21), ("ED448", 1 << 19)):
+only = [a.upper() for a in sys.argv[1:]]
+for name, n in (("ED25519", 1 << 21), ("ED448", 1 << 19), ("NIST256", 1 << 20)):
+    if only and name not in only:
+        continue
     Ed = Curve(name)
     g = torch.Generator(device="cuda").manual_seed(3)
     e = torch.randint(0, 256, (n, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=g)
@@ -21,7 +24,9 @@ for name, n in (("ED25519", 1 << 21), ("ED448", 1 << 19)):
         name, n.bit_length() - 1, n / bf, bf * 1e3, n / bt, bt * 1e3, bt / bf, bool(torch.equal(x, wx) and torch.equal(y, wy))), flush=True)
 
 # fused double multiplication (verification pattern) against mul2 + get
-for name2, n in (("ED25519", 1 << 20), ("ED448", 1 << 18)):
+for name2, n in (("ED25519", 1 << 20), ("ED448", 1 << 18), ("NIST256", 1 << 19)):
+  if only and name2 not in only:
+      continue
   Ed = Curve(name2)
   g = torch.Generator(device="cuda").manual_seed(4)
   rnd = lambda: torch.randint(0, 256, (n, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=g)
