@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""one fused ecn mul_get pass per curve (for profiling): ED25519 2^21, ED448 2^19 scalars"""
+"""one fused ecn mul_get pass per curve (for profiling): ED25519 2^21, ED448 2^19, NIST256 2^20 scalars"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from modarith_amd.edwards import Curve
-for name, n in (("ED25519", 1 << 21), ("ED448", 1 << 19)):
+for name, n in (("ED25519", 1 << 21), ("ED448", 1 << 19), ("NIST256", 1 << 20)):
     if sys.argv[1:] and name not in sys.argv[1:]:
         continue
     Ed = Curve(name)

@@ -6,6 +6,8 @@
                   in-range values: the product policies must agree bit for bit (checksums compared across three child processes: MA_FORCE_EXACT=1, MA_FORCE_FAST=1, default)
   soak.py curves  2^13 .. 2^16 random scalars x random points for each of the eleven curves, fused ecn mul on the GPU against the CPU oracle,
                   projective limbs compared
+  soak.py fused   2^18 .. 2^20 random (scalar, projective point) pairs per fused curve (ED25519, ED448, NIST256): mul_get against mul + get and
+                  mul2_get against mul2 + get (the two-call forms are the ones `soak.py curves` pins to the oracle), bytes compared
 """
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -102,11 +104,39 @@ def curves():
     return rc
 
 
+def fused():
+    import torch
+    from modarith_amd.edwards import Curve
+    rc = 0
+    for name, lg in (("ED25519", 20), ("ED448", 18), ("NIST256", 20)):
+        n = 1 << lg
+        C = Curve(name)
+        g = torch.Generator(device="cuda").manual_seed(78)
+        rnd = lambda m: torch.randint(0, 256, (m, C.nbytes), dtype=torch.uint8, device="cuda", generator=g)
+        P = C.mul(rnd(n), C.gen(n))
+        e = rnd(n)
+        e[:16] = 0; e[16:32] = 255
+        x, y, _ = C.mul_get(e, P)
+        wx, wy, _ = C.get(C.mul(e, P.clone()))
+        ok = bool(torch.equal(x, wx) and torch.equal(y, wy))
+        m = n // 4
+        Q = C.mul(rnd(m), C.gen(m))
+        Pm, em, fm = P[:, :, :m].contiguous(), e[:m].contiguous(), rnd(m)
+        x, y, _ = C.mul2_get(em, Pm, fm, Q)
+        wx, wy, _ = C.get(C.mul2(em, Pm, fm, Q))
+        ok2 = bool(torch.equal(x, wx) and torch.equal(y, wy))
+        print("fused soak %-8s mul_get 2^%d: %s   mul2_get 2^%d: %s" % (name, lg, "EQUAL" if ok else "MISMATCH", lg - 2, "EQUAL" if ok2 else "MISMATCH"), flush=True)
+        rc |= 0 if (ok and ok2) else 1
+    return rc
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "field"
     if mode == "field-child":
         field_child(sys.argv[2])
     elif mode == "field":
         sys.exit(field())
+    elif mode == "fused":
+        sys.exit(fused())
     else:
         sys.exit(curves())
