@@ -335,6 +335,14 @@ int ecn_nist256_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y
 size_t ecn_nist256_mul2_get_workspace_bytes(size_t n);
 int ecn_nist256_mul2_get_batch(const char *e, const ma_spint *P, const char *f, const ma_spint *Q, char *x, char *y, int *sign,
                                size_t n, size_t ld, void *workspace, size_t workspace_bytes, void *stream);
+/* secp256k1 (curve.py:190-198; csrc/wn26.h on csrc/fk26.h): the same patterns on the a = 0 complete formulas
+ * (weierstrass.c:120-157, 189-226), ten signed 26-bit limbs with the pseudo-Mersenne fold 2^260 = 2^36 + 0x3d10 */
+size_t ecn_secp256k1_mul_get_workspace_bytes(size_t n);
+int ecn_secp256k1_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
+                                void *workspace, size_t workspace_bytes, void *stream);
+size_t ecn_secp256k1_mul2_get_workspace_bytes(size_t n);
+int ecn_secp256k1_mul2_get_batch(const char *e, const ma_spint *P, const char *f, const ma_spint *Q, char *x, char *y, int *sign,
+                                 size_t n, size_t ld, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

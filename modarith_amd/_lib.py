@@ -19,8 +19,8 @@ PRIMES = ("X25519", "NIST256", "X448",
 LADDERS = ("X25519", "X448")
 CURVES = {"ed25519": (5, 32), "ed448": (8, 56), "nist256": (5, 32), "nist384": (7, 48), "nist521": (9, 66), "secp256k1": (5, 32), "nums256w": (5, 32), "nums256e": (5, 32), "ed248": (5, 32), "ed376": (7, 48), "ed500": (9, 64)}       # curve -> (Nlimbs, Nbytes)
 ED_BATCH_FUNCS = ("mul", "mul2", "ran", "add", "sub", "cpy", "dbl", "neg", "inf", "gen", "cof", "affine", "cmp", "isinf", "set", "get")
-FUSED_CURVES = ("ed25519", "ed448", "nist256")       # fused mul + get kernels (csrc/ed26.h, csrc/ed28.h, csrc/wn26.h)
-FUSED2_CURVES = ("ed25519", "ed448", "nist256")        # fused mul2 + get
+FUSED_CURVES = ("ed25519", "ed448", "nist256", "secp256k1")       # fused mul + get kernels (csrc/ed26.h, csrc/ed28.h, csrc/wn26.h)
+FUSED2_CURVES = ("ed25519", "ed448", "nist256", "secp256k1")        # fused mul2 + get
 FUSED_FUNCS = (tuple("ecn_%s_mul_get_%s" % (c, f) for c in FUSED_CURVES for f in ("batch", "workspace_bytes"))
                + tuple("ecn_%s_mul2_get_%s" % (c, f) for c in FUSED2_CURVES for f in ("batch", "workspace_bytes")))
 ED_SCALAR_FUNCS = ("mul2", "ran", "get", "set", "inf", "isinf", "neg", "add", "sub", "dbl", "gen", "mul", "cmp", "affine", "cpy", "cof",

@@ -1,0 +1,67 @@
+// modarith_amd/csrc/capi_SECP256K1F.hip -- ecn_secp256k1_mul_get_batch: secp256k1 scalar multiplication fused with the affine
+// export (csrc/wn26.h), the call pattern ecnXXXmul + ecnXXXget of the reference's ECDSA code (nist256.c:155-161, 219-222; curve.py:190-198 builds the same layer for secp256k1).
+#include "../../include/modarith_amd.h"
+#include "capi_common.h"
+#include "generated/curve_SECP256K1.h"
+#include "kernels.h"
+#include "wn26.h"
+
+namespace ma {
+
+constexpr size_t SECP256K1_ROW_SKEW = 32 + 4;   // words added to the row pitch of the table workspace (as in capi_ED448F.hip)
+
+// one scalar multiplication per lane; the window table of lane slot s = blockIdx.x * 64 + threadIdx.x sits in the
+// workspace at word k -> ws[k * pitch + s] (every access of a wave is one coalesced 512-byte row)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_secp256k1_mul_get(const unsigned char* e, const spint* Pb, unsigned char* xb, unsigned char* yb, int* sign, size_t n, size_t ld,
+                       uint64_t* ws) {
+    using P = P_SECP256K1;
+    const size_t slots = (size_t)gridDim.x * blockDim.x;
+    const size_t tstride = slots + SECP256K1_ROW_SKEW;
+    uint64_t* tab = ws + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += slots) {
+        spint ew[4], X[5], Y[5], Z[5], xw[4], yw[4];
+        load_be_record<P>(e, t, ew);
+        static_for<0, 5>([&](auto I) {
+            X[I] = Pb[(size_t)I * ld + t];
+            Y[I] = Pb[(size_t)(5 + I) * ld + t];
+            Z[I] = Pb[(size_t)(10 + I) * ld + t];
+        });
+        wn26_mul_get_one<CvSecp256k1>(ew, X, Y, Z, tab, tstride, xw, yw);
+        if (xb) store_be_record<P>(xb, t, xw);
+        if (yb) store_be_record<P>(yb, t, yw);
+        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+    }
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+namespace {
+// resident grid: 2 waves on each of the 1024 SIMDs, grid-stride over the batch
+size_t fused_lanes(size_t n) {
+    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
+    return lanes < cap ? lanes : cap;
+}
+}  // namespace
+
+extern "C" size_t ecn_secp256k1_mul_get_workspace_bytes(size_t n) { return (fused_lanes(n) + SECP256K1_ROW_SKEW) * WN26_TABLE_WORDS * sizeof(uint64_t); }
+
+extern "C" int ecn_secp256k1_mul_get_batch(const char* e, const ma_spint* P, char* x, char* y, int* sign, size_t n, size_t ld,
+                                         void* workspace, size_t workspace_bytes, void* st) {
+    if (n == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 7u) {
+        set_error("ecn mul_get: byte records must be 8-byte aligned");
+        return (int)hipErrorInvalidValue;
+    }
+    const size_t lanes = fused_lanes(n);
+    if (workspace == nullptr || workspace_bytes < (lanes + SECP256K1_ROW_SKEW) * WN26_TABLE_WORDS * sizeof(uint64_t)) {
+        set_error("ecn mul_get: workspace too small (see ecn_secp256k1_mul_get_workspace_bytes)");
+        return (int)hipErrorInvalidValue;
+    }
+    k_secp256k1_mul_get<<<(unsigned)(lanes / 64), 64, 0, (hipStream_t)st>>>(
+        reinterpret_cast<const unsigned char*>(e), P, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n, ld,
+        reinterpret_cast<uint64_t*>(workspace));
+    return check_launch("ecn mul_get");
+}

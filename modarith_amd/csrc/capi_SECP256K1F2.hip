@@ -1,0 +1,70 @@
+// modarith_amd/csrc/capi_SECP256K1F2.hip -- ecn_secp256k1_mul2_get_batch: double multiplication e*P + f*Q fused with the
+// affine export (csrc/wn26.h), the verification pattern ecnXXXmul2 + ecnXXXget of the reference's ECDSA code
+// (nist256.c:251-256).  A result at infinity leaves as x = 0, y = 1 (what ecnXXXget gives; the caller's ecnXXXisinf test
+// becomes x == 0 && y == 1, no point of the curve has x = 0 ... y = 1 since b = 7 is not 1).
+#include "../../include/modarith_amd.h"
+#include "capi_common.h"
+#include "generated/curve_SECP256K1.h"
+#include "kernels.h"
+#include "wn26.h"
+
+namespace ma {
+
+constexpr size_t SECP256K1_ROW_SKEW2 = 32 + 4;
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_secp256k1_mul2_get(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb,
+                        int* sign, size_t n, size_t ld, uint64_t* ws) {
+    using P = P_SECP256K1;
+    const size_t slots = (size_t)gridDim.x * blockDim.x;
+    const size_t tstride = slots + SECP256K1_ROW_SKEW2;
+    uint64_t* tab = ws + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += slots) {
+        spint ew[4], fw[4], PX[5], PY[5], PZ[5], QX[5], QY[5], QZ[5], xw[4], yw[4];
+        load_be_record<P>(e, t, ew);
+        load_be_record<P>(f, t, fw);
+        static_for<0, 5>([&](auto I) {
+            PX[I] = Pb[(size_t)I * ld + t];
+            PY[I] = Pb[(size_t)(5 + I) * ld + t];
+            PZ[I] = Pb[(size_t)(10 + I) * ld + t];
+            QX[I] = Qb[(size_t)I * ld + t];
+            QY[I] = Qb[(size_t)(5 + I) * ld + t];
+            QZ[I] = Qb[(size_t)(10 + I) * ld + t];
+        });
+        wn26_mul2_get_one<CvSecp256k1>(ew, PX, PY, PZ, fw, QX, QY, QZ, tab, tstride, xw, yw);
+        if (xb) store_be_record<P>(xb, t, xw);
+        if (yb) store_be_record<P>(yb, t, yw);
+        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+    }
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+namespace {
+size_t fused_lanes(size_t n) {
+    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
+    return lanes < cap ? lanes : cap;
+}
+}  // namespace
+
+extern "C" size_t ecn_secp256k1_mul2_get_workspace_bytes(size_t n) { return (fused_lanes(n) + SECP256K1_ROW_SKEW2) * WN26_TABLE_WORDS * sizeof(uint64_t); }
+
+extern "C" int ecn_secp256k1_mul2_get_batch(const char* e, const ma_spint* P, const char* f, const ma_spint* Q, char* x, char* y, int* sign,
+                                          size_t n, size_t ld, void* workspace, size_t workspace_bytes, void* st) {
+    if (n == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 7u) {
+        set_error("ecn mul2_get: byte records must be 8-byte aligned");
+        return (int)hipErrorInvalidValue;
+    }
+    const size_t lanes = fused_lanes(n);
+    if (workspace == nullptr || workspace_bytes < (lanes + SECP256K1_ROW_SKEW2) * WN26_TABLE_WORDS * sizeof(uint64_t)) {
+        set_error("ecn mul2_get: workspace too small (see ecn_secp256k1_mul2_get_workspace_bytes)");
+        return (int)hipErrorInvalidValue;
+    }
+    k_secp256k1_mul2_get<<<(unsigned)(lanes / 64), 64, 0, (hipStream_t)st>>>(
+        reinterpret_cast<const unsigned char*>(e), P, reinterpret_cast<const unsigned char*>(f), Q, reinterpret_cast<unsigned char*>(x),
+        reinterpret_cast<unsigned char*>(y), sign, n, ld, reinterpret_cast<uint64_t*>(workspace));
+    return check_launch("ecn mul2_get");
+}

@@ -17,18 +17,23 @@
 // selects; the digit's sign negates Y.  Work per scalar: 256 doublings + 65 additions + table (4 + 3) + one inversion.
 //
 // K (fm26.h) is given in the comments: |limb| <= K 2^26.  Point coordinates entering add / dbl have K <= 4.
+//
+// secp256k1 (a = 0, b = 7; the second Weierstrass curve of curve.py:190-198 with a 256-bit pseudo-Mersenne field) runs the
+// same scalar-multiplication code on fk26.h with the a = 0 formulas (RCB algorithms 7 and 9, weierstrass.c:120-157,
+// 189-226): 3b = 21 is a small constant, the doubling costs 6M + 2S instead of 8M + 3S + 2m_b.
 #pragma once
 #include "fm26.h"
+#include "fk26.h"
 
 namespace ma {
 
-constexpr int NIST256_TABLE_WORDS = 8 * 15;     // 64-bit words per lane slot: eight entries of (X, Y, Z), two limbs per word
+constexpr int WN26_TABLE_WORDS = 8 * 15;        // 64-bit words per lane slot: eight entries of (X, Y, Z), two limbs per word
+constexpr int NIST256_TABLE_WORDS = WN26_TABLE_WORDS;
 
-template <class C>   // C: curve constants in the 5 x 52 field.c form (generated/curve_NIST256.h)
-struct Wn26 {
+// curve policies: the field representation, a, and the multiplication by the curve constant
+struct CvNist256 {
     using F = Fm26;
-    struct Pt { int32_t X[10], Y[10], Z[10]; };
-
+    static constexpr int A = -3;
     // b 2^286 mod p
     static constexpr int32_t bhat(int i) {
         constexpr int32_t v[10] = {0x30c0187, 0x4bddfd, 0x37d88a7, 0x274d89c, 0x327150a, 0x2cf005c, 0x84bb5a, 0x21a8ff7, 0x394025c, 0x1e0b74};
@@ -39,10 +44,84 @@ struct Wn26 {
         static_for<0, 10>([&](auto I) { b[I] = bhat(I); });
         F::mul(f, b, r);
     }
+};
+struct CvSecp256k1 {
+    using F = Fk26;
+    static constexpr int A = 0;
+    static MA_DEV void mul3b(const int32_t* f, int32_t* r) { F::template mul_small<21>(f, r); }   // 3b = 21
+};
+
+template <class CV>
+struct Wn26 {
+    using F = typename CV::F;
+    struct Pt { int32_t X[10], Y[10], Z[10]; };
+
+    static MA_DEV void mulb(const int32_t* f, int32_t* r) { CV::mulb(f, r); }
     static MA_DEV void inf(Pt& p) { F::zero(p.X); F::set_one(p.Y); F::zero(p.Z); }
+
+    // a = 0: P += Q (RCB algorithm 7; weierstrass.c:120-157).  Inputs K <= 2; X3, Y3, Z3 each one fold of two products.
+    static MA_DEV void add0(const Pt& q, Pt& p) {
+        int32_t T0[10], T1[10], T2[10], T3[10], T4[10], U[10], V[10];
+        F::mul(p.X, q.X, T0);
+        F::mul(p.Y, q.Y, T1);
+        F::mul(p.Z, q.Z, T2);
+        F::add(p.X, p.Y, T3);       // 4
+        F::add(q.X, q.Y, T4);       // 4
+        F::mul(T3, T4, T3);
+        F::add(T0, T1, T4);         // 2
+        F::sub(T3, T4, T3);         // 3   X1Y2 + X2Y1
+        F::add(p.Y, p.Z, T4);       // 4
+        F::add(q.Y, q.Z, U);        // 4
+        F::mul(T4, U, T4);
+        F::add(T1, T2, U);          // 2
+        F::sub(T4, U, T4);          // 3   Y1Z2 + Y2Z1
+        F::add(p.X, p.Z, U);        // 4
+        F::add(q.Z, q.X, V);        // 4
+        F::mul(U, V, U);
+        F::add(T0, T2, V);          // 2
+        F::sub(U, V, U);            // 3   X1Z2 + X2Z1
+        F::add(T0, T0, V);          // 2
+        F::add(T0, V, T0);          // 3   3 X1X2
+        CV::mul3b(T2, T2);          // 1   3b Z1Z2
+        CV::mul3b(U, U);            // 1   3b (X1Z2 + X2Z1)
+        F::add(T1, T2, V);          // 2   Y1Y2 + 3b Z1Z2
+        F::sub(T1, T2, T1);         // 2   Y1Y2 - 3b Z1Z2
+        F::neg(U, T2);              // 1
+        F::mul2(T3, T1, T2, T4, p.X);    // X3 = T3 T1 - U T4:   3 x 2 + 1 x 3
+        F::mul2(U, T0, T1, V, p.Y);      // Y3 = U T0 + T1 V:    1 x 3 + 2 x 2
+        F::mul2(V, T4, T0, T3, p.Z);     // Z3 = V T4 + T0 T3:   2 x 3 + 3 x 3
+    }
+    // a = 0: P = 2P (RCB algorithm 9; weierstrass.c:189-226).  Outputs: X K = 2, Y, Z K = 1.
+    static MA_DEV void dbl0(Pt& p) {
+        int32_t T0[10], T1[10], T2[10], T3[10], T4[10], U[10];
+        F::sqr(p.Y, T0);
+        F::add(T0, T0, T3);         // 2
+        F::add(T3, T3, T3);         // 4
+        F::add(T3, T3, T3);         // 8   8 Y^2
+        F::mul(p.X, p.Y, T4);
+        F::mul(p.Y, p.Z, T1);
+        F::sqr(p.Z, T2);
+        CV::mul3b(T2, T2);          // 1   3b Z^2
+        F::add(T0, T2, U);          // 2   Y^2 + 3b Z^2
+        F::mul(T3, T1, p.Z);        // Z3 = 8 Y^3 Z
+        F::add(T2, T2, T1);         // 2
+        F::add(T2, T1, T1);         // 3   9b Z^2
+        F::sub(T0, T1, T0);         // 4   Y^2 - 9b Z^2
+        F::mul2(U, T0, T2, T3, p.Y);     // Y3 = (Y^2 + 3b Z^2)(Y^2 - 9b Z^2) + 3b Z^2 8 Y^2:  2 x 4 + 1 x 8
+        F::mul(T0, T4, p.X);
+        F::add(p.X, p.X, p.X);      // 2   X3 = 2 X Y (Y^2 - 9b Z^2)
+    }
 
     // P += Q (RCB algorithm 4, a = -3; operation order of weierstrass.c:68-175)
     static MA_DEV void add(const Pt& q, Pt& p) {
+        if constexpr (CV::A == 0) { add0(q, p); return; }
+        else add3(q, p);
+    }
+    static MA_DEV void dbl(Pt& p) {
+        if constexpr (CV::A == 0) { dbl0(p); return; }
+        else dbl3(p);
+    }
+    static MA_DEV void add3(const Pt& q, Pt& p) {
         int32_t B[10], T0[10], T1[10], T2[10], T3[10], T4[10];
         F::mul(p.X, q.X, T0);
         F::mul(p.Y, q.Y, T1);
@@ -89,7 +168,7 @@ struct Wn26 {
     }
 
     // P = 2P (RCB algorithm 6, a = -3; weierstrass.c:187-281)
-    static MA_DEV void dbl(Pt& p) {
+    static MA_DEV void dbl3(Pt& p) {
         int32_t T0[10], T1[10], T2[10], T3[10], T4[10];
         F::sqr(p.X, T0);
         F::sqr(p.Y, T1);
@@ -261,10 +340,10 @@ MA_DEV uint32_t wn26_take(uint64_t* w) {
 //   ew: the scalar as four little-endian 64-bit words (the caller has byte-swapped the big-endian record);
 //   X, Y, Z: the projective point, 5 x 52-bit limbs each (field.c form); tab: this lane's table slot (NIST256_TABLE_WORDS
 //   words, tstride apart); xw, yw: canonical affine coordinates, four little-endian words each.
-template <class C>
-MA_DEV void nist256_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
-                                uint64_t* xw, uint64_t* yw) {
-    using E = Wn26<C>;
+template <class CV>
+MA_DEV void wn26_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
+                             uint64_t* xw, uint64_t* yw) {
+    using E = Wn26<CV>;
     typename E::Pt R, Q;
     E::load_point(X, Y, Z, Q);
     E::template build_table<8>(Q, tab, tstride, 0);
@@ -291,11 +370,11 @@ MA_DEV void nist256_mul_get_one(const uint64_t* ew, const spint* X, const spint*
 // [-4, 3]) so that the two tables {1..4}P and {1..4}Q share the eight entry slots of the same per-lane workspace; per
 // window three doublings and two additions, all lookups scan their table.  (The reference's mul2 is a joint sparse form
 // with data-dependent branches; any evaluation reaches the same affine point.)  An infinite result leaves as (0, 1).
-template <class C>
-MA_DEV void nist256_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
-                                 const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
-                                 uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
-    using E = Wn26<C>;
+template <class CV>
+MA_DEV void wn26_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
+                              const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
+                              uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
+    using E = Wn26<CV>;
     typename E::Pt R, Q;
     E::load_point(PX, PY, PZ, Q);
     E::template build_table<4>(Q, tab, tstride, 0);
@@ -322,6 +401,19 @@ MA_DEV void nist256_mul2_get_one(const uint64_t* ew, const spint* PX, const spin
         }
     }
     E::affine_words(R, xw, yw);
+}
+
+// the P-256 entry points (C: generated/curve_NIST256.h, documentation only: the constants of this form are in CvNist256)
+template <class C>
+MA_DEV void nist256_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
+                                uint64_t* xw, uint64_t* yw) {
+    wn26_mul_get_one<CvNist256>(ew, X, Y, Z, tab, tstride, xw, yw);
+}
+template <class C>
+MA_DEV void nist256_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
+                                 const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
+                                 uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
+    wn26_mul2_get_one<CvNist256>(ew, PX, PY, PZ, fw, QX, QY, QZ, tab, tstride, xw, yw);
 }
 
 }  // namespace ma

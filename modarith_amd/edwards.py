@@ -123,7 +123,7 @@ class Edwards:
         self._call("mul", self._scalars(e, n), P.data_ptr(), n, n, self._ws.data_ptr(), self._ws.numel(), _stream(self.device))
         return P
 
-    FUSED = ("ED25519", "ED448", "NIST256")       # curves with a fused mul + get kernel (csrc/ed26.h, csrc/ed28.h, csrc/wn26.h)
+    FUSED = ("ED25519", "ED448", "NIST256", "SECP256K1")       # curves with a fused mul + get kernel (csrc/ed26.h, csrc/ed28.h, csrc/wn26.h)
 
     def mul_get(self, e: torch.Tensor, P: torch.Tensor, want_x: bool = True, want_y: bool = True):
         """ecnXXXmul followed by ecnXXXget (the reference's call pattern, ed448.c:182-184) in ONE kernel: the affine
@@ -142,7 +142,7 @@ class Edwards:
                    sign.data_ptr(), n, n, self._fws.data_ptr() if need else None, need, _stream(self.device))
         return x, y, sign
 
-    FUSED2 = ("ED25519", "ED448", "NIST256")      # curves with a fused mul2 + get kernel
+    FUSED2 = ("ED25519", "ED448", "NIST256", "SECP256K1")      # curves with a fused mul2 + get kernel
 
     def mul2_get(self, e, P, f, Q, want_x: bool = True, want_y: bool = True):
         """ecnXXXmul2 followed by ecnXXXget (the verification pattern, ed448.c:305) in ONE kernel: the affine coordinates of

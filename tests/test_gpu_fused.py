@@ -9,8 +9,8 @@ import pytest
 from tests.conftest import load_golden
 
 pytestmark = pytest.mark.gpu
-FUSED = [("ed25519", "ED25519"), ("ed448", "ED448"), ("nist256", "NIST256")]
-WEIER = ("nist256",)
+FUSED = [("ed25519", "ED25519"), ("ed448", "ED448"), ("nist256", "NIST256"), ("secp256k1", "SECP256K1")]
+WEIER = ("nist256", "secp256k1")
 
 
 @pytest.fixture(scope="module", params=FUSED)
@@ -159,12 +159,12 @@ def test_fused_rejects_bad_arguments(fx):
     C, Ed, g, torch = fx
     from modarith_amd.edwards import Edwards
     with pytest.raises(ValueError):
-        Edwards("SECP256K1").mul_get(torch.zeros((1, 32), dtype=torch.uint8, device="cuda"), Edwards("SECP256K1").gen(1))
+        Edwards("NUMS256W").mul_get(torch.zeros((1, 32), dtype=torch.uint8, device="cuda"), Edwards("NUMS256W").gen(1))
     x, y, s = Ed.mul_get(torch.zeros((0, Ed.nbytes), dtype=torch.uint8, device="cuda"), Ed.empty(0))
     assert x.shape[0] == 0
 
 
-@pytest.mark.parametrize("C,name,lg", [("ed25519", "ED25519", 14), ("ed448", "ED448", 12), ("nist256", "NIST256", 14)])
+@pytest.mark.parametrize("C,name,lg", [("ed25519", "ED25519", 14), ("ed448", "ED448", 12), ("nist256", "NIST256", 14), ("secp256k1", "SECP256K1", 14)])
 def test_fused_mul2_get(oracle, C, name, lg):
     """e*P + f*Q and its affine export in one kernel: against mul2 + get on the GPU (2^14 / 2^12 random pairs) and the
     oracle's ecn mul2 + ecn get on a sample; special operands: neutral element, P = Q, zero scalars, small order"""

@@ -25,3 +25,77 @@ def test_device_arithmetic_on_host_against_oracle(oracle, tmp_path):
     assert p.returncode == 0, p.stdout[-2000:]
     lines = [l for l in p.stdout.splitlines() if "records" in l]
     assert len(lines) == 13 and all(" 0 differ" in l for l in lines), p.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")
+def test_secp256k1_fused_on_host_against_oracle(oracle, tmp_path):
+    """the per-lane functions of the fused secp256k1 kernels (csrc/wn26.h on csrc/fk26.h), compiled for the host
+    (tools/wn26_host.hip), against the oracle's ecn mul / mul2 followed by ecn get: random projective points, the point at
+    infinity, scalars 0, 1, 2, the group order q, q +- 1, all ones, single windows; for mul2 also Q = +-P and f = e"""
+    import ctypes
+    import random
+    so = str(tmp_path / "libwn26_host.so")
+    cc = HIPCC if os.path.exists(HIPCC) else "hipcc"
+    subprocess.run([cc, "-O2", "-std=c++17", "-w", "-shared", "-fPIC", "--offload-host-only", os.path.join(ROOT, "tools", "wn26_host.hip"), "-o", so],
+                   check=True, timeout=900)
+    lib = ctypes.CDLL(so)
+    U64 = ctypes.c_uint64
+    C = "secp256k1"
+    Pt, nb = oracle.ed[C]
+    q = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    rng = random.Random(11)
+    be = lambda v: v.to_bytes(32, "big")
+    words = lambda v: (U64 * 4)(*[(v >> (64 * k)) & (2**64 - 1) for k in range(4)])
+
+    def point(kind):
+        p = Pt()
+        if kind == "inf":
+            oracle.ecn(C, "inf")(ctypes.byref(p))
+            return p
+        oracle.ecn(C, "gen")(ctypes.byref(p))
+        if kind == "rand":
+            oracle.ecn(C, "mul")(be(rng.getrandbits(256)), ctypes.byref(p))      # projective, Z != 1
+        return p
+
+    def affine(p):
+        x, y = ctypes.create_string_buffer(nb), ctypes.create_string_buffer(nb)
+        oracle.ecn(C, "get")(ctypes.byref(p), x, y)
+        return x.raw, y.raw
+
+    def out_bytes(xw, yw):
+        return b"".join(int(xw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0)), b"".join(int(yw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0))
+
+    corner = [0, 1, 2, 7, 8, 9, 15, 16, 0x88, q - 1, q, q + 1, 2**256 - 1, 2**255, 2**256 - q, 2**256 - 8]
+    for it in range(120):
+        kind = "inf" if it % 16 == 1 else ("gen" if it % 16 == 4 else "rand")
+        e = corner[it] if it < len(corner) else rng.getrandbits(256)
+        p = point(kind)
+        xw, yw = (U64 * 4)(), (U64 * 4)()
+        lib.secp256k1_mul_get_host(words(e), p.x, p.y, p.z, xw, yw)
+        oracle.ecn(C, "mul")(be(e), ctypes.byref(p))
+        assert out_bytes(xw, yw) == affine(p), ("mul_get", it)
+    for it in range(60):
+        e, f = rng.getrandbits(256), rng.getrandbits(256)
+        p, qq = point("rand"), point("rand")
+        if it % 8 == 1:
+            p = point("inf")
+        if it % 8 == 2:
+            qq = point("inf")
+        if it % 8 in (3, 4, 5):
+            oracle.ecn(C, "cpy")(ctypes.byref(p), ctypes.byref(qq))
+            if it % 8 != 4:
+                oracle.ecn(C, "neg")(ctypes.byref(qq))                            # Q = -P
+            if it % 8 == 3:
+                f = e                                                            # e P + e (-P) = infinity -> (0, 1)
+        if it == 6:
+            e = f = 0
+        if it == 7:
+            e = f = 2**256 - 1
+        xw, yw = (U64 * 4)(), (U64 * 4)()
+        lib.secp256k1_mul2_get_host(words(e), p.x, p.y, p.z, words(f), qq.x, qq.y, qq.z, xw, yw)
+        r = Pt()
+        oracle.ecn(C, "mul2")(be(e), ctypes.byref(p), be(f), ctypes.byref(qq), ctypes.byref(r))
+        want = affine(r)
+        assert out_bytes(xw, yw) == want, ("mul2_get", it)
+        if it % 8 == 3:
+            assert want == (be(0), be(1))

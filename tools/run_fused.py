@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from modarith_amd.edwards import Curve
-for name, n in (("ED25519", 1 << 21), ("ED448", 1 << 19), ("NIST256", 1 << 20)):
+for name, n in (("ED25519", 1 << 21), ("ED448", 1 << 19), ("NIST256", 1 << 20), ("SECP256K1", 1 << 20)):
     if sys.argv[1:] and name not in sys.argv[1:]:
         continue
     Ed = Curve(name)

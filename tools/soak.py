@@ -6,7 +6,7 @@
                   in-range values: the product policies must agree bit for bit (checksums compared across three child processes: MA_FORCE_EXACT=1, MA_FORCE_FAST=1, default)
   soak.py curves  2^13 .. 2^16 random scalars x random points for each of the eleven curves, fused ecn mul on the GPU against the CPU oracle,
                   projective limbs compared
-  soak.py fused   2^18 .. 2^20 random (scalar, projective point) pairs per fused curve (ED25519, ED448, NIST256): mul_get against mul + get and
+  soak.py fused   2^18 .. 2^20 random (scalar, projective point) pairs per fused curve (ED25519, ED448, NIST256, SECP256K1): mul_get against mul + get and
                   mul2_get against mul2 + get (the two-call forms are the ones `soak.py curves` pins to the oracle), bytes compared
 """
 import os, subprocess, sys
@@ -108,7 +108,7 @@ def fused():
     import torch
     from modarith_amd.edwards import Curve
     rc = 0
-    for name, lg in (("ED25519", 20), ("ED448", 18), ("NIST256", 20)):
+    for name, lg in (("ED25519", 20), ("ED448", 18), ("NIST256", 20), ("SECP256K1", 20)):
         n = 1 << lg
         C = Curve(name)
         g = torch.Generator(device="cuda").manual_seed(78)

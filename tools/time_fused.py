@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from modarith_amd.edwards import Curve
 only = [a.upper() for a in sys.argv[1:]]
-for name, n in (("ED25519", 1 << 21), ("ED448", 1 << 19), ("NIST256", 1 << 20)):
+for name, n in (("ED25519", 1 << 21), ("ED448", 1 << 19), ("NIST256", 1 << 20), ("SECP256K1", 1 << 20)):
     if only and name not in only:
         continue
     Ed = Curve(name)
@@ -24,7 +24,7 @@ for name, n in (("ED25519", 1 << 21), ("ED448", 1 << 19), ("NIST256", 1 << 20)):
         name, n.bit_length() - 1, n / bf, bf * 1e3, n / bt, bt * 1e3, bt / bf, bool(torch.equal(x, wx) and torch.equal(y, wy))), flush=True)
 
 # fused double multiplication (verification pattern) against mul2 + get
-for name2, n in (("ED25519", 1 << 20), ("ED448", 1 << 18), ("NIST256", 1 << 19)):
+for name2, n in (("ED25519", 1 << 20), ("ED448", 1 << 18), ("NIST256", 1 << 19), ("SECP256K1", 1 << 19)):
   if only and name2 not in only:
       continue
   Ed = Curve(name2)

@@ -1,0 +1,17 @@
+// tools/wn26_host.hip -- the per-lane functions of the fused secp256k1 kernels (csrc/wn26.h on csrc/fk26.h) compiled for
+// the HOST into a small shared library, so that tests/test_host_arith.py can run them against the CPU oracle through
+// ctypes (the secp256k1 oracle is bound to its parameter block at run time by tests/oracle_binding.py, which a C main
+// cannot do).  Test tooling, not product code.
+//   hipcc -O2 -std=c++17 -shared -fPIC --offload-host-only tools/wn26_host.hip -o /tmp/libwn26_host.so
+#define MA_DEV __host__ __device__ inline
+#include "../modarith_amd/csrc/wn26.h"
+
+extern "C" void secp256k1_mul_get_host(const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, uint64_t* xw, uint64_t* yw) {
+    uint64_t tab[ma::WN26_TABLE_WORDS];
+    ma::wn26_mul_get_one<ma::CvSecp256k1>(ew, X, Y, Z, tab, 1, xw, yw);
+}
+extern "C" void secp256k1_mul2_get_host(const uint64_t* ew, const uint64_t* PX, const uint64_t* PY, const uint64_t* PZ,
+                                        const uint64_t* fw, const uint64_t* QX, const uint64_t* QY, const uint64_t* QZ, uint64_t* xw, uint64_t* yw) {
+    uint64_t tab[ma::WN26_TABLE_WORDS];
+    ma::wn26_mul2_get_one<ma::CvSecp256k1>(ew, PX, PY, PZ, fw, QX, QY, QZ, tab, 1, xw, yw);
+}
