@@ -345,7 +345,7 @@ def main():
             del xa, xb, xc
         # the curve layer built on the path, one pass each: side figures (VALU-bound kernels)
         from modarith_amd.edwards import Curve
-        for cname, m in (("ED25519", 1 << 20), ("ED448", 1 << 19), ("SECP256K1", 1 << 18), ("NIST256", 1 << 19)):
+        for cname, m in (("ED25519", 1 << 20), ("ED448", 1 << 19), ("SECP256K1", 1 << 19), ("NIST256", 1 << 19)):
             Cv = Curve(cname, dev)
             e = torch.randint(0, 256, (m, Cv.nbytes), dtype=torch.uint8, device=dev, generator=gen)
             f = torch.randint(0, 256, (m, Cv.nbytes), dtype=torch.uint8, device=dev, generator=gen)
