@@ -5,7 +5,8 @@ import csv, glob, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = "gpurun_out/prof_%s" % tag
 os.makedirs("profiles", exist_ok=True)
-rows = list(csv.reader(open(glob.glob(src + "/stats/*/*_kernel_stats.csv")[0])))
+newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1]      # gpurun_out/ keeps the files of earlier runs of the same tag
+rows = list(csv.reader(open(newest(src + "/stats/*/*_kernel_stats.csv"))))
 with open("profiles/%s_bench_kernel_stats.csv" % tag, "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu (kernel names trimmed to 140 chars)"])
@@ -13,7 +14,7 @@ with open("profiles/%s_bench_kernel_stats.csv" % tag, "w", newline="") as f:
         r[0] = r[0][:140]
         w.writerow(r)
 def pmc(kind):
-    f = glob.glob(src + "/pmc_%s/*/*_counter_collection.csv" % kind)[0]
+    f = newest(src + "/pmc_%s/*/*_counter_collection.csv" % kind)
     return [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_binary<ma::P_X25519, ma::OpMulAuto<ma::P_X25519" in r["Kernel_Name"]]
 fetch, write = pmc("fetch"), pmc("write")
 fk, wk = sum(fetch) / len(fetch), sum(write) / len(write)
