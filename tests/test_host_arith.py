@@ -99,3 +99,49 @@ def test_secp256k1_fused_on_host_against_oracle(oracle, tmp_path):
         assert out_bytes(xw, yw) == want, ("mul2_get", it)
         if it % 8 == 3:
             assert want == (be(0), be(1))
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")
+def test_lazy_limb_bounds_of_the_fused_weierstrass_fields(tmp_path):
+    """fm26.h / fk26.h at the limb magnitudes wn26.h lets them reach (|limb| <= K 2^26 with the K of the comments there):
+    products, squarings and two-product reductions of worst-case operands (all limbs at +-(K 2^26 - 1), alternating signs,
+    random) against Python integers -- the random points of the other tests never come near these bounds"""
+    import ctypes
+    import random
+    so = str(tmp_path / "libwn26_host.so")
+    cc = HIPCC if os.path.exists(HIPCC) else "hipcc"
+    subprocess.run([cc, "-O2", "-std=c++17", "-w", "-shared", "-fPIC", "--offload-host-only", os.path.join(ROOT, "tools", "wn26_host.hip"), "-o", so],
+                   check=True, timeout=900)
+    lib = ctypes.CDLL(so)
+    I32, U64 = ctypes.c_int32 * 10, ctypes.c_uint64 * 4
+    rng = random.Random(7)
+    val = lambda l: sum(int(x) << (26 * i) for i, x in enumerate(l))
+
+    def operand(K, kind):
+        top = K * (1 << 26) - 1
+        if kind == 0:
+            return [top] * 10
+        if kind == 1:
+            return [-top] * 10
+        if kind == 2:
+            return [top if i % 2 == 0 else -top for i in range(10)]
+        if kind == 3:
+            return [rng.choice((top, -top, 0, 1, -1)) for _ in range(10)]
+        return [rng.randint(-top, top) for _ in range(10)]
+
+    fields = ((0, 2**256 - 2**224 + 2**192 + 2**96 - 1, True,
+               [(0, 13, 13, 0, 0), (0, 8, 8, 0, 0), (0, 6, 15, 0, 0), (1, 4, 0, 0, 0), (3, 13, 3, 3, 15), (3, 13, 3, 3, 6), (3, 10, 10, 6, 15), (3, 10, 2, 15, 2)]),
+              (1, 2**256 - 2**32 - 977, False,
+               [(0, 4, 4, 0, 0), (0, 8, 1, 0, 0), (1, 2, 0, 0, 0), (1, 4, 0, 0, 0), (3, 3, 2, 1, 3), (3, 1, 3, 2, 2), (3, 2, 3, 3, 3), (3, 2, 4, 1, 8)]))
+    for which, p, mont, cases in fields:
+        rinv2 = pow(pow(2, 286, p), -2, p) if mont else 1
+        for mode, kf, kg, ku, kv in cases:
+            for kind in range(5):
+                for rep in range(1 if kind < 3 else 40):
+                    f, g = operand(kf, kind), operand(kg or 1, (kind + rep) % 5)
+                    u, v = operand(ku or 1, (kind + 1) % 5), operand(kv or 1, (kind + 2 + rep) % 5)
+                    w = U64()
+                    lib.wn26_field_product(which, mode, I32(*f), I32(*g), I32(*u), I32(*v), w)
+                    got = sum(int(w[k]) << (64 * k) for k in range(4))
+                    t = val(f) * val(g) if mode == 0 else (val(f) ** 2 if mode == 1 else val(f) * val(g) + val(u) * val(v))
+                    assert got == t * rinv2 % p, (which, mode, kf, kg, ku, kv, kind, rep)

@@ -15,3 +15,20 @@ extern "C" void secp256k1_mul2_get_host(const uint64_t* ew, const uint64_t* PX, 
     uint64_t tab[ma::WN26_TABLE_WORDS];
     ma::wn26_mul2_get_one<ma::CvSecp256k1>(ew, PX, PY, PZ, fw, QX, QY, QZ, tab, 1, xw, yw);
 }
+
+// field-level entry points for the limb-bound tests (tests/test_host_arith.py): one product (MODE as in fm26.h / fk26.h)
+// of lazy signed limbs, exported canonically.  which = 0: Fm26 (P-256, result = value / R'^2 mod p), 1: Fk26 (secp256k1)
+extern "C" void wn26_field_product(int which, int mode, const int32_t* f, const int32_t* g, const int32_t* u, const int32_t* v, uint64_t* w) {
+    int32_t r[10];
+    if (which == 0) {
+        if (mode == 0) ma::Fm26::mul(f, g, r);
+        else if (mode == 1) ma::Fm26::sqr(f, r);
+        else ma::Fm26::mul2(f, g, u, v, r);
+        ma::Fm26::to_words(r, w);
+    } else {
+        if (mode == 0) ma::Fk26::mul(f, g, r);
+        else if (mode == 1) ma::Fk26::sqr(f, r);
+        else ma::Fk26::mul2(f, g, u, v, r);
+        ma::Fk26::to_words(r, w);
+    }
+}
