@@ -155,6 +155,25 @@ def test_fused_weierstrass_special_points_and_scalars(fx):
     assert torch.equal(x2, w2x) and torch.equal(y2, w2y)
 
 
+def test_fused_more_points_than_resident_lanes(fx):
+    """the kernels hold one table slot per RESIDENT lane (131 072) and walk larger batches grid-stride, rebuilding the
+    table in the same slot: 2 full passes + a ragged third one, against the two-call form"""
+    C, Ed, g, torch = fx
+    n = 2 * 131072 + 77
+    gen = torch.Generator(device="cuda").manual_seed(93)
+    rnd = lambda m: torch.randint(0, 256, (m, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=gen)
+    P = Ed.mul(rnd(n), Ed.gen(n))
+    e = rnd(n)
+    x, y, _ = Ed.mul_get(e, P)
+    wx, wy, _ = Ed.get(Ed.mul(e, P.clone()))
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+    m = 131072 + 4099
+    Pm, Qm, em, fm = P[:, :, :m].contiguous(), P[:, :, n - m:].contiguous(), e[:m].contiguous(), rnd(m)
+    x, y, _ = Ed.mul2_get(em, Pm, fm, Qm)
+    wx, wy, _ = Ed.get(Ed.mul2(em, Pm, fm, Qm))
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+
+
 def test_fused_rejects_bad_arguments(fx):
     C, Ed, g, torch = fx
     from modarith_amd.edwards import Edwards
