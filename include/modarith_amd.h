@@ -344,6 +344,14 @@ size_t ecn_secp256k1_mul2_get_workspace_bytes(size_t n);
 int ecn_secp256k1_mul2_get_batch(const char *e, const ma_spint *P, const char *f, const ma_spint *Q, char *x, char *y, int *sign,
                                  size_t n, size_t ld, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Generator multiplication + affine export: ecnXXXgen, ecnXXXmul, ecnXXXget in one kernel -- the opening of
+ * NIST256_KEY_PAIR and NIST256_SIGN (nist256.c:150-161, 214-222).  x, y, sign as for mul_get; there is no point
+ * argument and no workspace: the multiples m * 16^i * G live in a 41 600-byte constant table (generated/comb_<C>.h),
+ * every window reads all eight of its entries (constant-time) and adds one with the complete mixed addition.  Same
+ * bytes as ecn_<c>_gen_batch + ecn_<c>_mul_batch + ecn_<c>_get_batch for every 32-byte scalar. */
+int ecn_nist256_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_t n, void *stream);
+int ecn_secp256k1_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

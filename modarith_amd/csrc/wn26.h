@@ -206,6 +206,71 @@ struct Wn26 {
         F::add(p.Z, p.Z, p.Z);      // 4
     }
 
+    // P += (x2, y2), an AFFINE point of the curve (never the point at infinity): the complete mixed additions, RCB
+    // algorithm 5 (a = -3) / 8 (a = 0), i.e. add() with Z2 = 1.  P may be anything, infinity included.  x2, y2 tight.
+    static MA_DEV void madd(const int32_t* x2, const int32_t* y2, Pt& p) {
+        if constexpr (CV::A == 0) {
+            int32_t T0[10], T1[10], T2[10], T3[10], T4[10], U[10], V[10];
+            F::mul(p.X, x2, T0);
+            F::mul(p.Y, y2, T1);
+            F::add(p.X, p.Y, T3);       // 2
+            F::add(x2, y2, T4);         // 2
+            F::mul(T3, T4, T3);
+            F::add(T0, T1, T4);         // 2
+            F::sub(T3, T4, T3);         // 3   X1 y2 + x2 Y1
+            F::mul(y2, p.Z, T4);
+            F::add(T4, p.Y, T4);        // 2   Y1 + y2 Z1
+            F::mul(x2, p.Z, U);
+            F::add(U, p.X, U);          // 2   X1 + x2 Z1
+            F::add(T0, T0, V);          // 2
+            F::add(T0, V, T0);          // 3   3 X1 x2
+            CV::mul3b(p.Z, T2);         // 1   3b Z1
+            CV::mul3b(U, U);            // 1
+            F::add(T1, T2, V);          // 2
+            F::sub(T1, T2, T1);         // 2
+            F::neg(U, T2);              // 1
+            F::mul2(T3, T1, T2, T4, p.X);    // 3 x 2 + 1 x 2
+            F::mul2(U, T0, T1, V, p.Y);      // 1 x 3 + 2 x 2
+            F::mul2(V, T4, T0, T3, p.Z);     // 2 x 2 + 3 x 3
+        } else {
+            int32_t B[10], T0[10], T1[10], T2[10], T3[10], T4[10];
+            F::mul(p.X, x2, T0);
+            F::mul(p.Y, y2, T1);
+            F::add(p.X, p.Y, T3);       // 4
+            F::add(x2, y2, T4);         // 2
+            F::mul(T3, T4, T3);
+            F::add(T0, T1, T4);         // 2
+            F::sub(T3, T4, T3);         // 3   X1 y2 + x2 Y1
+            F::mul(y2, p.Z, T4);
+            F::add(T4, p.Y, T4);        // 3   Y1 + y2 Z1
+            F::mul(x2, p.Z, B);
+            F::add(B, p.X, p.Y);        // 3   X1 + x2 Z1
+            F::copy(p.Z, T2);           // Z1 Z2 = Z1 (K = 1: Z of every sum is one fold of two products)
+            mulb(T2, p.Z);
+            F::sub(p.Y, p.Z, p.X);      // 4
+            F::add(p.X, p.X, p.Z);      // 8
+            F::add(p.X, p.Z, p.X);      // 12
+            F::sub(T1, p.X, p.Z);       // 13
+            F::add(p.X, T1, p.X);       // 13
+            mulb(p.Y, p.Y);
+            F::add(T2, T2, T1);         // 2
+            F::add(T2, T1, T2);         // 3
+            F::sub(p.Y, T2, p.Y);       // 4
+            F::sub(p.Y, T0, p.Y);       // 5
+            F::add(p.Y, p.Y, T1);       // 10
+            F::add(p.Y, T1, p.Y);       // 15
+            F::add(T0, T0, T1);         // 2
+            F::add(T0, T1, T0);         // 3
+            F::sub(T0, T2, T0);         // 6
+            F::mul(T0, p.Y, T2);        // 6 x 15
+            F::neg(p.Y, T1);            // 15
+            F::mul(p.X, p.Z, p.Y);      // 13 x 13
+            F::add(p.Y, T2, p.Y);       // 2
+            F::mul2(p.X, T3, T4, T1, p.X);   // 13 x 3 + 3 x 15
+            F::mul2(p.Z, T4, T3, T0, p.Z);   // 13 x 3 + 3 x 6
+        }
+    }
+
     static MA_DEV void load_point(const spint* X, const spint* Y, const spint* Z, Pt& p) {
         F::from52(X, p.X);
         F::from52(Y, p.Y);
@@ -399,6 +464,67 @@ MA_DEV void wn26_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* 
             E::template lookup<4>(tab, tstride, 4 * which, m, neg, Q);
             E::add(Q, R);
         }
+    }
+    E::affine_words(R, xw, yw);
+}
+
+// Fused GENERATOR multiplication + affine export: the affine coordinates of e*G -- ecnXXXgen, ecnXXXmul, ecnXXXget, the
+// opening of key generation and signing in the reference's ECDSA code (nist256.c:150-161 NIST256_KEY_PAIR, 214-222
+// NIST256_SIGN).  With the base point fixed the doublings disappear: e' = e + sum_{i<65} 8*16^i as before, and
+// e*G = sum_i digit_i * (16^i G) with the 65 x 8 affine multiples m * 16^i * G precomputed (generated/comb_<C>.h, 41 600
+// bytes, the same table for every lane).  Per window the eight entries are read through wave-uniform addresses (TAB: the
+// table in the constant address space, scalar loads) and selected by lane predication, the sign negates y, and one
+// complete MIXED addition follows; a zero digit adds entry 1 and keeps the old sum.  65 mixed additions + one inversion per
+// scalar against 256 doublings + 65 additions: the same bytes as ecn gen + ecn mul + ecn get for every scalar.
+template <class CV, class TAB>
+MA_DEV void wn26_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw) {
+    using E = Wn26<CV>;
+    using F = typename CV::F;
+    typename E::Pt R;
+    uint64_t w[5];
+    {
+        uint64_t t[5];
+        wn26_recode<4, 260>(ew, t);                 // left-aligned by 60 bits: undo, the windows are taken from the bottom here
+        static_for<0, 5>([&](auto K) {
+            constexpr int k = K;
+            w[k] = t[k] >> 60;
+            if constexpr (k < 4) w[k] |= t[k + 1] << 4;
+        });
+    }
+    E::inf(R);
+#pragma unroll 1
+    for (int i = 0; i < 65; i++) {
+        const int dgt = (int)((uint32_t)w[0] & 15u) - 8;        // [-8, 7]
+        static_for<0, 5>([&](auto K) {
+            constexpr int k = K;
+            w[k] >>= 4;
+            if constexpr (k < 4) w[k] |= w[k + 1] << 60;
+        });
+        const bool neg = dgt < 0;
+        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0..8
+        int32_t sx[10], sy[10], ny[10];
+        static_for<0, 10>([&](auto K) {
+            sx[K] = TAB::get((i * 8 * 2 + 0) * 10 + K);
+            sy[K] = TAB::get((i * 8 * 2 + 1) * 10 + K);
+        });
+        static_for<1, 8>([&](auto MM) {
+            constexpr int mm = MM;
+            const bool hit = (m == (uint32_t)(mm + 1));
+            static_for<0, 10>([&](auto K) {
+                const int32_t ax = TAB::get(((i * 8 + mm) * 2 + 0) * 10 + K), ay = TAB::get(((i * 8 + mm) * 2 + 1) * 10 + K);
+                const int32_t bx = sx[K], by = sy[K];
+                sx[K] = hit ? ax : bx;
+                sy[K] = hit ? ay : by;
+            });
+        });
+        F::neg(sy, ny);
+        F::select(neg, sy, ny, sy);
+        typename E::Pt S = R;
+        E::madd(sx, sy, S);
+        const bool keep = (m == 0);
+        F::select(keep, S.X, R.X, R.X);
+        F::select(keep, S.Y, R.Y, R.Y);
+        F::select(keep, S.Z, R.Z, R.Z);
     }
     E::affine_words(R, xw, yw);
 }

@@ -142,6 +142,24 @@ class Edwards:
                    sign.data_ptr(), n, n, self._fws.data_ptr() if need else None, need, _stream(self.device))
         return x, y, sign
 
+    FUSEDG = ("NIST256", "SECP256K1")      # curves with a fused gen + mul + get kernel (fixed-base table)
+
+    def mulgen_get(self, e: torch.Tensor, want_x: bool = True, want_y: bool = True):
+        """ecnXXXgen, ecnXXXmul, ecnXXXget (the opening of key generation and signing, nist256.c:150-161, 214-222) in ONE
+        kernel: the affine coordinates of e*G as canonical big-endian byte records and the sign of the omitted coordinate.
+        Same bytes as get(mul(e, gen(n))); no doublings (precomputed multiples of G), about four times the rate of mul_get."""
+        if self.name.upper() not in self.FUSEDG:
+            raise ValueError("no fused mulgen_get kernel for %s (available: %s)" % (self.name, ", ".join(self.FUSEDG)))
+        if e is None or e.dim() != 2:
+            raise ValueError("scalar records are required (uint8 [n, %d], big-endian)" % self.nbytes)
+        n = e.shape[0]
+        x = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device) if want_x else None
+        y = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device) if want_y else None
+        sign = torch.empty(n, dtype=torch.int32, device=self.device)
+        self._call("mulgen_get", self._scalars(e, n), None if x is None else x.data_ptr(), None if y is None else y.data_ptr(),
+                   sign.data_ptr(), n, _stream(self.device))
+        return x, y, sign
+
     FUSED2 = ("ED25519", "ED448", "NIST256", "SECP256K1")      # curves with a fused mul2 + get kernel
 
     def mul2_get(self, e, P, f, Q, want_x: bool = True, want_y: bool = True):

@@ -440,9 +440,57 @@ def wcurve_header_text(name: str) -> str:
     return "\n".join(L) + "\n"
 
 
+COMB_CURVES = {"NIST256": 286, "SECP256K1": 0}      # curve -> log2 of the Montgomery factor of the fused kernels' field form (fm26.h / fk26.h)
+
+
+def comb_header_text(name: str) -> str:
+    """fixed-base table of the fused generator multiplication (csrc/wn26.h wn26_mulgen_get_one): for every 4-bit window
+    i = 0..64 the affine multiples m * 16^i * G, m = 1..8, coordinates as ten 26-bit limbs of the fused kernels' field form
+    (value * 2^286 mod p for P-256, the plain value for secp256k1).  Plain integer curve arithmetic on the constants of
+    curves.py (curve.py:157-198)."""
+    from .curves import wcurve
+    c = wcurve(name)
+    p, a = c.fp.p, c.a
+    shift = COMB_CURVES[name]
+
+    def add(P, Q):
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        (x1, y1), (x2, y2) = P, Q
+        if x1 == x2:
+            if (y1 + y2) % p == 0:
+                return None
+            lam = (3 * x1 * x1 + a) * pow(2 * y1, -1, p) % p
+        else:
+            lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (lam * lam - x1 - x2) % p
+        return x3, (lam * (x1 - x3) - y1) % p
+
+    limbs = lambda v: [((v << shift) % p >> (26 * k)) & ((1 << 26) - 1) for k in range(10)]
+    rows = []
+    B = (c.gx, c.gy)
+    for i in range(65):
+        T = None
+        for m in range(1, 9):
+            T = add(T, B)
+            rows.append("    " + ", ".join("0x%x" % v for v in limbs(T[0]) + limbs(T[1])) + ",   /* %d * 16^%d * G */ \\" % (m, i))
+        for _ in range(4):
+            B = add(B, B)
+    L = ["// GENERATED by modarith_amd/emit.py from modarith_amd/curves.py -- do not edit.",
+         "// Fixed-base table of %s for ecn_%s_mulgen_get_batch: [window 0..64][multiple 1..8][x, y][10 limbs of 26 bits]," % (name, name.lower()),
+         "// coordinates in the field form of the fused kernels (%s)." % ("value * 2^%d mod p" % shift if shift else "plain value"),
+         "#pragma once",
+         "#define COMB_%s_VALUES \\" % name] + rows + ["    /* end */", ""]
+    return "\n".join(L)
+
+
 def emit_all(primes=BUILT_PRIMES, out_dir: str = GEN_DIR) -> List[str]:
     os.makedirs(out_dir, exist_ok=True)
     paths = [_write(os.path.join(out_dir, "field_table.inc"), field_table_text(primes))]
+    for name in COMB_CURVES:
+        paths.append(_write(os.path.join(out_dir, "comb_%s.h" % name), comb_header_text(name)))
     for name in EXTRA_PRIMES:
         if name in primes:
             paths.append(_write(os.path.join(out_dir, "capi_%s.hip" % name), capi_unit_text(name)))

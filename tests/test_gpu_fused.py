@@ -228,3 +228,41 @@ def test_fused_mul2_get(oracle, C, name, lg):
         assert bytes(hx[j]) == ox.raw and bytes(hy[j]) == oy.raw, j
     none, yo, sx = Ed.mul2_get(e[:100], P[:, :, :100].contiguous(), f[:100], Q[:, :, :100].contiguous(), want_x=False)
     assert none is None and torch.equal(yo, y[:100]) and torch.equal(sx, (x[:100, -1] & 1).to(torch.int32))
+
+
+@pytest.mark.parametrize("name", ["NIST256", "SECP256K1"])
+def test_fused_generator_multiplication(oracle, name):
+    """ecn gen + ecn mul + ecn get in one kernel (fixed-base table, mixed additions): against the fused mul_get on the
+    generator, the two-call form and, on a sample, the oracle; corner scalars; more scalars than resident lanes"""
+    import torch
+    from modarith_amd.edwards import Edwards
+    W = Edwards(name)
+    g = load_golden("weierstrass_%s.json" % name)
+    order = int(g["order"], 16)
+    n = 4 * 65536 + 4099
+    gen = torch.Generator(device="cuda").manual_seed(94)
+    e = torch.randint(0, 256, (n, W.nbytes), dtype=torch.uint8, device="cuda", generator=gen)
+    corner = [0, 1, 2, 8, 9, 15, 16, 0x88, order - 1, order, order + 1, (1 << 256) - 1, 1 << 255, (1 << 256) - order, int("8" * 64, 16), int("9" * 64, 16)]
+    e[:len(corner)] = dev_bytes(torch, [v.to_bytes(32, "big").hex() for v in corner])
+    x, y, s0 = W.mulgen_get(e)
+    G = W.gen(n)
+    fx_, fy_, _ = W.mul_get(e, G)
+    assert torch.equal(x, fx_) and torch.equal(y, fy_)
+    m = 1 << 14
+    wx, wy, _ = W.get(W.mul(e[:m].contiguous(), W.gen(m)))
+    assert torch.equal(x[:m], wx) and torch.equal(y[:m], wy)
+    assert hexrows(x[:1]) == ["00" * 32] and hexrows(y[:1]) == ["00" * 31 + "01"]         # 0 * G = infinity -> (0, 1)
+    assert [hexrows(x[1:2])[0], hexrows(y[1:2])[0]] == g["gen"]
+    assert s0.cpu().tolist() == [0] * n
+    xo, none, sy = W.mulgen_get(e[:4099].contiguous(), want_y=False)                       # compressed public keys
+    assert none is None and torch.equal(xo, x[:4099]) and torch.equal(sy, (y[:4099, -1] & 1).to(torch.int32))
+    C = name.lower()
+    Pt, nb = oracle.ed[C]
+    he, hx, hy = e.cpu().numpy(), x.cpu().numpy(), y.cpu().numpy()
+    for j in list(range(0, 20)) + list(range(20, n, 9973)):
+        p = Pt()
+        oracle.ecn(C, "gen")(ctypes.byref(p))
+        oracle.ecn(C, "mul")(bytes(he[j]), ctypes.byref(p))
+        ox, oy = ctypes.create_string_buffer(nb), ctypes.create_string_buffer(nb)
+        oracle.ecn(C, "get")(ctypes.byref(p), ox, oy)
+        assert bytes(hx[j]) == ox.raw and bytes(hy[j]) == oy.raw, j

@@ -145,3 +145,37 @@ def test_lazy_limb_bounds_of_the_fused_weierstrass_fields(tmp_path):
                     got = sum(int(w[k]) << (64 * k) for k in range(4))
                     t = val(f) * val(g) if mode == 0 else (val(f) ** 2 if mode == 1 else val(f) * val(g) + val(u) * val(v))
                     assert got == t * rinv2 % p, (which, mode, kf, kg, ku, kv, kind, rep)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")
+def test_fused_generator_multiplication_on_host_against_oracle(oracle, tmp_path):
+    """wn26_mulgen_get_one (fixed-base tables generated/comb_<C>.h, complete mixed additions) for P-256 and secp256k1 on the host
+    against the oracle's ecn gen + ecn mul + ecn get: corner scalars (0, 1, single windows, 8 / 9 in every nibble position, the
+    group order and its neighbours, all ones) and random ones"""
+    import ctypes
+    import random
+    so = str(tmp_path / "libwn26_host.so")
+    cc = HIPCC if os.path.exists(HIPCC) else "hipcc"
+    subprocess.run([cc, "-O2", "-std=c++17", "-w", "-shared", "-fPIC", "--offload-host-only", os.path.join(ROOT, "tools", "wn26_host.hip"), "-o", so],
+                   check=True, timeout=900)
+    lib = ctypes.CDLL(so)
+    U64 = ctypes.c_uint64 * 4
+    rng = random.Random(13)
+    orders = {"nist256": 0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551,
+              "secp256k1": 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141}
+    for which, C in enumerate(("nist256", "secp256k1")):
+        Pt, nb = oracle.ed[C]
+        q = orders[C]
+        scalars = [0, 1, 2, 7, 8, 9, 15, 16, 17, 0x88, 0x80, q - 1, q, q + 1, 2**256 - 1, 2**255, 2**256 - q, 2**256 - 8]
+        scalars += [8 << (4 * i) for i in range(0, 64, 7)] + [9 << (4 * i) for i in range(3, 64, 9)] + [int("8" * 64, 16), int("7" * 64, 16), int("9" * 64, 16)]
+        scalars += [rng.getrandbits(256) for _ in range(60)]
+        for e in scalars:
+            xw, yw = U64(), U64()
+            lib.wn26_mulgen_get_host(which, U64(*[(e >> (64 * k)) & (2**64 - 1) for k in range(4)]), xw, yw)
+            p = Pt()
+            oracle.ecn(C, "gen")(ctypes.byref(p))
+            oracle.ecn(C, "mul")(e.to_bytes(32, "big"), ctypes.byref(p))
+            x, y = ctypes.create_string_buffer(nb), ctypes.create_string_buffer(nb)
+            oracle.ecn(C, "get")(ctypes.byref(p), x, y)
+            got = (b"".join(int(xw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0)), b"".join(int(yw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0)))
+            assert got == (x.raw, y.raw), (C, hex(e))

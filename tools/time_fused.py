@@ -40,3 +40,20 @@ for name2, n in (("ED25519", 1 << 20), ("ED448", 1 << 18), ("NIST256", 1 << 19),
       t0 = time.perf_counter(); wx, wy, _ = Ed.get(Ed.mul2(e, P, f, Q)); torch.cuda.synchronize(); bt = min(bt, time.perf_counter() - t0)
   print(name2 + " 2^%d: fused mul2_get" % (n.bit_length() - 1) + " %.3e/s (%.1f ms)   mul2 + get %.3e/s (%.1f ms)   ratio %.2f   equal: %s" % (
       n / bf, bf * 1e3, n / bt, bt * 1e3, bt / bf, bool(torch.equal(x, wx) and torch.equal(y, wy))), flush=True)
+
+# fused generator multiplication (key generation / signing pattern) against gen + mul + get and against mul_get on the generator
+for name3, n in (("NIST256", 1 << 21), ("SECP256K1", 1 << 21)):
+    if only and name3 not in only:
+        continue
+    Ed = Curve(name3)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    e = torch.randint(0, 256, (n, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=g)
+    Ed.mulgen_get(e[:4096].contiguous()); torch.cuda.synchronize()
+    bf = bt = bm = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter(); x, y, s = Ed.mulgen_get(e); torch.cuda.synchronize(); bf = min(bf, time.perf_counter() - t0)
+    for _ in range(2):
+        t0 = time.perf_counter(); wx, wy, _ = Ed.get(Ed.mul(e, Ed.gen(n))); torch.cuda.synchronize(); bt = min(bt, time.perf_counter() - t0)
+        t0 = time.perf_counter(); mx, my, _ = Ed.mul_get(e, Ed.gen(n)); torch.cuda.synchronize(); bm = min(bm, time.perf_counter() - t0)
+    print("%s 2^%d: fused mulgen_get %.3e/s (%.1f ms)   gen + mul + get %.3e/s (%.1f ms)   ratio %.2f   (gen + mul_get %.3e/s)   equal: %s" % (
+        name3, n.bit_length() - 1, n / bf, bf * 1e3, n / bt, bt * 1e3, bt / bf, n / bm, bool(torch.equal(x, wx) and torch.equal(y, wy))), flush=True)

@@ -5,6 +5,8 @@
 //   hipcc -O2 -std=c++17 -shared -fPIC --offload-host-only tools/wn26_host.hip -o /tmp/libwn26_host.so
 #define MA_DEV __host__ __device__ inline
 #include "../modarith_amd/csrc/wn26.h"
+#include "../modarith_amd/csrc/generated/comb_NIST256.h"
+#include "../modarith_amd/csrc/generated/comb_SECP256K1.h"
 
 extern "C" void secp256k1_mul_get_host(const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, uint64_t* xw, uint64_t* yw) {
     uint64_t tab[ma::WN26_TABLE_WORDS];
@@ -31,4 +33,14 @@ extern "C" void wn26_field_product(int which, int mode, const int32_t* f, const 
         else ma::Fk26::mul2(f, g, u, v, r);
         ma::Fk26::to_words(r, w);
     }
+}
+
+// fused generator multiplication (wn26_mulgen_get_one) with the fixed-base tables as host arrays.  which = 0: P-256, 1: secp256k1
+static const int32_t comb_nist256_host[65 * 8 * 2 * 10] = { COMB_NIST256_VALUES };
+static const int32_t comb_secp256k1_host[65 * 8 * 2 * 10] = { COMB_SECP256K1_VALUES };
+struct HostCombNist256 { static int32_t get(int idx) { return comb_nist256_host[idx]; } };
+struct HostCombSecp256k1 { static int32_t get(int idx) { return comb_secp256k1_host[idx]; } };
+extern "C" void wn26_mulgen_get_host(int which, const uint64_t* ew, uint64_t* xw, uint64_t* yw) {
+    if (which == 0) ma::wn26_mulgen_get_one<ma::CvNist256, HostCombNist256>(ew, xw, yw);
+    else ma::wn26_mulgen_get_one<ma::CvSecp256k1, HostCombSecp256k1>(ew, xw, yw);
 }
