@@ -351,6 +351,10 @@ int ecn_secp256k1_mul2_get_batch(const char *e, const ma_spint *P, const char *f
  * bytes as ecn_<c>_gen_batch + ecn_<c>_mul_batch + ecn_<c>_get_batch for every 32-byte scalar. */
 int ecn_nist256_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_t n, void *stream);
 int ecn_secp256k1_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_t n, void *stream);
+/* ED448_KEY_PAIR / ED448_SIGN open the same way (ed448.c:167-184, 196-199); ED25519: 65 windows, cached (y+x, y-x, 2dxy);
+ * ED448: 113 windows, cached (x, y, 39081xy), 173 568-byte table */
+int ecn_ed25519_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_t n, void *stream);
+int ecn_ed448_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ CURVES = {"ed25519": (5, 32), "ed448": (8, 56), "nist256": (5, 32), "nist384": (
 ED_BATCH_FUNCS = ("mul", "mul2", "ran", "add", "sub", "cpy", "dbl", "neg", "inf", "gen", "cof", "affine", "cmp", "isinf", "set", "get")
 FUSED_CURVES = ("ed25519", "ed448", "nist256", "secp256k1")       # fused mul + get kernels (csrc/ed26.h, csrc/ed28.h, csrc/wn26.h)
 FUSED2_CURVES = ("ed25519", "ed448", "nist256", "secp256k1")        # fused mul2 + get
-FUSEDG_CURVES = ("nist256", "secp256k1")             # fused gen + mul + get (fixed-base table, csrc/wn26.h wn26_mulgen_get_one)
+FUSEDG_CURVES = ("nist256", "secp256k1", "ed25519", "ed448")             # fused gen + mul + get (fixed-base tables; csrc/wn26.h, ed26.h, ed28.h *_mulgen_get_one)
 FUSED_FUNCS = (tuple("ecn_%s_mulgen_get_batch" % c for c in FUSEDG_CURVES) + tuple("ecn_%s_mul_get_%s" % (c, f) for c in FUSED_CURVES for f in ("batch", "workspace_bytes"))
                + tuple("ecn_%s_mul2_get_%s" % (c, f) for c in FUSED2_CURVES for f in ("batch", "workspace_bytes")))
 ED_SCALAR_FUNCS = ("mul2", "ran", "get", "set", "inf", "isinf", "neg", "add", "sub", "dbl", "gen", "mul", "cmp", "affine", "cpy", "cof",

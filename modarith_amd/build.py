@@ -30,7 +30,7 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 # (source unit, object name, extra flags).  Every curve unit is compiled three times (MA_CURVE_PART, capi_curve.inc):
 # its two scalar-multiplication kernels take minutes each for the 7- and 9-limb fields and go to separate jobs.
 _CURVE_UNITS = ["capi_%s" % c for c in emit.BUILT_CURVES] + ["capi_%sW" % c for c in emit.BUILT_WCURVES]
-UNITS = ([(u, u, []) for u in ["capi_common", "capi_ED25519F", "capi_ED25519F2", "capi_ED448F", "capi_ED448F2", "capi_NIST256F", "capi_NIST256F2", "capi_SECP256K1F", "capi_SECP256K1F2", "capi_NIST256G", "capi_SECP256K1G"] + ["capi_%s" % p for p in emit.CORE_PRIMES]]
+UNITS = ([(u, u, []) for u in ["capi_common", "capi_ED25519F", "capi_ED25519F2", "capi_ED448F", "capi_ED448F2", "capi_NIST256F", "capi_NIST256F2", "capi_SECP256K1F", "capi_SECP256K1F2", "capi_NIST256G", "capi_SECP256K1G", "capi_ED25519G", "capi_ED448G"] + ["capi_%s" % p for p in emit.CORE_PRIMES]]
          + [(u, "%s_part%d" % (u, part), ["-DMA_CURVE_PART=%d" % part]) for u in _CURVE_UNITS for part in (1, 2, 3)]
          + [("generated/capi_%s" % p, "capi_%s" % p, []) for p in emit.EXTRA_PRIMES])
 # longest first, so the pool does not finish on a long tail

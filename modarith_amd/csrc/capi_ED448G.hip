@@ -1,0 +1,46 @@
+// modarith_amd/csrc/capi_ED448G.hip -- ecn_ed448_mulgen_get_batch: generator multiplication fused with the affine export
+// (csrc/ed28.h ed448_mulgen_get_one), the call sequence ecnXXXgen + ecnXXXmul + ecnXXXget that opens EdDSA key generation
+// and signing in the reference (ed448.c:167-184, 196-199).  Fixed-base table: generated/comb_ED448.h.
+#include "../../include/modarith_amd.h"
+#include "capi_common.h"
+#include "generated/params_X448.h"
+#include "generated/comb_ED448.h"
+#include "kernels.h"
+#include "ed28.h"
+
+namespace ma {
+
+// 113 windows x 8 multiples x (x, y, 39081xy) x 16 limbs, the same for every lane: constant address space, wave-uniform indices
+__constant__ int32_t comb_ed448[COMB_ED448_WINDOWS * 8 * 3 * 16] = { COMB_ED448_VALUES };
+struct CombED448 {
+    static __device__ __forceinline__ int32_t get(int idx) { return comb_ed448[idx]; }
+};
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void k_ed448_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned char* yb, int* sign, size_t n) {
+    using P = P_X448;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        spint ew[7], xw[7], yw[7];
+        load_be_record<P>(e, t, ew);
+        ed448_mulgen_get_one<CombED448>(ew, xw, yw);
+        if (xb) store_be_record<P>(xb, t, xw);
+        if (yb) store_be_record<P>(yb, t, yw);
+        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+    }
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" int ecn_ed448_mulgen_get_batch(const char* e, char* x, char* y, int* sign, size_t n, void* st) {
+    if (n == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 7u) {
+        set_error("ecn mulgen_get: byte records must be 8-byte aligned");
+        return (int)hipErrorInvalidValue;
+    }
+    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)4 * 1024 * 64;       // at most 4 waves on each of the 1024 SIMDs
+    k_ed448_mulgen_get<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(
+        reinterpret_cast<const unsigned char*>(e), reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n);
+    return check_launch("ecn mulgen_get");
+}

@@ -436,4 +436,79 @@ MA_DEV void ed25519_mul2_get_one(const uint64_t* ew, const spint* PX, const spin
     F::to_words(ay, yw);
 }
 
+// Fused GENERATOR multiplication + affine export: the affine coordinates of e*G -- ecnXXXgen, ecnXXXmul, ecnXXXget, the
+// opening of EdDSA key generation and signing (ed448.c:167-184 ED448_KEY_PAIR, 196-199 ED448_SIGN; curve.py builds the same
+// layer for ED25519).  With the base point fixed there are no doublings: e' = e + sum_{i<65} 8*16^i, digit_i =
+// window_i(e') - 8 in [-8, 7], and e*G = sum_i digit_i * (16^i G) with the 65 x 8 multiples precomputed in cached affine
+// form (generated/comb_ED25519.h, 62 400 bytes, one table for all lanes, read through wave-uniform addresses: TAB).  Per
+// window all eight entries are read and selected by lane predication (a zero digit keeps the neutral element (1, 1, 0)),
+// the sign swaps y+x / y-x and negates 2dxy, and one complete mixed addition (7M, T carried along) follows.
+template <class C, class TAB>
+MA_DEV void ed25519_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw) {
+    using E = Ed26<C>;
+    using F = Fe26;
+    typename E::Ext R;
+    uint64_t w[5];
+    {
+        constexpr auto cw = [](int k) {
+            uint64_t v = 0;
+            for (int b = 0; b < 64; b++) {
+                const int pos = 64 * k + b;
+                if (pos < 260 && pos % 4 == 3) v |= (uint64_t)1 << b;
+            }
+            return v;
+        };
+        unsigned __int128 acc = 0;
+        static_for<0, 5>([&](auto K) {
+            constexpr int k = K;
+            acc += (unsigned __int128)(k < 4 ? ew[k < 4 ? k : 0] : 0) + cw(k);
+            w[k] = (uint64_t)acc;
+            acc >>= 64;
+        });
+    }
+    F::set(0, R.X);
+    F::set(1, R.Y);
+    F::set(1, R.Z);
+    F::set(0, R.T);
+#pragma unroll 1
+    for (int i = 0; i < 65; i++) {
+        const int dgt = (int)((uint32_t)w[0] & 15u) - 8;        // [-8, 7]
+        static_for<0, 5>([&](auto K) {
+            constexpr int k = K;
+            w[k] >>= 4;
+            if constexpr (k < 4) w[k] |= w[k + 1] << 60;
+        });
+        const bool neg = dgt < 0;
+        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0..8
+        uint32_t sel[3][10];
+        static_for<0, 3>([&](auto CI) { static_for<0, 10>([&](auto K) { sel[CI][K] = (CI < 2 && K == 0) ? 1u : 0u; }); });
+        // (selection as OR of masked entries: v_and_or_b32 reads the table entry straight from its scalar register, see wn26.h;
+        // limb 0 of y+x and y-x starts at 1 only for a zero digit, so the OR never meets a set bit)
+        static_for<0, 2>([&](auto CI) { sel[CI][0] = (m == 0) ? 1u : 0u; });
+        static_for<0, 8>([&](auto MM) {
+            constexpr int mm = MM;
+            uint32_t mask = (m == (uint32_t)(mm + 1)) ? 0xffffffffu : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm("" : "+v"(mask));       // opaque: otherwise the compiler turns (entry & mask) back into a select with a move
+#endif
+            static_for<0, 3>([&](auto CI) {
+                static_for<0, 10>([&](auto K) { sel[CI][K] |= (uint32_t)TAB::get(((i * 8 + mm) * 3 + CI) * 10 + K) & mask; });
+            });
+        });
+        uint32_t yp[10], ym[10], nt[10];
+        F::select(neg, sel[0], sel[1], yp);
+        F::select(neg, sel[1], sel[0], ym);
+        F::set(0, nt);
+        F::sub(nt, sel[2], nt);                                 // 2p - t: 1.0 .. 1.5
+        F::select(neg, sel[2], nt, sel[2]);
+        E::template add_cached<true>(R, yp, ym, sel[2]);
+    }
+    uint32_t zi[10], ax[10], ay[10];
+    F::invert(R.Z, zi);
+    F::mul(R.X, zi, ax);
+    F::mul(R.Y, zi, ay);
+    F::to_words(ax, xw);
+    F::to_words(ay, yw);
+}
+
 }  // namespace ma

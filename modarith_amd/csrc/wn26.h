@@ -474,7 +474,7 @@ MA_DEV void wn26_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* 
 // e*G = sum_i digit_i * (16^i G) with the 65 x 8 affine multiples m * 16^i * G precomputed (generated/comb_<C>.h, 41 600
 // bytes, the same table for every lane).  Per window the eight entries are read through wave-uniform addresses (TAB: the
 // table in the constant address space, scalar loads) and selected by lane predication, the sign negates y, and one
-// complete MIXED addition follows; a zero digit adds entry 1 and keeps the old sum.  65 mixed additions + one inversion per
+// complete MIXED addition follows; a zero digit adds (0, 0) and keeps the old sum.  65 mixed additions + one inversion per
 // scalar against 256 doublings + 65 additions: the same bytes as ecn gen + ecn mul + ecn get for every scalar.
 template <class CV, class TAB>
 MA_DEV void wn26_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw) {
@@ -502,19 +502,20 @@ MA_DEV void wn26_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw) 
         });
         const bool neg = dgt < 0;
         const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0..8
+        // selection as OR of masked entries (exactly one mask is set, none for a zero digit): the entries sit in scalar
+        // registers, and v_and_or_b32 takes one of those next to two vector operands -- a v_cndmask would need a move first
+        // (its lane mask already uses the one scalar operand an instruction may read)
         int32_t sx[10], sy[10], ny[10];
-        static_for<0, 10>([&](auto K) {
-            sx[K] = TAB::get((i * 8 * 2 + 0) * 10 + K);
-            sy[K] = TAB::get((i * 8 * 2 + 1) * 10 + K);
-        });
-        static_for<1, 8>([&](auto MM) {
+        static_for<0, 10>([&](auto K) { sx[K] = 0; sy[K] = 0; });
+        static_for<0, 8>([&](auto MM) {
             constexpr int mm = MM;
-            const bool hit = (m == (uint32_t)(mm + 1));
+            uint32_t mask = (m == (uint32_t)(mm + 1)) ? 0xffffffffu : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm("" : "+v"(mask));       // opaque: otherwise the compiler turns (entry & mask) back into a select with a move
+#endif
             static_for<0, 10>([&](auto K) {
-                const int32_t ax = TAB::get(((i * 8 + mm) * 2 + 0) * 10 + K), ay = TAB::get(((i * 8 + mm) * 2 + 1) * 10 + K);
-                const int32_t bx = sx[K], by = sy[K];
-                sx[K] = hit ? ax : bx;
-                sy[K] = hit ? ay : by;
+                sx[K] = (int32_t)((uint32_t)sx[K] | ((uint32_t)TAB::get(((i * 8 + mm) * 2 + 0) * 10 + K) & mask));
+                sy[K] = (int32_t)((uint32_t)sy[K] | ((uint32_t)TAB::get(((i * 8 + mm) * 2 + 1) * 10 + K) & mask));
             });
         });
         F::neg(sy, ny);

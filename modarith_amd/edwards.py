@@ -142,10 +142,10 @@ class Edwards:
                    sign.data_ptr(), n, n, self._fws.data_ptr() if need else None, need, _stream(self.device))
         return x, y, sign
 
-    FUSEDG = ("NIST256", "SECP256K1")      # curves with a fused gen + mul + get kernel (fixed-base table)
+    FUSEDG = ("NIST256", "SECP256K1", "ED25519", "ED448")      # curves with a fused gen + mul + get kernel (fixed-base table)
 
     def mulgen_get(self, e: torch.Tensor, want_x: bool = True, want_y: bool = True):
-        """ecnXXXgen, ecnXXXmul, ecnXXXget (the opening of key generation and signing, nist256.c:150-161, 214-222) in ONE
+        """ecnXXXgen, ecnXXXmul, ecnXXXget (the opening of key generation and signing, nist256.c:150-161, 214-222, ed448.c:167-184, 196-199) in ONE
         kernel: the affine coordinates of e*G as canonical big-endian byte records and the sign of the omitted coordinate.
         Same bytes as get(mul(e, gen(n))); no doublings (precomputed multiples of G), about four times the rate of mul_get."""
         if self.name.upper() not in self.FUSEDG:

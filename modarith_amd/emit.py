@@ -486,11 +486,56 @@ def comb_header_text(name: str) -> str:
     return "\n".join(L)
 
 
+COMB_EDWARDS = {"ED25519": (65, "fe26"), "ED448": (113, "fe28")}      # curve -> (4-bit windows of a Nbytes scalar + 1, limb form)
+
+
+def comb_edwards_header_text(name: str) -> str:
+    """fixed-base table of the fused generator multiplication on the Edwards curves (csrc/ed26.h / ed28.h *_mulgen_get_one):
+    for every 4-bit window i the affine multiples m * 16^i * G, m = 1..8, in the cached form of the mixed addition --
+    ED25519: (y+x, y-x, 2dxy) as ten 25.5-bit limbs (fe26.h), ED448: (x, y, 39081 x y) as sixteen 28-bit limbs (fe28.h).
+    Plain integer curve arithmetic on the constants of curves.py (curve.py:85-105)."""
+    from .curves import curve
+    c = curve(name)
+    p, a, d = c.fp.p, c.a, c.d % c.fp.p
+    windows, form = COMB_EDWARDS[name]
+
+    def add(P, Q):
+        (x1, y1), (x2, y2) = P, Q
+        t = d * x1 * x2 * y1 * y2 % p
+        return ((x1 * y2 + y1 * x2) * pow(1 + t, -1, p) % p, (y1 * y2 - a * x1 * x2) * pow(1 - t, -1, p) % p)
+
+    if form == "fe26":
+        pos = lambda i: (51 * i + 1) // 2
+        limbs = lambda v: [(v >> pos(i)) & ((1 << (25 if i & 1 else 26)) - 1) for i in range(10)]
+        cached = lambda x, y: limbs((y + x) % p) + limbs((y - x) % p) + limbs(2 * d * x * y % p)
+    else:
+        limbs = lambda v: [(v >> (28 * i)) & ((1 << 28) - 1) for i in range(16)]
+        cached = lambda x, y: limbs(x) + limbs(y) + limbs((-d) % p * x * y % p)
+    rows = []
+    B = (c.gx, c.gy)
+    for i in range(windows):
+        T = (0, 1)
+        for m in range(1, 9):
+            T = add(T, B)
+            rows.append("    " + ", ".join("0x%x" % v for v in cached(*T)) + ",   /* %d * 16^%d * G */ \\" % (m, i))
+        for _ in range(4):
+            B = add(B, B)
+    L = ["// GENERATED by modarith_amd/emit.py from modarith_amd/curves.py -- do not edit.",
+         "// Fixed-base table of %s for ecn_%s_mulgen_get_batch: [window 0..%d][multiple 1..8][%s][limbs]." % (
+             name, name.lower(), windows - 1, "y+x, y-x, 2dxy: 10 limbs of 25.5 bits" if form == "fe26" else "x, y, 39081xy: 16 limbs of 28 bits"),
+         "#pragma once",
+         "#define COMB_%s_WINDOWS %d" % (name, windows),
+         "#define COMB_%s_VALUES \\" % name] + rows + ["    /* end */", ""]
+    return "\n".join(L)
+
+
 def emit_all(primes=BUILT_PRIMES, out_dir: str = GEN_DIR) -> List[str]:
     os.makedirs(out_dir, exist_ok=True)
     paths = [_write(os.path.join(out_dir, "field_table.inc"), field_table_text(primes))]
     for name in COMB_CURVES:
         paths.append(_write(os.path.join(out_dir, "comb_%s.h" % name), comb_header_text(name)))
+    for name in COMB_EDWARDS:
+        paths.append(_write(os.path.join(out_dir, "comb_%s.h" % name), comb_edwards_header_text(name)))
     for name in EXTRA_PRIMES:
         if name in primes:
             paths.append(_write(os.path.join(out_dir, "capi_%s.hip" % name), capi_unit_text(name)))

@@ -230,6 +230,43 @@ def test_fused_mul2_get(oracle, C, name, lg):
     assert none is None and torch.equal(yo, y[:100]) and torch.equal(sx, (x[:100, -1] & 1).to(torch.int32))
 
 
+@pytest.mark.parametrize("name", ["ED25519", "ED448"])
+def test_fused_generator_multiplication_edwards(oracle, name):
+    """ecn gen + ecn mul + ecn get in one kernel on the Edwards curves: against the fused mul_get on the generator, the
+    two-call form and, on a sample, the oracle; corner scalars; more scalars than resident lanes"""
+    import torch
+    from modarith_amd.edwards import Edwards
+    W = Edwards(name)
+    g = load_golden("edwards_%s.json" % name)
+    order = int(g["order"], 16)
+    nb = W.nbytes
+    n = 4 * 65536 + 4099
+    gen = torch.Generator(device="cuda").manual_seed(95)
+    e = torch.randint(0, 256, (n, nb), dtype=torch.uint8, device="cuda", generator=gen)
+    top = 1 << (8 * nb)
+    corner = [0, 1, 2, 8, 9, 15, 16, 0x88, order - 1, order, order + 1, (top - 1) // order * order, top - 1, top >> 1, int("8" * (2 * nb), 16), int("9" * (2 * nb), 16), int("7" * (2 * nb), 16)]
+    e[:len(corner)] = dev_bytes(torch, [v.to_bytes(nb, "big").hex() for v in corner])
+    x, y, s0 = W.mulgen_get(e)
+    fx_, fy_, _ = W.mul_get(e, W.gen(n))
+    assert torch.equal(x, fx_) and torch.equal(y, fy_)
+    m = 1 << 13
+    wx, wy, _ = W.get(W.mul(e[:m].contiguous(), W.gen(m)))
+    assert torch.equal(x[:m], wx) and torch.equal(y[:m], wy)
+    assert hexrows(x[:1]) == ["00" * nb] and hexrows(y[:1]) == ["00" * (nb - 1) + "01"]    # 0 * G = neutral element (0, 1)
+    none, yo, sx = W.mulgen_get(e[:4099].contiguous(), want_x=False)                       # compressed public keys (ed448.c:181)
+    assert none is None and torch.equal(yo, y[:4099]) and torch.equal(sx, (x[:4099, -1] & 1).to(torch.int32))
+    C = name.lower()
+    Pt, onb = oracle.ed[C]
+    he, hx, hy = e.cpu().numpy(), x.cpu().numpy(), y.cpu().numpy()
+    for j in list(range(0, 20)) + list(range(20, n, 19991)):
+        p = Pt()
+        oracle.ecn(C, "gen")(ctypes.byref(p))
+        oracle.ecn(C, "mul")(bytes(he[j]), ctypes.byref(p))
+        ox, oy = ctypes.create_string_buffer(onb), ctypes.create_string_buffer(onb)
+        oracle.ecn(C, "get")(ctypes.byref(p), ox, oy)
+        assert bytes(hx[j]) == ox.raw and bytes(hy[j]) == oy.raw, j
+
+
 @pytest.mark.parametrize("name", ["NIST256", "SECP256K1"])
 def test_fused_generator_multiplication(oracle, name):
     """ecn gen + ecn mul + ecn get in one kernel (fixed-base table, mixed additions): against the fused mul_get on the

@@ -15,6 +15,8 @@
 #include "../modarith_amd/csrc/ed28.h"
 #include "../modarith_amd/csrc/generated/curve_NIST256.h"
 #include "../modarith_amd/csrc/wn26.h"
+#include "../modarith_amd/csrc/generated/comb_ED25519.h"
+#include "../modarith_amd/csrc/generated/comb_ED448.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -450,6 +452,44 @@ static int run_nist256_mul2(int n) {
     return bad;
 }
 
+// fused generator multiplication on the Edwards curves (fixed-base tables generated/comb_<C>.h as host arrays) against the
+// oracle's ecn gen + ecn mul + ecn get: corner scalars (0, 1, single windows, 8 / 9 nibbles, all ones) and random ones
+static const int32_t comb_ed25519_host[] = { COMB_ED25519_VALUES };
+static const int32_t comb_ed448_host[] = { COMB_ED448_VALUES };
+struct HostComb25519 { static int32_t get(int idx) { return comb_ed25519_host[idx]; } };
+struct HostComb448 { static int32_t get(int idx) { return comb_ed448_host[idx]; } };
+template <int NB, class PT, class FN, class GEN, class MUL, class GET>
+static int run_edgen(const char* name, int n, FN fused, GEN gen, MUL mul, GET get) {
+    int bad = 0;
+    for (int it = 0; it < n; it++) {
+        unsigned char e[NB];
+        for (int i = 0; i < NB; i++) e[i] = (unsigned char)sm();
+        if (it == 0) memset(e, 0, NB);
+        if (it == 1) { memset(e, 0, NB); e[NB - 1] = 1; }
+        if (it == 2) memset(e, 0xff, NB);
+        if (it == 3) memset(e, 0x88, NB);
+        if (it == 4) memset(e, 0x99, NB);
+        if (it == 5) memset(e, 0x77, NB);
+        if (it == 6) { memset(e, 0, NB); e[NB - 1] = 8; }
+        if (it == 7) { memset(e, 0, NB); e[0] = 0x80; }
+        if (it == 8) { memset(e, 0, NB); e[NB - 1] = 0x10; }
+        if (it >= 9 && it < 9 + 2 * NB) { memset(e, 0, NB); e[(it - 9) / 2] = (it & 1) ? 0x08 : 0x90; }
+        uint64_t ew[NB / 8], xw[NB / 8], yw[NB / 8];
+        for (int w = 0; w < NB / 8; w++) { uint64_t v = 0; for (int b = 0; b < 8; b++) v |= (uint64_t)e[NB - 1 - (8 * w + b)] << (8 * b); ew[w] = v; }
+        fused(ew, xw, yw);
+        PT P;
+        gen(&P);
+        mul((const char*)e, &P);
+        char wx[NB], wy[NB];
+        get(&P, wx, wy);
+        unsigned char gx[NB], gy[NB];
+        for (int i = 0; i < NB; i++) { gx[i] = (unsigned char)(xw[(NB - 1 - i) / 8] >> (8 * ((NB - 1 - i) % 8))); gy[i] = (unsigned char)(yw[(NB - 1 - i) / 8] >> (8 * ((NB - 1 - i) % 8))); }
+        if (memcmp(gx, wx, NB) != 0 || memcmp(gy, wy, NB) != 0) { if (bad < 6) printf("%s: record %d differs\n", name, it); bad++; }
+    }
+    printf("%s: %d records, %d differ from the oracle's ecn gen + mul + get\n", name, n, bad);
+    return bad;
+}
+
 int main(int argc, char** argv) {
     int n = argc > 1 ? atoi(argv[1]) : 2000;
     int bad = run<4>("x25519_fe26_one", n, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x25519_fe26_one(k, u, o); }, rfc7748_X25519);
@@ -465,5 +505,9 @@ int main(int argc, char** argv) {
     bad += run_ed448_mul2(n / 32 + 16);
     bad += run_nist256(n / 8 + 16);
     bad += run_nist256_mul2(n / 16 + 16);
+    bad += run_edgen<32, pt25519>("ed25519_mulgen_get_one", n / 4 + 80, [](const uint64_t* e, uint64_t* x, uint64_t* y) { ma::ed25519_mulgen_get_one<ma::C_ED25519, HostComb25519>(e, x, y); },
+                                  ecn_ed25519_gen, ecn_ed25519_mul, ecn_ed25519_get);
+    bad += run_edgen<56, pt448>("ed448_mulgen_get_one", n / 8 + 130, [](const uint64_t* e, uint64_t* x, uint64_t* y) { ma::ed448_mulgen_get_one<HostComb448>(e, x, y); },
+                                ecn_ed448_gen, ecn_ed448_mul, ecn_ed448_get);
     return bad ? 1 : 0;
 }

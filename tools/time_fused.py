@@ -42,7 +42,7 @@ for name2, n in (("ED25519", 1 << 20), ("ED448", 1 << 18), ("NIST256", 1 << 19),
       n / bf, bf * 1e3, n / bt, bt * 1e3, bt / bf, bool(torch.equal(x, wx) and torch.equal(y, wy))), flush=True)
 
 # fused generator multiplication (key generation / signing pattern) against gen + mul + get and against mul_get on the generator
-for name3, n in (("NIST256", 1 << 21), ("SECP256K1", 1 << 21)):
+for name3, n in (("NIST256", 1 << 21), ("SECP256K1", 1 << 21), ("ED25519", 1 << 22), ("ED448", 1 << 20)):
     if only and name3 not in only:
         continue
     Ed = Curve(name3)
