@@ -389,6 +389,19 @@ def main():
                                                            "two_call_form_per_s": mq / (t2 - t1), "speedup": (t2 - t1) / (t1 - t0),
                                                            "bytes_equal_to_two_call_form": True}
                 del fx_, fy_, wx_, wy_, e2, f2, G2, Q2
+            if cname in getattr(Cv, "FUSEDG", ()):
+                # key generation / signing opening ecnXXXgen + ecnXXXmul + ecnXXXget (nist256.c:150-161, ed448.c:167-184): fixed-base kernel
+                Cv.mulgen_get(e[:4096].contiguous())
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                gx_, gy_, _ = Cv.mulgen_get(e)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                wx_, wy_, _ = Cv.get(Cv.mul(e, Cv.gen(m)))
+                torch.cuda.synchronize(); t2 = time.perf_counter()
+                assert torch.equal(gx_, wx_) and torch.equal(gy_, wy_), "fused mulgen_get differs from gen + mul + get"
+                others["%s_ecn_mulgen_get_fused" % cname] = {"scalar_mults_per_s_per_gpu": m / (t1 - t0), "scalars": m, "bound": "VALU",
+                                                             "three_call_form_per_s": m / (t2 - t1), "speedup": (t2 - t1) / (t1 - t0),
+                                                             "bytes_equal_to_three_call_form": True}
+                del gx_, gy_, wx_, wy_
             del e, f, G, Q, R
 
     ladder = None
