@@ -16,16 +16,26 @@ struct CombSECP256K1 {
     static __device__ __forceinline__ int32_t get(int idx) { return comb_secp256k1[idx]; }
 };
 
+// MULGEN_G scalars per lane (elements t, t + lanes, ... of a MULGEN_G * lanes stride) share one inversion
+#ifndef MULGEN_G
+#define MULGEN_G 4
+#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
 void k_secp256k1_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned char* yb, int* sign, size_t n) {
     using P = P_SECP256K1;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        spint ew[4], xw[4], yw[4];
-        load_be_record<P>(e, t, ew);
-        wn26_mulgen_get_one<CvSecp256k1, CombSECP256K1>(ew, xw, yw);
-        if (xb) store_be_record<P>(xb, t, xw);
-        if (yb) store_be_record<P>(yb, t, yw);
-        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+    const size_t lanes = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += MULGEN_G * lanes) {
+        spint xw[MULGEN_G][4], yw[MULGEN_G][4];
+        wn26_mulgen_get_many<CvSecp256k1, CombSECP256K1, MULGEN_G>(
+            [&](int g, spint* ew) { const size_t tg = t + (size_t)g * lanes; load_be_record<P>(e, tg < n ? tg : t, ew); }, xw, yw);
+        static_for<0, MULGEN_G>([&](auto GI) {
+            const size_t tg = t + (size_t)GI * lanes;
+            if (tg < n) {
+                if (xb) store_be_record<P>(xb, tg, xw[GI]);
+                if (yb) store_be_record<P>(yb, tg, yw[GI]);
+                if (sign) sign[tg] = !yb ? (int)(yw[GI][0] & 1) : (!xb ? (int)(xw[GI][0] & 1) : 0);
+            }
+        });
     }
 }
 
@@ -39,7 +49,7 @@ extern "C" int ecn_secp256k1_mulgen_get_batch(const char* e, char* x, char* y, i
         set_error("ecn mulgen_get: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
     }
-    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)4 * 1024 * 64;       // at most 4 waves on each of the 1024 SIMDs
+    const size_t lanes = ((n + MULGEN_G - 1) / MULGEN_G + 63) / 64 * 64, cap = (size_t)4 * 1024 * 64;       // MULGEN_G scalars per lane; at most 4 waves on each of the 1024 SIMDs
     k_secp256k1_mulgen_get<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(
         reinterpret_cast<const unsigned char*>(e), reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n);
     return check_launch("ecn mulgen_get");

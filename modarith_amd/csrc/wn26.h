@@ -361,6 +361,41 @@ struct Wn26 {
             yw[K] = z0 ? (K == 0 ? 1u : 0u) : yw[K];
         });
     }
+    // affine_words for G points with ONE inversion (Montgomery's trick on the prefix products of the Z); a point at infinity
+    // takes Z = 1 into the shared product and leaves as (0, 1) as above.  xw, yw: G x 4 words.
+    template <int G>
+    static MA_DEV void affine_words_many(const Pt* pts, uint64_t (*xw)[4], uint64_t (*yw)[4]) {
+        int32_t z[G][10], pre[G][10], inv[10], t[10], u[10], one[10];
+        bool inf_[G];
+        F::set_one(one);
+        static_for<0, G>([&](auto GI) {
+            constexpr int g = GI;
+            uint64_t zw[4];
+            F::to_words(pts[g].Z, zw);
+            inf_[g] = (zw[0] | zw[1] | zw[2] | zw[3]) == 0;
+            F::select(inf_[g], pts[g].Z, one, z[g]);
+            if constexpr (g == 0) F::copy(z[0], pre[0]);
+            else F::mul(pre[g - 1], z[g], pre[g]);
+        });
+        F::invert(pre[G - 1], inv);
+        static_for<0, G>([&](auto GI) {
+            constexpr int g = G - 1 - GI;
+            if constexpr (g > 0) {
+                F::mul(inv, pre[g - 1], t);         // 1 / z_g
+                F::mul(inv, z[g], inv);             // 1 / (z_0 ... z_{g-1})
+            } else {
+                F::copy(inv, t);
+            }
+            F::mul(pts[g].X, t, u);
+            F::to_words(u, xw[g]);
+            F::mul(pts[g].Y, t, u);
+            F::to_words(u, yw[g]);
+            static_for<0, 4>([&](auto K) {
+                xw[g][K] = inf_[g] ? 0u : xw[g][K];
+                yw[g][K] = inf_[g] ? (K == 0 ? 1u : 0u) : yw[g][K];
+            });
+        });
+    }
 };
 
 // s = e + bias (bias: a 1 in bit positions b < BITS with b % W == W - 1), then left-aligned so that the top window
@@ -477,10 +512,9 @@ MA_DEV void wn26_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* 
 // complete MIXED addition follows; a zero digit adds (0, 0) and keeps the old sum.  65 mixed additions + one inversion per
 // scalar against 256 doublings + 65 additions: the same bytes as ecn gen + ecn mul + ecn get for every scalar.
 template <class CV, class TAB>
-MA_DEV void wn26_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw) {
+MA_DEV void wn26_mulgen_acc(const uint64_t* ew, typename Wn26<CV>::Pt& R) {
     using E = Wn26<CV>;
     using F = typename CV::F;
-    typename E::Pt R;
     uint64_t w[5];
     {
         uint64_t t[5];
@@ -527,7 +561,26 @@ MA_DEV void wn26_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw) 
         F::select(keep, S.Y, R.Y, R.Y);
         F::select(keep, S.Z, R.Z, R.Z);
     }
-    E::affine_words(R, xw, yw);
+}
+template <class CV, class TAB>
+MA_DEV void wn26_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw) {
+    typename Wn26<CV>::Pt R;
+    wn26_mulgen_acc<CV, TAB>(ew, R);
+    Wn26<CV>::affine_words(R, xw, yw);
+}
+// G scalars per lane, one inversion for all of them (the inversion is a fifth of the single-scalar kernel).  load(g, ew)
+// fetches the g-th scalar of this lane; the window loop is rolled over g (one copy in the instruction stream).
+template <class CV, class TAB, int G, class LOAD>
+MA_DEV void wn26_mulgen_get_many(LOAD load, uint64_t (*xw)[4], uint64_t (*yw)[4]) {
+    typename Wn26<CV>::Pt Rs[G], R;
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        uint64_t ew[4];
+        load(g, ew);
+        wn26_mulgen_acc<CV, TAB>(ew, R);
+        static_for<0, G>([&](auto GI) { if (g == GI) Rs[GI] = R; });       // (static register indices only)
+    }
+    Wn26<CV>::template affine_words_many<G>(Rs, xw, yw);
 }
 
 // the P-256 entry points (C: generated/curve_NIST256.h, documentation only: the constants of this form are in CvNist256)

@@ -24,7 +24,7 @@ def test_device_arithmetic_on_host_against_oracle(oracle, tmp_path):
     p = subprocess.run([exe, "400"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:]
     lines = [l for l in p.stdout.splitlines() if "records" in l]
-    assert len(lines) == 15 and all(" 0 differ" in l for l in lines), p.stdout
+    assert len(lines) == 16 and all(" 0 differ" in l for l in lines), p.stdout
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")
@@ -179,3 +179,26 @@ def test_fused_generator_multiplication_on_host_against_oracle(oracle, tmp_path)
             oracle.ecn(C, "get")(ctypes.byref(p), x, y)
             got = (b"".join(int(xw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0)), b"".join(int(yw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0)))
             assert got == (x.raw, y.raw), (C, hex(e))
+        # G scalars per lane with one shared inversion (the kernels' form): groups that mix infinite and finite results
+        want = {}
+
+        def ref(e):
+            if e not in want:
+                p = Pt()
+                oracle.ecn(C, "gen")(ctypes.byref(p))
+                oracle.ecn(C, "mul")(e.to_bytes(32, "big"), ctypes.byref(p))
+                x, y = ctypes.create_string_buffer(nb), ctypes.create_string_buffer(nb)
+                oracle.ecn(C, "get")(ctypes.byref(p), x, y)
+                want[e] = (x.raw, y.raw)
+            return want[e]
+
+        for G in (2, 4):
+            groups = [[0] * G, [q] * G, [0, 5, q, 1][:G], [7, 0, 0, q][:G], [1, 2, 3, 0][:G], [q, q + 1, q - 1, 2 * 0][:G]]
+            groups += [[scalars[(7 * i + 3 * g) % 40] for g in range(G)] for i in range(24)]
+            for grp in groups:
+                E_ = (ctypes.c_uint64 * (4 * G))(*[(e >> (64 * k)) & (2**64 - 1) for e in grp for k in range(4)])
+                X_, Y_ = (ctypes.c_uint64 * (4 * G))(), (ctypes.c_uint64 * (4 * G))()
+                lib.wn26_mulgen_get_many_host(which, G, E_, X_, Y_)
+                for g, e in enumerate(grp):
+                    got = (b"".join(int(X_[4 * g + k]).to_bytes(8, "big") for k in (3, 2, 1, 0)), b"".join(int(Y_[4 * g + k]).to_bytes(8, "big") for k in (3, 2, 1, 0)))
+                    assert got == ref(e), (C, G, [hex(v) for v in grp], g)

@@ -44,3 +44,14 @@ extern "C" void wn26_mulgen_get_host(int which, const uint64_t* ew, uint64_t* xw
     if (which == 0) ma::wn26_mulgen_get_one<ma::CvNist256, HostCombNist256>(ew, xw, yw);
     else ma::wn26_mulgen_get_one<ma::CvSecp256k1, HostCombSecp256k1>(ew, xw, yw);
 }
+// G scalars with one shared inversion (the kernels' form); e, x, y: G x 4 words
+template <class CV, class TAB, int G>
+static void many(const uint64_t* e, uint64_t* x, uint64_t* y) {
+    uint64_t xw[G][4], yw[G][4];
+    ma::wn26_mulgen_get_many<CV, TAB, G>([&](int g, uint64_t* ew) { for (int k = 0; k < 4; k++) ew[k] = e[4 * g + k]; }, xw, yw);
+    for (int g = 0; g < G; g++) for (int k = 0; k < 4; k++) { x[4 * g + k] = xw[g][k]; y[4 * g + k] = yw[g][k]; }
+}
+extern "C" void wn26_mulgen_get_many_host(int which, int G, const uint64_t* e, uint64_t* x, uint64_t* y) {
+    if (which == 0) { if (G == 2) many<ma::CvNist256, HostCombNist256, 2>(e, x, y); else many<ma::CvNist256, HostCombNist256, 4>(e, x, y); }
+    else { if (G == 2) many<ma::CvSecp256k1, HostCombSecp256k1, 2>(e, x, y); else many<ma::CvSecp256k1, HostCombSecp256k1, 4>(e, x, y); }
+}
