@@ -346,12 +346,13 @@ int ecn_secp256k1_mul2_get_batch(const char *e, const ma_spint *P, const char *f
 
 /* Generator multiplication + affine export: ecnXXXgen, ecnXXXmul, ecnXXXget in one kernel -- the opening of
  * NIST256_KEY_PAIR and NIST256_SIGN (nist256.c:150-161, 214-222).  x, y, sign as for mul_get; there is no point
- * argument and no workspace: the multiples m * 16^i * G live in a 41 600-byte constant table (generated/comb_<C>.h),
- * every window reads all eight of its entries (constant-time) and adds one with the complete mixed addition.  Same
+ * argument and no workspace: the multiples m * 32^i * G, m = 1..16, live in a 66 560-byte constant table
+ * (generated/comb_<C>.h), every window reads all of its entries (constant-time) and adds one with the complete mixed addition;
+ * four scalars per lane share one inversion.  Same
  * bytes as ecn_<c>_gen_batch + ecn_<c>_mul_batch + ecn_<c>_get_batch for every 32-byte scalar. */
 int ecn_nist256_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_t n, void *stream);
 int ecn_secp256k1_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_t n, void *stream);
-/* ED448_KEY_PAIR / ED448_SIGN open the same way (ed448.c:167-184, 196-199); ED25519: 65 windows, cached (y+x, y-x, 2dxy);
+/* ED448_KEY_PAIR / ED448_SIGN open the same way (ed448.c:167-184, 196-199); ED25519: 65 4-bit windows, cached (y+x, y-x, 2dxy);
  * ED448: 113 windows, cached (x, y, 39081xy), 173 568-byte table */
 int ecn_ed25519_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_t n, void *stream);
 int ecn_ed448_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_t n, void *stream);

@@ -10,9 +10,10 @@
 
 namespace ma {
 
-// 65 windows x 8 multiples x (y+x, y-x, 2dxy) x 10 limbs, the same for every lane: constant address space, wave-uniform indices
-__constant__ int32_t comb_ed25519[COMB_ED25519_WINDOWS * 8 * 3 * 10] = { COMB_ED25519_VALUES };
+// COMB_ED25519_WINDOWS windows of COMB_ED25519_W bits x 2^(W-1) multiples x coordinates x limbs, the same for every lane: constant address space, wave-uniform indices
+__constant__ int32_t comb_ed25519[] = { COMB_ED25519_VALUES };
 struct CombED25519 {
+    static constexpr int W = COMB_ED25519_W, NW = COMB_ED25519_WINDOWS;
     static __device__ __forceinline__ int32_t get(int idx) { return comb_ed25519[idx]; }
 };
 

@@ -10,9 +10,10 @@
 
 namespace ma {
 
-// 113 windows x 8 multiples x (x, y, 39081xy) x 16 limbs, the same for every lane: constant address space, wave-uniform indices
-__constant__ int32_t comb_ed448[COMB_ED448_WINDOWS * 8 * 3 * 16] = { COMB_ED448_VALUES };
+// COMB_ED448_WINDOWS windows of COMB_ED448_W bits x 2^(W-1) multiples x coordinates x limbs, the same for every lane: constant address space, wave-uniform indices
+__constant__ int32_t comb_ed448[] = { COMB_ED448_VALUES };
 struct CombED448 {
+    static constexpr int W = COMB_ED448_W, NW = COMB_ED448_WINDOWS;
     static __device__ __forceinline__ int32_t get(int idx) { return comb_ed448[idx]; }
 };
 

@@ -10,9 +10,10 @@
 
 namespace ma {
 
-// 65 windows x 8 multiples x (x, y) x 10 limbs, the same for every lane: constant address space, wave-uniform indices
-__constant__ int32_t comb_nist256[65 * 8 * 2 * 10] = { COMB_NIST256_VALUES };
+// COMB_NIST256_WINDOWS windows of COMB_NIST256_W bits x 2^(W-1) multiples x coordinates x limbs, the same for every lane: constant address space, wave-uniform indices
+__constant__ int32_t comb_nist256[] = { COMB_NIST256_VALUES };
 struct CombNIST256 {
+    static constexpr int W = COMB_NIST256_W, NW = COMB_NIST256_WINDOWS;
     static __device__ __forceinline__ int32_t get(int idx) { return comb_nist256[idx]; }
 };
 

@@ -10,9 +10,10 @@
 
 namespace ma {
 
-// 65 windows x 8 multiples x (x, y) x 10 limbs, the same for every lane: constant address space, wave-uniform indices
-__constant__ int32_t comb_secp256k1[65 * 8 * 2 * 10] = { COMB_SECP256K1_VALUES };
+// COMB_SECP256K1_WINDOWS windows of COMB_SECP256K1_W bits x 2^(W-1) multiples x coordinates x limbs, the same for every lane: constant address space, wave-uniform indices
+__constant__ int32_t comb_secp256k1[] = { COMB_SECP256K1_VALUES };
 struct CombSECP256K1 {
+    static constexpr int W = COMB_SECP256K1_W, NW = COMB_SECP256K1_WINDOWS;
     static __device__ __forceinline__ int32_t get(int idx) { return comb_secp256k1[idx]; }
 };
 

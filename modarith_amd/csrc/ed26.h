@@ -438,22 +438,24 @@ MA_DEV void ed25519_mul2_get_one(const uint64_t* ew, const spint* PX, const spin
 
 // Fused GENERATOR multiplication + affine export: the affine coordinates of e*G -- ecnXXXgen, ecnXXXmul, ecnXXXget, the
 // opening of EdDSA key generation and signing (ed448.c:167-184 ED448_KEY_PAIR, 196-199 ED448_SIGN; curve.py builds the same
-// layer for ED25519).  With the base point fixed there are no doublings: e' = e + sum_{i<65} 8*16^i, digit_i =
-// window_i(e') - 8 in [-8, 7], and e*G = sum_i digit_i * (16^i G) with the 65 x 8 multiples precomputed in cached affine
-// form (generated/comb_ED25519.h, 62 400 bytes, one table for all lanes, read through wave-uniform addresses: TAB).  Per
-// window all eight entries are read and selected by lane predication (a zero digit keeps the neutral element (1, 1, 0)),
+// layer for ED25519).  With the base point fixed there are no doublings: e' = e + sum_i 2^(W-1) 2^(W i), digit_i =
+// window_i(e') - 2^(W-1), and e*G = sum_i digit_i * (2^(W i) G) with the NW x 2^(W-1) multiples precomputed in cached affine
+// form (generated/comb_ED25519.h: W = 4, 65 windows x 8 entries, 62 400 bytes, one table for all lanes, read through
+// wave-uniform addresses: TAB; with W = 5 the scan of 16 entries costs more than the 13 additions it saves).  Per window all its entries are read and selected by lane predication (a zero digit keeps the neutral element (1, 1, 0)),
 // the sign swaps y+x / y-x and negates 2dxy, and one complete mixed addition (7M, T carried along) follows.
 template <class C, class TAB>
 MA_DEV void ed25519_mulgen_acc(const uint64_t* ew, typename Ed26<C>::Ext& R) {
     using E = Ed26<C>;
     using F = Fe26;
+    constexpr int W = TAB::W, NW = TAB::NW, E2 = 1 << (W - 1);       // window width, windows, entries per window
+    static_assert(W * NW >= 257 && W * NW <= 320, "e + bias must fit the windows and five words");
     uint64_t w[5];
     {
         constexpr auto cw = [](int k) {
             uint64_t v = 0;
             for (int b = 0; b < 64; b++) {
                 const int pos = 64 * k + b;
-                if (pos < 260 && pos % 4 == 3) v |= (uint64_t)1 << b;
+                if (pos < W * NW && pos % W == W - 1) v |= (uint64_t)1 << b;
             }
             return v;
         };
@@ -470,28 +472,28 @@ MA_DEV void ed25519_mulgen_acc(const uint64_t* ew, typename Ed26<C>::Ext& R) {
     F::set(1, R.Z);
     F::set(0, R.T);
 #pragma unroll 1
-    for (int i = 0; i < 65; i++) {
-        const int dgt = (int)((uint32_t)w[0] & 15u) - 8;        // [-8, 7]
+    for (int i = 0; i < NW; i++) {
+        const int dgt = (int)((uint32_t)w[0] & (uint32_t)(2 * E2 - 1)) - E2;        // [-2^(W-1), 2^(W-1) - 1]
         static_for<0, 5>([&](auto K) {
             constexpr int k = K;
-            w[k] >>= 4;
-            if constexpr (k < 4) w[k] |= w[k + 1] << 60;
+            w[k] >>= W;
+            if constexpr (k < 4) w[k] |= w[k + 1] << (64 - W);
         });
         const bool neg = dgt < 0;
-        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0..8
+        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0 .. 2^(W-1)
         uint32_t sel[3][10];
         static_for<0, 3>([&](auto CI) { static_for<0, 10>([&](auto K) { sel[CI][K] = (CI < 2 && K == 0) ? 1u : 0u; }); });
         // (selection as OR of masked entries: v_and_or_b32 reads the table entry straight from its scalar register, see wn26.h;
         // limb 0 of y+x and y-x starts at 1 only for a zero digit, so the OR never meets a set bit)
         static_for<0, 2>([&](auto CI) { sel[CI][0] = (m == 0) ? 1u : 0u; });
-        static_for<0, 8>([&](auto MM) {
+        static_for<0, E2>([&](auto MM) {
             constexpr int mm = MM;
             uint32_t mask = (m == (uint32_t)(mm + 1)) ? 0xffffffffu : 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
             asm("" : "+v"(mask));       // opaque: otherwise the compiler turns (entry & mask) back into a select with a move
 #endif
             static_for<0, 3>([&](auto CI) {
-                static_for<0, 10>([&](auto K) { sel[CI][K] |= (uint32_t)TAB::get(((i * 8 + mm) * 3 + CI) * 10 + K) & mask; });
+                static_for<0, 10>([&](auto K) { sel[CI][K] |= (uint32_t)TAB::get(((i * E2 + mm) * 3 + CI) * 10 + K) & mask; });
             });
         });
         uint32_t yp[10], ym[10], nt[10];

@@ -425,21 +425,23 @@ MA_DEV void ed448_mul2_get_one(const uint64_t* ew, const spint* PX, const spint*
 }
 
 // Fused GENERATOR multiplication + affine export for ED448 (see ed26.h ed25519_mulgen_get_one): ED448_KEY_PAIR and
-// ED448_SIGN open with ecnXXXgen, ecnXXXmul, ecnXXXget (ed448.c:167-184, 196-199).  e' = e + sum_{i<113} 8*16^i, 113
+// ED448_SIGN open with ecnXXXgen, ecnXXXmul, ecnXXXget (ed448.c:167-184, 196-199).  W = 4: e' = e + sum_{i<113} 8*16^i, 113
 // signed 4-bit digits, the 113 x 8 multiples m * 16^i * G precomputed as (x, y, 39081 x y) in sixteen 28-bit limbs
-// (generated/comb_ED448.h, 173 568 bytes, wave-uniform reads), one complete mixed addition per window, no doublings.
+// (generated/comb_ED448.h, 173 568 bytes, wave-uniform reads; W = 5 measured the same), one complete mixed addition per window, no doublings.
 template <class TAB>
 MA_DEV void ed448_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw) {
     using E = Ed28;
     using F = Fe28;
     E::Ext R;
+    constexpr int W = TAB::W, NW = TAB::NW, E2 = 1 << (W - 1);       // window width, windows, entries per window
+    static_assert(W * NW >= 449 && W * NW <= 512, "e + bias must fit the windows and eight words");
     uint64_t w[8];
     {
         constexpr auto cw = [](int k) {
             uint64_t v = 0;
             for (int b = 0; b < 64; b++) {
                 const int pos = 64 * k + b;
-                if (pos < 452 && pos % 4 == 3) v |= (uint64_t)1 << b;
+                if (pos < W * NW && pos % W == W - 1) v |= (uint64_t)1 << b;
             }
             return v;
         };
@@ -456,27 +458,27 @@ MA_DEV void ed448_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw)
     F::set(1, R.Z);
     F::set(0, R.T);
 #pragma unroll 1
-    for (int i = 0; i < 113; i++) {
-        const int dgt = (int)((uint32_t)w[0] & 15u) - 8;        // [-8, 7]
+    for (int i = 0; i < NW; i++) {
+        const int dgt = (int)((uint32_t)w[0] & (uint32_t)(2 * E2 - 1)) - E2;        // [-2^(W-1), 2^(W-1) - 1]
         static_for<0, 8>([&](auto K) {
             constexpr int k = K;
-            w[k] >>= 4;
-            if constexpr (k < 7) w[k] |= w[k + 1] << 60;
+            w[k] >>= W;
+            if constexpr (k < 7) w[k] |= w[k + 1] << (64 - W);
         });
         const bool neg = dgt < 0;
-        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0..8
+        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0 .. 2^(W-1)
         uint32_t sel[3][16];
         static_for<0, 3>([&](auto CI) { static_for<0, 16>([&](auto K) { sel[CI][K] = (CI == 1 && K == 0) ? 1u : 0u; }); });
         // (selection as OR of masked entries, see wn26.h; limb 0 of y starts at 1 only for a zero digit)
         sel[1][0] = (m == 0) ? 1u : 0u;
-        static_for<0, 8>([&](auto MM) {
+        static_for<0, E2>([&](auto MM) {
             constexpr int mm = MM;
             uint32_t mask = (m == (uint32_t)(mm + 1)) ? 0xffffffffu : 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
             asm("" : "+v"(mask));       // opaque: otherwise the compiler turns (entry & mask) back into a select with a move
 #endif
             static_for<0, 3>([&](auto CI) {
-                static_for<0, 16>([&](auto K) { sel[CI][K] |= (uint32_t)TAB::get(((i * 8 + mm) * 3 + CI) * 16 + K) & mask; });
+                static_for<0, 16>([&](auto K) { sel[CI][K] |= (uint32_t)TAB::get(((i * E2 + mm) * 3 + CI) * 16 + K) & mask; });
             });
         });
         uint32_t nx[16], nt[16];

@@ -505,51 +505,55 @@ MA_DEV void wn26_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* 
 
 // Fused GENERATOR multiplication + affine export: the affine coordinates of e*G -- ecnXXXgen, ecnXXXmul, ecnXXXget, the
 // opening of key generation and signing in the reference's ECDSA code (nist256.c:150-161 NIST256_KEY_PAIR, 214-222
-// NIST256_SIGN).  With the base point fixed the doublings disappear: e' = e + sum_{i<65} 8*16^i as before, and
-// e*G = sum_i digit_i * (16^i G) with the 65 x 8 affine multiples m * 16^i * G precomputed (generated/comb_<C>.h, 41 600
-// bytes, the same table for every lane).  Per window the eight entries are read through wave-uniform addresses (TAB: the
+// NIST256_SIGN).  With the base point fixed the doublings disappear: e' = e + sum_i 2^(W-1) 2^(W i), digit_i = window_i(e')
+// - 2^(W-1), and e*G = sum_i digit_i * (2^(W i) G) with the NW x 2^(W-1) affine multiples precomputed (generated/comb_<C>.h:
+// W = 5, 52 windows x 16 entries, 66 560 bytes, the same table for every lane; W = 4 is 6 % slower, W = 6 -- 43 mixed
+// additions but 32 entries to scan -- no faster than W = 5 on P-256 and slower on secp256k1).  Per window ALL its entries are read through wave-uniform addresses (TAB: the
 // table in the constant address space, scalar loads) and selected by lane predication, the sign negates y, and one
-// complete MIXED addition follows; a zero digit adds (0, 0) and keeps the old sum.  65 mixed additions + one inversion per
-// scalar against 256 doublings + 65 additions: the same bytes as ecn gen + ecn mul + ecn get for every scalar.
+// complete MIXED addition follows; a zero digit adds (0, 0) and keeps the old sum.  52 mixed additions + a share of one
+// inversion per scalar against 256 doublings + 65 additions: the same bytes as ecn gen + ecn mul + ecn get for every scalar.
 template <class CV, class TAB>
 MA_DEV void wn26_mulgen_acc(const uint64_t* ew, typename Wn26<CV>::Pt& R) {
     using E = Wn26<CV>;
     using F = typename CV::F;
+    constexpr int W = TAB::W, NW = TAB::NW, E2 = 1 << (W - 1);       // window width, windows, entries per window
+    static_assert(W * NW >= 257 && W * NW <= 316, "e + bias must fit the windows and five words");
     uint64_t w[5];
     {
         uint64_t t[5];
-        wn26_recode<4, 260>(ew, t);                 // left-aligned by 60 bits: undo, the windows are taken from the bottom here
+        wn26_recode<W, W * NW>(ew, t);              // left-aligned: undo, the windows are taken from the bottom here
+        constexpr int SH = 320 - W * NW;
         static_for<0, 5>([&](auto K) {
             constexpr int k = K;
-            w[k] = t[k] >> 60;
-            if constexpr (k < 4) w[k] |= t[k + 1] << 4;
+            w[k] = t[k] >> SH;
+            if constexpr (k < 4) w[k] |= t[k + 1] << (64 - SH);
         });
     }
     E::inf(R);
 #pragma unroll 1
-    for (int i = 0; i < 65; i++) {
-        const int dgt = (int)((uint32_t)w[0] & 15u) - 8;        // [-8, 7]
+    for (int i = 0; i < NW; i++) {
+        const int dgt = (int)((uint32_t)w[0] & (uint32_t)(2 * E2 - 1)) - E2;        // [-2^(W-1), 2^(W-1) - 1]
         static_for<0, 5>([&](auto K) {
             constexpr int k = K;
-            w[k] >>= 4;
-            if constexpr (k < 4) w[k] |= w[k + 1] << 60;
+            w[k] >>= W;
+            if constexpr (k < 4) w[k] |= w[k + 1] << (64 - W);
         });
         const bool neg = dgt < 0;
-        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0..8
+        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0 .. 2^(W-1)
         // selection as OR of masked entries (exactly one mask is set, none for a zero digit): the entries sit in scalar
         // registers, and v_and_or_b32 takes one of those next to two vector operands -- a v_cndmask would need a move first
         // (its lane mask already uses the one scalar operand an instruction may read)
         int32_t sx[10], sy[10], ny[10];
         static_for<0, 10>([&](auto K) { sx[K] = 0; sy[K] = 0; });
-        static_for<0, 8>([&](auto MM) {
+        static_for<0, E2>([&](auto MM) {
             constexpr int mm = MM;
             uint32_t mask = (m == (uint32_t)(mm + 1)) ? 0xffffffffu : 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
             asm("" : "+v"(mask));       // opaque: otherwise the compiler turns (entry & mask) back into a select with a move
 #endif
             static_for<0, 10>([&](auto K) {
-                sx[K] = (int32_t)((uint32_t)sx[K] | ((uint32_t)TAB::get(((i * 8 + mm) * 2 + 0) * 10 + K) & mask));
-                sy[K] = (int32_t)((uint32_t)sy[K] | ((uint32_t)TAB::get(((i * 8 + mm) * 2 + 1) * 10 + K) & mask));
+                sx[K] = (int32_t)((uint32_t)sx[K] | ((uint32_t)TAB::get(((i * E2 + mm) * 2 + 0) * 10 + K) & mask));
+                sy[K] = (int32_t)((uint32_t)sy[K] | ((uint32_t)TAB::get(((i * E2 + mm) * 2 + 1) * 10 + K) & mask));
             });
         });
         F::neg(sy, ny);

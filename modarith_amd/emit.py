@@ -440,18 +440,19 @@ def wcurve_header_text(name: str) -> str:
     return "\n".join(L) + "\n"
 
 
-COMB_CURVES = {"NIST256": 286, "SECP256K1": 0}      # curve -> log2 of the Montgomery factor of the fused kernels' field form (fm26.h / fk26.h)
+COMB_CURVES = {"NIST256": (286, 5), "SECP256K1": (0, 5)}      # curve -> (log2 of the Montgomery factor of the fused kernels' field form, window width)
 
 
 def comb_header_text(name: str) -> str:
-    """fixed-base table of the fused generator multiplication (csrc/wn26.h wn26_mulgen_get_one): for every 4-bit window
-    i = 0..64 the affine multiples m * 16^i * G, m = 1..8, coordinates as ten 26-bit limbs of the fused kernels' field form
+    """fixed-base table of the fused generator multiplication (csrc/wn26.h wn26_mulgen_acc): for every W-bit window i
+    the affine multiples m * 2^(W i) * G, m = 1..2^(W-1), coordinates as ten 26-bit limbs of the fused kernels' field form
     (value * 2^286 mod p for P-256, the plain value for secp256k1).  Plain integer curve arithmetic on the constants of
     curves.py (curve.py:157-198)."""
     from .curves import wcurve
     c = wcurve(name)
     p, a = c.fp.p, c.a
-    shift = COMB_CURVES[name]
+    shift, W = COMB_CURVES[name]
+    windows = -(-(8 * c.fp.nbytes + 1) // W)
 
     def add(P, Q):
         if P is None:
@@ -471,33 +472,37 @@ def comb_header_text(name: str) -> str:
     limbs = lambda v: [((v << shift) % p >> (26 * k)) & ((1 << 26) - 1) for k in range(10)]
     rows = []
     B = (c.gx, c.gy)
-    for i in range(65):
+    for i in range(windows):
         T = None
-        for m in range(1, 9):
+        for m in range(1, (1 << (W - 1)) + 1):
             T = add(T, B)
-            rows.append("    " + ", ".join("0x%x" % v for v in limbs(T[0]) + limbs(T[1])) + ",   /* %d * 16^%d * G */ \\" % (m, i))
-        for _ in range(4):
+            rows.append("    " + ", ".join("0x%x" % v for v in limbs(T[0]) + limbs(T[1])) + ",   /* %d * 2^%d * G */ \\" % (m, W * i))
+        for _ in range(W):
             B = add(B, B)
     L = ["// GENERATED by modarith_amd/emit.py from modarith_amd/curves.py -- do not edit.",
-         "// Fixed-base table of %s for ecn_%s_mulgen_get_batch: [window 0..64][multiple 1..8][x, y][10 limbs of 26 bits]," % (name, name.lower()),
+         "// Fixed-base table of %s for ecn_%s_mulgen_get_batch: [window 0..%d][multiple 1..%d][x, y][10 limbs of 26 bits]," % (
+             name, name.lower(), windows - 1, 1 << (W - 1)),
          "// coordinates in the field form of the fused kernels (%s)." % ("value * 2^%d mod p" % shift if shift else "plain value"),
          "#pragma once",
+         "#define COMB_%s_W %d" % (name, W),
+         "#define COMB_%s_WINDOWS %d" % (name, windows),
          "#define COMB_%s_VALUES \\" % name] + rows + ["    /* end */", ""]
     return "\n".join(L)
 
 
-COMB_EDWARDS = {"ED25519": (65, "fe26"), "ED448": (113, "fe28")}      # curve -> (4-bit windows of a Nbytes scalar + 1, limb form)
+COMB_EDWARDS = {"ED25519": (4, "fe26"), "ED448": (4, "fe28")}      # curve -> (window width, limb form)
 
 
 def comb_edwards_header_text(name: str) -> str:
     """fixed-base table of the fused generator multiplication on the Edwards curves (csrc/ed26.h / ed28.h *_mulgen_get_one):
-    for every 4-bit window i the affine multiples m * 16^i * G, m = 1..8, in the cached form of the mixed addition --
+    for every W-bit window i the affine multiples m * 2^(W i) * G, m = 1..2^(W-1), in the cached form of the mixed addition --
     ED25519: (y+x, y-x, 2dxy) as ten 25.5-bit limbs (fe26.h), ED448: (x, y, 39081 x y) as sixteen 28-bit limbs (fe28.h).
     Plain integer curve arithmetic on the constants of curves.py (curve.py:85-105)."""
     from .curves import curve
     c = curve(name)
     p, a, d = c.fp.p, c.a, c.d % c.fp.p
-    windows, form = COMB_EDWARDS[name]
+    W, form = COMB_EDWARDS[name]
+    windows = -(-(8 * c.fp.nbytes + 1) // W)
 
     def add(P, Q):
         (x1, y1), (x2, y2) = P, Q
@@ -515,15 +520,16 @@ def comb_edwards_header_text(name: str) -> str:
     B = (c.gx, c.gy)
     for i in range(windows):
         T = (0, 1)
-        for m in range(1, 9):
+        for m in range(1, (1 << (W - 1)) + 1):
             T = add(T, B)
-            rows.append("    " + ", ".join("0x%x" % v for v in cached(*T)) + ",   /* %d * 16^%d * G */ \\" % (m, i))
-        for _ in range(4):
+            rows.append("    " + ", ".join("0x%x" % v for v in cached(*T)) + ",   /* %d * 2^%d * G */ \\" % (m, W * i))
+        for _ in range(W):
             B = add(B, B)
     L = ["// GENERATED by modarith_amd/emit.py from modarith_amd/curves.py -- do not edit.",
-         "// Fixed-base table of %s for ecn_%s_mulgen_get_batch: [window 0..%d][multiple 1..8][%s][limbs]." % (
-             name, name.lower(), windows - 1, "y+x, y-x, 2dxy: 10 limbs of 25.5 bits" if form == "fe26" else "x, y, 39081xy: 16 limbs of 28 bits"),
+         "// Fixed-base table of %s for ecn_%s_mulgen_get_batch: [window 0..%d][multiple 1..%d][%s][limbs]." % (
+             name, name.lower(), windows - 1, 1 << (W - 1), "y+x, y-x, 2dxy: 10 limbs of 25.5 bits" if form == "fe26" else "x, y, 39081xy: 16 limbs of 28 bits"),
          "#pragma once",
+         "#define COMB_%s_W %d" % (name, W),
          "#define COMB_%s_WINDOWS %d" % (name, windows),
          "#define COMB_%s_VALUES \\" % name] + rows + ["    /* end */", ""]
     return "\n".join(L)

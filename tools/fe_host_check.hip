@@ -456,8 +456,8 @@ static int run_nist256_mul2(int n) {
 // oracle's ecn gen + ecn mul + ecn get: corner scalars (0, 1, single windows, 8 / 9 nibbles, all ones) and random ones
 static const int32_t comb_ed25519_host[] = { COMB_ED25519_VALUES };
 static const int32_t comb_ed448_host[] = { COMB_ED448_VALUES };
-struct HostComb25519 { static int32_t get(int idx) { return comb_ed25519_host[idx]; } };
-struct HostComb448 { static int32_t get(int idx) { return comb_ed448_host[idx]; } };
+struct HostComb25519 { static constexpr int W = COMB_ED25519_W, NW = COMB_ED25519_WINDOWS; static int32_t get(int idx) { return comb_ed25519_host[idx]; } };
+struct HostComb448 { static constexpr int W = COMB_ED448_W, NW = COMB_ED448_WINDOWS; static int32_t get(int idx) { return comb_ed448_host[idx]; } };
 template <int NB, class PT, class FN, class GEN, class MUL, class GET>
 static int run_edgen(const char* name, int n, FN fused, GEN gen, MUL mul, GET get) {
     int bad = 0;

@@ -36,10 +36,10 @@ extern "C" void wn26_field_product(int which, int mode, const int32_t* f, const 
 }
 
 // fused generator multiplication (wn26_mulgen_get_one) with the fixed-base tables as host arrays.  which = 0: P-256, 1: secp256k1
-static const int32_t comb_nist256_host[65 * 8 * 2 * 10] = { COMB_NIST256_VALUES };
-static const int32_t comb_secp256k1_host[65 * 8 * 2 * 10] = { COMB_SECP256K1_VALUES };
-struct HostCombNist256 { static int32_t get(int idx) { return comb_nist256_host[idx]; } };
-struct HostCombSecp256k1 { static int32_t get(int idx) { return comb_secp256k1_host[idx]; } };
+static const int32_t comb_nist256_host[] = { COMB_NIST256_VALUES };
+static const int32_t comb_secp256k1_host[] = { COMB_SECP256K1_VALUES };
+struct HostCombNist256 { static constexpr int W = COMB_NIST256_W, NW = COMB_NIST256_WINDOWS; static int32_t get(int idx) { return comb_nist256_host[idx]; } };
+struct HostCombSecp256k1 { static constexpr int W = COMB_SECP256K1_W, NW = COMB_SECP256K1_WINDOWS; static int32_t get(int idx) { return comb_secp256k1_host[idx]; } };
 extern "C" void wn26_mulgen_get_host(int which, const uint64_t* ew, uint64_t* xw, uint64_t* yw) {
     if (which == 0) ma::wn26_mulgen_get_one<ma::CvNist256, HostCombNist256>(ew, xw, yw);
     else ma::wn26_mulgen_get_one<ma::CvSecp256k1, HostCombSecp256k1>(ew, xw, yw);
