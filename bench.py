@@ -402,6 +402,21 @@ def main():
                                                              "three_call_form_per_s": m / (t2 - t1), "speedup": (t2 - t1) / (t1 - t0),
                                                              "bytes_equal_to_three_call_form": True}
                 del gx_, gy_, wx_, wy_
+            if cname in getattr(Cv, "FUSEDG2", ()):
+                # verification ecnXXXgen + ecnXXXmul2(e, G, f, Q) + ecnXXXget (nist256.c:251-256, ed448.c:305): generator part on the fixed-base table
+                mq = m // 2
+                e2, f2, Q2 = e[:mq].contiguous(), f[:mq].contiguous(), Q[:, :, :mq].contiguous()
+                Cv.mulgen2_get(e2[:4096].contiguous(), f2[:4096].contiguous(), Q2[:, :, :4096].contiguous())
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                vx_, vy_, _ = Cv.mulgen2_get(e2, f2, Q2)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                wx_, wy_, _ = Cv.get(Cv.mul2(e2, Cv.gen(mq), f2, Q2))
+                torch.cuda.synchronize(); t2 = time.perf_counter()
+                assert torch.equal(vx_, wx_) and torch.equal(vy_, wy_), "fused mulgen2_get differs from gen + mul2 + get"
+                others["%s_ecn_mulgen2_get_fused" % cname] = {"double_mults_per_s_per_gpu": mq / (t1 - t0), "pairs": mq, "bound": "VALU",
+                                                              "three_call_form_per_s": mq / (t2 - t1), "speedup": (t2 - t1) / (t1 - t0),
+                                                              "bytes_equal_to_three_call_form": True}
+                del vx_, vy_, wx_, wy_, e2, f2, Q2
             del e, f, G, Q, R
 
     ladder = None

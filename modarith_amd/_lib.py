@@ -22,7 +22,9 @@ ED_BATCH_FUNCS = ("mul", "mul2", "ran", "add", "sub", "cpy", "dbl", "neg", "inf"
 FUSED_CURVES = ("ed25519", "ed448", "nist256", "secp256k1")       # fused mul + get kernels (csrc/ed26.h, csrc/ed28.h, csrc/wn26.h)
 FUSED2_CURVES = ("ed25519", "ed448", "nist256", "secp256k1")        # fused mul2 + get
 FUSEDG_CURVES = ("nist256", "secp256k1", "ed25519", "ed448")             # fused gen + mul + get (fixed-base tables; csrc/wn26.h, ed26.h, ed28.h *_mulgen_get_one)
-FUSED_FUNCS = (tuple("ecn_%s_mulgen_get_batch" % c for c in FUSEDG_CURVES) + tuple("ecn_%s_mul_get_%s" % (c, f) for c in FUSED_CURVES for f in ("batch", "workspace_bytes"))
+FUSEDG2_CURVES = ("nist256", "secp256k1", "ed25519")    # fused gen + mul2 + get (e*G + f*Q, verification)
+FUSED_FUNCS = (tuple("ecn_%s_mulgen_get_batch" % c for c in FUSEDG_CURVES)
+               + tuple("ecn_%s_mulgen2_get_%s" % (c, f) for c in FUSEDG2_CURVES for f in ("batch", "workspace_bytes")) + tuple("ecn_%s_mul_get_%s" % (c, f) for c in FUSED_CURVES for f in ("batch", "workspace_bytes"))
                + tuple("ecn_%s_mul2_get_%s" % (c, f) for c in FUSED2_CURVES for f in ("batch", "workspace_bytes")))
 ED_SCALAR_FUNCS = ("mul2", "ran", "get", "set", "inf", "isinf", "neg", "add", "sub", "dbl", "gen", "mul", "cmp", "affine", "cpy", "cof",
                    "mul_workspace_bytes")
@@ -134,6 +136,13 @@ def load() -> ctypes.CDLL:
         f = getattr(lib, "ecn_%s_mulgen_get_batch" % c)
         f.argtypes = [_P, _P, _P, _P, c_size_t, _P]
         f.restype = c_int
+    for c in FUSEDG2_CURVES:
+        f = getattr(lib, "ecn_%s_mulgen2_get_batch" % c)
+        f.argtypes = [_P, _P, _P, _P, _P, _P, c_size_t, c_size_t, _P, c_size_t, _P]
+        f.restype = c_int
+        f = getattr(lib, "ecn_%s_mulgen2_get_workspace_bytes" % c)
+        f.argtypes = [c_size_t]
+        f.restype = c_size_t
     for c in FUSED2_CURVES:
         f = getattr(lib, "ecn_%s_mul2_get_batch" % c)
         f.argtypes = [_P, _P, _P, _P, _P, _P, _P, c_size_t, c_size_t, _P, c_size_t, _P]

@@ -40,9 +40,47 @@ void k_ed25519_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned ch
     }
 }
 
+// e*G + f*Q and its affine export (verification, ed448.c:305): the table of Q in registers as for mul_get, the generator part
+// through the constant table above
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_ed25519_mulgen2_get(const unsigned char* e, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb, int* sign,
+                           size_t n, size_t ld) {
+    using P = P_X25519;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        spint ew[4], fw[4], X[5], Y[5], Z[5], xw[4], yw[4];
+        load_be_record<P>(e, t, ew);
+        load_be_record<P>(f, t, fw);
+        static_for<0, 5>([&](auto I) {
+            X[I] = Qb[(size_t)I * ld + t];
+            Y[I] = Qb[(size_t)(5 + I) * ld + t];
+            Z[I] = Qb[(size_t)(10 + I) * ld + t];
+        });
+        ed25519_mulgen2_get_one<C_ED25519, CombED25519>(ew, fw, X, Y, Z, xw, yw);
+        if (xb) store_be_record<P>(xb, t, xw);
+        if (yb) store_be_record<P>(yb, t, yw);
+        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+    }
+}
+
 }  // namespace ma
 
 using namespace ma;
+
+extern "C" size_t ecn_ed25519_mulgen2_get_workspace_bytes(size_t) { return 0; }
+
+extern "C" int ecn_ed25519_mulgen2_get_batch(const char* e, const char* f, const ma_spint* Q, char* x, char* y, int* sign, size_t n, size_t ld,
+                                             void*, size_t, void* st) {
+    if (n == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 7u) {
+        set_error("ecn mulgen2_get: byte records must be 8-byte aligned");
+        return (int)hipErrorInvalidValue;
+    }
+    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
+    k_ed25519_mulgen2_get<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(
+        reinterpret_cast<const unsigned char*>(e), reinterpret_cast<const unsigned char*>(f), Q, reinterpret_cast<unsigned char*>(x),
+        reinterpret_cast<unsigned char*>(y), sign, n, ld);
+    return check_launch("ecn mulgen2_get");
+}
 
 extern "C" int ecn_ed25519_mulgen_get_batch(const char* e, char* x, char* y, int* sign, size_t n, void* st) {
     if (n == 0) return 0;

@@ -123,6 +123,27 @@ struct Ed26 {
         F::add(p.Z, p.Z, d);        // 1.0
         add_tail<WANT_T>(a, b, c, d, p);
     }
+    // add_cached with a wave-uniform run-time flag for T (a loop counter, never data): one copy of the addition in the
+    // instruction stream serves the windows that do not need T and the last one, which hands its sum to the fixed-base part
+    static MA_DEV void add_cached_rt(Ext& p, const uint32_t* yp, const uint32_t* ym, const uint32_t* t2d, bool want_t) {
+        uint32_t a[10], b[10], c[10], d[10], e[10], f[10], g[10], h[10], g19[10], e19[10];
+        F::sub(p.Y, p.X, a);        // 1.5
+        F::mul(a, ym, a);
+        F::add(p.Y, p.X, b);        // 1.0
+        F::mul(b, yp, b);
+        F::mul(p.T, t2d, c);
+        F::add(p.Z, p.Z, d);        // 1.0
+        F::sub(b, a, e);            // 1.5
+        F::sub(d, c, f);            // 2.0
+        F::add(d, c, g);            // 1.5
+        F::add(b, a, h);            // 1.0
+        F::pre19(g, g19);
+        F::pre19(e, e19);
+        F::mul(f, e, e19, p.X);
+        F::mul(f, g, g19, p.Z);
+        F::mul(h, g, g19, p.Y);
+        if (want_t) F::mul(h, e, e19, p.T);
+    }
     // P += Q, both extended (add-2008-hwcd-3, a = -1); used once, to build 3P
     static MA_DEV void add_ext(Ext& p, const Ext& q) {
         uint32_t a[10], b[10], c[10], d[10], t[10], dd[10];
@@ -145,11 +166,11 @@ struct Ed26 {
 //   ew: the scalar as four little-endian 64-bit words (the caller has byte-swapped the big-endian record);
 //   X, Y, Z: the projective point, 5 x 51-bit limbs each (field.c form); xw, yw: canonical affine coordinates,
 //   four little-endian words each.
-template <class C>
-MA_DEV void ed25519_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* xw, uint64_t* yw) {
+template <class C, bool FINAL_T = false>       // FINAL_T: the sum leaves with its T coordinate (a further addition follows)
+MA_DEV void ed25519_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, typename Ed26<C>::Ext& R) {
     using E = Ed26<C>;
     using F = Fe26;
-    typename E::Ext R, Q;
+    typename E::Ext Q;
     uint64_t tab[4][3][4];                  // {1,2,3,4}P as canonical packed (y+x, y-x, 2dxy)
 
     {   // ---- table: projective P -> extended; 2P, 3P, 4P; one shared inversion; cached affine form
@@ -275,9 +296,15 @@ MA_DEV void ed25519_mul_get_one(const uint64_t* ew, const spint* X, const spint*
         F::set(0, nt);
         F::sub(nt, t2, nt);                                 // 2p - t: 1.0 .. 1.5
         F::select(neg, t2, nt, t2);
-        E::add_cached(R, yp, ym, t2);
+        if constexpr (FINAL_T) E::add_cached_rt(R, yp, ym, t2, i == 85);
+        else E::add_cached(R, yp, ym, t2);
     }
-
+}
+template <class C>
+MA_DEV void ed25519_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* xw, uint64_t* yw) {
+    using F = Fe26;
+    typename Ed26<C>::Ext R;
+    ed25519_mul_acc<C>(ew, X, Y, Z, R);
     // ---- affine, canonical (ecnXXXget: edwards.c:221-239)
     uint32_t zi[10], ax[10], ay[10];
     F::invert(R.Z, zi);
@@ -443,7 +470,7 @@ MA_DEV void ed25519_mul2_get_one(const uint64_t* ew, const spint* PX, const spin
 // form (generated/comb_ED25519.h: W = 4, 65 windows x 8 entries, 62 400 bytes, one table for all lanes, read through
 // wave-uniform addresses: TAB; with W = 5 the scan of 16 entries costs more than the 13 additions it saves).  Per window all its entries are read and selected by lane predication (a zero digit keeps the neutral element (1, 1, 0)),
 // the sign swaps y+x / y-x and negates 2dxy, and one complete mixed addition (7M, T carried along) follows.
-template <class C, class TAB>
+template <class C, class TAB, bool INIT = true>       // INIT = false: R += e*G (R holds a sum with its T coordinate)
 MA_DEV void ed25519_mulgen_acc(const uint64_t* ew, typename Ed26<C>::Ext& R) {
     using E = Ed26<C>;
     using F = Fe26;
@@ -467,10 +494,12 @@ MA_DEV void ed25519_mulgen_acc(const uint64_t* ew, typename Ed26<C>::Ext& R) {
             acc >>= 64;
         });
     }
-    F::set(0, R.X);
-    F::set(1, R.Y);
-    F::set(1, R.Z);
-    F::set(0, R.T);
+    if constexpr (INIT) {
+        F::set(0, R.X);
+        F::set(1, R.Y);
+        F::set(1, R.Z);
+        F::set(0, R.T);
+    }
 #pragma unroll 1
     for (int i = 0; i < NW; i++) {
         const int dgt = (int)((uint32_t)w[0] & (uint32_t)(2 * E2 - 1)) - E2;        // [-2^(W-1), 2^(W-1) - 1]
@@ -551,6 +580,25 @@ MA_DEV void ed25519_mulgen_get_many(LOAD load, uint64_t (*xw)[4], uint64_t (*yw)
         F::mul(Y[g], t, u);
         F::to_words(u, yw[g]);
     });
+}
+
+// Fused e*G + f*Q + affine export: the verification pattern ecnXXXmul2(u, &G, v, &Q, &R); ecnXXXget (ed448.c:305, the first
+// point is the GENERATOR).  f*Q as in ed25519_mul_get_one (3-bit windows, table of Q in registers, the last addition also
+// produces T), then e*G through the fixed-base table with mixed additions and no doublings (ed25519_mulgen_acc): 255
+// doublings + 86 + 65 additions against the 258 + 258 of the general ed25519_mul2_get_one.
+template <class C, class TAB>
+MA_DEV void ed25519_mulgen2_get_one(const uint64_t* ew, const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
+                                    uint64_t* xw, uint64_t* yw) {
+    using F = Fe26;
+    typename Ed26<C>::Ext R;
+    ed25519_mul_acc<C, true>(fw, QX, QY, QZ, R);
+    ed25519_mulgen_acc<C, TAB, false>(ew, R);
+    uint32_t zi[10], ax[10], ay[10];
+    F::invert(R.Z, zi);
+    F::mul(R.X, zi, ax);
+    F::mul(R.Y, zi, ay);
+    F::to_words(ax, xw);
+    F::to_words(ay, yw);
 }
 
 }  // namespace ma

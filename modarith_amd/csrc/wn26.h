@@ -441,10 +441,10 @@ MA_DEV uint32_t wn26_take(uint64_t* w) {
 //   X, Y, Z: the projective point, 5 x 52-bit limbs each (field.c form); tab: this lane's table slot (NIST256_TABLE_WORDS
 //   words, tstride apart); xw, yw: canonical affine coordinates, four little-endian words each.
 template <class CV>
-MA_DEV void wn26_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
-                             uint64_t* xw, uint64_t* yw) {
+MA_DEV void wn26_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
+                         typename Wn26<CV>::Pt& R) {
     using E = Wn26<CV>;
-    typename E::Pt R, Q;
+    typename E::Pt Q;
     E::load_point(X, Y, Z, Q);
     E::template build_table<8>(Q, tab, tstride, 0);
     uint64_t w[5];
@@ -462,7 +462,13 @@ MA_DEV void wn26_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y,
         E::template lookup<8>(tab, tstride, 0, m, neg, Q);
         E::add(Q, R);
     }
-    E::affine_words(R, xw, yw);
+}
+template <class CV>
+MA_DEV void wn26_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
+                             uint64_t* xw, uint64_t* yw) {
+    typename Wn26<CV>::Pt R;
+    wn26_mul_acc<CV>(ew, X, Y, Z, tab, tstride, R);
+    Wn26<CV>::affine_words(R, xw, yw);
 }
 
 // Fused double multiplication + affine export: the affine coordinates of e*P + f*Q (ecnXXXmul2 followed by ecnXXXget,
@@ -512,7 +518,7 @@ MA_DEV void wn26_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* 
 // table in the constant address space, scalar loads) and selected by lane predication, the sign negates y, and one
 // complete MIXED addition follows; a zero digit adds (0, 0) and keeps the old sum.  52 mixed additions + a share of one
 // inversion per scalar against 256 doublings + 65 additions: the same bytes as ecn gen + ecn mul + ecn get for every scalar.
-template <class CV, class TAB>
+template <class CV, class TAB, bool INIT = true>       // INIT = false: R += e*G (R holds a sum already)
 MA_DEV void wn26_mulgen_acc(const uint64_t* ew, typename Wn26<CV>::Pt& R) {
     using E = Wn26<CV>;
     using F = typename CV::F;
@@ -529,7 +535,7 @@ MA_DEV void wn26_mulgen_acc(const uint64_t* ew, typename Wn26<CV>::Pt& R) {
             if constexpr (k < 4) w[k] |= t[k + 1] << (64 - SH);
         });
     }
-    E::inf(R);
+    if constexpr (INIT) E::inf(R);
 #pragma unroll 1
     for (int i = 0; i < NW; i++) {
         const int dgt = (int)((uint32_t)w[0] & (uint32_t)(2 * E2 - 1)) - E2;        // [-2^(W-1), 2^(W-1) - 1]
@@ -585,6 +591,20 @@ MA_DEV void wn26_mulgen_get_many(LOAD load, uint64_t (*xw)[4], uint64_t (*yw)[4]
         static_for<0, G>([&](auto GI) { if (g == GI) Rs[GI] = R; });       // (static register indices only)
     }
     Wn26<CV>::template affine_words_many<G>(Rs, xw, yw);
+}
+
+// Fused e*G + f*Q + affine export: the verification pattern ecnXXXmul2(u, &G, v, &Q, &Q); ecnXXXget (nist256.c:251-256) --
+// the first point of the reference's double multiplication there is always the GENERATOR.  f*Q runs as in
+// wn26_mul_get_one (4-bit windows on a per-lane table of Q), e*G joins through the fixed-base table with mixed additions
+// and no doublings of its own (wn26_mulgen_acc): 256 doublings + 65 additions + 52 mixed additions against the 258 + 172 of
+// the general wn26_mul2_get_one.  Same bytes as ecn gen, ecn mul2, ecn get.
+template <class CV, class TAB>
+MA_DEV void wn26_mulgen2_get_one(const uint64_t* ew, const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
+                                 uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
+    typename Wn26<CV>::Pt R;
+    wn26_mul_acc<CV>(fw, QX, QY, QZ, tab, tstride, R);
+    wn26_mulgen_acc<CV, TAB, false>(ew, R);
+    Wn26<CV>::affine_words(R, xw, yw);
 }
 
 // the P-256 entry points (C: generated/curve_NIST256.h, documentation only: the constants of this form are in CvNist256)

@@ -160,6 +160,26 @@ class Edwards:
                    sign.data_ptr(), n, _stream(self.device))
         return x, y, sign
 
+    FUSEDG2 = ("NIST256", "SECP256K1", "ED25519")      # curves with a fused gen + mul2 + get kernel (e*G + f*Q)
+
+    def mulgen2_get(self, e, f, Q, want_x: bool = True, want_y: bool = True):
+        """ecnXXXgen, ecnXXXmul2(e, G, f, Q, R), ecnXXXget (signature verification, nist256.c:251-256, ed448.c:305) in ONE kernel:
+        the affine coordinates of e*G + f*Q as canonical big-endian byte records.  Q is not modified.  Same bytes as
+        mul2_get(e, gen(n), f, Q); the generator part runs on the fixed-base table."""
+        if self.name.upper() not in self.FUSEDG2:
+            raise ValueError("no fused mulgen2_get kernel for %s (available: %s)" % (self.name, ", ".join(self.FUSEDG2)))
+        n = self._chk(Q)
+        x = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device) if want_x else None
+        y = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device) if want_y else None
+        sign = torch.empty(n, dtype=torch.int32, device=self.device)
+        need = int(getattr(self.lib, "ecn_%s_mulgen2_get_workspace_bytes" % self.name)(n))
+        if need and (self._fws is None or self._fws.numel() < need):
+            self._fws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._call("mulgen2_get", self._scalars(e, n), self._scalars(f, n), Q.data_ptr(),
+                   None if x is None else x.data_ptr(), None if y is None else y.data_ptr(), sign.data_ptr(), n, n,
+                   self._fws.data_ptr() if need else None, need, _stream(self.device))
+        return x, y, sign
+
     FUSED2 = ("ED25519", "ED448", "NIST256", "SECP256K1")      # curves with a fused mul2 + get kernel
 
     def mul2_get(self, e, P, f, Q, want_x: bool = True, want_y: bool = True):

@@ -32,7 +32,7 @@ def _declared_symbols():
     for fn in re.findall(r"\becn_##c##_(\w+)\s*\(", emacro):
         for c in re.findall(r"^MODARITH_AMD_DECLARE_EDWARDS\((\w+),", text, flags=re.M):
             names.add("ecn_%s_%s" % (c, fn))
-    names.update(re.findall(r"\b(ecn_\w+_mul(?:2|gen)?_get_(?:batch|workspace_bytes))\s*\(", text))
+    names.update(re.findall(r"\b(ecn_\w+_mul(?:2|gen|gen2)?_get_(?:batch|workspace_bytes))\s*\(", text))
     return sorted(names), primes
 
 

@@ -303,3 +303,51 @@ def test_fused_generator_multiplication(oracle, name):
         ox, oy = ctypes.create_string_buffer(nb), ctypes.create_string_buffer(nb)
         oracle.ecn(C, "get")(ctypes.byref(p), ox, oy)
         assert bytes(hx[j]) == ox.raw and bytes(hy[j]) == oy.raw, j
+
+
+@pytest.mark.parametrize("name", ["NIST256", "SECP256K1", "ED25519"])
+def test_fused_verification_form(oracle, name):
+    """e*G + f*Q and its affine export (ecn gen + ecn mul2 + ecn get, the verification pattern): against the general fused
+    mul2_get with P = G, the three-call form, and the oracle on a sample; Q infinite / +-G, zero scalars, f = e with Q = -G
+    (infinite result), more pairs than resident lanes"""
+    import torch
+    from modarith_amd.edwards import Edwards
+    W = Edwards(name)
+    nb = W.nbytes
+    n = 131072 + 8197
+    gen = torch.Generator(device="cuda").manual_seed(96)
+    rnd = lambda m: torch.randint(0, 256, (m, nb), dtype=torch.uint8, device="cuda", generator=gen)
+    e, f = rnd(n), rnd(n)
+    Q = W.mul(rnd(n), W.gen(n))
+    Q[:, :, 0:8] = W.inf(8)
+    Q[:, :, 8:16] = W.gen(8)
+    Q[:, :, 16:24] = W.neg(W.gen(8))
+    f[16:20] = e[16:20]                              # e G + e (-G): the neutral element / point at infinity -> (0, 1)
+    e[24:28] = 0
+    f[28:32] = 0
+    e[32:34] = 255
+    f[32:34] = 255
+    keep = Q.clone()
+    x, y, _ = W.mulgen2_get(e, f, Q)
+    assert torch.equal(Q, keep)
+    G = W.gen(n)
+    gx_, gy_, _ = W.mul2_get(e, G, f, Q)
+    assert torch.equal(x, gx_) and torch.equal(y, gy_)
+    m = 1 << 13
+    wx, wy, _ = W.get(W.mul2(e[:m].contiguous(), W.gen(m), f[:m].contiguous(), Q[:, :, :m].contiguous()))
+    assert torch.equal(x[:m], wx) and torch.equal(y[:m], wy)
+    assert hexrows(x[16:20]) == ["00" * nb] * 4 and hexrows(y[16:20]) == ["00" * (nb - 1) + "01"] * 4
+    C = name.lower()
+    Pt, onb = oracle.ed[C]
+    sq = Q.cpu().numpy().view(np.uint64)
+    he, hf, hx, hy = e.cpu().numpy(), f.cpu().numpy(), x.cpu().numpy(), y.cpu().numpy()
+    for j in list(range(0, 36, 3)) + list(range(36, n, 14983)):
+        g_, q, r = Pt(), Pt(), Pt()
+        oracle.ecn(C, "gen")(ctypes.byref(g_))
+        for c, nm in enumerate(("x", "y", "z")):
+            for i in range(W.N):
+                getattr(q, nm)[i] = int(sq[c, i, j])
+        oracle.ecn(C, "mul2")(bytes(he[j]), ctypes.byref(g_), bytes(hf[j]), ctypes.byref(q), ctypes.byref(r))
+        ox, oy = ctypes.create_string_buffer(onb), ctypes.create_string_buffer(onb)
+        oracle.ecn(C, "get")(ctypes.byref(r), ox, oy)
+        assert bytes(hx[j]) == ox.raw and bytes(hy[j]) == oy.raw, j

@@ -24,7 +24,7 @@ def test_device_arithmetic_on_host_against_oracle(oracle, tmp_path):
     p = subprocess.run([exe, "400"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:]
     lines = [l for l in p.stdout.splitlines() if "records" in l]
-    assert len(lines) == 16 and all(" 0 differ" in l for l in lines), p.stdout
+    assert len(lines) == 17 and all(" 0 differ" in l for l in lines), p.stdout
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")
@@ -202,3 +202,36 @@ def test_fused_generator_multiplication_on_host_against_oracle(oracle, tmp_path)
                 for g, e in enumerate(grp):
                     got = (b"".join(int(X_[4 * g + k]).to_bytes(8, "big") for k in (3, 2, 1, 0)), b"".join(int(Y_[4 * g + k]).to_bytes(8, "big") for k in (3, 2, 1, 0)))
                     assert got == ref(e), (C, G, [hex(v) for v in grp], g)
+
+        # e*G + f*Q (verification pattern): against the oracle's gen, mul2, get; Q random / infinite / +-G, scalars cancelling
+        def point(kind):
+            p = Pt()
+            if kind == "inf":
+                oracle.ecn(C, "inf")(ctypes.byref(p))
+                return p
+            oracle.ecn(C, "gen")(ctypes.byref(p))
+            if kind == "rand":
+                oracle.ecn(C, "mul")(rng.getrandbits(256).to_bytes(32, "big"), ctypes.byref(p))
+            if kind == "neg":
+                oracle.ecn(C, "neg")(ctypes.byref(p))
+            return p
+
+        for it in range(48):
+            e, f = rng.getrandbits(256), rng.getrandbits(256)
+            kind = ("rand", "inf", "gen", "neg", "rand", "rand")[it % 6]
+            if it % 6 == 3:
+                f = e                                   # e G + e (-G) = infinity
+            if it % 6 == 4:
+                e = 0
+            if it % 6 == 5 and it > 20:
+                f = 0
+            Qp = point(kind)
+            xw, yw = U64(), U64()
+            lib.wn26_mulgen2_get_host(which, U64(*[(e >> (64 * k)) & (2**64 - 1) for k in range(4)]),
+                                      U64(*[(f >> (64 * k)) & (2**64 - 1) for k in range(4)]), Qp.x, Qp.y, Qp.z, xw, yw)
+            G, R = point("gen"), Pt()
+            oracle.ecn(C, "mul2")(e.to_bytes(32, "big"), ctypes.byref(G), f.to_bytes(32, "big"), ctypes.byref(Qp), ctypes.byref(R))
+            x, y = ctypes.create_string_buffer(nb), ctypes.create_string_buffer(nb)
+            oracle.ecn(C, "get")(ctypes.byref(R), x, y)
+            got = (b"".join(int(xw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0)), b"".join(int(yw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0)))
+            assert got == (x.raw, y.raw), (C, "mulgen2", it)

@@ -490,6 +490,36 @@ static int run_edgen(const char* name, int n, FN fused, GEN gen, MUL mul, GET ge
     return bad;
 }
 
+// e*G + f*Q on ED25519 (verification pattern) against the oracle's gen, mul2, get: Q random / neutral / small order / +-G
+static int run_ed25519_mulgen2(int n) {
+    int bad = 0;
+    for (int it = 0; it < n; it++) {
+        pt25519 G, Q, R;
+        unsigned char e[32], f[32], k[32];
+        for (int i = 0; i < 32; i++) { e[i] = (unsigned char)sm(); f[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
+        ecn_ed25519_gen(&G);
+        ecn_ed25519_gen(&Q); ecn_ed25519_mul((const char*)k, &Q);
+        if (it % 8 == 1) ecn_ed25519_inf(&Q);
+        if (it % 8 == 2) { char y[32]; memset(y, 0, 32); ecn_ed25519_set(0, nullptr, y, &Q); }            // order 4
+        if (it % 8 == 3) ecn_ed25519_gen(&Q);
+        if (it % 8 == 4) memset(e, 0, 32);
+        if (it % 8 == 5) memset(f, 0, 32);
+        if (it == 6) { memset(e, 0xff, 32); memset(f, 0xff, 32); }
+        pt25519 Q0 = Q;
+        uint64_t ew[4], fw[4], xw[4], yw[4];
+        for (int w = 0; w < 4; w++) { uint64_t v = 0, u = 0; for (int b = 0; b < 8; b++) { v |= (uint64_t)e[31 - (8 * w + b)] << (8 * b); u |= (uint64_t)f[31 - (8 * w + b)] << (8 * b); } ew[w] = v; fw[w] = u; }
+        ma::ed25519_mulgen2_get_one<ma::C_ED25519, HostComb25519>(ew, fw, Q.x, Q.y, Q.z, xw, yw);
+        char wx[32], wy[32];
+        ecn_ed25519_mul2((const char*)e, &G, (const char*)f, &Q0, &R);
+        ecn_ed25519_get(&R, wx, wy);
+        unsigned char gx[32], gy[32];
+        for (int i = 0; i < 32; i++) { gx[i] = (unsigned char)(xw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); gy[i] = (unsigned char)(yw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); }
+        if (memcmp(gx, wx, 32) != 0 || memcmp(gy, wy, 32) != 0) { if (bad < 6) printf("ed25519_mulgen2_get_one: record %d differs\n", it); bad++; }
+    }
+    printf("ed25519_mulgen2_get_one: %d records, %d differ from the oracle's ecn gen + mul2 + get\n", n, bad);
+    return bad;
+}
+
 int main(int argc, char** argv) {
     int n = argc > 1 ? atoi(argv[1]) : 2000;
     int bad = run<4>("x25519_fe26_one", n, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x25519_fe26_one(k, u, o); }, rfc7748_X25519);
@@ -515,6 +545,7 @@ int main(int argc, char** argv) {
                                       }, xw, yw);
                                       for (int k = 0; k < 4; k++) { x[k] = xw[2][k]; y[k] = yw[2][k]; }
                                   }, ecn_ed25519_gen, ecn_ed25519_mul, ecn_ed25519_get);
+    bad += run_ed25519_mulgen2(n / 8 + 24);
     bad += run_edgen<56, pt448>("ed448_mulgen_get_one", n / 8 + 130, [](const uint64_t* e, uint64_t* x, uint64_t* y) { ma::ed448_mulgen_get_one<HostComb448>(e, x, y); },
                                 ecn_ed448_gen, ecn_ed448_mul, ecn_ed448_get);
     return bad ? 1 : 0;

@@ -55,3 +55,9 @@ extern "C" void wn26_mulgen_get_many_host(int which, int G, const uint64_t* e, u
     if (which == 0) { if (G == 2) many<ma::CvNist256, HostCombNist256, 2>(e, x, y); else many<ma::CvNist256, HostCombNist256, 4>(e, x, y); }
     else { if (G == 2) many<ma::CvSecp256k1, HostCombSecp256k1, 2>(e, x, y); else many<ma::CvSecp256k1, HostCombSecp256k1, 4>(e, x, y); }
 }
+extern "C" void wn26_mulgen2_get_host(int which, const uint64_t* ew, const uint64_t* fw, const uint64_t* QX, const uint64_t* QY, const uint64_t* QZ,
+                                      uint64_t* xw, uint64_t* yw) {
+    uint64_t tab[ma::WN26_TABLE_WORDS];
+    if (which == 0) ma::wn26_mulgen2_get_one<ma::CvNist256, HostCombNist256>(ew, fw, QX, QY, QZ, tab, 1, xw, yw);
+    else ma::wn26_mulgen2_get_one<ma::CvSecp256k1, HostCombSecp256k1>(ew, fw, QX, QY, QZ, tab, 1, xw, yw);
+}
