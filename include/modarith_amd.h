@@ -359,7 +359,7 @@ int ecn_ed448_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_
 
 /* e*G + f*Q and its affine export: ecnXXXgen, ecnXXXmul2(e, &G, f, &Q, &R), ecnXXXget -- signature verification, where the
  * first point of the reference's double multiplication is always the generator (nist256.c:251-256, ed448.c:305).  f*Q as in
- * mul_get (workspace of ecn_<c>_mulgen2_get_workspace_bytes(n) bytes for nist256 / secp256k1, 0 and NULL for ed25519), e*G through
+ * mul_get (workspace of ecn_<c>_mulgen2_get_workspace_bytes(n) bytes for nist256 / secp256k1 / ed448, 0 and NULL for ed25519), e*G through
  * the fixed-base table without doublings of its own; Q is not modified; same bytes as the three calls. */
 size_t ecn_nist256_mulgen2_get_workspace_bytes(size_t n);
 int ecn_nist256_mulgen2_get_batch(const char *e, const char *f, const ma_spint *Q, char *x, char *y, int *sign, size_t n, size_t ld,
@@ -367,6 +367,9 @@ int ecn_nist256_mulgen2_get_batch(const char *e, const char *f, const ma_spint *
 size_t ecn_secp256k1_mulgen2_get_workspace_bytes(size_t n);
 int ecn_secp256k1_mulgen2_get_batch(const char *e, const char *f, const ma_spint *Q, char *x, char *y, int *sign, size_t n, size_t ld,
                                     void *workspace, size_t workspace_bytes, void *stream);
+size_t ecn_ed448_mulgen2_get_workspace_bytes(size_t n);   /* ED448_VERIFY, ed448.c:290-310 */
+int ecn_ed448_mulgen2_get_batch(const char *e, const char *f, const ma_spint *Q, char *x, char *y, int *sign, size_t n, size_t ld,
+                                void *workspace, size_t workspace_bytes, void *stream);
 size_t ecn_ed25519_mulgen2_get_workspace_bytes(size_t n);
 int ecn_ed25519_mulgen2_get_batch(const char *e, const char *f, const ma_spint *Q, char *x, char *y, int *sign, size_t n, size_t ld,
                                   void *workspace, size_t workspace_bytes, void *stream);

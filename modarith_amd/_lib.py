@@ -22,7 +22,7 @@ ED_BATCH_FUNCS = ("mul", "mul2", "ran", "add", "sub", "cpy", "dbl", "neg", "inf"
 FUSED_CURVES = ("ed25519", "ed448", "nist256", "secp256k1")       # fused mul + get kernels (csrc/ed26.h, csrc/ed28.h, csrc/wn26.h)
 FUSED2_CURVES = ("ed25519", "ed448", "nist256", "secp256k1")        # fused mul2 + get
 FUSEDG_CURVES = ("nist256", "secp256k1", "ed25519", "ed448")             # fused gen + mul + get (fixed-base tables; csrc/wn26.h, ed26.h, ed28.h *_mulgen_get_one)
-FUSEDG2_CURVES = ("nist256", "secp256k1", "ed25519")    # fused gen + mul2 + get (e*G + f*Q, verification)
+FUSEDG2_CURVES = ("nist256", "secp256k1", "ed25519", "ed448")    # fused gen + mul2 + get (e*G + f*Q, verification)
 FUSED_FUNCS = (tuple("ecn_%s_mulgen_get_batch" % c for c in FUSEDG_CURVES)
                + tuple("ecn_%s_mulgen2_get_%s" % (c, f) for c in FUSEDG2_CURVES for f in ("batch", "workspace_bytes")) + tuple("ecn_%s_mul_get_%s" % (c, f) for c in FUSED_CURVES for f in ("batch", "workspace_bytes"))
                + tuple("ecn_%s_mul2_get_%s" % (c, f) for c in FUSED2_CURVES for f in ("batch", "workspace_bytes")))

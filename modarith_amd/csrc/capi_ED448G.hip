@@ -30,9 +30,61 @@ void k_ed448_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned char
     }
 }
 
+// e*G + f*Q and its affine export (ED448_VERIFY, ed448.c:290-310): the per-lane table of Q in the workspace as for mul_get, the
+// generator part through the constant table above
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_ed448_mulgen2_get(const unsigned char* e, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb, int* sign,
+                         size_t n, size_t ld, uint64_t* ws) {
+    using P = P_X448;
+    const size_t slots = (size_t)gridDim.x * blockDim.x;
+    const size_t tstride = slots + 36;                      // row pitch skewed as in capi_ED448F.hip
+    uint64_t* tab = ws + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += slots) {
+        spint ew[7], fw[7], X[8], Y[8], Z[8], xw[7], yw[7];
+        load_be_record<P>(e, t, ew);
+        load_be_record<P>(f, t, fw);
+        static_for<0, 8>([&](auto I) {
+            X[I] = Qb[(size_t)I * ld + t];
+            Y[I] = Qb[(size_t)(8 + I) * ld + t];
+            Z[I] = Qb[(size_t)(16 + I) * ld + t];
+        });
+        ed448_mulgen2_get_one<CombED448>(ew, fw, X, Y, Z, tab, tstride, xw, yw);
+        if (xb) store_be_record<P>(xb, t, xw);
+        if (yb) store_be_record<P>(yb, t, yw);
+        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+    }
+}
+
 }  // namespace ma
 
 using namespace ma;
+
+namespace {
+size_t fused2_lanes(size_t n) {
+    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
+    return lanes < cap ? lanes : cap;
+}
+}  // namespace
+
+extern "C" size_t ecn_ed448_mulgen2_get_workspace_bytes(size_t n) { return (fused2_lanes(n) + 36) * ED448_TABLE_WORDS * sizeof(uint64_t); }
+
+extern "C" int ecn_ed448_mulgen2_get_batch(const char* e, const char* f, const ma_spint* Q, char* x, char* y, int* sign, size_t n, size_t ld,
+                                           void* workspace, size_t workspace_bytes, void* st) {
+    if (n == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 7u) {
+        set_error("ecn mulgen2_get: byte records must be 8-byte aligned");
+        return (int)hipErrorInvalidValue;
+    }
+    const size_t lanes = fused2_lanes(n);
+    if (workspace == nullptr || workspace_bytes < (lanes + 36) * ED448_TABLE_WORDS * sizeof(uint64_t)) {
+        set_error("ecn mulgen2_get: workspace too small (see ecn_ed448_mulgen2_get_workspace_bytes)");
+        return (int)hipErrorInvalidValue;
+    }
+    k_ed448_mulgen2_get<<<(unsigned)(lanes / 64), 64, 0, (hipStream_t)st>>>(
+        reinterpret_cast<const unsigned char*>(e), reinterpret_cast<const unsigned char*>(f), Q, reinterpret_cast<unsigned char*>(x),
+        reinterpret_cast<unsigned char*>(y), sign, n, ld, reinterpret_cast<uint64_t*>(workspace));
+    return check_launch("ecn mulgen2_get");
+}
 
 extern "C" int ecn_ed448_mulgen_get_batch(const char* e, char* x, char* y, int* sign, size_t n, void* st) {
     if (n == 0) return 0;

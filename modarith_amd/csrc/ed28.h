@@ -130,11 +130,10 @@ constexpr int ED448_TABLE_WORDS = 4 * 3 * 7;       // 64-bit words per lane in t
 
 // One fused ED448 scalar multiplication + affine export.  ew: the scalar as seven little-endian words; X, Y, Z: 8 x 56-bit
 // limbs each; tab: this lane's table slots, word k at tab[k * tstride]; xw, yw: canonical affine coordinates, seven words.
-MA_DEV void ed448_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
-                              uint64_t* xw, uint64_t* yw) {
+template <bool FINAL_T = false>         // FINAL_T: the sum leaves with its T coordinate (a further addition follows)
+MA_DEV void ed448_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride, Ed28::Ext& R) {
     using E = Ed28;
     using F = Fe28;
-    E::Ext R;
 
     {   // ---- table: projective P -> extended; 2P, 3P, 4P; one shared inversion; cached affine form
         E::Ext Q, P2, P3, P4;
@@ -267,9 +266,14 @@ MA_DEV void ed448_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y
         E::neg2p(ts, nt);
         F::select(neg, xs, nx, xs);
         F::select(neg, ts, nt, ts);
-        E::add_cached(R, xs, ys, ts);
+        E::add_cached(R, xs, ys, ts, FINAL_T && i == 149);
     }
-
+}
+MA_DEV void ed448_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
+                              uint64_t* xw, uint64_t* yw) {
+    using F = Fe28;
+    Ed28::Ext R;
+    ed448_mul_acc<false>(ew, X, Y, Z, tab, tstride, R);
     // ---- affine, canonical (ecnXXXget: edwards.c:221-239)
     uint32_t zi[16], ax[16], ay[16];
     F::invert(R.Z, zi);
@@ -428,11 +432,10 @@ MA_DEV void ed448_mul2_get_one(const uint64_t* ew, const spint* PX, const spint*
 // ED448_SIGN open with ecnXXXgen, ecnXXXmul, ecnXXXget (ed448.c:167-184, 196-199).  W = 4: e' = e + sum_{i<113} 8*16^i, 113
 // signed 4-bit digits, the 113 x 8 multiples m * 16^i * G precomputed as (x, y, 39081 x y) in sixteen 28-bit limbs
 // (generated/comb_ED448.h, 173 568 bytes, wave-uniform reads; W = 5 measured the same), one complete mixed addition per window, no doublings.
-template <class TAB>
-MA_DEV void ed448_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw) {
+template <class TAB, bool INIT = true>         // INIT = false: R += e*G (R holds a sum with its T coordinate)
+MA_DEV void ed448_mulgen_acc(const uint64_t* ew, Ed28::Ext& R) {
     using E = Ed28;
     using F = Fe28;
-    E::Ext R;
     constexpr int W = TAB::W, NW = TAB::NW, E2 = 1 << (W - 1);       // window width, windows, entries per window
     static_assert(W * NW >= 449 && W * NW <= 512, "e + bias must fit the windows and eight words");
     uint64_t w[8];
@@ -453,10 +456,12 @@ MA_DEV void ed448_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw)
             acc >>= 64;
         });
     }
-    F::set(0, R.X);
-    F::set(1, R.Y);
-    F::set(1, R.Z);
-    F::set(0, R.T);
+    if constexpr (INIT) {
+        F::set(0, R.X);
+        F::set(1, R.Y);
+        F::set(1, R.Z);
+        F::set(0, R.T);
+    }
 #pragma unroll 1
     for (int i = 0; i < NW; i++) {
         const int dgt = (int)((uint32_t)w[0] & (uint32_t)(2 * E2 - 1)) - E2;        // [-2^(W-1), 2^(W-1) - 1]
@@ -488,6 +493,29 @@ MA_DEV void ed448_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw)
         F::select(neg, sel[2], nt, sel[2]);
         E::add_cached(R, sel[0], sel[1], sel[2], true);
     }
+}
+template <class TAB>
+MA_DEV void ed448_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw) {
+    using F = Fe28;
+    Ed28::Ext R;
+    ed448_mulgen_acc<TAB>(ew, R);
+    uint32_t zi[16], ax[16], ay[16];
+    F::invert(R.Z, zi);
+    F::mul_k(R.X, zi, ax);
+    F::mul_k(R.Y, zi, ay);
+    F::to_words(ax, xw);
+    F::to_words(ay, yw);
+}
+// Fused e*G + f*Q + affine export for ED448: ED448_VERIFY's ecnXXXmul2(&G, &Q, ...) + ecnXXXget (ed448.c:290-310; the first
+// point is the generator).  f*Q as in ed448_mul_get_one (the last addition also produces T), then e*G through the fixed-base
+// table (ed448_mulgen_acc), see ed26.h ed25519_mulgen2_get_one.
+template <class TAB>
+MA_DEV void ed448_mulgen2_get_one(const uint64_t* ew, const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
+                                  uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
+    using F = Fe28;
+    Ed28::Ext R;
+    ed448_mul_acc<true>(fw, QX, QY, QZ, tab, tstride, R);
+    ed448_mulgen_acc<TAB, false>(ew, R);
     uint32_t zi[16], ax[16], ay[16];
     F::invert(R.Z, zi);
     F::mul_k(R.X, zi, ax);

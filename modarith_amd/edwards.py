@@ -160,7 +160,7 @@ class Edwards:
                    sign.data_ptr(), n, _stream(self.device))
         return x, y, sign
 
-    FUSEDG2 = ("NIST256", "SECP256K1", "ED25519")      # curves with a fused gen + mul2 + get kernel (e*G + f*Q)
+    FUSEDG2 = ("NIST256", "SECP256K1", "ED25519", "ED448")      # curves with a fused gen + mul2 + get kernel (e*G + f*Q)
 
     def mulgen2_get(self, e, f, Q, want_x: bool = True, want_y: bool = True):
         """ecnXXXgen, ecnXXXmul2(e, G, f, Q, R), ecnXXXget (signature verification, nist256.c:251-256, ed448.c:305) in ONE kernel:

@@ -305,7 +305,7 @@ def test_fused_generator_multiplication(oracle, name):
         assert bytes(hx[j]) == ox.raw and bytes(hy[j]) == oy.raw, j
 
 
-@pytest.mark.parametrize("name", ["NIST256", "SECP256K1", "ED25519"])
+@pytest.mark.parametrize("name", ["NIST256", "SECP256K1", "ED25519", "ED448"])
 def test_fused_verification_form(oracle, name):
     """e*G + f*Q and its affine export (ecn gen + ecn mul2 + ecn get, the verification pattern): against the general fused
     mul2_get with P = G, the three-call form, and the oracle on a sample; Q infinite / +-G, zero scalars, f = e with Q = -G

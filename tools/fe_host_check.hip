@@ -520,6 +520,36 @@ static int run_ed25519_mulgen2(int n) {
     return bad;
 }
 
+extern "C" void ecn_ed448_mul2(const char* e, pt448* P, const char* f, pt448* Q, pt448* R);
+static int run_ed448_mulgen2(int n) {
+    int bad = 0;
+    for (int it = 0; it < n; it++) {
+        pt448 G, Q, R;
+        unsigned char e[56], f[56], k[56];
+        for (int i = 0; i < 56; i++) { e[i] = (unsigned char)sm(); f[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
+        ecn_ed448_gen(&G);
+        ecn_ed448_gen(&Q); ecn_ed448_mul((const char*)k, &Q);
+        if (it % 8 == 1) ecn_ed448_inf(&Q);
+        if (it % 8 == 2) { char y[56]; memset(y, 0, 56); ecn_ed448_set(0, nullptr, y, &Q); }            // order 4
+        if (it % 8 == 3) ecn_ed448_gen(&Q);
+        if (it % 8 == 4) memset(e, 0, 56);
+        if (it % 8 == 5) memset(f, 0, 56);
+        if (it == 6) { memset(e, 0xff, 56); memset(f, 0xff, 56); }
+        pt448 Q0 = Q;
+        uint64_t ew[7], fw[7], xw[7], yw[7], tab[ma::ED448_TABLE_WORDS];
+        for (int w = 0; w < 7; w++) { uint64_t v = 0, u = 0; for (int b = 0; b < 8; b++) { v |= (uint64_t)e[55 - (8 * w + b)] << (8 * b); u |= (uint64_t)f[55 - (8 * w + b)] << (8 * b); } ew[w] = v; fw[w] = u; }
+        ma::ed448_mulgen2_get_one<HostComb448>(ew, fw, Q.x, Q.y, Q.z, tab, 1, xw, yw);
+        char wx[56], wy[56];
+        ecn_ed448_mul2((const char*)e, &G, (const char*)f, &Q0, &R);
+        ecn_ed448_get(&R, wx, wy);
+        unsigned char gx[56], gy[56];
+        for (int i = 0; i < 56; i++) { gx[i] = (unsigned char)(xw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); gy[i] = (unsigned char)(yw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); }
+        if (memcmp(gx, wx, 56) != 0 || memcmp(gy, wy, 56) != 0) { if (bad < 6) printf("ed448_mulgen2_get_one: record %d differs\n", it); bad++; }
+    }
+    printf("ed448_mulgen2_get_one: %d records, %d differ from the oracle's ecn gen + mul2 + get\n", n, bad);
+    return bad;
+}
+
 int main(int argc, char** argv) {
     int n = argc > 1 ? atoi(argv[1]) : 2000;
     int bad = run<4>("x25519_fe26_one", n, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x25519_fe26_one(k, u, o); }, rfc7748_X25519);
@@ -533,6 +563,7 @@ int main(int argc, char** argv) {
     bad += run_ed25519_mul2(n / 8 + 16);
     bad += run_ed448(n / 16 + 16);
     bad += run_ed448_mul2(n / 32 + 16);
+    bad += run_ed448_mulgen2(n / 32 + 16);
     bad += run_nist256(n / 8 + 16);
     bad += run_nist256_mul2(n / 16 + 16);
     bad += run_edgen<32, pt25519>("ed25519_mulgen_get_one", n / 4 + 80, [](const uint64_t* e, uint64_t* x, uint64_t* y) { ma::ed25519_mulgen_get_one<ma::C_ED25519, HostComb25519>(e, x, y); },

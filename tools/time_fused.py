@@ -59,7 +59,7 @@ for name3, n in (("NIST256", 1 << 21), ("SECP256K1", 1 << 21), ("ED25519", 1 << 
         name3, n.bit_length() - 1, n / bf, bf * 1e3, n / bt, bt * 1e3, bt / bf, n / bm, bool(torch.equal(x, wx) and torch.equal(y, wy))), flush=True)
 
 # e*G + f*Q (verification) against the general fused mul2_get with P = G and against gen + mul2 + get
-for name4, n in (("NIST256", 1 << 20), ("SECP256K1", 1 << 20), ("ED25519", 1 << 21)):
+for name4, n in (("NIST256", 1 << 20), ("SECP256K1", 1 << 20), ("ED25519", 1 << 21), ("ED448", 1 << 19)):
     if only and name4 not in only:
         continue
     Ed = Curve(name4)
