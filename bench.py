@@ -446,7 +446,17 @@ def main():
                 assert allv.shape[0] == world * m and torch.equal(allv[:m].to(o.device), o)
             del allv
             lt, gather_ms = max_over_ranks([lt, gather_ms])
+        # public-key generation: the same function on the base point u = 9 (rfc7748.c:297-333), fixed-base kernel
+        from modarith_amd.field import rfc7748_base
+        rfc7748_base("X25519", k[:4096].contiguous())
+        torch.cuda.synchronize(); tb0 = time.perf_counter()
+        pk = rfc7748_base("X25519", k)
+        torch.cuda.synchronize(); tb = time.perf_counter() - tb0
+        ub = torch.zeros((4096, 32), dtype=torch.uint8, device=dev); ub[:, 0] = 9
+        assert torch.equal(pk[:4096], rfc7748("X25519", k[:4096].contiguous(), ub)), "fixed-base public keys differ from the ladder on u = 9"
+        del pk, ub
         ladder = {"value": world * m / lt, "unit": "X25519 scalar-mults/s", "scalars_per_gpu": m, "ms_per_pass": lt * 1e3,
+                  "base_point_public_keys_per_s_per_gpu": m / tb,
                   "gather_ms": gather_ms, "io_bytes_per_scalar": 96,
                   "bound": "VALU 32-bit integer multiply-add issue (not HBM)",
                   "roofline": valu_roofline(m / lt)}

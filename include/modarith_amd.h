@@ -226,6 +226,11 @@ void rfc7748_X25519(const char *bk, const char *bu, char *bv);
 void rfc7748_X448(const char *bk, const char *bu, char *bv);
 int rfc7748_X25519_batch(const char *bk, const char *bu, char *bv, size_t n, void *stream);
 int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void *stream);
+/* rfc7748() on the curve's BASE POINT (u = 9 / u = 5): public-key generation, the first half of every exchange in the
+ * reference's main() (rfc7748.c:297-333 `rfc7748(alice, base, apk)`).  Same bytes as rfc7748_<C>_batch with bu = the base
+ * point; computed on the birationally equivalent / 4-isogenous Edwards curve from a fixed-base table (no ladder steps). */
+int rfc7748_X25519_base_batch(const char *bk, char *bv, size_t n, void *stream);
+int rfc7748_X448_base_batch(const char *bk, char *bv, size_t n, void *stream);
 
 /* ---- Curve layer on the field path: the API of curve.h:13-29 with XXX = _<curve>_
  * (curve.py:344-345), for ED25519 (over the X25519 field), ED448 (over the X448 field), and NUMS256E (over 2^256-189), ED248,

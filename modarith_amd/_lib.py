@@ -23,7 +23,7 @@ FUSED_CURVES = ("ed25519", "ed448", "nist256", "secp256k1")       # fused mul + 
 FUSED2_CURVES = ("ed25519", "ed448", "nist256", "secp256k1")        # fused mul2 + get
 FUSEDG_CURVES = ("nist256", "secp256k1", "ed25519", "ed448")             # fused gen + mul + get (fixed-base tables; csrc/wn26.h, ed26.h, ed28.h *_mulgen_get_one)
 FUSEDG2_CURVES = ("nist256", "secp256k1", "ed25519", "ed448")    # fused gen + mul2 + get (e*G + f*Q, verification)
-FUSED_FUNCS = (tuple("ecn_%s_mulgen_get_batch" % c for c in FUSEDG_CURVES)
+FUSED_FUNCS = (("rfc7748_X25519_base_batch", "rfc7748_X448_base_batch") + tuple("ecn_%s_mulgen_get_batch" % c for c in FUSEDG_CURVES)
                + tuple("ecn_%s_mulgen2_get_%s" % (c, f) for c in FUSEDG2_CURVES for f in ("batch", "workspace_bytes")) + tuple("ecn_%s_mul_get_%s" % (c, f) for c in FUSED_CURVES for f in ("batch", "workspace_bytes"))
                + tuple("ecn_%s_mul2_get_%s" % (c, f) for c in FUSED2_CURVES for f in ("batch", "workspace_bytes")))
 ED_SCALAR_FUNCS = ("mul2", "ran", "get", "set", "inf", "isinf", "neg", "add", "sub", "dbl", "gen", "mul", "cmp", "affine", "cpy", "cof",
@@ -135,6 +135,10 @@ def load() -> ctypes.CDLL:
     for c in FUSEDG_CURVES:
         f = getattr(lib, "ecn_%s_mulgen_get_batch" % c)
         f.argtypes = [_P, _P, _P, _P, c_size_t, _P]
+        f.restype = c_int
+    for C in LADDERS:
+        f = getattr(lib, "rfc7748_%s_base_batch" % C)
+        f.argtypes = [_P, _P, c_size_t, _P]
         f.restype = c_int
     for c in FUSEDG2_CURVES:
         f = getattr(lib, "ecn_%s_mulgen2_get_batch" % c)

@@ -40,6 +40,24 @@ void k_ed25519_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned ch
     }
 }
 
+// rfc7748() on the base point u = 9 (x25519_base_many): little-endian 32-byte records as rfc7748_X25519_batch takes them
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void k_x25519_base(const uint64_t* bk, uint64_t* bv, size_t n) {
+    const size_t lanes = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += MULGEN_G * lanes) {
+        uint64_t ow[MULGEN_G][4];
+        x25519_base_many<C_ED25519, CombED25519, MULGEN_G>(
+            [&](int g, uint64_t* kw) {
+                const size_t tg = t + (size_t)g * lanes, ts = tg < n ? tg : t;
+                static_for<0, 4>([&](auto K) { kw[K] = bk[ts * 4 + K]; });
+            }, ow);
+        static_for<0, MULGEN_G>([&](auto GI) {
+            const size_t tg = t + (size_t)GI * lanes;
+            if (tg < n) static_for<0, 4>([&](auto K) { bv[tg * 4 + K] = ow[GI][K]; });
+        });
+    }
+}
+
 // e*G + f*Q and its affine export (verification, ed448.c:305): the table of Q in registers as for mul_get, the generator part
 // through the constant table above
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -92,4 +110,17 @@ extern "C" int ecn_ed25519_mulgen_get_batch(const char* e, char* x, char* y, int
     k_ed25519_mulgen_get<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(
         reinterpret_cast<const unsigned char*>(e), reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n);
     return check_launch("ecn mulgen_get");
+}
+
+// bv = [bk](9): rfc7748(bk, base, bv) of rfc7748.c:297-333 for a batch of private keys, on the fixed-base table
+extern "C" int rfc7748_X25519_base_batch(const char* bk, char* bv, size_t n, void* st) {
+    if (n == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(bk) | reinterpret_cast<uintptr_t>(bv)) & 7u) {
+        set_error("rfc7748 base: byte records must be 8-byte aligned");
+        return (int)hipErrorInvalidValue;
+    }
+    const size_t lanes = ((n + MULGEN_G - 1) / MULGEN_G + 63) / 64 * 64, cap = (size_t)4 * 1024 * 64;
+    k_x25519_base<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(
+        reinterpret_cast<const uint64_t*>(bk), reinterpret_cast<uint64_t*>(bv), n);
+    return check_launch("rfc7748 base");
 }

@@ -30,6 +30,17 @@ void k_ed448_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned char
     }
 }
 
+// rfc7748() on the base point u = 5 (x448_base_one): little-endian 56-byte records as rfc7748_X448_batch takes them
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void k_x448_base(const uint64_t* bk, uint64_t* bv, size_t n) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        uint64_t kw[7], ow[7];
+        static_for<0, 7>([&](auto K) { kw[K] = bk[t * 7 + K]; });
+        x448_base_one<CombED448>(kw, ow);
+        static_for<0, 7>([&](auto K) { bv[t * 7 + K] = ow[K]; });
+    }
+}
+
 // e*G + f*Q and its affine export (ED448_VERIFY, ed448.c:290-310): the per-lane table of Q in the workspace as for mul_get, the
 // generator part through the constant table above
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -96,4 +107,17 @@ extern "C" int ecn_ed448_mulgen_get_batch(const char* e, char* x, char* y, int* 
     k_ed448_mulgen_get<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(
         reinterpret_cast<const unsigned char*>(e), reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n);
     return check_launch("ecn mulgen_get");
+}
+
+// bv = [bk](5): rfc7748(bk, base, bv) for a batch of private keys, on the fixed-base table of ED448 (4-isogenous to curve448)
+extern "C" int rfc7748_X448_base_batch(const char* bk, char* bv, size_t n, void* st) {
+    if (n == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(bk) | reinterpret_cast<uintptr_t>(bv)) & 7u) {
+        set_error("rfc7748 base: byte records must be 8-byte aligned");
+        return (int)hipErrorInvalidValue;
+    }
+    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)4 * 1024 * 64;
+    k_x448_base<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(
+        reinterpret_cast<const uint64_t*>(bk), reinterpret_cast<uint64_t*>(bv), n);
+    return check_launch("rfc7748 base");
 }

@@ -601,4 +601,42 @@ MA_DEV void ed25519_mulgen2_get_one(const uint64_t* ew, const uint64_t* fw, cons
     F::to_words(ay, yw);
 }
 
+// rfc7748() on the BASE POINT u = 9 (public-key generation: every Diffie-Hellman exchange opens with it, rfc7748.c:297-333
+// `rfc7748(alice, base, apk)`).  The generator of ED25519 is the image of (9, v) under the birational map u = (1 + y) / (1 - y),
+// so [k](9) = (Z + Y) / (Z - Y) of k*G on the Edwards curve, with k*G from the fixed-base table (ed25519_mulgen_acc: no
+// doublings, 65 mixed additions) instead of 255 ladder steps.  k is clamped as rfc7748.c:135-141 does; a clamped scalar is a
+// multiple of 8 below 2^255 < 8q, so k*G is never the neutral element and Z - Y never 0.  G scalars per lane share one inversion.
+template <class C, class TAB, int G, class LOAD>
+MA_DEV void x25519_base_many(LOAD load, uint64_t (*ow)[4]) {
+    using F = Fe26;
+    uint32_t num[G][10], den[G][10], pre[G][10];
+    typename Ed26<C>::Ext R;
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        uint64_t kw[4];
+        load(g, kw);
+        kw[0] &= ~7ull;                                     // clamp (rfc7748.c:135-141)
+        kw[3] = (kw[3] & 0x7fffffffffffffffull) | 0x4000000000000000ull;
+        ed25519_mulgen_acc<C, TAB>(kw, R);
+        static_for<0, G>([&](auto GI) {                     // (static register indices only)
+            if (g == GI) { F::add(R.Z, R.Y, num[GI]); F::sub(R.Z, R.Y, den[GI]); }      // 1.0, 1.5
+        });
+    }
+    F::copy(den[0], pre[0]);
+    static_for<1, G>([&](auto GI) { F::mul(pre[GI - 1], den[GI], pre[GI]); });
+    uint32_t inv[10], t[10], u[10];
+    F::invert(pre[G - 1], inv);
+    static_for<0, G>([&](auto GI) {
+        constexpr int g = G - 1 - GI;
+        if constexpr (g > 0) {
+            F::mul(inv, pre[g - 1], t);
+            F::mul(inv, den[g], inv);
+        } else {
+            F::copy(inv, t);
+        }
+        F::mul(num[g], t, u);
+        F::to_words(u, ow[g]);
+    });
+}
+
 }  // namespace ma

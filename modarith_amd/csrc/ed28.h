@@ -524,4 +524,25 @@ MA_DEV void ed448_mulgen2_get_one(const uint64_t* ew, const uint64_t* fw, const 
     F::to_words(ay, yw);
 }
 
+// rfc7748() on the BASE POINT u = 5 of X448 (public-key generation, rfc7748.c:297-333).  ED448 (x^2 + y^2 = 1 - 39081 x^2 y^2) is
+// 4-isogenous to curve448 with (u, v) = (y^2 / x^2, ...) (RFC 7748 section 4.2), and its generator maps to u = 5: the isogeny is
+// a group homomorphism, so [k](5) = Y^2 / X^2 of k*G, k*G from the fixed-base table (ed448_mulgen_acc).  k clamped as
+// rfc7748.c:135-141; k = 4q gives the neutral element, X = 0, and 0^(p-2) = 0 makes the result 0 as the ladder's.
+template <class TAB>
+MA_DEV void x448_base_one(const uint64_t* kw_in, uint64_t* ow) {
+    using F = Fe28;
+    uint64_t kw[7];
+    static_for<0, 7>([&](auto K) { kw[K] = kw_in[K]; });
+    kw[0] &= ~3ull;
+    kw[6] |= 0x8000000000000000ull;
+    Ed28::Ext R;
+    ed448_mulgen_acc<TAB>(kw, R);
+    uint32_t x2[16], y2[16], xi[16], u[16];
+    F::sqr_k(R.X, x2);
+    F::sqr_k(R.Y, y2);
+    F::invert(x2, xi);
+    F::mul_k(y2, xi, u);
+    F::to_words(u, ow);
+}
+
 }  // namespace ma

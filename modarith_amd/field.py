@@ -315,3 +315,22 @@ def rfc7748(curve: str, bk: torch.Tensor, bu: torch.Tensor, out: Optional[torch.
     with torch.cuda.device(bu.device):
         _lib.check(f(bk.data_ptr(), bu.data_ptr(), out.data_ptr(), bk.shape[0], torch.cuda.current_stream().cuda_stream), "rfc7748_%s_batch" % curve)
     return out
+
+
+def rfc7748_base(curve: str, bk: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Batched `rfc7748(bk, base, bv)` (public-key generation, reference rfc7748.c:297-333): the same bytes as
+    rfc7748(curve, bk, bu = base point u = 9 / 5), computed from a fixed-base table on the equivalent Edwards curve."""
+    if curve not in _lib.LADDERS:
+        raise ValueError("curve must be one of %s" % (_lib.LADDERS,))
+    lib = _lib.load()
+    nb = 32 if curve == "X25519" else 56
+    if bk.dtype != torch.uint8 or bk.dim() != 2 or bk.shape[1] != nb or not bk.is_contiguous() or not bk.is_cuda:
+        raise ValueError("expected a contiguous uint8 device tensor [n, %d]" % nb)
+    if out is None:
+        out = torch.empty_like(bk)
+    elif (out.dtype != torch.uint8 or out.shape != bk.shape or not out.is_contiguous() or out.device != bk.device):
+        raise ValueError("out must be a contiguous uint8 tensor of shape %s on %s" % (tuple(bk.shape), bk.device))
+    f = getattr(lib, "rfc7748_%s_base_batch" % curve)
+    with torch.cuda.device(bk.device):
+        _lib.check(f(bk.data_ptr(), out.data_ptr(), bk.shape[0], torch.cuda.current_stream().cuda_stream), "rfc7748_%s_base_batch" % curve)
+    return out

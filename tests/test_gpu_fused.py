@@ -351,3 +351,32 @@ def test_fused_verification_form(oracle, name):
         ox, oy = ctypes.create_string_buffer(onb), ctypes.create_string_buffer(onb)
         oracle.ecn(C, "get")(ctypes.byref(r), ox, oy)
         assert bytes(hx[j]) == ox.raw and bytes(hy[j]) == oy.raw, j
+
+
+@pytest.mark.parametrize("curve", ["X25519", "X448"])
+def test_rfc7748_on_the_base_point(oracle, curve):
+    """rfc7748(k, base) from the fixed-base table of the equivalent Edwards curve: against the ladder kernel with u = 9 / 5 on
+    2^18 + 77 random private keys and corner keys (zeros, ones, 0x88.., 0x77.., 4q for X448), and the oracle on a sample"""
+    import torch
+    from modarith_amd.field import rfc7748, rfc7748_base
+    nb = 32 if curve == "X25519" else 56
+    n = (1 << 18) + 77
+    gen = torch.Generator(device="cuda").manual_seed(97)
+    k = torch.randint(0, 256, (n, nb), dtype=torch.uint8, device="cuda", generator=gen)
+    k[0] = 0
+    k[1] = 255
+    k[2] = 0x88
+    k[3] = 0x77
+    if curve == "X448":
+        q4 = 0xfffffffffffffffffffffffffffffffffffffffffffffffffffffffdf3288fa7113b6d26bb58da4085b309ca37163d548de30a4aad6113cc
+        k[4] = torch.tensor(list(q4.to_bytes(56, "little")), dtype=torch.uint8, device="cuda")
+    u = torch.zeros((n, nb), dtype=torch.uint8, device="cuda")
+    u[:, 0] = 9 if curve == "X25519" else 5
+    want = rfc7748(curve, k, u)
+    got = rfc7748_base(curve, k)
+    assert torch.equal(got, want)
+    if curve == "X448":
+        assert int(got[4].sum()) == 0                       # 4q * base = the point at infinity -> 0, as the ladder gives
+    hk, hg, hu = k.cpu().numpy(), got.cpu().numpy(), bytes(u[0].cpu().numpy())
+    for j in list(range(8)) + list(range(8, n, 33331)):
+        assert bytes(hg[j]) == oracle.ladder(curve, bytes(hk[j]), hu), j

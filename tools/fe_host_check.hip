@@ -334,7 +334,7 @@ static int run_ed448_mul2(int n) {
 }
 
 template <int NW, class Fn, class Ref>
-static int run(const char* name, int n, Fn fn, Ref ref) {
+static int run(const char* name, int n, Fn fn, Ref ref, uint64_t fixed_u = 0) {
     int bad = 0;
     for (int it = 0; it < n; it++) {
         uint64_t k[NW], u[NW], got[NW], want[NW];
@@ -348,6 +348,16 @@ static int run(const char* name, int n, Fn fn, Ref ref) {
         if (it == 5) memset(k, 0, sizeof k);
         if (it == 6) memset(k, 0xff, sizeof k);
         if (it == 7) { memset(u, 0, sizeof u); u[0] = (NW == 4) ? 9 : 5; }
+        if (fixed_u) {                                       // base-point runs: u is the base point, more scalar corners
+            memset(u, 0, sizeof u);
+            u[0] = fixed_u;
+            if (it == 8 && NW == 7) {                        // 4q: the clamped scalar that reaches the neutral element of ED448 -> 0
+                const uint64_t q4[7] = {0x8de30a4aad6113ccull, 0x85b309ca37163d54ull, 0x113b6d26bb58da40ull, 0xfffffffdf3288fa7ull, ~0ull, ~0ull, ~0ull};
+                memcpy(k, q4, sizeof q4);
+            }
+            if (it == 9) { memset(k, 0x88, sizeof k); }
+            if (it == 10) { memset(k, 0x77, sizeof k); }
+        }
         fn(k, u, got);
         ref((const char*)k, (const char*)u, (char*)want);
         if (memcmp(got, want, sizeof got) != 0) {
@@ -566,6 +576,12 @@ int main(int argc, char** argv) {
     bad += run_ed448_mulgen2(n / 32 + 16);
     bad += run_nist256(n / 8 + 16);
     bad += run_nist256_mul2(n / 16 + 16);
+    bad += run<4>("x25519_base_many<4> (u = 9)", n, [](const uint64_t* k, const uint64_t*, uint64_t* o) {
+                      uint64_t ow[4][4];          // this scalar as element 1 of a group of four sharing the inversion
+                      ma::x25519_base_many<ma::C_ED25519, HostComb25519, 4>([&](int g, uint64_t* kw) { for (int i = 0; i < 4; i++) kw[i] = g == 1 ? k[i] : (0x0123456789abcdefull * (g + 1)) ^ k[(i + g) & 3]; }, ow);
+                      for (int i = 0; i < 4; i++) o[i] = ow[1][i];
+                  }, rfc7748_X25519, 9);
+    bad += run<7>("x448_base_one (u = 5)", n / 4 + 8, [](const uint64_t* k, const uint64_t*, uint64_t* o) { ma::x448_base_one<HostComb448>(k, o); }, rfc7748_X448, 5);
     bad += run_edgen<32, pt25519>("ed25519_mulgen_get_one", n / 4 + 80, [](const uint64_t* e, uint64_t* x, uint64_t* y) { ma::ed25519_mulgen_get_one<ma::C_ED25519, HostComb25519>(e, x, y); },
                                   ecn_ed25519_gen, ecn_ed25519_mul, ecn_ed25519_get);
     bad += run_edgen<32, pt25519>("ed25519_mulgen_get_many<4>", n / 4 + 80, [](const uint64_t* e, uint64_t* x, uint64_t* y) {
