@@ -17,27 +17,52 @@ struct CombED448 {
     static __device__ __forceinline__ int32_t get(int idx) { return comb_ed448[idx]; }
 };
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
+// the first of the two results of a lane waits here (48 words per lane, [word][lane]: conflict-free) while the second scalar runs
+struct LdsPark {
+    uint32_t* base;
+    __device__ __forceinline__ void put(int k, uint32_t v) { base[k * 64] = v; }
+    __device__ __forceinline__ uint32_t get(int k) const { return base[k * 64]; }
+};
+
+// two scalars per lane (elements t and t + lanes of a 2 * lanes stride) share one inversion
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_ed448_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned char* yb, int* sign, size_t n) {
     using P = P_X448;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        spint ew[7], xw[7], yw[7];
-        load_be_record<P>(e, t, ew);
-        ed448_mulgen_get_one<CombED448>(ew, xw, yw);
-        if (xb) store_be_record<P>(xb, t, xw);
-        if (yb) store_be_record<P>(yb, t, yw);
-        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+    __shared__ uint32_t lds[48 * 64];
+    LdsPark park{lds + threadIdx.x};
+    const size_t lanes = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += 2 * lanes) {
+        spint xw[2][7], yw[2][7];
+        ed448_mulgen_get_two<CombED448>(
+            [&](int g, spint* ew) { const size_t tg = t + (size_t)g * lanes; load_be_record<P>(e, tg < n ? tg : t, ew); }, park, xw, yw);
+        static_for<0, 2>([&](auto GI) {
+            const size_t tg = t + (size_t)GI * lanes;
+            if (tg < n) {
+                if (xb) store_be_record<P>(xb, tg, xw[GI]);
+                if (yb) store_be_record<P>(yb, tg, yw[GI]);
+                if (sign) sign[tg] = !yb ? (int)(yw[GI][0] & 1) : (!xb ? (int)(xw[GI][0] & 1) : 0);
+            }
+        });
     }
 }
 
 // rfc7748() on the base point u = 5 (x448_base_one): little-endian 56-byte records as rfc7748_X448_batch takes them
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_x448_base(const uint64_t* bk, uint64_t* bv, size_t n) {
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        uint64_t kw[7], ow[7];
-        static_for<0, 7>([&](auto K) { kw[K] = bk[t * 7 + K]; });
-        x448_base_one<CombED448>(kw, ow);
-        static_for<0, 7>([&](auto K) { bv[t * 7 + K] = ow[K]; });
+    __shared__ uint32_t lds[48 * 64];
+    LdsPark park{lds + threadIdx.x};
+    const size_t lanes = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += 2 * lanes) {
+        uint64_t ow[2][7];
+        x448_base_two<CombED448>(
+            [&](int g, uint64_t* kw) {
+                const size_t tg = t + (size_t)g * lanes, ts = tg < n ? tg : t;
+                static_for<0, 7>([&](auto K) { kw[K] = bk[ts * 7 + K]; });
+            }, park, ow);
+        static_for<0, 2>([&](auto GI) {
+            const size_t tg = t + (size_t)GI * lanes;
+            if (tg < n) static_for<0, 7>([&](auto K) { bv[tg * 7 + K] = ow[GI][K]; });
+        });
     }
 }
 
@@ -103,7 +128,7 @@ extern "C" int ecn_ed448_mulgen_get_batch(const char* e, char* x, char* y, int* 
         set_error("ecn mulgen_get: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
     }
-    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)4 * 1024 * 64;       // at most 4 waves on each of the 1024 SIMDs
+    const size_t lanes = ((n + 1) / 2 + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;       // two scalars per lane; two waves on each of the 1024 SIMDs
     k_ed448_mulgen_get<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(
         reinterpret_cast<const unsigned char*>(e), reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n);
     return check_launch("ecn mulgen_get");
@@ -116,7 +141,7 @@ extern "C" int rfc7748_X448_base_batch(const char* bk, char* bv, size_t n, void*
         set_error("rfc7748 base: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
     }
-    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)4 * 1024 * 64;
+    const size_t lanes = ((n + 1) / 2 + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
     k_x448_base<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(
         reinterpret_cast<const uint64_t*>(bk), reinterpret_cast<uint64_t*>(bv), n);
     return check_launch("rfc7748 base");
