@@ -7,7 +7,8 @@
   soak.py curves  2^13 .. 2^16 random scalars x random points for each of the eleven curves, fused ecn mul on the GPU against the CPU oracle,
                   projective limbs compared
   soak.py fused   2^18 .. 2^20 random (scalar, projective point) pairs per fused curve (ED25519, ED448, NIST256, SECP256K1): mul_get against mul + get and
-                  mul2_get against mul2 + get (the two-call forms are the ones `soak.py curves` pins to the oracle), bytes compared
+                  mul2_get against mul2 + get (the two-call forms are the ones `soak.py curves` pins to the oracle), the generator forms mulgen_get / mulgen2_get against
+                  those, rfc7748 on the base point against the ladder; bytes compared
 """
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -125,8 +126,26 @@ def fused():
         x, y, _ = C.mul2_get(em, Pm, fm, Q)
         wx, wy, _ = C.get(C.mul2(em, Pm, fm, Q))
         ok2 = bool(torch.equal(x, wx) and torch.equal(y, wy))
-        print("fused soak %-8s mul_get 2^%d: %s   mul2_get 2^%d: %s" % (name, lg, "EQUAL" if ok else "MISMATCH", lg - 2, "EQUAL" if ok2 else "MISMATCH"), flush=True)
-        rc |= 0 if (ok and ok2) else 1
+        # generator forms against the general fused kernels on the generator (those are pinned to the two-call forms above)
+        x, y, _ = C.mulgen_get(e)
+        gx, gy, _ = C.mul_get(e, C.gen(n))
+        ok3 = bool(torch.equal(x, gx) and torch.equal(y, gy))
+        x, y, _ = C.mulgen2_get(em, fm, Q)
+        gx, gy, _ = C.mul2_get(em, C.gen(m), fm, Q)
+        ok4 = bool(torch.equal(x, gx) and torch.equal(y, gy))
+        print("fused soak %-8s mul_get 2^%d: %s   mul2_get 2^%d: %s   mulgen_get 2^%d: %s   mulgen2_get 2^%d: %s" % (
+            name, lg, "EQUAL" if ok else "MISMATCH", lg - 2, "EQUAL" if ok2 else "MISMATCH", lg, "EQUAL" if ok3 else "MISMATCH",
+            lg - 2, "EQUAL" if ok4 else "MISMATCH"), flush=True)
+        rc |= 0 if (ok and ok2 and ok3 and ok4) else 1
+    from modarith_amd.field import rfc7748, rfc7748_base
+    for curve, nb, lg in (("X25519", 32, 21), ("X448", 56, 19)):
+        n = 1 << lg
+        g = torch.Generator(device="cuda").manual_seed(79)
+        k = torch.randint(0, 256, (n, nb), dtype=torch.uint8, device="cuda", generator=g)
+        u = torch.zeros((n, nb), dtype=torch.uint8, device="cuda"); u[:, 0] = 9 if curve == "X25519" else 5
+        ok = bool(torch.equal(rfc7748_base(curve, k), rfc7748(curve, k, u)))
+        print("fused soak %-8s rfc7748 on the base point 2^%d, fixed-base kernel vs ladder: %s" % (curve, lg, "EQUAL" if ok else "MISMATCH"), flush=True)
+        rc |= 0 if ok else 1
     return rc
 
 
