@@ -1,6 +1,7 @@
 /* examples/ecn_batch.c -- the reference's curve API (curve.h:13-29) against libmodarith_amd.so, scalar and batched, on
  * secp256k1: the check of testcurve.c:224-237 (order*G = O; r1*G + r2*G = O through ecnXXXmul2) with the reference's
- * own function names, then n public keys k_j*G in ONE batched launch, compared with the scalar path.
+ * own function names, then n public keys k_j*G in ONE batched launch, compared with the scalar path, then the fused forms of the
+ * key-generation / verification call sequences against those.
  * Plain C, no HIP headers.
  *
  *   gcc -O2 examples/ecn_batch.c -Iinclude -Lmodarith_amd -l:libmodarith_amd.so \
@@ -79,8 +80,45 @@ int main(int argc, char **argv) {
         equal &= memcmp(x, hx + j * Nbytes, Nbytes) == 0;
     }
     printf("public key 0 x\n"); print_hex(hx);
+
+    /* the same call sequences fused into one kernel each (byte-identical results):
+     *   ecnXXXgen + ecnXXXmul + ecnXXXget            -> ecn_secp256k1_mulgen_get_batch   (key generation / signing)
+     *   ecnXXXmul + ecnXXXget on a given point       -> ecn_secp256k1_mul_get_batch
+     *   ecnXXXgen + ecnXXXmul2(e, G, f, Q) + ecnXXXget -> ecn_secp256k1_mulgen2_get_batch  (verification)                */
+    char *hf = malloc(n * Nbytes);
+    int fused = 1;
+    void *dx2, *dy2, *dQ, *ws2;
+    CHECK(modarith_amd_malloc(&dx2, n * Nbytes));
+    CHECK(modarith_amd_malloc(&dy2, n * Nbytes));
+    CHECK(modarith_amd_malloc(&dQ, 3 * Nlimbs * n * sizeof(ma_spint)));
+    CHECK(ecn_secp256k1_mulgen_get_batch((const char *)de, (char *)dx2, NULL, NULL, n, NULL));
+    CHECK(modarith_amd_memcpy_d2h(hf, dx2, n * Nbytes, NULL));
+    CHECK(modarith_amd_sync(NULL));
+    fused &= memcmp(hf, hx, n * Nbytes) == 0;
+    size_t wsb2 = ecn_secp256k1_mul_get_workspace_bytes(n), wsb3 = ecn_secp256k1_mulgen2_get_workspace_bytes(n);
+    CHECK(modarith_amd_malloc(&ws2, wsb2 > wsb3 ? wsb2 : wsb3));
+    CHECK(ecn_secp256k1_gen_batch((ma_spint *)dQ, n, n, NULL));
+    CHECK(ecn_secp256k1_mul_get_batch((const char *)de, (const ma_spint *)dQ, (char *)dx2, (char *)dy2, NULL, n, n, ws2, wsb2, NULL));
+    CHECK(modarith_amd_memcpy_d2h(hf, dx2, n * Nbytes, NULL));
+    CHECK(modarith_amd_sync(NULL));
+    fused &= memcmp(hf, hx, n * Nbytes) == 0;
+    /* verification shape: e*G + e*Q with Q = e*G left in dP by the batched mul above (projective, not normalised) */
+    CHECK(ecn_secp256k1_mulgen2_get_batch((const char *)de, (const char *)de, (const ma_spint *)dP, (char *)dx2, NULL, NULL, n, n, ws2, wsb3, NULL));
+    CHECK(modarith_amd_memcpy_d2h(hf, dx2, n * Nbytes, NULL));
+    CHECK(modarith_amd_sync(NULL));
+    for (size_t j = 0; j < n; j += (n > 4 ? n / 4 : 1)) {
+        point A, B, R;
+        ecnXXXgen(&A);
+        ecnXXXgen(&B);
+        ecnXXXmul(he + j * Nbytes, &B);
+        ecnXXXmul2(he + j * Nbytes, &A, he + j * Nbytes, &B, &R);
+        ecnXXXget(&R, x, NULL);
+        fused &= memcmp(x, hf + j * Nbytes, Nbytes) == 0;
+    }
+    printf("fused == call sequences: %s\n", fused ? "equal" : "DIFFERENT");
     printf("batched == scalar: %s\n", equal ? "equal" : "DIFFERENT");
     modarith_amd_free(dP); modarith_amd_free(de); modarith_amd_free(dx); modarith_amd_free(ws);
-    free(he); free(hx);
-    return equal ? 0 : 1;
+    modarith_amd_free(dx2); modarith_amd_free(dy2); modarith_amd_free(dQ); modarith_amd_free(ws2);
+    free(he); free(hx); free(hf);
+    return (equal && fused) ? 0 : 1;
 }

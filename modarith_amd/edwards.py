@@ -19,7 +19,9 @@ def _stream(device=None) -> int:
 
 
 class Edwards:
-    """Batched curve API; despite the name it serves every built curve of the reference's curve layer:
+    """Batched curve API (one object per stream: the window-table workspaces it allocates for `mul`, `mul_get`, ... are reused by the
+    next call, so two host threads / streams driving the SAME object concurrently would share them; the C-ABI takes the workspace
+    explicitly).  Despite the name it serves every built curve of the reference's curve layer:
     Edwards ("ED25519", "ED448", "NUMS256E", "ED248", "ED376", "ED500") and short Weierstrass ("NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W").  `Curve` is an alias."""
 
     def __init__(self, curve: str, device: Optional[torch.device] = None):

@@ -145,4 +145,4 @@ def test_c_curve_api_example(tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     assert out[1] == "79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798"
     assert out[2].endswith("yes") and out[3].endswith("yes")
-    assert out[-1] == "batched == scalar: equal"
+    assert out[-1] == "batched == scalar: equal" and out[-2] == "fused == call sequences: equal"
