@@ -73,10 +73,29 @@ template <class P> struct OpSubLazy { static MA_DEV void apply(const spint* a, c
 // modmul / modsqr with a wave-uniform choice of product policy: the split products (Field<P,true>, fewer VALU
 // instructions) when every active lane's operands are inside their limb contract (< 2^(Radix+2), field.h), the exact
 // 128-bit products otherwise -- identical results either way, for every input
+// (radix 62 and up: 2^(Radix+2) does not fit a word, every 64-bit limb is below it -- the predicate is vacuously true,
+// and a shift by 64 would be undefined)
 template <class P> MA_DEV bool in_split_contract(const spint* a) {
-    spint m = 0;
-    static_for<0, P::N>([&](auto I) { m |= a[I]; });
-    return (m >> (P::RADIX + 2)) == 0;
+    if constexpr (P::RADIX + 2 >= 64) {
+        return true;
+    } else {
+        spint m = 0;
+        static_for<0, P::N>([&](auto I) { m |= a[I]; });
+        return (m >> (P::RADIX + 2)) == 0;
+    }
+}
+// the budget modlimbs / Curve.limbs_ok report: 2^(Radix+2) as above, except for the 5 x 52-bit pseudo-Mersenne primes whose curve
+// kernels run the folded half-limb products (field.h FOLD52, 2^256-189): there the reference itself wraps mm * a_k at 64
+// bits, and the two product forms agree only for limbs up to (2^64-1)/mm (2^52.4) -- which every field-function output keeps
+template <class P> MA_DEV bool in_limb_budget(const spint* a) {
+    constexpr bool fold52 = !P::MONTGOMERY && P::EPM && !P::OVERFLOW && P::RADIX == 52 && P::N == 5 && P::MM < (1ull << 16) && P::SPLIT == 0;
+    if constexpr (fold52) {
+        bool ok = true;
+        static_for<0, P::N>([&](auto I) { ok = ok && a[I] <= ~(spint)0 / (spint)P::MM; });
+        return ok;
+    } else {
+        return in_split_contract<P>(a);
+    }
 }
 template <class P> struct OpMulAuto {
     static MA_DEV void apply(const spint* a, const spint* b, spint* c) {
@@ -182,16 +201,28 @@ __global__ __launch_bounds__(BLOCK) void k_unary(const spint* a, spint* c, size_
     }
 }
 
-// shared multiplicand: c[j] = a[j] * b0, b0 passed by value (lands in SGPRs, broadcast to all lanes)
+// shared multiplicand: c[j] = a[j] * b0, b0 passed by value (lands in SGPRs, broadcast to all lanes).
+// AUTO: the per-wave product policy of OpMulAuto with the vote on a[] only -- the host has already checked b0 against
+// the limb contract (capi_prime.inc modmuls), and everything the split / half-limb products derive from b0 alone (its halves,
+// mm * half, the prepared Opd pairs) is wave-uniform: the compiler keeps it in SGPRs, computed once per kernel in
+// scalar ALU, and every multiply-add reads ONE scalar and one vector source (the VOP3 constant-bus limit), so no
+// v_mov / s_nop copies surround the products as they do around the exact 64 x 64 -> 128 ones.  Same limbs either way.
 template <class P> struct Elem { spint l[P::N]; };
-template <class P, int EPT>
+template <class P, int EPT, bool AUTO>
 __global__ __launch_bounds__(BLOCK) void k_mul_shared(const spint* a, Elem<P> b0, spint* c,
                                                       size_t nthreads, size_t lda, size_t ldc) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
         spint x[EPT][P::N], z[EPT][P::N];
         load_soa<P, EPT>(a, lda, t, x);
 #pragma unroll
-        for (int e = 0; e < EPT; e++) Field<P>::modmul(x[e], b0.l, z[e]);
+        for (int e = 0; e < EPT; e++) {
+            // one element at a time, each with its own vote (as OpMulAuto): voting once for both elements lets the scheduler
+            // interleave two products and takes 136 VGPRs instead of 64
+            if constexpr (AUTO && P::SPLIT > 0) {
+                if (__all(in_split_contract<P>(x[e]))) { Field<P, true>::modmul(x[e], b0.l, z[e]); continue; }
+            }
+            Field<P, false>::modmul(x[e], b0.l, z[e]);
+        }
         store_soa<P, EPT>(c, ldc, t, z);
     }
 }
@@ -289,7 +320,7 @@ __global__ __launch_bounds__(BLOCK) void k_inplace(spint* a, int* out, size_t n,
         if constexpr (KIND == K_MODIS1) r = Field<P>::modis1(x[0]);
         if constexpr (KIND == K_MODIS0) r = Field<P>::modis0(x[0]);
         if constexpr (KIND == K_MODSIGN) r = Field<P>::modsign(x[0]);
-        if constexpr (KIND == K_MODLIMBS) r = in_split_contract<P>(x[0]) ? 1 : 0;   // every limb < 2^(Radix+2)
+        if constexpr (KIND == K_MODLIMBS) r = in_limb_budget<P>(x[0]) ? 1 : 0;      // every limb < 2^(Radix+2) (FOLD52 primes: <= (2^64-1)/mm)
         if constexpr (KIND == K_MODHAF) { Field<P>::modhaf(x[0]); wr = true; }
         if constexpr (KIND == K_MODQR) {
             bool fast = false;

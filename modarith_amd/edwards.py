@@ -30,7 +30,8 @@ class Edwards:
             raise ValueError("curve %r is not built; available: %s" % (curve, ", ".join(_lib.CURVES)))
         self.lib = _lib.load()
         self.N, self.nbytes = _lib.CURVES[self.name]
-        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        from .field import normalise_device
+        self.device = normalise_device(device)
         self._ws = None
         self._fws = None          # window tables of the fused mul_get kernels (ED448, NIST256)
 

@@ -24,6 +24,21 @@ def _stream(device=None) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def normalise_device(device, current=None) -> torch.device:
+    """the device an object is bound to, always WITH an index: None, "cuda", torch.device("cuda") and a bare integer all
+    resolve to the calling thread's current device (torch.device("cuda") != torch.device("cuda:0"), so an index-less form
+    stored verbatim would reject every tensor, including the ones the object allocates itself).  `current` overrides
+    torch.cuda.current_device (CPU-side unit test)."""
+    if isinstance(device, int):
+        return torch.device("cuda", device)
+    dev = torch.device(device) if device is not None else torch.device("cuda")
+    if dev.type != "cuda":
+        raise ValueError("modarith_amd objects are bound to a GPU (got device %r): there is no CPU path" % (device,))
+    if dev.index is None:
+        dev = torch.device("cuda", (current or torch.cuda.current_device)())
+    return dev
+
+
 class Field:
     """Batched field arithmetic for one of the built primes (X25519, NIST256, X448)."""
 
@@ -36,7 +51,7 @@ class Field:
         self.N = self.params.nlimbs
         self.radix = self.params.radix
         self.nbytes = self.params.nbytes
-        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.device = normalise_device(device)
 
     # ------------------------------------------------------------------ buffers
     def empty(self, n: int) -> torch.Tensor:

@@ -85,3 +85,18 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip", ".inc")):
                 text = open(os.path.join(root, f)).read()
                 assert "liboracle" not in text and "oracle_binding" not in text and "from tests" not in text, f
+
+
+def test_device_is_normalised_to_an_indexed_form():
+    """Field(p, "cuda") / Curve(name, torch.device("cuda")) must bind to the CURRENT device with its index:
+    torch.device("cuda") != torch.device("cuda:0"), so the index-less form stored verbatim rejected every tensor."""
+    import torch
+    from modarith_amd.field import normalise_device
+    cur = lambda: 3
+    for d in (None, "cuda", torch.device("cuda")):
+        assert normalise_device(d, current=cur) == torch.device("cuda:3")
+    assert normalise_device("cuda:1", current=cur) == torch.device("cuda:1")
+    assert normalise_device(torch.device("cuda", 5), current=cur) == torch.device("cuda:5")
+    assert normalise_device(2, current=cur) == torch.device("cuda:2")
+    with pytest.raises(ValueError):
+        normalise_device("cpu", current=cur)

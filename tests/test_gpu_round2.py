@@ -131,6 +131,15 @@ def test_mixed_waves_vs_oracle(oracle, torch_cuda, P):
     assert np.array_equal(to_np(F.modsqr(A)), oracle_un(oracle, "modsqr", P, a)), "modsqr"
     assert np.array_equal(to_np(F.nres(A)), oracle_un(oracle, "nres", P, a)), "nres"
     assert np.array_equal(to_np(F.redc(A)), oracle_un(oracle, "redc", P, a)), "redc"
+    # shared multiplicand (k_mul_shared: the vote is on a[] alone, b0 is checked on the host): an in-contract b0 from a clean
+    # lane (split products in the clean waves, exact ones in the others) and an out-of-contract b0 (exact everywhere)
+    for j in (int(np.nonzero(~bad_b)[0][7]), int(np.nonzero(bad_b)[0][3])):
+        b0 = [int(v) for v in np.roll(b, -13, axis=1)[:, j]]
+        bb = np.ascontiguousarray(np.repeat(np.array(b0, dtype=np.uint64)[:, None], n, axis=1))
+        assert np.array_equal(to_np(F.modmuls(A, b0)), oracle_bin(oracle, "modmul", P, a, bb)), "modmuls (b0 from lane %d)" % j
+        got = torch_cuda.empty_like(A)
+        F.modmuls(A[:, 1:], b0, out=got[:, 1:])
+        assert np.array_equal(to_np(got)[:, 1:], oracle_bin(oracle, "modmul", P, a, bb)[:, 1:]), "modmuls (unaligned)"
     # unaligned view (8-byte-per-lane kernels) takes the same vote
     out = torch_cuda.empty_like(A)
     F.modmul(A[:, 1:], B[:, 1:], out=out[:, 1:])
@@ -161,6 +170,10 @@ def test_contract_edge_classes_vs_oracle(oracle, torch_cuda, P):
     assert np.array_equal(to_np(F.modsqr(A)), oracle_un(oracle, "modsqr", P, a)), "modsqr"
     assert np.array_equal(to_np(F.nres(A)), oracle_un(oracle, "nres", P, a)), "nres"
     assert np.array_equal(to_np(F.redc(A)), oracle_un(oracle, "redc", P, a)), "redc"
+    for j in range(6):                                                 # shared multiplicand: each edge class as the common operand
+        b0 = [int(v) for v in b[:, j]]
+        bb = np.ascontiguousarray(np.repeat(b[:, j:j + 1], n, axis=1))
+        assert np.array_equal(to_np(F.modmuls(A, b0)), oracle_bin(oracle, "modmul", P, a, bb)), "modmuls class %d" % j
 
 
 @pytest.mark.parametrize("P", CORE + ["NIST521", "GM384", "NIST224", "ED25519Q"])
@@ -338,3 +351,18 @@ def test_curve_mul_rate_floor(torch_cuda, name):
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
     assert n / best >= RATE_FLOORS[name], "%s ecn mul %.3g/s, floor %.3g/s" % (name, n / best, RATE_FLOORS[name])
+
+
+def test_index_less_device_forms(torch_cuda):
+    """Field(p, "cuda") and Curve(name, torch.device("cuda")) bind to the current device and accept their own tensors"""
+    torch = torch_cuda
+    from modarith_amd.edwards import Curve
+    from modarith_amd.field import Field
+    for d in ("cuda", torch.device("cuda"), None, 0):
+        F = Field("X25519", d)
+        assert F.device == torch.device("cuda", torch.cuda.current_device())
+        a = F.uniform(100, seed=1)
+        assert torch.equal(F.modmul(a, a), F.modsqr(a))
+        C = Curve("ED25519", d)
+        G = C.gen(8)
+        assert bool(C.limbs_ok(C.dbl(G)).all())
