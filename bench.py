@@ -62,6 +62,43 @@ def _native_baseline_lib():
     return lib, cc, flags, built
 
 
+# the reference's time.c operands (seed 42) and check words per field: SURVEY 8(c), tests/golden/field_<P>.json "time"
+TIME_C = {
+    "X25519": (51, 5, ("11dc60f4392456de3eb13b9046685257bdd640fb06671ad11c80317fa3b1799d", "4b95423416419f828b9d2434e465e150bd9c66b3ad3c2d6d1a3d1fa7bc8960a9",
+                       "4d0ef322815ef6d13b8faa1837f8a88b17fc695a07a0ca6e0822e8f36c031199", "35b2d3528b8148f6b38a088ca65ed389b74d0fb132e706298fadc1a606cb0fb3"),
+               (0x116640, 0x675a88, 0xe70a06)),
+    "NIST256": (52, 5, ("23b8c1e9392456de3eb13b9046685257bdd640fb06671ad11c80317fa3b1799d", "972a846916419f828b9d2434e465e150bd9c66b3ad3c2d6d1a3d1fa7bc8960a9",
+                        "9a1de644815ef6d13b8faa1837f8a88b17fc695a07a0ca6e0822e8f36c031199", "6b65a6a48b8148f6b38a088ca65ed389b74d0fb132e706298fadc1a606cb0fb3"),
+                (0xa47501, 0x717a99, 0xe1e067)),
+    "X448": (56, 8, ("8b9d2434e465e150bd9c66b3ad3c2d6d1a3d1fa7bc8960a923b8c1e9392456de3eb13b9046685257bdd640fb06671ad11c80317fa3b1799d",
+                     "b74d0fb132e706298fadc1a606cb0fb39a1de644815ef6d13b8faa1837f8a88b17fc695a07a0ca6e0822e8f36c031199972a846916419f82",
+                     "28df6ec4ce4a2bbdc241330b01a9e71fde8a774bcf36d58b4737819096da1dac72ff5d2a386ecbe06b65a6a48b8148f6b38a088ca65ed389",
+                     "5be6128e18c267976142ea7d17be31111a2a73ed562b0f79c37459eef50bea63371ecd7b27cd813047229389571aa8766c307511b2b9437a"),
+             (0xbcdde4, 0xa8450d, 0x189f52)),
+}
+
+
+def time_c_protocol(lib, P):
+    """the three legs of the reference's time.c for field P on ONE host core, full depth; every check word is asserted"""
+    radix, nl, ops, want = TIME_C[P]
+    U = ctypes.c_uint64 * nl
+    mk = lambda h: U(*[(int(h, 16) >> (radix * i)) & ((1 << radix) - 1) for i in range(nl)])      # makebig, pseudo.py:190-199
+    fm, fs, fi = getattr(lib, "time_modmul_" + P), getattr(lib, "time_modsqr_" + P), getattr(lib, "time_modinv_" + P)
+    fm.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_long]
+    fs.argtypes = fi.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_long]
+    fm.restype = fs.restype = fi.restype = ctypes.c_uint
+    out = {}
+    for leg, call, nops, ref in (("modmul", lambda: fm(mk(ops[0]), mk(ops[1]), 100000), 10**8, want[0]),
+                                 ("modsqr", lambda: fs(mk(ops[2]), 100000), 10**8, want[1]),
+                                 ("modinv", lambda: fi(mk(ops[3]), 50000), 10**5, want[2])):
+        t0 = time.perf_counter()
+        w = call()
+        dt = time.perf_counter() - t0
+        assert w == ref, "time.c %s %s check word %#x, the reference's is %#x" % (P, leg, w, ref)
+        out[leg] = {"ns_per_op": dt / nops * 1e9, "ops": nops, "check_word": "0x%06x" % w, "reference_check_word": "0x%06x" % ref}
+    return out
+
+
 def cpu_baseline(a_host, b_host, min_seconds=6.0):
     """oracle (kind "port": CPU restatement of the reference's generated field.c, limb-exact against the
     reference's golden vectors) timed on the host cores: all-core modmul throughput over the same
@@ -84,17 +121,17 @@ def cpu_baseline(a_host, b_host, min_seconds=6.0):
             break
     thr = passes * n / dt
     del c
-    # reference-faithful latency: the full time.c protocol, 10^8 dependent modmuls on one core
-    # (pseudo.py:1235-1250); the check word must be the reference's 0x116640
-    U = ctypes.c_uint64 * 5
-    mk = lambda v: U(*[(v >> (51 * i)) & ((1 << 51) - 1) for i in range(5)])
-    ra = 0x11dc60f4392456de3eb13b9046685257bdd640fb06671ad11c80317fa3b1799d
-    rb = 0x4b95423416419f828b9d2434e465e150bd9c66b3ad3c2d6d1a3d1fa7bc8960a9
-    x, y = mk(ra), mk(rb)
-    t0 = time.perf_counter()
-    chk = lib.time_modmul_X25519(x, y, 100000)
-    lat = (time.perf_counter() - t0) / 1e8
-    assert chk == 0x116640, "time.c check word mismatch: %#x" % chk
+    # reference-faithful latency: the full time.c protocol on one core -- all three legs, the reference's loop counts, its
+    # seed-42 operands (random.seed(42), four randint(0,p-1): pseudo.py:1862-1866) and its 24-bit check words:
+    # 10^8 dependent modmul (pseudo.py:1177-1253), 10^8 modsqr (1256-1322), 10^5 modinv (1324-1386)
+    time_c = time_c_protocol(lib, "X25519")
+    lat = time_c["modmul"]["ns_per_op"] * 1e-9
+    chk = int(time_c["modmul"]["check_word"], 16)
+    # the Montgomery fields of configs[2], configs[3] the same way, their nine legs spread over host threads (ctypes
+    # releases the GIL); X25519 above runs alone so that its figures are undisturbed
+    import concurrent.futures as cf
+    with cf.ThreadPoolExecutor(max_workers=2) as ex:
+        time_c_other = dict(zip(("NIST256", "X448"), ex.map(lambda P: time_c_protocol(lib, P), ("NIST256", "X448"))))
     # ladder on all cores, bounded sample
     rng = np.random.default_rng(7)
     m = 512 * cores
@@ -111,8 +148,9 @@ def cpu_baseline(a_host, b_host, min_seconds=6.0):
         "value": thr, "unit": "modmul/s", "cores": cores, "kind": "port",
         "sample": "oracle modmul_X25519 over the 2^%d-element workload (the GPU's own input arrays) x %d passes, %d threads, %.1f s wall" % (n.bit_length() - 1, passes, cores, dt),
         "compiler": cc, "flags": flags, "built": built,
-        "time_c_protocol": {"ns_per_modmul": lat * 1e9, "modmul_per_s": 1.0 / lat, "cores": 1, "dependent_modmuls": 10**8,
-                            "check_word": hex(chk), "reference_check_word": "0x116640"},
+        "time_c_protocol": dict(time_c, ns_per_modmul=lat * 1e9, modmul_per_s=1.0 / lat, cores=1, dependent_modmuls=10**8,
+                                check_word=hex(chk), reference_check_word="0x116640"),
+        "time_c_protocol_other_fields": time_c_other,
         "x25519_scalar_mults_per_s": m / ldt, "x25519_sample": "%d ladders, %d threads, %.1f s wall" % (m, cores, ldt),
         "x25519_one_thread_per_s": l1,
         "effective_parallelism": {"x25519": (m / ldt) / l1, "modmul": thr * lat,
@@ -172,6 +210,7 @@ def main():
     ap.add_argument("--no-ladder", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-others", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the per-rank spot check of the timed outputs against the CPU oracle")
     ap.add_argument("--launch-check", action="store_true",
                     help="only check the rank launch: gloo group over the N ranks, no GPU work (tests/test_bench_launch.py)")
     args = ap.parse_args()
@@ -219,6 +258,8 @@ def main():
         tt = torch.tensor(vals, dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return [float(v) for v in tt]
+
+    single = world == 1            # side figures (other data sets, other fields, the curve layer) are N=1 material only
 
     from modarith_amd.field import Field, rfc7748
     F = Field("X25519", dev)
@@ -276,6 +317,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps      # mean launch duration on the launch stream
+    my_dt, my_kern_ms = dt, kern_ms                   # this rank's own figures (reported per rank below)
     if use_dist:
         dt, kern_ms = max_over_ranks([dt, kern_ms])
     value = world * n * args.steps / dt
@@ -303,7 +345,7 @@ def main():
     # the previous pass's outputs fed back in (what time.c and the ladders do, pseudo.py:1235-1242)
     data_sets = {"uniform_mod_p": {"modmul_per_s_per_gpu": n / (kern_ms * 1e-3), "GBps": achieved, "kernel_ms": kern_ms,
                                    "recipe": "splitmix64(seed 42, array id, j), %d words, mod p; canonical limbs" % 5}}
-    if not args.no_others:
+    if not args.no_others and single:
         a2 = F.uniform(n, seed=SEED, array=AID + 0, plus_p=True)
         b2 = F.uniform(n, seed=SEED, array=AID + 1, plus_p=True)
         c2 = torch.empty_like(a2)
@@ -320,13 +362,19 @@ def main():
         # shared multiplicand c[j] = a[j]*b0 (80 B per element)
         b0 = [int(v) for v in b[:, 0].cpu().numpy().view("uint64")]
         ms = rate(lambda: F.modmuls(a, b0, out=fb))
-        data_sets["shared_multiplicand"] = {"modmul_per_s_per_gpu": n / (ms * 1e-3), "GBps": 80 * n / (ms * 1e-3) / 1e9, "kernel_ms": ms, "bytes_per_element": 80}
+        data_sets["shared_multiplicand"] = {"modmul_per_s_per_gpu": n / (ms * 1e-3), "GBps": 80 * n / (ms * 1e-3) / 1e9, "kernel_ms": ms, "bytes_per_element": 80,
+                                            "frac_of_hbm_peak": 80 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "k_mul_shared<P_X25519,2,true>"}
+        # streaming controls on the same buffers: the same three (two) streams with no multiplication
+        ms = rate(lambda: F.modadd(a, b, out=fb))
+        data_sets["control_modadd_3_streams"] = {"GBps": BYTES_PER_MODMUL * n / (ms * 1e-3) / 1e9, "kernel_ms": ms, "frac_of_hbm_peak": BYTES_PER_MODMUL * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        ms = rate(lambda: F.modcpy(a, out=fb))
+        data_sets["control_modcpy_2_streams"] = {"GBps": 80 * n / (ms * 1e-3) / 1e9, "kernel_ms": ms, "frac_of_hbm_peak": 80 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del c2, fb
 
     # the other single-GPU configs of BASELINE.json (configs[2], configs[3]) with the same protocol, short runs:
     # parity for them is in tests/; these are side figures, not the headline
     others = {}
-    if not args.no_others:
+    if not args.no_others and single:
         for P, ops in (("NIST256", ("modmul",)), ("X448", ("modmul", "modsqr"))):
             Fp = Field(P, dev)
             # uniform in [0,p) by the same recipe, then nres (Montgomery form)
@@ -350,10 +398,15 @@ def main():
             e = torch.randint(0, 256, (m, Cv.nbytes), dtype=torch.uint8, device=dev, generator=gen)
             f = torch.randint(0, 256, (m, Cv.nbytes), dtype=torch.uint8, device=dev, generator=gen)
             G = Cv.gen(m)
-            Pp = Cv.mul(e[:4096].contiguous(), Cv.gen(4096))          # warm-up (also loads the code objects)
+            # warm-up of EVERY function timed below on a small slice (loads the code objects, allocates the workspaces), so that
+            # the multi-call reference legs are not charged first-call costs the fused legs have already paid
+            Pp = Cv.mul(e[:4096].contiguous(), Cv.gen(4096))
+            Cv.get(Pp)
+            Cv.mul2(e[:4096].contiguous(), Cv.gen(4096), f[:4096].contiguous(), Pp)
             del Pp
+            Gc = G.clone()
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            Q = Cv.mul(e, G.clone())
+            Q = Cv.mul(e, Gc)
             torch.cuda.synchronize(); t1 = time.perf_counter()
             R = Cv.mul2(e, G, f, Q)
             torch.cuda.synchronize(); t2 = time.perf_counter()
@@ -362,18 +415,19 @@ def main():
             if cname in Cv.FUSED:
                 # the reference's call pattern ecnXXXmul + ecnXXXget (ed448.c:182-184): two-call form against the fused kernel
                 Cv.mul_get(e[:4096].contiguous(), Q[:, :, :4096].contiguous())
+                Qc = Q.clone()                                           # (outside the timed legs)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 fx_, fy_, _ = Cv.mul_get(e, Q)
                 torch.cuda.synchronize(); t1 = time.perf_counter()
-                W = Cv.mul(e, Q.clone())
-                torch.cuda.synchronize(); t2 = time.perf_counter()       # (the clone is inside: 60 MB, negligible)
+                W = Cv.mul(e, Qc)
+                torch.cuda.synchronize(); t2 = time.perf_counter()
                 wx_, wy_, _ = Cv.get(W)
                 torch.cuda.synchronize(); t3 = time.perf_counter()
                 assert torch.equal(fx_, wx_) and torch.equal(fy_, wy_), "fused mul_get differs from mul + get"
                 others["%s_ecn_mul_get_fused" % cname] = {"scalar_mults_per_s_per_gpu": m / (t1 - t0), "points": m, "bound": "VALU",
                                                           "two_call_form_per_s": m / (t3 - t1), "speedup": (t3 - t1) / (t1 - t0),
                                                           "bytes_equal_to_two_call_form": True}
-                del fx_, fy_, wx_, wy_, W
+                del fx_, fy_, wx_, wy_, W, Qc
             if cname in getattr(Cv, "FUSED2", ()):
                 # verification pattern ecnXXXmul2 + ecnXXXget (ed448.c:305): fused against the two calls
                 mq = m // 2
@@ -417,9 +471,10 @@ def main():
                                                               "three_call_form_per_s": mq / (t2 - t1), "speedup": (t2 - t1) / (t1 - t0),
                                                               "bytes_equal_to_three_call_form": True}
                 del vx_, vy_, wx_, wy_, e2, f2, Q2
-            del e, f, G, Q, R
+            del e, f, G, Gc, Q, R
 
     ladder = None
+    my_lt = None
     if not args.no_ladder:
         m = 1 << LOG2_LADDER
         k = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)
@@ -433,6 +488,7 @@ def main():
             rfc7748("X25519", k, u, out=o)
         barrier()
         lt = (time.perf_counter() - t0) / reps
+        my_lt = lt
         gather_ms = None
         if use_dist:
             from modarith_amd.dist import gather_records
@@ -446,44 +502,79 @@ def main():
                 assert allv.shape[0] == world * m and torch.equal(allv[:m].to(o.device), o)
             del allv
             lt, gather_ms = max_over_ranks([lt, gather_ms])
-        # public-key generation: the same function on the base point u = 9 (rfc7748.c:297-333), fixed-base kernel
-        from modarith_amd.field import rfc7748_base
-        rfc7748_base("X25519", k[:4096].contiguous())
-        torch.cuda.synchronize(); tb0 = time.perf_counter()
-        pk = rfc7748_base("X25519", k)
-        torch.cuda.synchronize(); tb = time.perf_counter() - tb0
-        ub = torch.zeros((4096, 32), dtype=torch.uint8, device=dev); ub[:, 0] = 9
-        assert torch.equal(pk[:4096], rfc7748("X25519", k[:4096].contiguous(), ub)), "fixed-base public keys differ from the ladder on u = 9"
-        del pk, ub
         ladder = {"value": world * m / lt, "unit": "X25519 scalar-mults/s", "scalars_per_gpu": m, "ms_per_pass": lt * 1e3,
-                  "base_point_public_keys_per_s_per_gpu": m / tb,
                   "gather_ms": gather_ms, "io_bytes_per_scalar": 96,
+                  "gather_GBps": (world * m * 32 / (gather_ms * 1e-3) / 1e9) if gather_ms else None,
+                  "gather_payload_bytes": world * m * 32 if gather_ms else None,
                   "bound": "VALU 32-bit integer multiply-add issue (not HBM)",
                   "roofline": valu_roofline(m / lt)}
+        if single:
+            # public-key generation: the same function on the base point u = 9 (rfc7748.c:297-333), fixed-base kernel
+            from modarith_amd.field import rfc7748_base
+            rfc7748_base("X25519", k[:4096].contiguous())
+            torch.cuda.synchronize(); tb0 = time.perf_counter()
+            pk = rfc7748_base("X25519", k)
+            torch.cuda.synchronize(); tb = time.perf_counter() - tb0
+            ub = torch.zeros((4096, 32), dtype=torch.uint8, device=dev); ub[:, 0] = 9
+            assert torch.equal(pk[:4096], rfc7748("X25519", k[:4096].contiguous(), ub)), "fixed-base public keys differ from the ladder on u = 9"
+            del pk, ub
+            ladder["base_point_public_keys_per_s_per_gpu"] = m / tb
 
-    verified = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        # spot-check the timed outputs against the CPU oracle (checker only, outside every timed region):
-        # first / last 4096 and a strided sample of the modmul batch and of the ladder records
+    # EVERY rank spot-checks its own timed outputs against the CPU oracle (checker only, outside every timed
+    # region): first / last 4096 and a strided sample of the modmul batch and of the ladder records.  The verdicts are
+    # AND-reduced over the ranks, so that one N-GPU line says whether all N devices computed the reference's results.
+    verified, my_ok = None, None
+    if not args.no_verify:
         import numpy as np
         from tests.oracle_binding import load_oracle
         from tests.util import vp
-        oracle = load_oracle(build=not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")))
+        if rank != 0 and use_dist:
+            dist.barrier()                                   # rank 0 builds the checker first if it did not travel
+        oracle = load_oracle(build=(rank == 0 and not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so"))))
+        if rank == 0 and use_dist:
+            dist.barrier()
         idx = torch.cat([torch.arange(0, 4096), torch.arange(n - 4096, n), torch.arange(0, n, max(n // 4096, 1))]).unique().to(dev)
         ha = np.ascontiguousarray(a[:, idx].cpu().numpy().view(np.uint64))
         hb = np.ascontiguousarray(b[:, idx].cpu().numpy().view(np.uint64))
         hc = np.empty_like(ha)
         oracle.fn("batch_modmul", "X25519")(vp(ha), vp(hb), vp(hc), ha.shape[1], ha.shape[1])
-        assert np.array_equal(c[:, idx].cpu().numpy().view(np.uint64), hc), "modmul differs from the oracle"
-        verified = {"modmul_elements": int(idx.numel())}
+        ok_mul = bool(np.array_equal(c[:, idx].cpu().numpy().view(np.uint64), hc))
+        verified = {"modmul_elements_per_rank": int(idx.numel())}
+        ok_lad = True
         if ladder is not None:
             m = k.shape[0]
             lidx = torch.cat([torch.arange(0, 4096), torch.arange(m - 4096, m), torch.arange(0, m, max(m // 2048, 1))]).unique().to(dev)
             hk = np.ascontiguousarray(k[lidx].cpu().numpy()); hu = np.ascontiguousarray(u[lidx].cpu().numpy())
             ho = np.empty_like(hu)
-            oracle.lib.oracle_parallel(3, vp(hk), vp(hu), vp(ho), hk.shape[0], 0, len(os.sched_getaffinity(0)))
-            assert np.array_equal(o[lidx].cpu().numpy(), ho), "rfc7748 differs from the oracle"
-            verified["x25519_records"] = int(lidx.numel())
+            oracle.lib.oracle_parallel(3, vp(hk), vp(hu), vp(ho), hk.shape[0], 0, max(1, len(os.sched_getaffinity(0)) // world))
+            ok_lad = bool(np.array_equal(o[lidx].cpu().numpy(), ho))
+            verified["x25519_records_per_rank"] = int(lidx.numel())
+        my_ok = ok_mul and ok_lad
+        all_ok = my_ok
+        if use_dist:
+            tt = torch.tensor([1 if my_ok else 0], dtype=torch.int32, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+            all_ok = bool(int(tt[0]))
+        verified.update(all_ranks_equal_oracle=all_ok, ranks_checked=world)
+        if single:
+            assert ok_mul, "modmul differs from the oracle"
+            assert ok_lad, "rfc7748 differs from the oracle"
+
+    # per-rank inventory: which device each rank ran on and what it measured itself
+    props = torch.cuda.get_device_properties(dev)
+    bus = getattr(props, "pci_bus_id", None)
+    mine = {"rank": rank, "local_rank": local, "device_index": dev.index, "device_name": torch.cuda.get_device_name(dev),
+            "pci_bus_id": ("%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), bus, getattr(props, "pci_device_id", 0))) if bus is not None else None,
+            "uuid": str(getattr(props, "uuid", "")) or None,
+            "modmul_per_s": n * args.steps / my_dt, "kernel_ms": my_kern_ms, "hbm_GBps": BYTES_PER_MODMUL * n / (my_kern_ms * 1e-3) / 1e9,
+            "x25519_per_s": (k.shape[0] / my_lt) if my_lt else None, "verified_against_oracle": my_ok}
+    ranks = [mine]
+    dist_info = None
+    if use_dist:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "distinct_devices": len({(r["pci_bus_id"], r["uuid"], r["device_index"]) for r in ranks})}
 
     if rank == 0:
         cpu = None
@@ -499,6 +590,11 @@ def main():
             if tdoc.get("algorithmic_bytes_per_launch") == BYTES_PER_MODMUL * n:
                 traffic = tdoc.get("hbm_bytes_per_launch")
                 traffic_source = "profiles/traffic_modmul_X25519.json (rocprofv3 --pmc passes, tag %s)" % tdoc.get("tag")
+        per_rank = [r["modmul_per_s"] for r in ranks]
+        kms = [r["kernel_ms"] for r in ranks]
+        med = sorted(probe_rates)[len(probe_rates) // 2] if probe_rates else None      # upper median of the probe rates
+        if probe_rates and len(probe_rates) % 2 == 0:
+            med = 0.5 * (sorted(probe_rates)[len(probe_rates) // 2 - 1] + sorted(probe_rates)[len(probe_rates) // 2])
         out = {
             "metric": "256-bit modmul/s (2^255-19)", "value": value, "unit": "modmul/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -506,15 +602,25 @@ def main():
             "data": "synthetic",
             "config": {"workload": "batched modmul 2^255-19, 5x51-bit limbs, 2^%d elements per GPU, limb-interleaved SoA" % LOG2_ELEMS,
                        "elements_per_gpu": n, "placement_probe_GBps": [round(r, 1) for r in probe_rates], "inputs": "uniform mod p: splitmix64 stream (seed 42, array id, j) reduced mod p, generated on the device",
+                       "placement_policy": "timed on the fastest of %d probed operand placements (identical contents); a caller that allocates once without probing gets one draw from this spread -- see roofline.frac_first_placement / frac_median_placement" % placements if placements > 1 else "single placement, no probe",
                        "parallelism": "independent batches, %d rank(s), no data-path collective" % world},
+            # the same quantity from the placement probe (10 launches each, rank 0): median and first-allocated placement
+            "value_median_placement": (med * 1e9 / BYTES_PER_MODMUL * world) if med else None,
+            "value_first_placement": (probe_rates[0] * 1e9 / BYTES_PER_MODMUL * world) if probe_rates else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": "k_binary<P_X25519,OpMulAuto,2>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": BYTES_PER_MODMUL * n},
+                         "algorithmic_bytes_per_launch": BYTES_PER_MODMUL * n,
+                         "frac_median_placement": (med / HBM_PEAK_GBS) if med else None,
+                         "frac_first_placement": (probe_rates[0] / HBM_PEAK_GBS) if probe_rates else None},
             "cpu_baseline": cpu,
             "x25519": ladder,
             "data_sets": data_sets,
             "other_configs": others,
             "verified_against_oracle": verified,
+            "ranks": ranks,
+            "rank_spread": {"modmul_per_s": {"min": min(per_rank), "mean": sum(per_rank) / len(per_rank), "max": max(per_rank)},
+                            "kernel_ms": {"min": min(kms), "mean": sum(kms) / len(kms), "max": max(kms)}},
+            "dist": dist_info,
         }
         print(json.dumps(out))
     if use_dist:

@@ -33,6 +33,9 @@ def test_bench_line_contract():
     # value and the roofline describe the same launches: modmul/s * 120 B within 10 % of the achieved rate
     assert abs(d["value"] * 120 / 1e9 - r["achieved"]) / r["achieved"] < 0.10
     assert d["x25519"]["value"] > 1e7
+    assert d["verified_against_oracle"]["all_ranks_equal_oracle"] is True and len(d["ranks"]) == 1
+    assert d["roofline"]["frac_median_placement"] <= d["roofline"]["frac"] * 1.05 and d["value_median_placement"] > 0
+    assert len(d["config"]["placement_probe_GBps"]) == 4
 
 
 def test_bench_rccl_path_one_rank():
@@ -53,3 +56,18 @@ def test_bench_self_launch_two_ranks_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["elements_per_gpu"] == 1 << 22
     assert d["x25519"]["scalars_per_gpu"] == 1 << 18 and d["x25519"]["gather_ms"] > 0 and d["x25519"]["value"] > 0
+    assert d["x25519"]["gather_GBps"] > 0
+    # the N > 1 line verifies itself: every rank checked its own outputs against the oracle, AND-reduced
+    v = d["verified_against_oracle"]
+    assert v is not None and v["all_ranks_equal_oracle"] is True and v["ranks_checked"] == 2
+    assert v["modmul_elements_per_rank"] >= 8192 and v["x25519_records_per_rank"] >= 8192
+    # per-rank inventory and what the collective layer saw
+    assert [r["rank"] for r in d["ranks"]] == [0, 1]
+    for r in d["ranks"]:
+        assert r["device_name"] and r["modmul_per_s"] > 0 and r["x25519_per_s"] > 0 and r["verified_against_oracle"] is True
+    assert d["dist"] == {"backend": "gloo", "world_size": 2, "distinct_devices": 1}
+    sp = d["rank_spread"]["modmul_per_s"]
+    assert sp["min"] <= sp["mean"] <= sp["max"]
+    assert d["value"] <= 2 * sp["max"] * 1.001
+    # the N = 1 side figures are not run at N > 1
+    assert d["other_configs"] == {} and list(d["data_sets"]) == ["uniform_mod_p"]

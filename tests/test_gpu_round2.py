@@ -366,3 +366,34 @@ def test_index_less_device_forms(torch_cuda):
         C = Curve("ED25519", d)
         G = C.gen(8)
         assert bool(C.limbs_ok(C.dbl(G)).all())
+
+
+@pytest.mark.skipif(os.environ.get("MA_POLICY_CHILD") == "1", reason="no product policy involved")
+@pytest.mark.parametrize("P", CORE + EXTRA)
+def test_modlimbs_predicate_every_prime(torch_cuda, P):
+    """modlimbs against a host model for every built prime: 1 iff every limb < 2^(Radix+2); vacuously 1 for radix >= 62
+    (GM384: 2^64 is not a 64-bit value -- a shift by 64 used to make the kernel answer 0 for every non-zero element);
+    for the 2^256-189 field (NUMS256W, whose curve kernels run the folded half-limb products) the bound is (2^64-1)/mm."""
+    from modarith_amd.field import Field
+    F = Field(P)
+    R, N = F.radix, F.N
+    n = 4099
+    rng = np.random.default_rng(77)
+    top = min(R + 2, 64)
+    edges = [0, 1, (1 << R) - 1, 1 << R, (1 << top) - 1, (1 << 64) - 1, 1 << 63]
+    if top < 64:
+        edges += [1 << top, (1 << top) + 1]
+    limit = (1 << top) - 1
+    if P == "NUMS256W":
+        limit = ((1 << 64) - 1) // 0xbd0
+        edges += [limit, limit + 1]
+    e = np.array(edges, dtype=np.uint64)
+    a = rng.integers(0, 1 << R, size=(N, n), dtype=np.uint64)
+    pick = rng.integers(0, 3 * len(e), size=(N, n))
+    a = np.where(pick < len(e), e[np.minimum(pick, len(e) - 1)], a)
+    a[:, 0] = 0
+    a[:, 1] = np.uint64(limit)
+    want = (a <= np.uint64(limit)).all(axis=0).astype(np.int32)
+    assert 0 < want.sum() <= n
+    got = F.modlimbs(to_dev(np.ascontiguousarray(a))).cpu().numpy()
+    assert np.array_equal(got, want), P
