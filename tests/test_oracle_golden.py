@@ -302,3 +302,22 @@ def test_out_of_contract_limbs_golden(oracle, fx):
         z = oracle.arr(P)
         oracle.fn("modmli", P)(oracle.arr(P, a), 121665, z)
         assert list(z) == limbs(rec["modmli_121665"]), (P, "modmli", i)
+
+
+# ---- round-3 fixture (tests/golden/make_bulk_digests.py): 2^18 elements per input class through the REFERENCE's emitted
+# modmul / modsqr / modadd / modsub / modneg / nres / redc / modmli, committed as one sha256 digest per 4096-element block
+@pytest.mark.parametrize("P", ["X25519", "NIST256", "X448"])
+def test_bulk_digests_oracle(oracle, P):
+    """the oracle reproduces the reference on 3 x 2^18 elements per prime and operation (SURVEY.md:359)"""
+    from tests.util import BULK_CLASSES, BULK_OPS, block_digests, bulk_inputs, oracle_bin, oracle_mli, oracle_un
+    g = load_golden("bulk_digests.json")
+    for cls in BULK_CLASSES:
+        a, b = bulk_inputs(P, cls, g["n"])
+        for op in BULK_OPS:
+            if op in ("modmul", "modadd", "modsub"):
+                c = oracle_bin(oracle, op, P, a, b)
+            elif op == "modmli_121665":
+                c = oracle_mli(oracle, P, a, 121665)
+            else:
+                c = oracle_un(oracle, op, P, a)
+            assert block_digests(c, g["block"]) == g["primes"][P][cls][op], (P, cls, op)
