@@ -385,10 +385,16 @@ def main():
             xc = torch.empty_like(xa)
             for op in ops:
                 fn = (lambda: Fp.modmul(xa, xb, out=xc)) if op == "modmul" else (lambda: Fp.modsqr(xa, out=xc))
+                # streaming control on the SAME three (two) buffers: the same streams without the multiplication
+                ctl = (lambda: Fp.modadd(xa, xb, out=xc)) if op == "modmul" else (lambda: Fp.modcpy(xa, out=xc))
                 ms = rate(fn)
+                cms = rate(ctl)
+                ms = min(ms, rate(fn))                       # (kernel, control, kernel: the rate of a buffer set drifts by a per cent or two)
                 nbytes = (3 if op == "modmul" else 2) * 8 * Fp.N * n
                 others["%s_%s" % (P, op)] = {"ops_per_s_per_gpu": n / (ms * 1e-3), "GBps": nbytes / (ms * 1e-3) / 1e9,
                                              "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms,
+                                             "control": "modadd" if op == "modmul" else "modcpy", "control_GBps": nbytes / (cms * 1e-3) / 1e9,
+                                             "frac_of_control": cms / ms,
                                              "inputs": "uniform mod p (splitmix64 recipe), nres'd"}
             del xa, xb, xc
         # the curve layer built on the path, one pass each: side figures (VALU-bound kernels)
