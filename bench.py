@@ -159,29 +159,39 @@ def cpu_baseline(a_host, b_host, min_seconds=6.0):
 
 
 def valu_roofline(scalars_per_s_per_gpu):
-    """VALU-issue roofline of the X25519 ladder kernel.  The instruction counts per scalar multiplication come from the
-    committed PMC summary (profiles/, SQ_INSTS_VALU of one pass / scalars); the rate is the one measured in THIS run.
+    """VALU-issue roofline of the X25519 ladder kernels.  The instruction counts per scalar multiplication come from the
+    committed PMC summary (profiles/, SQ_INSTS_VALU of one pass / scalars; round 3: the ladder kernel k_x25519_fe26_xz plus
+    the batched finish k_fe_finish<Fe26>); the rate is the one measured in THIS run.
       achieved = scalars/s x wave-instructions per scalar (= per-lane instructions / 64 lanes)      [wave-instr/s]
       peak     = 1024 SIMDs x 2.4 GHz / cost,  cost = (5.0 x mad + 2.5 x (instr - mad)) / instr     [wave-instr/s]
     5.0 / 2.5 cycles per wave-instruction per SIMD: measured issue costs of v_mad_u64_u32 and of simple 32-bit ALU
     instructions (profiles/r01_valubench.log); 2.4 GHz is the nominal peak clock, so frac is a lower bound when the
     part clocks lower under this load (the PMC file records the clock seen during its pass)."""
-    for tag in ("r02", "r01g"):
+    for tag in ("r03", "r02", "r01g"):
         path = os.path.join(ROOT, "profiles", "%s_valu_pmc.json" % tag)
         if os.path.exists(path):
             break
     else:
         return None
-    k = json.load(open(path)).get("k_x25519_fe26")
-    if not k:
-        return None
-    instr = k["SQ_INSTS_VALU"] * 64.0 / k["scalars"]          # per-lane VALU instructions per scalar multiplication
-    mad = k.get("mad_per_scalar", 739 * 255 + 11 * 100 + 254 * 55 + 100)
+    doc = json.load(open(path))
+    if "k_x25519_fe26_xz" in doc and "k_fe_finish_fe26" in doc:
+        k, f = doc["k_x25519_fe26_xz"], doc["k_fe_finish_fe26"]
+        instr = k["SQ_INSTS_VALU"] * 64.0 / k["scalars"] + f["SQ_INSTS_VALU"] * 64.0 / f["scalars"]
+        # multiply-adds per scalar from the ISA: 255 steps x 739; finish: 4 multiplications (101 each) + 1/32 of an inversion
+        mad = k.get("mad_per_scalar", 739 * 255) + f.get("mad_per_scalar", 4 * 101 + (254 * 56 + 11 * 101) / 32.0)
+        kernels = "k_x25519_fe26_xz + k_fe_finish<Fe26,10,4>"
+    else:
+        k = doc.get("k_x25519_fe26")
+        if not k:
+            return None
+        instr = k["SQ_INSTS_VALU"] * 64.0 / k["scalars"]          # per-lane VALU instructions per scalar multiplication
+        mad = k.get("mad_per_scalar", 739 * 255 + 11 * 100 + 254 * 55 + 100)
+        kernels = "k_x25519_fe26 (one inversion per lane: counters of the round-2 kernel)"
     cost = (5.0 * mad + 2.5 * (instr - mad)) / instr
     achieved = scalars_per_s_per_gpu * instr / 64.0
     peak = 1024 * 2.4e9 / cost
     return {"bound": "valu", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s", "frac": achieved / peak,
-            "instr_per_scalar": instr, "mad_per_scalar": mad, "issue_cost_of_mix_cycles": cost,
+            "instr_per_scalar": instr, "mad_per_scalar": mad, "issue_cost_of_mix_cycles": cost, "kernels": kernels,
             "cycles_per_instr": 1024 * 2.4e9 / achieved, "clock_GHz_assumed": 2.4, "source": "profiles/%s_valu_pmc.json" % tag,
             "mad_only_ceiling_scalars_per_s": 1024 * 2.4e9 * 64 / (5.0 * mad)}
 
@@ -387,9 +397,8 @@ def main():
                 fn = (lambda: Fp.modmul(xa, xb, out=xc)) if op == "modmul" else (lambda: Fp.modsqr(xa, out=xc))
                 # streaming control on the SAME three (two) buffers: the same streams without the multiplication
                 ctl = (lambda: Fp.modadd(xa, xb, out=xc)) if op == "modmul" else (lambda: Fp.modcpy(xa, out=xc))
-                ms = rate(fn)
-                cms = rate(ctl)
-                ms = min(ms, rate(fn))                       # (kernel, control, kernel: the rate of a buffer set drifts by a per cent or two)
+                ms, cms = rate(fn), rate(ctl)                # interleaved, best of two each: the rate of a buffer set drifts by a per cent or two
+                ms, cms = min(ms, rate(fn)), min(cms, rate(ctl))
                 nbytes = (3 if op == "modmul" else 2) * 8 * Fp.N * n
                 others["%s_%s" % (P, op)] = {"ops_per_s_per_gpu": n / (ms * 1e-3), "GBps": nbytes / (ms * 1e-3) / 1e9,
                                              "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms,
@@ -486,9 +495,9 @@ def main():
         k = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)
         u = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)
         o = torch.empty_like(u)
-        rfc7748("X25519", k[:4096], u[:4096], out=o[:4096])  # warm-up
+        rfc7748("X25519", k, u, out=o)                       # warm-up at full size (code objects, the split form's workspace)
         barrier()
-        reps = 2
+        reps = 3
         t0 = time.perf_counter()
         for _ in range(reps):
             rfc7748("X25519", k, u, out=o)

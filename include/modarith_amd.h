@@ -226,6 +226,17 @@ void rfc7748_X25519(const char *bk, const char *bu, char *bv);
 void rfc7748_X448(const char *bk, const char *bu, char *bv);
 int rfc7748_X25519_batch(const char *bk, const char *bu, char *bv, size_t n, void *stream);
 int rfc7748_X448_batch(const char *bk, const char *bu, char *bv, size_t n, void *stream);
+/* The batched form does not owe one field inversion (rfc7748.c:225-254 modinv: 7-8 % of the function) to every record: for
+ * n >= 8192 it runs the ladders in one kernel and finishes up to 32 records per inversion in a second one (Montgomery's
+ * simultaneous inversion; z2 = 0 handled by lane predication) -- the same bytes for every input.  rfc7748_<C>_batch takes
+ * the scratch this needs (rfc7748_<C>_batch_workspace_bytes(n): Nbytes + 40 / 64 bytes per record) from a stream-ordered
+ * pool of the library's own, and falls back to one inversion per record while the stream is being captured or when the
+ * pool is unavailable; rfc7748_<C>_batch_ws takes it from the caller (device memory, 8-byte aligned, any n) and is what a
+ * resident caller or a graph capture uses. */
+size_t rfc7748_X25519_batch_workspace_bytes(size_t n);
+size_t rfc7748_X448_batch_workspace_bytes(size_t n);
+int rfc7748_X25519_batch_ws(const char *bk, const char *bu, char *bv, size_t n, void *workspace, size_t workspace_bytes, void *stream);
+int rfc7748_X448_batch_ws(const char *bk, const char *bu, char *bv, size_t n, void *workspace, size_t workspace_bytes, void *stream);
 /* rfc7748() on the curve's BASE POINT (u = 9 / u = 5): public-key generation, the first half of every exchange in the
  * reference's main() (rfc7748.c:297-333 `rfc7748(alice, base, apk)`).  Same bytes as rfc7748_<C>_batch with bu = the base
  * point; computed on the birationally equivalent / 4-isogenous Edwards curve from a fixed-base table (no ladder steps). */
@@ -313,7 +324,11 @@ MODARITH_AMD_DECLARE_EDWARDS(nums256w, 5)
  * returns (of y when y is NULL, of x when x is NULL, else 0).  P is NOT modified (the two-call form leaves e*P in it).
  * Only canonical bytes leave the kernel, so it runs on 32-bit-limb internals with extended-coordinate formulas that are
  * complete on the curve (csrc/ed26.h): the same bytes as ecn_<c>_mul_batch + ecn_<c>_get_batch for every input point
- * on the curve, constant-time fixed window like ecnXXXmul.  workspace: a device buffer of
+ * on the curve whose coordinate limbs keep the limb budget -- every limb below 2^(Radix+2), which every point the library
+ * (or field.c-style code) produced does; the fused kernels re-pack the 64-bit limbs into 32-bit ones and silently drop what
+ * lies above (checkable beforehand with modlimbs_<P>_batch on the three coordinates; the plain ecn_<c>_mul_batch instead
+ * reproduces the reference's 64-bit wrap-around for such fabricated limbs).  This precondition holds for every fused entry
+ * point below (mul_get, mul2_get, mulgen2_get).  Constant-time fixed window like ecnXXXmul.  workspace: a device buffer of
  * ecn_<c>_mul_get_workspace_bytes(n) bytes for the per-lane window tables (0 for ed25519, whose table lives in
  * registers: workspace may then be NULL; ed448: 672 bytes per resident lane, at most 88 MB). */
 size_t ecn_ed25519_mul_get_workspace_bytes(size_t n);

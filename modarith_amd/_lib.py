@@ -107,6 +107,12 @@ def load() -> ctypes.CDLL:
         g = getattr(lib, "rfc7748_%s" % C)
         g.argtypes = [c_char_p, c_char_p, c_char_p]
         g.restype = None
+        w = getattr(lib, "rfc7748_%s_batch_workspace_bytes" % C)
+        w.argtypes = [c_size_t]
+        w.restype = c_size_t
+        h = getattr(lib, "rfc7748_%s_batch_ws" % C)
+        h.argtypes = [_P, _P, _P, c_size_t, _P, c_size_t, _P]
+        h.restype = c_int
     for C in CURVES:
         nl, nb = CURVES[C]
         g = lambda f: getattr(lib, "ecn_%s_%s" % (C, f))

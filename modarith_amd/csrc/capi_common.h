@@ -17,6 +17,7 @@ int max_blocks();          // grid cap for grid-stride streaming kernels (env MA
 int ladder_block();        // workgroup size of the ladder kernel (env MA_LADDER_BLOCK)
 bool force_fast();         // env MA_FORCE_FAST=1: element-wise modmul/modsqr/nres/redc/modinv on the FAST product path (tests)
 bool force_exact();        // env MA_FORCE_EXACT=1: element-wise modmul/modsqr on the exact 128-bit products only (tests)
+bool ladder_split();       // env MA_LADDER_SPLIT=0: the batched ladders never take the split form (one inversion per lane)
 bool ladder_use_field();   // env MA_LADDER_IMPL=field: X25519 ladder on the 5x51 field.c-form arithmetic
 
 inline unsigned grid_for(size_t nthreads, int block = 256) {
@@ -38,6 +39,8 @@ struct Staging {
     unsigned char* get();
 };
 Staging& staging();
+void* scratch_alloc(size_t bytes, hipStream_t s);   // stream-ordered scratch from the library's own pool; nullptr if unavailable
+void scratch_free(void* p, hipStream_t s);
 [[noreturn]] void die(const char* what, hipError_t e);
 
 }  // namespace ma

@@ -46,6 +46,10 @@ bool force_exact() {
     static bool v = [] { const char* s = getenv("MA_FORCE_EXACT"); return s && *s == '1'; }();
     return v;
 }
+bool ladder_split() {
+    static bool v = [] { const char* s = getenv("MA_LADDER_SPLIT"); return !(s && *s == '0'); }();
+    return v;
+}
 bool ladder_use_field() {
     static bool v = [] { const char* s = getenv("MA_LADDER_IMPL"); return s && strcmp(s, "field") == 0; }();
     return v;
@@ -61,6 +65,47 @@ unsigned char* Staging::get() {
         if (e != hipSuccess) die("hipMalloc(staging)", e);
     }
     return dev[d];
+}
+// stream-ordered scratch of the library's own (the batched ladders' split form): one memory pool per device, created on
+// first use, that keeps what it has handed out once (release threshold = max), so that a resident caller pays for the
+// workspace of its largest batch once and not per call.  nullptr when pools are unavailable: callers then take the
+// self-contained kernels.
+void* scratch_alloc(size_t bytes, hipStream_t s) {
+    static std::mutex mu;
+    static hipMemPool_t pools[Staging::MAX_DEVICES] = {};
+    static bool failed[Staging::MAX_DEVICES] = {};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= Staging::MAX_DEVICES) return nullptr;
+    hipMemPool_t pool = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!pools[d] && !failed[d]) {
+            hipMemPoolProps props = {};
+            props.allocType = hipMemAllocationTypePinned;
+            props.handleTypes = hipMemHandleTypeNone;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = d;
+            if (hipMemPoolCreate(&pools[d], &props) == hipSuccess) {
+                uint64_t keep = ~(uint64_t)0;
+                (void)hipMemPoolSetAttribute(pools[d], hipMemPoolAttrReleaseThreshold, &keep);
+            } else {
+                pools[d] = nullptr;
+                failed[d] = true;
+                (void)hipGetLastError();
+            }
+        }
+        pool = pools[d];
+    }
+    if (!pool) return nullptr;
+    void* p = nullptr;
+    if (hipMallocFromPoolAsync(&p, bytes, pool, s) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void scratch_free(void* p, hipStream_t s) {
+    if (p) (void)hipFreeAsync(p, s);
 }
 Staging& staging() {
     static Staging s;

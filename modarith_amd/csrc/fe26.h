@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "field.h"
+#include "fe_finish.h"
 
 namespace ma {
 
@@ -248,7 +249,8 @@ struct Fe26 {
 // sign under the square), and the doubling only needs A' = swap ? C : A and B' = swap ? D : B.  Two 10-limb selects
 // replace the two 10-limb swaps of rfc7748.c:190-191 (20 v_cndmask instead of 40 + mask arithmetic); the state after
 // every step is exactly the reference's ("2" = the doubled point, "3" = the sum), so the swap bit chains as there.
-MA_DEV void x25519_fe26_one(const uint64_t* kw_in, const uint64_t* uw_in, uint64_t* ow) {
+// the ladder proper: leaves (x2 : z2) of k*u, tight limbs
+MA_DEV void x25519_fe26_ladder(const uint64_t* kw_in, const uint64_t* uw_in, uint32_t* x2, uint32_t* z2) {
     using F = Fe26;
     uint64_t kw[4], uw[4];
     static_for<0, 4>([&](auto K) { kw[K] = kw_in[K]; uw[K] = uw_in[K]; });
@@ -261,7 +263,7 @@ MA_DEV void x25519_fe26_one(const uint64_t* kw_in, const uint64_t* uw_in, uint64
     kw[1] = (kw[1] << 1) | (kw[0] >> 63);
     kw[0] <<= 1;
 
-    uint32_t x1[10], x1_19[10], x2[10], z2[10], x3[10], z3[10];
+    uint32_t x1[10], x1_19[10], x3[10], z3[10];
     F::from_words(uw, x1);
     F::pre19(x1, x1_19);
     x1_19[0] = 0;
@@ -303,6 +305,12 @@ MA_DEV void x25519_fe26_one(const uint64_t* kw_in, const uint64_t* uw_in, uint64
     }
     F::select(swap != 0, x2, x3, x2);
     F::select(swap != 0, z2, z3, z2);
+}
+
+MA_DEV void x25519_fe26_one(const uint64_t* kw_in, const uint64_t* uw_in, uint64_t* ow) {
+    using F = Fe26;
+    uint32_t x2[10], z2[10];
+    x25519_fe26_ladder(kw_in, uw_in, x2, z2);
     F::invert(z2, z2);
     F::mul(x2, z2, x2);
     F::to_words(x2, ow);
@@ -320,6 +328,20 @@ __global__ __launch_bounds__(256) void k_x25519_fe26(const uint64_t* bk, const u
     }
 }
 
+// the split form: ladders only; canonical x2 -> the output record, canonical z2 -> wz[4][n] (word-major)
+__global__ __launch_bounds__(256) void k_x25519_fe26_xz(const uint64_t* bk, const uint64_t* bu, uint64_t* bv, uint64_t* wz, size_t n) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        uint64_t kw[4], uw[4], xw[4], zw[4];
+        static_for<0, 4>([&](auto K) { kw[K] = bk[t * 4 + K]; });
+        static_for<0, 4>([&](auto K) { uw[K] = bu[t * 4 + K]; });
+        uint32_t x2[10], z2[10];
+        x25519_fe26_ladder(kw, uw, x2, z2);
+        Fe26::to_words(x2, xw);
+        Fe26::to_words(z2, zw);
+        static_for<0, 4>([&](auto K) { bv[t * 4 + K] = xw[K]; });
+        static_for<0, 4>([&](auto K) { wz[(size_t)K * n + t] = zw[K]; });
+    }
+}
 #endif
 
 }  // namespace ma

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "field.h"
+#include "fe_finish.h"
 
 namespace ma {
 
@@ -323,14 +324,15 @@ struct Fe28 {
 // One X448 scalar multiplication (rfc7748.c:156-256, A24 = 39081, COF = 2) on the fe28 representation; kw, uw = the
 // 56-byte records as seven little-endian words.  The conditional swap is folded into two selects exactly as in
 // fe26.h (x25519_fe26_one): {DA, CB} is invariant under the swap, only the doubling needs A' and B'.
-MA_DEV void x448_fe28_one(const uint64_t* kw_in, const uint64_t* uw_in, uint64_t* ow) {
+// the ladder proper: leaves (x2 : z2) of k*u, tight limbs
+MA_DEV void x448_fe28_ladder(const uint64_t* kw_in, const uint64_t* uw_in, uint32_t* x2, uint32_t* z2) {
     using F = Fe28;
     uint64_t kw[7], uw[7];
     static_for<0, 7>([&](auto K) { kw[K] = kw_in[K]; uw[K] = uw_in[K]; });
     kw[0] &= ~3ull;                                       // clamp (rfc7748.c:135-141): Nbits % 8 == 0
     kw[6] |= 0x8000000000000000ull;                       // bit 447 set; already left-aligned
 
-    uint32_t x1[16], x2[16], z2[16], x3[16], z3[16];
+    uint32_t x1[16], x3[16], z3[16];
     F::from_words(uw, x1);
     F::set(1, x2);
     F::set(0, z2);
@@ -371,6 +373,12 @@ MA_DEV void x448_fe28_one(const uint64_t* kw_in, const uint64_t* uw_in, uint64_t
     }
     F::select(swap != 0, x2, x3, x2);
     F::select(swap != 0, z2, z3, z2);
+}
+
+MA_DEV void x448_fe28_one(const uint64_t* kw_in, const uint64_t* uw_in, uint64_t* ow) {
+    using F = Fe28;
+    uint32_t x2[16], z2[16];
+    x448_fe28_ladder(kw_in, uw_in, x2, z2);
     F::invert(z2, z2);
     F::mul(x2, z2, x2);
     F::to_words(x2, ow);
@@ -385,6 +393,21 @@ __global__ __launch_bounds__(256, 2) void k_x448_fe28(const uint64_t* bk, const 
         static_for<0, 7>([&](auto K) { uw[K] = bu[t * 7 + K]; });
         x448_fe28_one(kw, uw, ow);
         static_for<0, 7>([&](auto K) { bv[t * 7 + K] = ow[K]; });
+    }
+}
+
+// the split form (fe_finish.h): ladders only; canonical x2 -> the output record, canonical z2 -> wz[7][n] (word-major)
+__global__ __launch_bounds__(256, 2) void k_x448_fe28_xz(const uint64_t* bk, const uint64_t* bu, uint64_t* bv, uint64_t* wz, size_t n) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        uint64_t kw[7], uw[7], xw[7], zw[7];
+        static_for<0, 7>([&](auto K) { kw[K] = bk[t * 7 + K]; });
+        static_for<0, 7>([&](auto K) { uw[K] = bu[t * 7 + K]; });
+        uint32_t x2[16], z2[16];
+        x448_fe28_ladder(kw, uw, x2, z2);
+        Fe28::to_words(x2, xw);
+        Fe28::to_words(z2, zw);
+        static_for<0, 7>([&](auto K) { bv[t * 7 + K] = xw[K]; });
+        static_for<0, 7>([&](auto K) { wz[(size_t)K * n + t] = zw[K]; });
     }
 }
 

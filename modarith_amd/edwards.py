@@ -101,8 +101,9 @@ class Edwards:
         return P
 
     def limbs_ok(self, P: torch.Tensor) -> torch.Tensor:
-        """int32 [n]: 1 where all three coordinates of the point keep the limb budget (every limb < 2^(Radix+2)) that the
-        outputs of every function of this library keep and the scalar-multiplication kernels rely on; a 0 marks limbs
+        """int32 [n]: 1 where all three coordinates of the point keep the limb budget (every limb < 2^(Radix+2); for the
+        2^256-189 field of NUMS256W / NUMS256E: every limb <= (2^64-1)/mm = 2^52.4, the range in which the folded half-limb
+        products of their curve kernels agree with the reference) that the outputs of every function of this library keep and the scalar-multiplication kernels rely on; a 0 marks limbs
         fabricated outside the API (the reference's functions "silently overflow" there too, SURVEY 8b, but differently)."""
         from . import curves
         from .field import Field
@@ -131,7 +132,10 @@ class Edwards:
     def mul_get(self, e: torch.Tensor, P: torch.Tensor, want_x: bool = True, want_y: bool = True):
         """ecnXXXmul followed by ecnXXXget (the reference's call pattern, ed448.c:182-184) in ONE kernel: the affine
         coordinates of e*P as canonical big-endian byte records, and the sign of the omitted coordinate.  P is not
-        modified.  Same bytes as mul() + get() for every point on the curve, about twice as fast."""
+        modified.  Same bytes as mul() + get() for every point on the curve, about twice as fast.  Precondition (all fused
+        *_get methods): the coordinate limbs of P keep the limb budget (every limb < 2^(Radix+2): `limbs_ok(P)`), as every
+        point produced by this library does; limbs fabricated above it are truncated by the 32-bit re-packing, whereas
+        mul() reproduces the reference's 64-bit behaviour for them."""
         if self.name.upper() not in self.FUSED:
             raise ValueError("no fused mul_get kernel for %s (available: %s)" % (self.name, ", ".join(self.FUSED)))
         n = self._chk(P)

@@ -11,6 +11,8 @@ Conversions (`from_ints`, `to_ints`) are host-side helpers for tests and glue.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Iterable, List, Optional, Sequence
 
 import numpy as np
@@ -326,9 +328,19 @@ def rfc7748(curve: str, bk: torch.Tensor, bu: torch.Tensor, out: Optional[torch.
         out = torch.empty_like(bu)
     elif (out.dtype != torch.uint8 or out.shape != bu.shape or not out.is_contiguous() or out.device != bu.device):
         raise ValueError("out must be a contiguous uint8 tensor of shape %s on %s" % (tuple(bu.shape), bu.device))
-    f = getattr(lib, "rfc7748_%s_batch" % curve)
+    n = bk.shape[0]
     with torch.cuda.device(bu.device):
-        _lib.check(f(bk.data_ptr(), bu.data_ptr(), out.data_ptr(), bk.shape[0], torch.cuda.current_stream().cuda_stream), "rfc7748_%s_batch" % curve)
+        st = torch.cuda.current_stream().cuda_stream
+        if n >= 8192 and os.environ.get("MA_LADDER_SPLIT") != "0":
+            # split form (include/modarith_amd.h): ladders, then one inversion per up to 32 records; the scratch comes from
+            # torch's caching allocator (stream-ordered, reused across calls, legal under graph capture)
+            nbytes = getattr(lib, "rfc7748_%s_batch_workspace_bytes" % curve)(n)
+            ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=bu.device)
+            f = getattr(lib, "rfc7748_%s_batch_ws" % curve)
+            _lib.check(f(bk.data_ptr(), bu.data_ptr(), out.data_ptr(), n, ws.data_ptr(), ws.numel() * 8, st), "rfc7748_%s_batch_ws" % curve)
+        else:
+            f = getattr(lib, "rfc7748_%s_batch" % curve)
+            _lib.check(f(bk.data_ptr(), bu.data_ptr(), out.data_ptr(), n, st), "rfc7748_%s_batch" % curve)
     return out
 
 

@@ -50,7 +50,8 @@ def test_binding_tables_cover_header(lib):
     names, _ = _declared_symbols()
     bound = {"%s_%s_batch" % (f, P) for f in _lib.BATCH_FUNCS for P in _lib.PRIMES}
     bound |= {"%s_%s_ct" % (f, P) for f in _lib.SCALAR_FUNCS for P in _lib.PRIMES}
-    bound |= set(_lib.UTIL_FUNCS) | {"rfc7748_X25519", "rfc7748_X448", "rfc7748_X25519_batch", "rfc7748_X448_batch"}
+    bound |= set(_lib.UTIL_FUNCS) | {"rfc7748_X25519", "rfc7748_X448", "rfc7748_X25519_batch", "rfc7748_X448_batch",
+                                     "rfc7748_X25519_batch_ws", "rfc7748_X448_batch_ws", "rfc7748_X25519_batch_workspace_bytes", "rfc7748_X448_batch_workspace_bytes"}
     bound |= {"ecn_%s_%s_batch" % (c, f) for c in _lib.CURVES for f in _lib.ED_BATCH_FUNCS}
     bound |= {"ecn_%s_%s" % (c, f) for c in _lib.CURVES for f in _lib.ED_SCALAR_FUNCS}
     bound |= set(_lib.FUSED_FUNCS)

@@ -321,3 +321,49 @@ def test_bulk_digests_oracle(oracle, P):
             else:
                 c = oracle_un(oracle, op, P, a)
             assert block_digests(c, g["block"]) == g["primes"][P][cls][op], (P, cls, op)
+
+
+# ---- the reference's corner-case protocol (edge.py / edge.c), restated in tests/edge_protocol.py
+class _OracleEdgeEngine:
+    def __init__(self, oracle, P, nbytes):
+        self.o, self.P, self.nb = oracle, P, nbytes
+    def imp(self, ints):
+        out = []
+        for v in ints:
+            x = self.o.arr(self.P)
+            self.o.fn("modimp", self.P)(int(v).to_bytes(self.nb, "big"), x)
+            out.append(list(x))
+        return out
+    def _un(self, f, xs):
+        return [self.o.un(f, self.P, x) for x in xs]
+    def _bi(self, f, xs, ys):
+        return [self.o.bi(f, self.P, x, y) for x, y in zip(xs, ys)]
+    def inv(self, xs):
+        out = []
+        for x in xs:
+            z = self.o.arr(self.P)
+            self.o.fn("modinv", self.P)(self.o.arr(self.P, x), None, z)
+            out.append(list(z))
+        return out
+    def sqrt(self, xs):
+        out = []
+        for x in xs:
+            z = self.o.arr(self.P)
+            self.o.fn("modsqrt", self.P)(self.o.arr(self.P, x), None, z)
+            out.append(list(z))
+        return out
+    def add(self, xs, ys): return self._bi("modadd", xs, ys)
+    def sub(self, xs, ys): return self._bi("modsub", xs, ys)
+    def mul(self, xs, ys): return self._bi("modmul", xs, ys)
+    def sqr(self, xs): return self._un("modsqr", xs)
+    def cmp(self, xs, ys):
+        return [self.o.fn("modcmp", self.P)(self.o.arr(self.P, x), self.o.arr(self.P, y)) for x, y in zip(xs, ys)]
+
+
+@pytest.mark.parametrize("P", ["X25519", "NIST256", "X448", "NIST384", "NIST521", "SECP256K1", "NUMS256W", "ED248", "ED376", "ED500"])
+def test_edge_protocol_oracle(oracle, P):
+    """edge.py's 17 corner pairs and their doubled forms through the oracle: 1/(1/a), a+b, a-b, b-a, a*b, sqr(sqrt(sqr a))"""
+    from modarith_amd.params import derive
+    from tests import edge_protocol
+    fp = derive(P)
+    assert edge_protocol.run(_OracleEdgeEngine(oracle, P, fp.nbytes), fp.p, fp.n, fp.nbytes) == []

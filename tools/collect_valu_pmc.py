@@ -14,7 +14,10 @@ import collections, csv, glob, json, os, sys
 
 tag = sys.argv[1]
 src = "gpurun_out/prof_%s" % tag
-want = {"k_x25519_fe26": ("k_x25519_fe26", 1 << 22), "k_x448_fe28": ("k_x448_fe28", 1 << 20)}
+# (substring of the demangled kernel name, units of the profiled pass); round 3: the split ladders = ladder kernel + batched finish
+want = {"k_x25519_fe26_xz": ("k_x25519_fe26_xz", 1 << 22), "k_fe_finish_fe26": ("k_fe_finish<ma::Fe26", 1 << 22),
+        "k_x448_fe28_xz": ("k_x448_fe28_xz", 1 << 20), "k_fe_finish_fe28": ("k_fe_finish<ma::Fe28", 1 << 20),
+        "k_x25519_fe26": ("k_x25519_fe26(", 1 << 22), "k_x448_fe28": ("k_x448_fe28(", 1 << 20)}
 for a in sys.argv[2:]:
     name, rest = a.split("=")
     sub, units = rest.rsplit(":", 1)
