@@ -1112,15 +1112,50 @@ struct Field {
 
     // progenitor x^PE (pseudo.py:758-785).  The reference takes its addition chain from the external
     // `addchain` tool; ours comes from the driver (P::modpro_chain).  Limbs differ, values do not.
-    // A real (non-inlined) device function: the chain is ~250 squarings + a dozen multiplications, so the call
-    // costs nothing, and every kernel of a translation unit that needs a progenitor (modpro, modinv, modsqrt,
-    // modqr, the ladders, point decompression) shares ONE copy of it instead of inlining its own.
+    // The chain is ~250 squarings + a dozen multiplications.  It is built from TWO out-of-line primitives -- a rolled run
+    // of squarings and one multiplication (chain_nsqr, chain_mul: real device functions, one copy each per field and
+    // policy in a translation unit) -- that every step of the chain calls.  Round 2 inlined the whole chain into one
+    // non-inlined function: a dozen copies of both bodies in a function without a register bound, which the scheduler
+    // filled to 228-248 VGPRs (1-2 waves per SIMD for every kernel that calls it) unless the multiply-add chains were
+    // left unpinned -- and unpinned, LLVM's reassociation turns a 110-instruction squaring into 264 instructions
+    // (PMC: 67 000 VALU instructions per X25519 modpro instead of 31 000).  Out of line, each primitive keeps the pinned
+    // product (the same code as the streaming kernels) in a small function of its own; the operands cross the call in
+    // private memory, 10 / 30 dword accesses per call against thousands of cycles of arithmetic.
+    static __device__ __attribute__((noinline)) void chain_nsqr(spint* a, int n) {
+        spint x[N];
+        modcpy(a, x);
+#pragma unroll 1
+        for (int i = 0; i < n; i++) modsqr(x, x);
+        modcpy(x, a);
+    }
+    static __device__ __attribute__((noinline)) void chain_mul(const spint* a, const spint* b, spint* c) {
+        spint x[N], y[N], z[N];
+        modcpy(a, x);
+        modcpy(b, y);
+        modmul(x, y, z);
+        modcpy(z, c);
+    }
+    struct ChainOps {           // what P::modpro_chain<F> calls
+        static MA_DEV void modcpy(const spint* a, spint* c) { Field::modcpy(a, c); }
+        static MA_DEV void modnsqr(spint* a, int n) { Field::chain_nsqr(a, n); }
+        static MA_DEV void modsqr(const spint* a, spint* c) { if (a != c) Field::modcpy(a, c); Field::chain_nsqr(c, 1); }
+        static MA_DEV void modmul(const spint* a, const spint* b, spint* c) { Field::chain_mul(a, b, c); }
+    };
+#ifdef MA_MODPRO_ROUND2         // experiment switch: the round-2 form (whole chain inlined into one non-inlined function, unpinned)
     static __device__ __attribute__((noinline)) void modpro(const spint* w, spint* z) {
         spint x[N], r[N];
         modcpy(w, x);
         P::template modpro_chain<Field<P, FAST_, false>>(x, r);
         modcpy(r, z);
     }
+#else
+    static MA_DEV void modpro(const spint* w, spint* z) {
+        spint x[N], r[N];
+        modcpy(w, x);
+        P::template modpro_chain<ChainOps>(x, r);
+        modcpy(r, z);
+    }
+#endif
 
     // pseudo.py:788-812
     static MA_DEV void modinv(const spint* x, const spint* h, spint* z) {

@@ -168,8 +168,11 @@ __global__ __launch_bounds__(BLOCK) void k_binary(const spint* a, const spint* b
         spint x[EPT][P::N], y[EPT][P::N], z[EPT][P::N];
         load_soa<P, EPT>(a, lda, t, x);
         load_soa<P, EPT>(b, ldb, t, y);
-#pragma unroll
-        for (int e = 0; e < EPT; e++) Op::apply(x[e], y[e], z[e]);
+        // (written out, not `#pragma unroll`: for the 8-limb two-path functors the optimizer declined to unroll the loop --
+        // "loop not unrolled" for ED448Q / SIDH434 -- which leaves x[e] indexed at run time, i.e. in scratch)
+        static_assert(EPT == 1 || EPT == 2, "one or two elements per lane");
+        Op::apply(x[0], y[0], z[0]);
+        if constexpr (EPT == 2) Op::apply(x[1], y[1], z[1]);
         store_soa<P, EPT>(c, ldc, t, z);
     }
 }
@@ -195,8 +198,9 @@ __global__ __launch_bounds__(BLOCK) void k_unary(const spint* a, spint* c, size_
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
         spint x[EPT][P::N], z[EPT][P::N];
         load_soa<P, EPT>(a, lda, t, x);
-#pragma unroll
-        for (int e = 0; e < EPT; e++) Op::apply(x[e], z[e]);
+        static_assert(EPT == 1 || EPT == 2, "one or two elements per lane");
+        Op::apply(x[0], z[0]);
+        if constexpr (EPT == 2) Op::apply(x[1], z[1]);
         store_soa<P, EPT>(c, ldc, t, z);
     }
 }
@@ -208,21 +212,24 @@ __global__ __launch_bounds__(BLOCK) void k_unary(const spint* a, spint* c, size_
 // scalar ALU, and every multiply-add reads ONE scalar and one vector source (the VOP3 constant-bus limit), so no
 // v_mov / s_nop copies surround the products as they do around the exact 64 x 64 -> 128 ones.  Same limbs either way.
 template <class P> struct Elem { spint l[P::N]; };
+template <class P, bool AUTO>
+MA_DEV void mul_shared_one(const spint* x, const spint* b, spint* z) {
+    if constexpr (AUTO && P::SPLIT > 0) {
+        if (__all(in_split_contract<P>(x))) { Field<P, true>::modmul(x, b, z); return; }
+    }
+    Field<P, false>::modmul(x, b, z);
+}
 template <class P, int EPT, bool AUTO>
 __global__ __launch_bounds__(BLOCK) void k_mul_shared(const spint* a, Elem<P> b0, spint* c,
                                                       size_t nthreads, size_t lda, size_t ldc) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
         spint x[EPT][P::N], z[EPT][P::N];
         load_soa<P, EPT>(a, lda, t, x);
-#pragma unroll
-        for (int e = 0; e < EPT; e++) {
-            // one element at a time, each with its own vote (as OpMulAuto): voting once for both elements lets the scheduler
-            // interleave two products and takes 136 VGPRs instead of 64
-            if constexpr (AUTO && P::SPLIT > 0) {
-                if (__all(in_split_contract<P>(x[e]))) { Field<P, true>::modmul(x[e], b0.l, z[e]); continue; }
-            }
-            Field<P, false>::modmul(x[e], b0.l, z[e]);
-        }
+        // one element at a time, each with its own vote (as OpMulAuto): voting once for both elements lets the scheduler
+        // interleave two products and takes 136 VGPRs instead of 64
+        static_assert(EPT == 1 || EPT == 2, "one or two elements per lane");
+        mul_shared_one<P, AUTO>(x[0], b0.l, z[0]);
+        if constexpr (EPT == 2) mul_shared_one<P, AUTO>(x[1], b0.l, z[1]);
         store_soa<P, EPT>(c, ldc, t, z);
     }
 }
@@ -234,8 +241,9 @@ __global__ __launch_bounds__(BLOCK) void k_mli(const spint* a, int b, spint* c, 
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
         spint x[EPT][P::N], z[EPT][P::N];
         load_soa<P, EPT>(a, lda, t, x);
-#pragma unroll
-        for (int e = 0; e < EPT; e++) Field<P>::modmli(x[e], b, z[e]);
+        static_assert(EPT == 1 || EPT == 2, "one or two elements per lane");
+        Field<P>::modmli(x[0], b, z[0]);
+        if constexpr (EPT == 2) Field<P>::modmli(x[1], b, z[1]);
         store_soa<P, EPT>(c, ldc, t, z);
     }
 }
