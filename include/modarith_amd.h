@@ -218,6 +218,12 @@ MODARITH_AMD_DECLARE(C41417)
 MODARITH_AMD_DECLARE(ED248)
 MODARITH_AMD_DECLARE(ED376)
 MODARITH_AMD_DECLARE(ED500)
+MODARITH_AMD_DECLARE(SIDH610)
+MODARITH_AMD_DECLARE(SIDH751)
+MODARITH_AMD_DECLARE(MFP4)
+MODARITH_AMD_DECLARE(MFP7)
+MODARITH_AMD_DECLARE(MFP1973)
+MODARITH_AMD_DECLARE(CSIDH512)
 
 /* RFC 7748 ladder, bv = [bk] * bu (reference rfc7748.c:156 `void rfc7748(const char *bk,const char *bu,char *bv)`).
  * Scalar form: host pointers, Nbytes each (32 / 56), RFC little-endian.  Batched form: device pointers,

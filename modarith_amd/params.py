@@ -58,6 +58,13 @@ NAMED = {
     "TWEEDLE": (0x40000000000000000000000000000000038aa127696286c9842cafd400000001, "monty"),
     "SIDH434": (2**216 * 3**137 - 1, "monty"),
     "SIDH503": (2**250 * 3**159 - 1, "monty"),
+    # the larger isogeny / MFP moduli of the same list (monty.py:2067-2105), round 3
+    "SIDH610": (2**305 * 3**192 - 1, "monty"),
+    "SIDH751": (2**372 * 3**239 - 1, "monty"),
+    "MFP4": (3 * 67 * 2**246 - 1, "monty"),
+    "MFP7": (2**145 * 3**9 * 59**3 * 311**3 * 317**3 * 503**3 - 1, "monty"),
+    "MFP1973": (0x34e29e286b95d98c33a6a86587407437252c9e49355147ffffffffffffffffff, "monty"),
+    "CSIDH512": (5326738796327623094747867617954605554069371494832722337612446642054009560026576537626892113026381253624626941643949444792662881241621373288942880288065659, "monty"),
     # group orders (curve.py:324-329 runs monty.py on "00<decimal q>"): general primes, full Montgomery
     "NIST256Q": (0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551, "monty"),
     "ED25519Q": (0x1000000000000000000000000000000014DEF9DEA2F79CD65812631A5CF5D3ED, "monty"),
@@ -65,7 +72,7 @@ NAMED = {
 }
 
 # per-name radix choices the generators hard-wire for 64-bit words (monty.py:2002-2037, `if WL==64: base=...`)
-RADIX_64 = {"GM240": 61, "GM360": 57, "GM480": 60, "GM384": 62, "GM512": 58}
+RADIX_64 = {"GM240": 61, "GM360": 57, "GM480": 60, "GM384": 62, "GM512": 58, "MFP4": 52, "MFP7": 52, "MFP1973": 52}
 
 # keys of NAMED that are not the generators' own spelling
 REFERENCE_NAME = {"SECP256K1M": "SECP256K1"}

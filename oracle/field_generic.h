@@ -5,7 +5,7 @@
 #include "oracle_types.h"
 #include <stddef.h>
 
-#define GMAXN 12
+#define GMAXN 16
 
 typedef struct {
     int family;          /* 0 = pseudo-Mersenne, 1 = Montgomery */

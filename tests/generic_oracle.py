@@ -6,7 +6,7 @@ from ctypes import c_int, c_longlong, c_size_t, c_uint64, c_void_p, POINTER
 
 from tests.conftest import load_golden
 
-GMAXN = 12
+GMAXN = 16
 U64P = POINTER(c_uint64)
 
 
