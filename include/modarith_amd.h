@@ -224,6 +224,7 @@ MODARITH_AMD_DECLARE(MFP4)
 MODARITH_AMD_DECLARE(MFP7)
 MODARITH_AMD_DECLARE(MFP1973)
 MODARITH_AMD_DECLARE(CSIDH512)
+MODARITH_AMD_DECLARE(GM378)
 
 /* RFC 7748 ladder, bv = [bk] * bu (reference rfc7748.c:156 `void rfc7748(const char *bk,const char *bu,char *bv)`).
  * Scalar form: host pointers, Nbytes each (32 / 56), RFC little-endian.  Batched form: device pointers,

@@ -24,7 +24,7 @@ CORE_PRIMES = ("X25519", "NIST256", "X448")            # BASELINE.json configs; 
 EXTRA_PRIMES = ("NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1M", "NIST256Q", "ED25519Q", "ED448Q",
                 "C2065", "PM336", "PM512", "GM270", "GM240", "GM360", "GM480", "GM384", "GM512", "TWEEDLE", "SIDH434", "SIDH503",
                 "SECP256K1", "C41417", "ED248", "ED376", "ED500",
-                "SIDH610", "SIDH751", "MFP4", "MFP7", "MFP1973", "CSIDH512")
+                "SIDH610", "SIDH751", "MFP4", "MFP7", "MFP1973", "CSIDH512", "GM378")
 BUILT_PRIMES = CORE_PRIMES + EXTRA_PRIMES
 
 

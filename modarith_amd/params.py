@@ -54,6 +54,7 @@ NAMED = {
     "GM480": (2**480 - 2**240 - 1, "monty"),
     "GM384": (2**384 - 2**186 - 1, "monty"),
     "GM512": (2**512 - 2**127 - 1, "monty"),
+    "GM378": (2**378 - 2**324 - 1, "monty"),
     "PM512": (2**512 - 569, "pseudo"),
     "TWEEDLE": (0x40000000000000000000000000000000038aa127696286c9842cafd400000001, "monty"),
     "SIDH434": (2**216 * 3**137 - 1, "monty"),
@@ -299,9 +300,9 @@ def derive_monty(name: str, p: int, radix: Optional[int] = None) -> FieldParams:
     pp = [(i, -1 if v < 0 else +1, abs(v)) for i, v in enumerate(ppw[:N]) if v]
     if E:
         # fold +1 * 2^(radix*N) into limb N-1 as +2^radix
-        pp = [t for t in pp if t[0] != N - 1] + [(N - 1, +1, (ppw[N - 1] if ppw[N - 1] > 0 else 0) + b)]
-        if ppw[N - 1] < 0:
-            raise NotImplementedError("negative top limb below a virtual limb")
+        # (a negative top limb, GM378's -1 at limb N-1, joins it: -x + x*q = x*(q-1) in the 64-bit arithmetic of
+        # caddp / addp / subp, monty.py:301-349)
+        pp = [t for t in pp if t[0] != N - 1] + [(N - 1, +1, ppw[N - 1] + b)]
     fp.pp = pp
     return fp
 

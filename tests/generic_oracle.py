@@ -50,7 +50,7 @@ def params_from_golden(prime):
             P.r2[i] = _i(v)
         pp = [(i, -1 if v < 0 else 1, abs(v)) for i, v in enumerate(ppw[:N]) if v]
         if P.E:
-            pp = [t for t in pp if t[0] != N - 1] + [(N - 1, 1, max(ppw[N - 1], 0) + (1 << radix))]
+            pp = [t for t in pp if t[0] != N - 1] + [(N - 1, 1, ppw[N - 1] + (1 << radix))]
     else:                                                    # pseudo.py
         P.family = 0
         P.m, P.mm = _i(g["m"]), _i(g["mm"])
