@@ -488,6 +488,33 @@ def main():
                 del vx_, vy_, wx_, wy_, e2, f2, Q2
             del e, f, G, Gc, Q, R
 
+    # The reference's time.c protocol ON THE GPU (the shape of simd/pseudo_cuda.py:1163-1231: every lane runs the serially
+    # dependent chains on the seed-42 operands, in registers): one wave for the latency per operation, 2^18 lanes for the
+    # in-register (VALU-bound) aggregate rate.  Depth 10^5 (the reference's loop counts / 1000: its `scale`; a single wave needs
+    # 0.7 us per dependent modmul, the full 10^8 would take a minute); check words of that depth from the reference-generated
+    # fixture tests/golden/field_X25519.json "time" (the modinv chain has period 2, so its word does not depend on the depth).
+    if not args.no_others and single:
+        radix, nl, ops, _ = TIME_C["X25519"]
+        mkl = lambda h: [(int(h, 16) >> (radix * i)) & ((1 << radix) - 1) for i in range(nl)]
+        tc = {}
+        for leg, opx, opy, outer, nops, ref in (("modmul", ops[0], ops[1], 100, 10**5, 0x570963), ("modsqr", ops[2], None, 100, 10**5, 0x9d7cea),
+                                                ("modinv", ops[3], None, 500, 10**3, 0xe70a06)):
+            res = {}
+            for tag, lanes in (("one_wave", 64), ("all_lanes", 1 << 18)):
+                xa = F.from_limbs([mkl(opx)]).expand(-1, lanes).contiguous()
+                ya = F.from_limbs([mkl(opy)]).expand(-1, lanes).contiguous() if opy else None
+                F.time_protocol(leg, xa, ya, 1)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                z = F.time_protocol(leg, xa, ya, outer)
+                torch.cuda.synchronize(); t1 = time.perf_counter() - t0
+                w = int(z[0, 0].item()) & 0xFFFFFF
+                assert w == ref and bool((z == z[:, :1]).all()), "time.c %s on the GPU: check word %#x, the reference's is %#x" % (leg, w, ref)
+                res[tag] = t1
+                del xa, ya, z
+            tc[leg] = {"one_wave_ns_per_op": res["one_wave"] / nops * 1e9, "ops": nops, "check_word": "0x%06x" % ref, "reference_check_word": "0x%06x" % ref,
+                       "all_lanes_ops_per_s": (1 << 18) * nops / res["all_lanes"], "lanes": 1 << 18}
+        others["time_c_protocol_gpu_X25519"] = tc
+
     ladder = None
     my_lt = None
     if not args.no_ladder:

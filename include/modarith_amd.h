@@ -225,6 +225,12 @@ MODARITH_AMD_DECLARE(MFP7)
 MODARITH_AMD_DECLARE(MFP1973)
 MODARITH_AMD_DECLARE(CSIDH512)
 MODARITH_AMD_DECLARE(GM378)
+MODARITH_AMD_DECLARE(PM383M)
+MODARITH_AMD_DECLARE(PM266M)
+MODARITH_AMD_DECLARE(PM336M)
+MODARITH_AMD_DECLARE(C41417M)
+MODARITH_AMD_DECLARE(PM512M)
+MODARITH_AMD_DECLARE(M607)
 
 /* RFC 7748 ladder, bv = [bk] * bu (reference rfc7748.c:156 `void rfc7748(const char *bk,const char *bu,char *bv)`).
  * Scalar form: host pointers, Nbytes each (32 / 56), RFC little-endian.  Batched form: device pointers,

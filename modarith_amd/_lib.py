@@ -16,7 +16,8 @@ PRIMES = ("X25519", "NIST256", "X448",
           "NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1M", "NIST256Q", "ED25519Q", "ED448Q",
           "C2065", "PM336", "PM512", "GM270", "GM240", "GM360", "GM480", "GM384", "GM512", "TWEEDLE", "SIDH434", "SIDH503",
           "SECP256K1", "C41417", "ED248", "ED376", "ED500",
-          "SIDH610", "SIDH751", "MFP4", "MFP7", "MFP1973", "CSIDH512", "GM378")
+          "SIDH610", "SIDH751", "MFP4", "MFP7", "MFP1973", "CSIDH512", "GM378",
+          "PM383M", "PM266M", "PM336M", "C41417M", "PM512M", "M607")
 LADDERS = ("X25519", "X448")
 CURVES = {"ed25519": (5, 32), "ed448": (8, 56), "nist256": (5, 32), "nist384": (7, 48), "nist521": (9, 66), "secp256k1": (5, 32), "nums256w": (5, 32), "nums256e": (5, 32), "ed248": (5, 32), "ed376": (7, 48), "ed500": (9, 64)}       # curve -> (Nlimbs, Nbytes)
 ED_BATCH_FUNCS = ("mul", "mul2", "ran", "add", "sub", "cpy", "dbl", "neg", "inf", "gen", "cof", "affine", "cmp", "isinf", "set", "get")

@@ -122,6 +122,7 @@ struct Field {
     static constexpr int RADIX = P::RADIX;
     static constexpr spint Q = (spint)1 << RADIX;
     static constexpr spint MASK = Q - 1;
+    using ov_t = std::conditional_t<P::BAD_OVERFLOW, dpint, spint>;     // see pm_modmul
     // (FOLD52: the 5 x 52 pseudo-Mersenne primes with a small mm -- 2^256-189 -- have no provable split form, mm * a does not
     // fit the three-accumulator scheme, but the half-limb columns with digit folding below do: pm_mul_half_ov)
     static constexpr bool FOLD52 = FAST_ && !P::MONTGOMERY && P::EPM && !P::OVERFLOW && P::RADIX == 52 && P::N == 5 && P::MM < (1ull << 16);
@@ -267,7 +268,9 @@ struct Field {
     static MA_DEV void pm_modmul(const spint* a, const spint* b, spint* c) {
         dpint t = 0;
         spint v[N];
-        spint hi_ov = 0;       // OVERFLOW form: high word of the previous row's folded sum (pseudo.py:407-420)
+        // OVERFLOW form: the carried high part of the previous row's folded sum (pseudo.py:407-420) -- one word, or a double
+        // word in the bad_overflow_mul form (pseudo.py:368-372, 412-416, 644-647: 601-610-bit moduli at 64 bits)
+        ov_t hi_ov = 0;
         Opd A[N], B[N], MA[N];
         static_for<0, N>([&](auto I) { A[I] = W::prep(a[I]); B[I] = W::prep(b[I]); });
         if constexpr (P::EPM) static_for<1, N>([&](auto I) { MA[I] = W::prep(a[I] * (spint)P::MM); });
@@ -291,8 +294,9 @@ struct Field {
                     // next row (bad_overflow_mul = False form; the driver refuses primes that need the other one)
                     const spint lo = (spint)tt & MASK;
                     if constexpr (row == 0) t += (dpint)lo * (dpint)P::MM;
+                    else if constexpr (P::BAD_OVERFLOW) t += (hi_ov + (dpint)lo) * (dpint)P::MM;
                     else t += (dpint)(spint)(lo + hi_ov) * (dpint)P::MM;
-                    hi_ov = (spint)(tt >> RADIX);
+                    hi_ov = (ov_t)(tt >> RADIX);
                 } else {
                     tt *= (dpint)P::MM;
                     t += tt;
@@ -314,7 +318,7 @@ struct Field {
     static MA_DEV void pm_modsqr(const spint* a, spint* c) {
         dpint t = 0;
         spint v[N];
-        spint hi_ov = 0;       // OVERFLOW form (pseudo.py:492-493, 536-550)
+        ov_t hi_ov = 0;        // OVERFLOW form (pseudo.py:492-493, 536-550; double word in the bad_overflow_sqr form)
         Opd A[N], TA[N], MA[N];
         static_for<0, N>([&](auto I) { A[I] = W::prep(a[I]); });
         if constexpr (P::EPM) {
@@ -351,8 +355,9 @@ struct Field {
                 if constexpr (P::OVERFLOW) {
                     const spint lo = (spint)tt & MASK;
                     if constexpr (row == 0) t += (dpint)lo * (dpint)P::MM;
+                    else if constexpr (P::BAD_OVERFLOW) t += (hi_ov + (dpint)lo) * (dpint)P::MM;
                     else t += (dpint)(spint)(lo + hi_ov) * (dpint)P::MM;
-                    hi_ov = (spint)(tt >> RADIX);
+                    hi_ov = (ov_t)(tt >> RADIX);
                 } else {
                     tt *= (dpint)P::MM;
                     t += tt;
@@ -656,8 +661,13 @@ struct Field {
     static constexpr int LMAX = P::MONTGOMERY ? (P::E ? N : N - 1) : 0;  // highest prime-limb index
     static constexpr int JMAX = LMAX;                                   // highest digit index
 
+    // monty.py's PM form (an exploitable pseudo-Mersenne 2^n - M given to monty.py: low prime limb -M, monty.py:284-288, 700-870):
+    // the low limb is carried with the borrow technique scaled by M -- column 0 adds M*(q - v0), every later column adds
+    // M*mask up front and takes M*v_i back with its own digit, and the last limb gives back M (or v_N - M below a virtual limb).
+    static constexpr spint PM_M = (spint)P::PM_M;
     template <int C>
     static MA_DEV void monty_reduce(dpint& t, Col& col, const spint* v, const Opd* V) {
+        if constexpr (PM_M != 0 && C >= 1) t += (dpint)(spint)(PM_M * MASK);
         constexpr int NEG = P::NEG_LIMB;       // index (>=1) of the single -1 limb, or 0 if none
         constexpr bool scratch = (NEG > 0) && (C > NEG);  // gone_neg at column start -> s = mask
         spint s = MASK;
@@ -688,9 +698,15 @@ struct Field {
 
     // reduction digit of a column (monty.py:698-712, 740-751): t & mask when ndash == 1 ("Montgomery
     // friendly"), else (t*ndash) & mask followed by t += v*p0 so that the low RADIX bits cancel
+    template <int COL>
     static MA_DEV spint monty_digit(dpint& t) {
         if constexpr (P::NDASH == 1) {
             return (spint)t & MASK;
+        } else if constexpr (PM_M != 0) {
+            const spint v = ((spint)t * (spint)P::NDASH) & MASK;
+            if constexpr (COL == 0) t += (dpint)(spint)(PM_M * (Q - v));
+            else t -= (dpint)(spint)(PM_M * v);
+            return v;
         } else {
             static_assert(P::ppw(0) > 0, "full Montgomery reduction expects a positive low prime limb");
             const spint v = ((spint)t * (spint)P::NDASH) & MASK;
@@ -743,7 +759,7 @@ struct Field {
             monty_reduce<col>(t, acc, v, V);
             t += acc.sum();
             if constexpr (col <= JMAX) {
-                v[col] = monty_digit(t);
+                v[col] = monty_digit<col>(t);
                 V[col] = W::prep(v[col]);
             } else {
                 c[col - JMAX - 1] = (spint)t & MASK;
@@ -751,10 +767,12 @@ struct Field {
             t >>= RADIX;
         });
         if constexpr (P::E) {
-            if constexpr (P::NEG_LIMB > 0) t += (dpint)(spint)(v[N] - (spint)1);
+            if constexpr (PM_M != 0) t += (dpint)(spint)(v[N] - PM_M);
+            else if constexpr (P::NEG_LIMB > 0) t += (dpint)(spint)(v[N] - (spint)1);
             else t += (dpint)v[N];
         } else {
-            if constexpr (P::NEG_LIMB > 0) t -= (dpint)1;
+            if constexpr (PM_M != 0) t -= (dpint)PM_M;
+            else if constexpr (P::NEG_LIMB > 0) t -= (dpint)1;
         }
         c[N - 1] = (spint)t;
     }
@@ -1025,7 +1043,12 @@ struct Field {
                 if constexpr (i >= 1 && i < N - 1 && d != 0) propc = true;
                 if constexpr (d == -1) c[i] += q;
                 else if constexpr (d == 1) c[i] -= q;
-                else if constexpr (d > 1 && (d & (d - 1)) == 0) {
+                else if constexpr (d < -1) {                           // PM form: the low limb -M (monty.py:958-959)
+                    static_assert(i == 0 && i < N - 1, "a negative prime limb other than -1 is the low limb of the PM form");
+                    dpint w = (dpint)q * (dpint)(spint)(-d);
+                    c[i] += (spint)w & MASK;
+                    c[i + 1] += (spint)(w >> RADIX);
+                } else if constexpr (d > 1 && (d & (d - 1)) == 0) {
                     constexpr int e = __builtin_ctzll((unsigned long long)d);
                     if constexpr (i < N - 1) {
                         dpint w = (dpint)q << e;

@@ -24,7 +24,8 @@ CORE_PRIMES = ("X25519", "NIST256", "X448")            # BASELINE.json configs; 
 EXTRA_PRIMES = ("NIST521", "PM266", "PM383", "NUMS256W", "NIST384", "NIST224", "SECP256K1M", "NIST256Q", "ED25519Q", "ED448Q",
                 "C2065", "PM336", "PM512", "GM270", "GM240", "GM360", "GM480", "GM384", "GM512", "TWEEDLE", "SIDH434", "SIDH503",
                 "SECP256K1", "C41417", "ED248", "ED376", "ED500",
-                "SIDH610", "SIDH751", "MFP4", "MFP7", "MFP1973", "CSIDH512", "GM378")
+                "SIDH610", "SIDH751", "MFP4", "MFP7", "MFP1973", "CSIDH512", "GM378",
+                "PM383M", "PM266M", "PM336M", "C41417M", "PM512M", "M607")
 BUILT_PRIMES = CORE_PRIMES + EXTRA_PRIMES
 
 
@@ -250,6 +251,8 @@ def split_point(fp: FieldParams) -> int:
     Contract: every limb < 2^(radix+2) (tight limbs, [p,2p) with the top limb unmasked, generic=False sums);
     pre-multiplied operands (ma = mm*a, ta = 2a) are wider by bits(mm) / 1 bit.  n = most products per column."""
     W = fp.radix + 2
+    if fp.pm or fp.bad_overflow:
+        return 0                # monty.py's PM form / pseudo.py's bad_overflow form: exact products only
     if fp.family == "pseudo":
         wa = W + (fp.mm.bit_length() if fp.epm else 0)
         wb = W + (1 if fp.epm else 0)
@@ -318,18 +321,19 @@ def header_text(fp: FieldParams) -> str:
     L.append("    static constexpr bool CHAIN = %s;   // FAST product loops on the 64-bit column chain (emit.chain_ok)" % ("true" if chain_ok(fp) else "false"))
     # pseudo-Mersenne block (dummies for Montgomery primes)
     L.append("    static constexpr unsigned long long M = %s, MM = %s;" % (_hexu(fp.m if not fp.montgomery else 0), _hexu(fp.mm)))
-    L.append("    static constexpr bool OVERFLOW = %s, FRED = %s, EPM = %s, CARRY_ON = %s;"
-             % tuple("true" if b else "false" for b in (fp.overflow, fp.fred, fp.epm, fp.carry_on)))
+    L.append("    static constexpr bool OVERFLOW = %s, FRED = %s, EPM = %s, CARRY_ON = %s, BAD_OVERFLOW = %s;"
+             % tuple("true" if b else "false" for b in (fp.overflow, fp.fred, fp.epm, fp.carry_on, fp.bad_overflow)))
     # Montgomery block (dummies for pseudo-Mersenne primes)
     neg = [i for i, v in enumerate(fp.ppw) if i > 0 and v == -1]
     L.append("    static constexpr bool E = %s;" % ("true" if fp.E else "false"))
+    L.append("    static constexpr unsigned long long PM_M = %s;   // monty.py's PM form: ppw(0) = -PM_M (0 = not that form)" % _hexu(fp.m if fp.pm else 0))
     L.append("    static constexpr unsigned long long NDASH = %s;" % _hexu(fp.ndash))
     L.append("    static constexpr int TRIN = %d, NEG_LIMB = %d;" % (fp.trin, neg[0] if neg else 0))
     br = (1 << (fp.n + fp.radix)) // fp.p if fp.montgomery else 0
     L.append("    static constexpr unsigned long long BARRETT_R = %s;  // floor(2^(n+Radix)/p) (monty.py:923)" % _hexu(br if br < 1 << 64 else 0))
     L.append("    static constexpr int BARRETT_SHIFT = %d;                 // (n-64) %% Radix (monty.py:930)" % ((fp.n - 64) % fp.radix))
     ppw = fp.ppw if fp.ppw else [0]
-    L.append(_switch("ppw", "long long", ppw, lambda v: "%dll" % v if abs(v) < 10 else ("0x%xll" % v)))
+    L.append(_switch("ppw", "long long", ppw, lambda v: "%dll" % v if (abs(v) < 10 or v < 0) else ("0x%xll" % v)))
     r2 = fp.r2 if fp.r2 else [0] * N
     L.append(_switch("r2", "unsigned long long", r2, _hexu))
     # non-zero prime limbs for caddp/addp/subp

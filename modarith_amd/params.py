@@ -43,6 +43,15 @@ NAMED = {
     "SECP256K1": (2**256 - 2**32 - 977, "pseudo"),
     "SECP256K1M": (2**256 - 2**32 - 977, "monty"),
     "C41417": (2**414 - 17, "pseudo"),
+    # the same pseudo-Mersennes as monty.py builds them when asked (monty.py:2010-2042 names them too): PM383 / PM266 / PM336 in
+    # its "exploitable pseudo-Mersenne" form (PM = True, monty.py:700-870), C41417 / PM512 as ordinary full-Montgomery primes
+    "PM383M": (2**383 - 187, "monty"),
+    "PM266M": (2**266 - 3, "monty"),
+    "PM336M": (2**336 - 3, "monty"),
+    "C41417M": (2**414 - 17, "monty"),
+    "PM512M": (2**512 - 569, "monty"),
+    # a 607-bit Mersenne prime: the only kind of modulus that takes pseudo.py's bad_overflow forms at 64 bits (601-610 bits)
+    "M607": (2**607 - 1, "pseudo"),
     # the fields of curve.py's ED248 / ED376 / ED500 (monty.py:2095-2102)
     "ED248": (5 * 2**248 - 1, "monty"),
     "ED376": (65 * 2**376 - 1, "monty"),
@@ -73,10 +82,11 @@ NAMED = {
 }
 
 # per-name radix choices the generators hard-wire for 64-bit words (monty.py:2002-2037, `if WL==64: base=...`)
-RADIX_64 = {"GM240": 61, "GM360": 57, "GM480": 60, "GM384": 62, "GM512": 58, "MFP4": 52, "MFP7": 52, "MFP1973": 52}
+RADIX_64 = {"GM240": 61, "GM360": 57, "GM480": 60, "GM384": 62, "GM512": 58, "MFP4": 52, "MFP7": 52, "MFP1973": 52, "PM512M": 58}
 
 # keys of NAMED that are not the generators' own spelling
-REFERENCE_NAME = {"SECP256K1M": "SECP256K1"}
+REFERENCE_NAME = {"SECP256K1M": "SECP256K1", "PM383M": "PM383", "PM266M": "PM266", "PM336M": "PM336", "C41417M": "C41417", "PM512M": "PM512",
+                  "M607": "2**607-1"}
 
 # how each built name is spelled on the reference generators' command line (group orders: "00" + decimal)
 def reference_argv(name: str):
@@ -105,6 +115,7 @@ class FieldParams:
     mm: int = 0                 # m * 2^xcess  (fold multiplier)
     tw: int = 0                 # top word of p in limb nlimbs-1 (as added by caddp)
     overflow: bool = False
+    bad_overflow: bool = False  # pseudo.py:1646-1648: the carried high part of the overflow form needs a double word
     fred: bool = False
     epm: bool = False
     carry_on: bool = False
@@ -115,6 +126,7 @@ class FieldParams:
     ndash: int = 1
     r2: List[int] = field(default_factory=list)    # R^2 mod p, limbs (nres multiplier)
     trin: int = 0
+    pm: bool = False            # monty.py's PM form: an exploitable pseudo-Mersenne given to monty.py (ppw[0] = -m)
     # derived for both families: non-zero prime limbs as (index, sign, magnitude) with the virtual
     # limb folded into limb nlimbs-1 as +2^radix (caddp/addp/subp: pseudo.py:202-220, monty.py:301-349)
     pp: List[tuple] = field(default_factory=list)
@@ -197,28 +209,33 @@ def derive_pseudo(name: str, p: int, radix: Optional[int] = None) -> FieldParams
         raise ValueError("excess too large for this radix")
     tw = b if n % radix == 0 else 1 << (n % radix)
     overflow = (b - 1) * (b - 1) * mm * N >= 1 << (2 * WL)
-    if overflow and (N - 1) * (b - 1) ** 2 >= 1 << (2 * WL - 3):
-        raise ValueError("pseudo.py's bad_overflow forms (pseudo.py:1646-1648) are not built")
+    bad_overflow = overflow and (N - 1) * (b - 1) ** 2 >= 1 << (2 * WL - 3)      # pseudo.py:1646-1648 (no Karatsuba at 64 bits)
     fred = _bits(N + 1) + radix + _bits(mm) < WL
     epm = (not overflow) and mm * (b - 1) < 1 << WL
     carry_on = m * ((1 << (2 * WL - radix + xcess)) + (1 << (radix - xcess))) >= 1 << (2 * radix)
     k, pe = _two_adic(p)
     fp = FieldParams(name=name, family="pseudo", p=p, n=n, radix=radix, nlimbs=N, xcess=xcess,
                      nbytes=-(-n // 8), pm1d2=k, pe=pe, roi=_makebig(_root_of_unity(p, k), radix, N),
-                     m=m, mm=mm, tw=tw, overflow=overflow, fred=fred, epm=epm, carry_on=carry_on)
+                     m=m, mm=mm, tw=tw, overflow=overflow, bad_overflow=bad_overflow, fred=fred, epm=epm, carry_on=carry_on)
     fp.pp = [(0, -1, m), (N - 1, +1, tw)]
     return fp
 
 
 # ------------------------------------------------------------------ Montgomery, shape-aware
-def _signed_limbs(p: int, radix: int, N: int):
+def _signed_limbs(p: int, radix: int, N: int, pm_m: int = 0):
     """rewrite limbs equal to 2^radix-1 as -1 with a carry into the next limb; a carry out of the
-    top limb becomes a virtual extra limb (process_prime, monty.py:258-298, PM=False path)."""
+    top limb becomes a virtual extra limb (process_prime, monty.py:258-298).  pm_m = m for the PM form: a low limb
+    2^radix - m becomes -m, with the same carry (monty.py:284-288)."""
     b = 1 << radix
     pw = _makebig(p, radix, N)
     out, carry = [], 0
     for i in range(N):
         v = pw[i] + carry
+        if pm_m and i == 0:
+            if v == b - pm_m:
+                v, carry = -pm_m, 1
+            out.append(v)
+            continue
         if carry:
             if v == b - 1:
                 v = -1                      # carry stays 1
@@ -283,9 +300,8 @@ def derive_monty(name: str, p: int, radix: Optional[int] = None) -> FieldParams:
     N = -(-n // radix)
     xcess = N * radix - n
     m = (1 << n) - p
-    if m > 1 and _bits(m) + radix < WL:
-        raise NotImplementedError("monty.py's pseudo-Mersenne shortcut (PM=True) is not built; use family 'pseudo'")
-    ppw, E = _signed_limbs(p, radix, N)
+    pm = m > 1 and _bits(m) + radix < WL               # "Exploitable Pseudo Mersenne detected" (monty.py:2151-2156)
+    ppw, E = _signed_limbs(p, radix, N, m if pm else 0)
     if sum(1 for i, v in enumerate(ppw) if i > 0 and v == -1) > 1:
         raise ValueError("too many -1 limbs (monty.py:2217-2219)")
     if xcess < 2 and not E:
@@ -296,7 +312,7 @@ def derive_monty(name: str, p: int, radix: Optional[int] = None) -> FieldParams:
     fp = FieldParams(name=name, family="monty", p=p, n=n, radix=radix, nlimbs=N, xcess=xcess,
                      nbytes=-(-n // 8), pm1d2=k, pe=pe, roi=_makebig(_root_of_unity(p, k), radix, N),
                      m=m, ppw=ppw, E=E, R=R, ndash=ndash, r2=_makebig(R * R % p, radix, N),
-                     trin=_trinomial(p, radix))
+                     trin=_trinomial(p, radix), pm=pm)
     pp = [(i, -1 if v < 0 else +1, abs(v)) for i, v in enumerate(ppw[:N]) if v]
     if E:
         # fold +1 * 2^(radix*N) into limb N-1 as +2^radix

@@ -99,7 +99,8 @@ static void pm_second_pass(const gparams *P, dpint t, spint *v, spint *c) {
 }
 static void pm_modmul(const gparams *P, const spint *a, const spint *b, spint *c) {
     dpint t = 0;
-    spint v[GMAXN], ma[GMAXN], hi = 0;
+    spint v[GMAXN], ma[GMAXN];
+    dpint hi = 0;                                   /* spint in the ordinary overflow form, dpint in the bad_overflow one */
     if (P->epm) for (int i = 1; i < N; i++) ma[i] = a[i] * P->mm;
     for (int row = 0; row < N; row++) {
         if (P->epm) {
@@ -107,18 +108,19 @@ static void pm_modmul(const gparams *P, const spint *a, const spint *b, spint *c
         } else if (row < N - 1) {
             dpint tt = 0;
             for (int k = row + 1; k < N; k++) tt += (dpint)a[k] * (dpint)b[N + row - k];
-            if (P->overflow) {                      /* getZM, pseudo.py:407-420 (bad_overflow_mul = False form) */
+            if (P->overflow) {                      /* getZM, pseudo.py:407-420: both bad_overflow_mul forms */
                 spint lo = (spint)tt & MASK;
                 if (row == 0) t += (dpint)lo * (dpint)P->mm;
-                else t += (dpint)(spint)(lo + hi) * (dpint)P->mm;
-                hi = (spint)(tt >> P->radix);
+                else if (P->bad_overflow) t += (hi + (dpint)lo) * (dpint)P->mm;
+                else t += (dpint)(spint)(lo + (spint)hi) * (dpint)P->mm;
+                hi = P->bad_overflow ? (tt >> P->radix) : (dpint)(spint)(tt >> P->radix);
             } else {
                 tt *= (dpint)P->mm;
                 t += tt;
             }
         }
         for (int k = 0; k <= row; k++) t += (dpint)a[k] * (dpint)b[row - k];
-        if (row == N - 1 && P->overflow) t += (dpint)hi * (dpint)P->mm;          /* pseudo.py:435-436 */
+        if (row == N - 1 && P->overflow) t += hi * (dpint)P->mm;                 /* pseudo.py:435-436 */
         v[row] = (spint)t & MASK;
         t >>= P->radix;
     }
@@ -126,7 +128,8 @@ static void pm_modmul(const gparams *P, const spint *a, const spint *b, spint *c
 }
 static void pm_modsqr(const gparams *P, const spint *a, spint *c) {
     dpint t = 0;
-    spint v[GMAXN], ta[GMAXN], ma[GMAXN], hi = 0;
+    spint v[GMAXN], ta[GMAXN], ma[GMAXN];
+    dpint hi = 0;
     if (P->epm) for (int i = 1; i < N; i++) { ta[i] = a[i] * (spint)2; ma[i] = a[i] * P->mm; }
     for (int row = 0; row < N; row++) {
         int k = row + 1, l = N - 1;
@@ -139,17 +142,18 @@ static void pm_modsqr(const gparams *P, const spint *a, spint *c) {
             for (; k < l; k++, l--) tt += (dpint)a[k] * (dpint)a[l];
             if (dble) tt *= 2;
             if (k == l) tt += (dpint)a[k] * (dpint)a[k];
-            if (P->overflow) {                      /* getZS, pseudo.py:492-493, 536-550 (bad_overflow_sqr = False form) */
+            if (P->overflow) {                      /* getZS, pseudo.py:492-493, 536-550: both bad_overflow_sqr forms */
                 spint lo = (spint)tt & MASK;
                 if (row == 0) t += (dpint)lo * (dpint)P->mm;
-                else t += (dpint)(spint)(lo + hi) * (dpint)P->mm;
-                hi = (spint)(tt >> P->radix);
+                else if (P->bad_overflow) t += (hi + (dpint)lo) * (dpint)P->mm;
+                else t += (dpint)(spint)(lo + (spint)hi) * (dpint)P->mm;
+                hi = P->bad_overflow ? (tt >> P->radix) : (dpint)(spint)(tt >> P->radix);
             } else {
                 tt *= (dpint)P->mm;
                 t += tt;
             }
         } else if (P->overflow) {
-            t += (dpint)hi * (dpint)P->mm;          /* row N-1: pseudo.py:537-538 */
+            t += hi * (dpint)P->mm;                 /* row N-1: pseudo.py:537-538 */
         }
         k = 0; l = row;
         if (P->epm) {
@@ -184,8 +188,13 @@ static int is_pow2(long long d) { return d > 1 && (d & (d - 1)) == 0; }
 static int log2ll(long long d) { int e = 0; while (((long long)1 << e) < d) e++; return e; }
 
 /* reduction contribution of column c: digit v_j meets signed prime limb l = c - j (mul_process, 597-627) */
+/* monty.py's PM form (an exploitable pseudo-Mersenne 2^n - M given to monty.py: ppw[0] = -M, monty.py:284-288): the low limb is
+ * carried with the borrow technique scaled by M -- column 0 adds M*(q - v0), every later column adds M*mask and takes M*v_i
+ * back with its own digit, and the last limb gives back M (monty.py:700-870) */
+static spint pm_m(const gparams *P) { return (P->family && P->ppw[0] < -1) ? (spint)(-P->ppw[0]) : 0; }
 static void mo_reduce(const gparams *P, int c, dpint *t, const spint *v) {
     const spint q = ((spint)1) << P->radix, mask = q - 1;
+    if (pm_m(P) && c >= 1) *t += (dpint)(spint)(pm_m(P) * mask);
     const int lmax = P->E ? N : N - 1;
     const int scratch = P->neg_limb > 0 && c > P->neg_limb;
     spint s = mask;
@@ -204,10 +213,13 @@ static void mo_reduce(const gparams *P, int c, dpint *t, const spint *v) {
     }
     if (scratch) *t += (dpint)s;
 }
-static spint mo_digit(const gparams *P, dpint *t) {
+static spint mo_digit(const gparams *P, dpint *t, int col) {
     if (P->ndash == 1) return (spint)*t & MASK;
     spint v = ((spint)*t * P->ndash) & MASK;
-    if (P->ppw[0] == 1) *t += (dpint)v; else *t += (dpint)v * (dpint)(spint)P->ppw[0];
+    if (pm_m(P)) {
+        const spint q = ((spint)1) << P->radix;
+        if (col == 0) *t += (dpint)(spint)(pm_m(P) * (q - v)); else *t -= (dpint)(spint)(pm_m(P) * v);
+    } else if (P->ppw[0] == 1) *t += (dpint)v; else *t += (dpint)v * (dpint)(spint)P->ppw[0];
     return v;
 }
 static void mo_mul(const gparams *P, const spint *a, const spint *b, spint *c, int sqr) {
@@ -230,12 +242,15 @@ static void mo_mul(const gparams *P, const spint *a, const spint *b, spint *c, i
             }
         }
         mo_reduce(P, col, &t, v);
-        if (col <= jmax) v[col] = mo_digit(P, &t);
+        if (col <= jmax) v[col] = mo_digit(P, &t, col);
         else c[col - jmax - 1] = (spint)t & MASK;
         t >>= P->radix;
     }
     if (P->E) {
-        if (P->neg_limb > 0) t += (dpint)(spint)(v[N] - (spint)1); else t += (dpint)v[N];
+        if (pm_m(P)) t += (dpint)(spint)(v[N] - pm_m(P));
+        else if (P->neg_limb > 0) t += (dpint)(spint)(v[N] - (spint)1); else t += (dpint)v[N];
+    } else if (pm_m(P)) {
+        t -= (dpint)pm_m(P);
     } else if (P->neg_limb > 0) {
         t -= (dpint)1;
     }
@@ -264,6 +279,7 @@ static void mo_modmli(const gparams *P, const spint *a, int b, spint *c) {
         if (d == 0) continue;
         if (d == -1) c[i] += q;
         else if (d == 1) c[i] -= q;
+        else if (d < 0) { dpint w = (dpint)q * (dpint)(spint)(-d); c[i] += (spint)w & MASK; c[i + 1] += (spint)(w >> R); }   /* PM: limb 0 */
         else if (is_pow2(d)) {
             if (i < N - 1) { dpint w = (dpint)q << log2ll(d); c[i] -= (spint)w & MASK; c[i + 1] -= (spint)(w >> R); }
             else c[i] -= q << log2ll(d);

@@ -27,6 +27,7 @@ typedef struct {
     spint roi[GMAXN];
     /* pseudo.py:1640-1657: column sums would overflow 128 bits, the folded high part is split (lo, hi) instead */
     int overflow;
+    int bad_overflow;    /* pseudo.py:1646-1648: the carried high part needs a double word too (bad_overflow_mul / _sqr) */
 } gparams;
 
 spint gen_flatten(const gparams *P, spint *n);

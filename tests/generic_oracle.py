@@ -16,7 +16,7 @@ class GParams(ctypes.Structure):
                 ("ppw", c_longlong * (GMAXN + 1)), ("E", c_int), ("trin", c_int), ("neg_limb", c_int),
                 ("ndash", c_uint64), ("barrett_r", c_uint64), ("r2", c_uint64 * GMAXN),
                 ("pp_cnt", c_int), ("pp_idx", c_int * GMAXN), ("pp_sgn", c_int * GMAXN), ("pp_val", c_uint64 * GMAXN),
-                ("pe_words", c_int), ("pe", c_uint64 * GMAXN), ("roi", c_uint64 * GMAXN), ("overflow", c_int)]
+                ("pe_words", c_int), ("pe", c_uint64 * GMAXN), ("roi", c_uint64 * GMAXN), ("overflow", c_int), ("bad_overflow", c_int)]
 
 
 def _i(v):
@@ -56,7 +56,8 @@ def params_from_golden(prime):
         P.m, P.mm = _i(g["m"]), _i(g["mm"])
         P.epm, P.fred, P.carry_on = int(g["EPM"]), int(g["fred"]), int(g["carry_on"])
         P.overflow = int(g["overflow"])
-        assert not (g["bad_overflow_mul"] or g["bad_overflow_sqr"]), "the bad_overflow forms are not restated"
+        assert g["bad_overflow_mul"] == g["bad_overflow_sqr"], "the generators set both flags together at 64 bits (no Karatsuba)"
+        P.bad_overflow = int(g["bad_overflow_mul"])
         
         pp = [(0, -1, _i(g["m"])), (N - 1, 1, _i(g["TW"]))]
     P.pp_cnt = len(pp)

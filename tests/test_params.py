@@ -30,11 +30,14 @@ def test_driver_matches_reference_constants(P):
     if fp.family == "pseudo":
         assert (fp.m, fp.mm, fp.tw) == (_i(g["m"]), _i(g["mm"]), _i(g["TW"]))
         assert (fp.overflow, fp.fred, fp.epm, fp.carry_on) == (g["overflow"], g["fred"], g["EPM"], g["carry_on"])
+        assert fp.bad_overflow == g["bad_overflow_mul"] == g["bad_overflow_sqr"]
     else:
         assert fp.ppw == [(-_i(v[1:]) if v.startswith("-") else _i(v)) for v in g["ppw"]]
         assert (fp.E, fp.R, fp.ndash, fp.trin) == (g["E"], _i(g["R"]), _i(g["ndash"]), g["trin"])
         assert fp.r2 == [_i(v) for v in g["cw"]]
-        assert g["fullmonty"] is (fp.ndash != 1) and g["PM"] is False
+        assert g["fullmonty"] is (fp.ndash != 1) and g["PM"] is fp.pm
+        if fp.pm:
+            assert _i(g["M"]) == fp.m == -fp.ppw[0]
 
 
 def test_reference_stdout_lines():
@@ -56,7 +59,7 @@ def test_addition_chain_computes_progenitor(P):
         assert emit.eval_chain(prog, x, fp.p) == pow(x, fp.pe, fp.p)
     sq, mu = emit.chain_cost(prog)
     assert sq <= fp.pe.bit_length()               # squarings == bit length - 1: the leading run ladder is the main chain
-    if not P.endswith("Q") and P not in ("TWEEDLE", "SIDH434", "SIDH503", "SIDH610", "SIDH751", "MFP4", "MFP7", "MFP1973", "CSIDH512"):
+    if not P.endswith("Q") and P not in ("TWEEDLE", "SIDH434", "SIDH503", "SIDH610", "SIDH751", "MFP4", "MFP7", "MFP1973", "CSIDH512", "M607"):
         assert mu <= 20                           # shaped primes: long runs of ones; general primes take the loop form
 
 
