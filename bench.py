@@ -34,6 +34,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 BYTES_PER_MODMUL = 120         # 3 arrays x 5 limbs x 8 B
 LOG2_ELEMS = int(os.environ.get("MA_BENCH_LOG2_ELEMS", "24"))
 LOG2_LADDER = int(os.environ.get("MA_BENCH_LOG2_LADDER", "23"))
+# HBM layout of the field batches: limb-interleaved SoA in tiles of TILE elements (include/modarith_amd.h "TILED");
+# MA_BENCH_TILE=0 benchmarks the flat layout buf[limb * n + j] instead.  The line reports the other layout as a data set.
+TILE = int(os.environ.get("MA_BENCH_TILE", "4096"))
 
 
 def _native_baseline_lib():
@@ -272,7 +275,7 @@ def main():
     single = world == 1            # side figures (other data sets, other fields, the curve layer) are N=1 material only
 
     from modarith_amd.field import Field, rfc7748
-    F = Field("X25519", dev)
+    F = Field("X25519", dev, tile=TILE or None)
     n = 1 << LOG2_ELEMS
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     # SURVEY 8(d) C2 input recipe: a[j], b[j] uniform in [0,p), element j of the splitmix64 stream keyed by
@@ -370,7 +373,7 @@ def main():
         ms = rate(lambda: F.modmul(c2, c, out=fb))
         data_sets["fed_back_outputs"] = {"modmul_per_s_per_gpu": n / (ms * 1e-3), "GBps": BYTES_PER_MODMUL * n / (ms * 1e-3) / 1e9, "kernel_ms": ms}
         # shared multiplicand c[j] = a[j]*b0 (80 B per element)
-        b0 = [int(v) for v in b[:, 0].cpu().numpy().view("uint64")]
+        b0 = [int(v) for v in F.to_limbs(F.uniform(1, seed=SEED, array=AID + 1))[0]]      # element 0 of b
         ms = rate(lambda: F.modmuls(a, b0, out=fb))
         data_sets["shared_multiplicand"] = {"modmul_per_s_per_gpu": n / (ms * 1e-3), "GBps": 80 * n / (ms * 1e-3) / 1e9, "kernel_ms": ms, "bytes_per_element": 80,
                                             "frac_of_hbm_peak": 80 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "k_mul_shared<P_X25519,2,true>"}
@@ -380,13 +383,23 @@ def main():
         ms = rate(lambda: F.modcpy(a, out=fb))
         data_sets["control_modcpy_2_streams"] = {"GBps": 80 * n / (ms * 1e-3) / 1e9, "kernel_ms": ms, "frac_of_hbm_peak": 80 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del c2, fb
+        # the same batch through the OTHER layout (flat rows n * 8 bytes apart when the headline runs on tiles, and vice versa)
+        Fo = Field("X25519", dev, tile=None if TILE else 4096)
+        ao, bo = (F.to_flat(a), F.to_flat(b)) if TILE else (Fo.to_tiled(a), Fo.to_tiled(b))
+        co = torch.empty_like(ao)
+        ms = rate(lambda: Fo.modmul(ao, bo, out=co))
+        assert torch.equal(F.to_flat(c), Fo.to_flat(co)), "the two layouts disagree"
+        data_sets["other_layout_%s" % ("flat" if TILE else "tiled_4096")] = {"modmul_per_s_per_gpu": n / (ms * 1e-3), "GBps": BYTES_PER_MODMUL * n / (ms * 1e-3) / 1e9,
+                                                                              "kernel_ms": ms, "frac_of_hbm_peak": BYTES_PER_MODMUL * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                                              "note": "same operand values, same kernel, the other HBM layout; one placement (no probe)"}
+        del ao, bo, co
 
     # the other single-GPU configs of BASELINE.json (configs[2], configs[3]) with the same protocol, short runs:
     # parity for them is in tests/; these are side figures, not the headline
     others = {}
     if not args.no_others and single:
         for P, ops in (("NIST256", ("modmul",)), ("X448", ("modmul", "modsqr"))):
-            Fp = Field(P, dev)
+            Fp = Field(P, dev, tile=TILE or None)
             # uniform in [0,p) by the same recipe, then nres (Montgomery form)
             xa = Fp.uniform(n, seed=SEED, array=AID + 2)
             xb = Fp.uniform(n, seed=SEED, array=AID + 3)
@@ -576,11 +589,13 @@ def main():
         if rank == 0 and use_dist:
             dist.barrier()
         idx = torch.cat([torch.arange(0, 4096), torch.arange(n - 4096, n), torch.arange(0, n, max(n // 4096, 1))]).unique().to(dev)
-        ha = np.ascontiguousarray(a[:, idx].cpu().numpy().view(np.uint64))
-        hb = np.ascontiguousarray(b[:, idx].cpu().numpy().view(np.uint64))
+        af, bf, cf = F.to_flat(a), F.to_flat(b), F.to_flat(c)           # element order j, whatever the HBM layout
+        ha = np.ascontiguousarray(af[:, idx].cpu().numpy().view(np.uint64))
+        hb = np.ascontiguousarray(bf[:, idx].cpu().numpy().view(np.uint64))
         hc = np.empty_like(ha)
         oracle.fn("batch_modmul", "X25519")(vp(ha), vp(hb), vp(hc), ha.shape[1], ha.shape[1])
-        ok_mul = bool(np.array_equal(c[:, idx].cpu().numpy().view(np.uint64), hc))
+        ok_mul = bool(np.array_equal(cf[:, idx].cpu().numpy().view(np.uint64), hc))
+        del af, bf, cf
         verified = {"modmul_elements_per_rank": int(idx.numel())}
         ok_lad = True
         if ladder is not None:
@@ -622,7 +637,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu:
             import numpy as np
-            cpu = cpu_baseline(np.ascontiguousarray(a.cpu().numpy().view(np.uint64)), np.ascontiguousarray(b.cpu().numpy().view(np.uint64)))
+            cpu = cpu_baseline(np.ascontiguousarray(F.to_flat(a).cpu().numpy().view(np.uint64)), np.ascontiguousarray(F.to_flat(b).cpu().numpy().view(np.uint64)))
         # HBM bytes per launch from the PMC passes (FETCH_SIZE, WRITE_SIZE; tools/gpu_profile.sh) of the same command on
         # the same build: a property of the kernel and the batch size, so it is only quoted for the profiled size
         traffic, traffic_source = None, None
@@ -642,7 +657,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "batched modmul 2^255-19, 5x51-bit limbs, 2^%d elements per GPU, limb-interleaved SoA" % LOG2_ELEMS,
+            "config": {"workload": "batched modmul 2^255-19, 5x51-bit limbs, 2^%d elements per GPU, limb-interleaved SoA, %s" % (LOG2_ELEMS, ("tiles of %d elements [n/%d][5][%d]" % (TILE, TILE, TILE)) if TILE else "flat rows [5][n]"),
+                       "layout": {"tile": TILE, "note": "limb i of element j at buf[((j / tile) * 5 + i) * tile + j % tile]; tile = 0: flat buf[i * n + j]; data_sets.other_layout_* times the other form"},
                        "elements_per_gpu": n, "placement_probe_GBps": [round(r, 1) for r in probe_rates], "inputs": "uniform mod p: splitmix64 stream (seed 42, array id, j) reduced mod p, generated on the device",
                        "placement_policy": "timed on the fastest of %d probed operand placements (identical contents); a caller that allocates once without probing gets one draw from this spread -- see roofline.frac_first_placement / frac_median_placement" % placements if placements > 1 else "single placement, no probe",
                        "parallelism": "independent batches, %d rank(s), no data-path collective" % world},

@@ -18,9 +18,16 @@
  * 5 x 52-bit, Montgomery form, R = 2^260), X448 (monty.py 64 X448: 8 x 56-bit, Montgomery form,
  * R = 2^504).  spint = uint64_t as in the 64-bit field.c (pseudo.py:1394-1398).
  *
- * Batched layout: limb-interleaved SoA.  A batch of n elements is a u64 array buf[limb*ld + j],
- * 0 <= limb < Nlimbs, 0 <= j < n, ld >= n the limb stride in elements ("lanes" of simd.h, j-major
- * within a limb).  ld lets a call work on a slice [off, off+n) of a larger batch (pass buf+off).
+ * Batched layout: limb-interleaved SoA, in one of two forms selected by the limb stride ld (in elements):
+ *   FLAT  (ld >= n): buf[limb*ld + j], 0 <= limb < Nlimbs, 0 <= j < n ("lanes" of simd.h, j-major within a limb).  ld lets
+ *         a call work on a slice [off, off+n) of a larger batch (pass buf+off).
+ *   TILED (ld < n, ld a power of two >= 128): the batch is a sequence of tiles of ld elements, each tile limb-interleaved with
+ *         stride ld and Nlimbs*ld words long: buf[((j / ld)*Nlimbs + limb)*ld + (j % ld)]; the buffer holds ceil(n/ld) whole
+ *         tiles.  All operands of one call share ld.  RECOMMENDED for large batches, ld = 4096: the Nlimbs rows a workgroup
+ *         streams then lie in one contiguous 160-256 KiB stretch instead of Nlimbs stretches n*8 bytes apart, and the HBM rate
+ *         stops depending on where the driver placed the arrays (+6 % on the slow placements of 5-limb fields, +11-16 % for
+ *         8-limb fields).  Every per-prime field function and the AoS converters take both forms; the
+ *         curve API (ecn_*) and the byte-record functions' record side are flat / AoS only.
  * For the 16-byte fast path keep buffers 16-byte aligned and ld even.  Byte records
  * (modimp/modexp/rfc7748) are contiguous AoS: rec[j*Nbytes + i].
  * Ownership / aliasing: the caller owns every buffer, nothing is allocated or retained; an output
@@ -65,7 +72,7 @@ int modarith_amd_stream_destroy(void *stream);
 int modarith_amd_stream_wait(void *stream, void *other);
 int modarith_amd_host_alloc(void **hptr, size_t bytes);
 int modarith_amd_host_free(void *hptr);
-/* element-major (spint x[n][nlimbs], how CPU callers hold arrays of elements) <-> SoA; any limb count */
+/* element-major (spint x[n][nlimbs], how CPU callers hold arrays of elements) <-> SoA (flat or tiled, by ld as above); any limb count */
 int modarith_amd_aos_to_soa(const ma_spint *aos, ma_spint *soa, size_t n, int nlimbs, size_t ld, void *stream);
 int modarith_amd_soa_to_aos(const ma_spint *soa, ma_spint *aos, size_t n, int nlimbs, size_t ld, void *stream);
 /* per-prime macro block of field.c (pseudo.py:1403-1407): returns 0 if `prime` is unknown */

@@ -116,14 +116,24 @@ void die(const char* what, hipError_t e) {
     abort();
 }
 
-// element-major (AoS, spint x[n][N] as CPU callers hold elements) <-> limb-interleaved SoA; any limb count
-static __global__ __launch_bounds__(BLOCK) void k_aos2soa(const spint* aos, spint* soa, size_t n, int nlimbs, size_t ld) {
-    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK)
-        for (int i = 0; i < nlimbs; i++) soa[(size_t)i * ld + t] = aos[t * (size_t)nlimbs + i];
+// element-major (AoS, spint x[n][N] as CPU callers hold elements) <-> limb-interleaved SoA (flat or tiled: kernels.h Ld); any limb count
+static __device__ __forceinline__ size_t soa_off(Ld L, int nlimbs, size_t j) {
+    return (((j >> L.s) * (size_t)nlimbs) << L.s) + (j & ((((size_t)1) << L.s) - 1));
 }
-static __global__ __launch_bounds__(BLOCK) void k_soa2aos(const spint* soa, spint* aos, size_t n, int nlimbs, size_t ld) {
+static __global__ __launch_bounds__(BLOCK) void k_aos2soa(const spint* aos, spint* soa, size_t n, int nlimbs, Ld L) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK)
-        for (int i = 0; i < nlimbs; i++) aos[t * (size_t)nlimbs + i] = soa[(size_t)i * ld + t];
+        for (int i = 0; i < nlimbs; i++) soa[soa_off(L, nlimbs, t) + (size_t)i * L.ld] = aos[t * (size_t)nlimbs + i];
+}
+static __global__ __launch_bounds__(BLOCK) void k_soa2aos(const spint* soa, spint* aos, size_t n, int nlimbs, Ld L) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK)
+        for (int i = 0; i < nlimbs; i++) aos[t * (size_t)nlimbs + i] = soa[soa_off(L, nlimbs, t) + (size_t)i * L.ld];
+}
+// ld >= n: flat; ld < n: tiles of ld elements (a power of two >= 128)
+static bool conv_ld(size_t n, size_t ld, Ld* L) {
+    if (ld >= n) { *L = Ld(ld); return true; }
+    if (ld < 128 || (ld & (ld - 1)) != 0) return false;
+    *L = Ld(ld, (unsigned)__builtin_ctzll((unsigned long long)ld));
+    return true;
 }
 
 static int wrap(hipError_t e, const char* what) {
@@ -178,14 +188,16 @@ int modarith_amd_host_free(void* hptr) { return wrap(hipHostFree(hptr), "hipHost
 
 int modarith_amd_aos_to_soa(const ma_spint* aos, ma_spint* soa, size_t n, int nlimbs, size_t ld, void* stream) {
     if (n == 0) return 0;
-    if (nlimbs < 1 || nlimbs > 64 || ld < n) { set_error("aos_to_soa: need 1 <= nlimbs <= 64 and ld >= n"); return (int)hipErrorInvalidValue; }
-    k_aos2soa<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(aos, soa, n, nlimbs, ld);
+    Ld L;
+    if (nlimbs < 1 || nlimbs > 64 || !conv_ld(n, ld, &L)) { set_error("aos_to_soa: need 1 <= nlimbs <= 64 and ld >= n (flat) or ld a power of two >= 128 (tiles)"); return (int)hipErrorInvalidValue; }
+    k_aos2soa<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(aos, soa, n, nlimbs, L);
     return check_launch("aos_to_soa");
 }
 int modarith_amd_soa_to_aos(const ma_spint* soa, ma_spint* aos, size_t n, int nlimbs, size_t ld, void* stream) {
     if (n == 0) return 0;
-    if (nlimbs < 1 || nlimbs > 64 || ld < n) { set_error("soa_to_aos: need 1 <= nlimbs <= 64 and ld >= n"); return (int)hipErrorInvalidValue; }
-    k_soa2aos<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(soa, aos, n, nlimbs, ld);
+    Ld L;
+    if (nlimbs < 1 || nlimbs > 64 || !conv_ld(n, ld, &L)) { set_error("soa_to_aos: need 1 <= nlimbs <= 64 and ld >= n (flat) or ld a power of two >= 128 (tiles)"); return (int)hipErrorInvalidValue; }
+    k_soa2aos<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(soa, aos, n, nlimbs, L);
     return check_launch("soa_to_aos");
 }
 

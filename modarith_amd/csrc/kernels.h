@@ -37,29 +37,46 @@ template <class T> __device__ __forceinline__ void st_stream(T* p, T v) {
 #endif
 }
 
+// Limb stride descriptor of a batch.  FLAT (ld >= n, the n-lane form of the reference's SIMD "batched form"): limb i of element
+// j at buf[i * ld + j].  TILED (ld = 2^s < n): the batch is a sequence of tiles of ld elements, each tile limb-interleaved with
+// stride ld, tiles N * ld words apart -- buf[((j >> s) * N + i) * ld + (j & (ld - 1))].  One formula serves both: the flat case
+// carries s = 63, so that j >> s = 0 and j & (2^s - 1) = j.  Why tiles: with rows of 2^12 elements (32 KiB) the N limb rows a
+// workgroup streams lie within one contiguous 160 KiB (5 limbs) / 256 KiB (8 limbs) stretch instead of N stretches 128 MiB
+// apart, and the streaming rate no longer depends on where the driver placed the arrays (profiles/r03_tiled_exp_*).
+struct Ld {
+    size_t ld;
+    unsigned s;
+    __host__ __device__ Ld(size_t ld_ = 0) : ld(ld_), s(63) {}
+    __host__ __device__ Ld(size_t ld_, unsigned s_) : ld(ld_), s(s_) {}
+    template <int N>
+    __host__ __device__ __forceinline__ size_t off(size_t j) const { return (((j >> s) * (size_t)N) << s) + (j & ((((size_t)1) << s) - 1)); }
+};
+
 // element index handled by (thread t, slot e): j = EPT*t + e  -> contiguous EPT*8 bytes per lane
 template <class P, int EPT>
-__device__ __forceinline__ void load_soa(const spint* base, size_t ld, size_t t, spint (*x)[P::N]) {
+__device__ __forceinline__ void load_soa(const spint* base, Ld L, size_t t, spint (*x)[P::N]) {
+    const spint* p = base + L.template off<P::N>((size_t)EPT * t);
     if constexpr (EPT == 1) {
-        static_for<0, P::N>([&](auto I) { x[0][I] = ld_stream(base + (size_t)I * ld + t); });
+        static_for<0, P::N>([&](auto I) { x[0][I] = ld_stream(p + (size_t)I * L.ld); });
     } else {
         static_for<0, P::N>([&](auto I) {
-            spint2 v = ld_stream(reinterpret_cast<const spint2*>(base + (size_t)I * ld + 2 * t));
+            spint2 v = ld_stream(reinterpret_cast<const spint2*>(p + (size_t)I * L.ld));
             x[0][I] = v.x;
             x[1][I] = v.y;
         });
     }
 }
 template <class P, int EPT>
-__device__ __forceinline__ void store_soa(spint* base, size_t ld, size_t t, spint (*x)[P::N]) {
+__device__ __forceinline__ void store_soa(spint* base, Ld L, size_t t, spint (*x)[P::N]) {
+    spint* p = base + L.template off<P::N>((size_t)EPT * t);
     if constexpr (EPT == 1) {
-        static_for<0, P::N>([&](auto I) { st_stream(base + (size_t)I * ld + t, x[0][I]); });
+        static_for<0, P::N>([&](auto I) { st_stream(p + (size_t)I * L.ld, x[0][I]); });
     } else {
         static_for<0, P::N>([&](auto I) {
             spint2 v;
             v.x = x[0][I];
             v.y = x[1][I];
-            st_stream(reinterpret_cast<spint2*>(base + (size_t)I * ld + 2 * t), v);
+            st_stream(reinterpret_cast<spint2*>(p + (size_t)I * L.ld), v);
         });
     }
 }
@@ -163,7 +180,7 @@ template <class P, template <class, bool> class Op> struct OpAutoUnary {
 // c[j] = op(a[j], b[j])
 template <class P, class Op, int EPT>
 __global__ __launch_bounds__(BLOCK) void k_binary(const spint* a, const spint* b,
-                                                  spint* c, size_t nthreads, size_t lda, size_t ldb, size_t ldc) {
+                                                  spint* c, size_t nthreads, Ld lda, Ld ldb, Ld ldc) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
         spint x[EPT][P::N], y[EPT][P::N], z[EPT][P::N];
         load_soa<P, EPT>(a, lda, t, x);
@@ -182,7 +199,7 @@ __global__ __launch_bounds__(BLOCK) void k_binary(const spint* a, const spint* b
 // VGPRs, and it does (400 for the pinned half-limb products of modinv): one wave per SIMD on a latency-bound chain
 template <class P, class Op>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(P::N <= 5 ? 3 : 1)))
-void k_unary_heavy(const spint* a, spint* c, size_t nthreads, size_t lda, size_t ldc) {
+void k_unary_heavy(const spint* a, spint* c, size_t nthreads, Ld lda, Ld ldc) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N], z[1][P::N];
         load_soa<P, 1>(a, lda, t, x);
@@ -194,7 +211,7 @@ void k_unary_heavy(const spint* a, spint* c, size_t nthreads, size_t lda, size_t
 // c[j] = op(a[j])
 template <class P, class Op, int EPT>
 __global__ __launch_bounds__(BLOCK) void k_unary(const spint* a, spint* c, size_t nthreads,
-                                                 size_t lda, size_t ldc) {
+                                                 Ld lda, Ld ldc) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
         spint x[EPT][P::N], z[EPT][P::N];
         load_soa<P, EPT>(a, lda, t, x);
@@ -221,7 +238,7 @@ MA_DEV void mul_shared_one(const spint* x, const spint* b, spint* z) {
 }
 template <class P, int EPT, bool AUTO>
 __global__ __launch_bounds__(BLOCK) void k_mul_shared(const spint* a, Elem<P> b0, spint* c,
-                                                      size_t nthreads, size_t lda, size_t ldc) {
+                                                      size_t nthreads, Ld lda, Ld ldc) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
         spint x[EPT][P::N], z[EPT][P::N];
         load_soa<P, EPT>(a, lda, t, x);
@@ -237,7 +254,7 @@ __global__ __launch_bounds__(BLOCK) void k_mul_shared(const spint* a, Elem<P> b0
 // c[j] = a[j] * b (small integer)
 template <class P, int EPT>
 __global__ __launch_bounds__(BLOCK) void k_mli(const spint* a, int b, spint* c, size_t nthreads,
-                                               size_t lda, size_t ldc) {
+                                               Ld lda, Ld ldc) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
         spint x[EPT][P::N], z[EPT][P::N];
         load_soa<P, EPT>(a, lda, t, x);
@@ -250,7 +267,7 @@ __global__ __launch_bounds__(BLOCK) void k_mli(const spint* a, int b, spint* c, 
 
 // a[j] = a[j]^(2^k)
 template <class P>
-__global__ __launch_bounds__(BLOCK) void k_nsqr(spint* a, int k, size_t n, size_t ld) {
+__global__ __launch_bounds__(BLOCK) void k_nsqr(spint* a, int k, size_t n, Ld ld) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N];
         load_soa<P, 1>(a, ld, t, x);
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(BLOCK) void k_nsqr(spint* a, int k, size_t n, size_
 // z[j] = 1/x[j] with caller-supplied progenitor h[j] (modinv(x,h,z), pseudo.py:788-812)
 template <class P>
 __global__ __launch_bounds__(BLOCK) void k_inv_h(const spint* xs, const spint* hs,
-                                                 spint* zs, size_t n, size_t ldx, size_t ldh, size_t ldz) {
+                                                 spint* zs, size_t n, Ld ldx, Ld ldh, Ld ldz) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N], h[1][P::N], z[1][P::N];
         load_soa<P, 1>(xs, ldx, t, x);
@@ -278,7 +295,7 @@ __global__ __launch_bounds__(BLOCK) void k_inv_h(const spint* xs, const spint* h
 
 // r[j] = sqrt(x[j]) / qr(x[j]) with caller-supplied progenitors h[j] (pseudo.py:815-874)
 template <class P, bool QR>
-__global__ __launch_bounds__(BLOCK) void k_sqrt_h(const spint* xs, const spint* hs, spint* rs, int* out, size_t n, size_t ld) {
+__global__ __launch_bounds__(BLOCK) void k_sqrt_h(const spint* xs, const spint* hs, spint* rs, int* out, size_t n, Ld ld) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N], h[1][P::N], r[1][P::N];
         load_soa<P, 1>(xs, ld, t, x);
@@ -298,7 +315,7 @@ __global__ __launch_bounds__(BLOCK) void k_sqrt_h(const spint* xs, const spint* 
 // (simd/pseudo_simd.py:1121-1162: selector widened to one value per lane)
 template <class P, bool SWAP>
 __global__ __launch_bounds__(BLOCK) void k_cond(const int* d, spint* g, spint* f, size_t n,
-                                                size_t ldg, size_t ldf) {
+                                                Ld ldg, Ld ldf) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N], y[1][P::N];
         load_soa<P, 1>(g, ldg, t, x);
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(BLOCK) void k_cond(const int* d, spint* g, spint* f
 // in-place normalisers / predicates; KIND selects the function, optional int result per element
 enum { K_MODFSB = 0, K_FLATTEN, K_MODIS1, K_MODIS0, K_MODSIGN, K_MODHAF, K_MODQR, K_MODLIMBS };
 template <class P, int KIND>
-__global__ __launch_bounds__(BLOCK) void k_inplace(spint* a, int* out, size_t n, size_t ld) {
+__global__ __launch_bounds__(BLOCK) void k_inplace(spint* a, int* out, size_t n, Ld ld) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N];
         load_soa<P, 1>(a, ld, t, x);
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(BLOCK) void k_inplace(spint* a, int* out, size_t n,
 
 template <class P>
 __global__ __launch_bounds__(BLOCK) void k_cmp(const spint* a, const spint* b, int* out,
-                                               size_t n, size_t lda, size_t ldb) {
+                                               size_t n, Ld lda, Ld ldb) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N], y[1][P::N];
         load_soa<P, 1>(a, lda, t, x);
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void k_cmp(const spint* a, const spint* b, i
 
 // shifts by less than a word (modshl / modshr), in place; shr returns the shifted-out bits
 template <class P, bool LEFT>
-__global__ __launch_bounds__(BLOCK) void k_shift(unsigned k, spint* a, int* out, size_t n, size_t ld) {
+__global__ __launch_bounds__(BLOCK) void k_shift(unsigned k, spint* a, int* out, size_t n, Ld ld) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N];
         load_soa<P, 1>(a, ld, t, x);
@@ -367,7 +384,7 @@ __global__ __launch_bounds__(BLOCK) void k_shift(unsigned k, spint* a, int* out,
 // fill with a constant element: modzer / modone / modint(x) / mod2r(r)
 enum { K_INT = 0, K_2R };
 template <class P, int KIND>
-__global__ __launch_bounds__(BLOCK) void k_fill(int val, spint* a, size_t n, size_t ld) {
+__global__ __launch_bounds__(BLOCK) void k_fill(int val, spint* a, size_t n, Ld ld) {
     spint x[1][P::N];
     if constexpr (KIND == K_INT) {
         if (val == 0) Field<P>::modzer(x[0]); else Field<P>::modint(val, x[0]);
@@ -411,7 +428,7 @@ __device__ __forceinline__ void store_be_record(unsigned char* bytes, size_t t, 
     }
 }
 template <class P>
-__global__ __launch_bounds__(BLOCK) void k_imp(const unsigned char* bytes, spint* a, int* flag, size_t n, size_t ld) {
+__global__ __launch_bounds__(BLOCK) void k_imp(const unsigned char* bytes, spint* a, int* flag, size_t n, Ld ld) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint w[Field<P>::NW];
         load_be_record<P>(bytes, t, w);
@@ -422,7 +439,7 @@ __global__ __launch_bounds__(BLOCK) void k_imp(const unsigned char* bytes, spint
     }
 }
 template <class P>
-__global__ __launch_bounds__(BLOCK) void k_exp(const spint* a, unsigned char* bytes, size_t n, size_t ld) {
+__global__ __launch_bounds__(BLOCK) void k_exp(const spint* a, unsigned char* bytes, size_t n, Ld ld) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N];
         load_soa<P, 1>(a, ld, t, x);
@@ -445,7 +462,7 @@ MA_DEV spint splitmix64_at(spint s0, spint t) {
     return z ^ (z >> 31);
 }
 template <class P>
-__global__ __launch_bounds__(BLOCK) void k_uniform(spint s0, size_t first, int plus_p, spint* out, size_t n, size_t ld) {
+__global__ __launch_bounds__(BLOCK) void k_uniform(spint s0, size_t first, int plus_p, spint* out, size_t n, Ld ld) {
     using F = Field<P>;
     constexpr int NWD = (P::NBITS + 63) / 64 + 1;
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
@@ -479,7 +496,7 @@ __global__ __launch_bounds__(BLOCK) void k_uniform(spint s0, size_t first, int p
 // serially dependent chain on its own operands, entirely in registers, and leaves redc(z).
 // KIND 0: `outer` x 200 x 5 modmul;  1: `outer` x 500 x 2 modsqr;  2: `outer` x 2 modinv.
 template <class P, int KIND, bool FAST = false>
-__global__ __launch_bounds__(BLOCK) void k_time(const spint* xs, const spint* ys, spint* zs, long outer, size_t n, size_t ld) {
+__global__ __launch_bounds__(BLOCK) void k_time(const spint* xs, const spint* ys, spint* zs, long outer, size_t n, Ld ld) {
     using F = Field<P, FAST>;
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N], y[1][P::N], z[1][P::N];

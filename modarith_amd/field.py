@@ -44,7 +44,7 @@ def normalise_device(device, current=None) -> torch.device:
 class Field:
     """Batched field arithmetic for one of the built primes (X25519, NIST256, X448)."""
 
-    def __init__(self, prime: str, device: Optional[torch.device] = None):
+    def __init__(self, prime: str, device: Optional[torch.device] = None, tile: Optional[int] = None):
         if prime not in _lib.PRIMES:
             raise ValueError("prime %r is not built; available: %s" % (prime, ", ".join(_lib.PRIMES)))
         self.lib = _lib.load()
@@ -54,18 +54,46 @@ class Field:
         self.radix = self.params.radix
         self.nbytes = self.params.nbytes
         self.device = normalise_device(device)
+        # Layout of the batches this object CREATES (empty / uniform / from_limbs / modimp ...): None = flat [N, n];
+        # tile = 2^k >= 128 (4096 recommended) = tiled [n / tile, N, tile] (include/modarith_amd.h "TILED"; n a multiple of
+        # tile).  Every method ACCEPTS both forms, whatever this is set to.
+        if tile is not None and (tile < 128 or tile & (tile - 1)):
+            raise ValueError("tile must be a power of two >= 128")
+        self.tile = tile
 
     # ------------------------------------------------------------------ buffers
     def empty(self, n: int) -> torch.Tensor:
+        if self.tile and n > self.tile:
+            if n % self.tile:
+                raise ValueError("tiled batches hold a whole number of tiles (n = %d, tile = %d)" % (n, self.tile))
+            return torch.empty((n // self.tile, self.N, self.tile), dtype=torch.int64, device=self.device)
         return torch.empty((self.N, n), dtype=torch.int64, device=self.device)
 
+    def to_tiled(self, t: torch.Tensor, tile: Optional[int] = None) -> torch.Tensor:
+        """flat [N, n] -> tiled [n / tile, N, tile] (a copy; torch ops only)"""
+        tile = tile or self.tile or 4096
+        N, n = t.shape
+        if n % tile:
+            raise ValueError("n must be a multiple of the tile size")
+        return t.reshape(N, n // tile, tile).permute(1, 0, 2).contiguous()
+
+    def to_flat(self, t: torch.Tensor) -> torch.Tensor:
+        """tiled [ntiles, N, tile] -> flat [N, n] (a copy); flat batches pass through"""
+        if t.dim() == 2:
+            return t
+        nt, N, tile = t.shape
+        return t.permute(1, 0, 2).reshape(N, nt * tile).contiguous()
+
     def from_limbs(self, limbs: Sequence[Sequence[int]]) -> torch.Tensor:
-        """list of per-element limb lists -> device batch [N, n]."""
+        """list of per-element limb lists -> device batch [N, n] (tiled if this object creates tiled batches)."""
         arr = np.array(limbs, dtype=np.uint64).reshape(len(limbs), self.N).T.copy()
-        return torch.from_numpy(arr.view(np.int64)).to(self.device)
+        t = torch.from_numpy(arr.view(np.int64)).to(self.device)
+        if self.tile and t.shape[1] > self.tile and t.shape[1] % self.tile == 0:
+            t = self.to_tiled(t)
+        return t
 
     def to_limbs(self, t: torch.Tensor) -> List[List[int]]:
-        arr = t.detach().cpu().numpy().view(np.uint64)
+        arr = self.to_flat(t.detach()).cpu().numpy().view(np.uint64)
         return [[int(v) for v in arr[:, j]] for j in range(arr.shape[1])]
 
     def from_ints(self, xs: Iterable[int]) -> torch.Tensor:
@@ -81,20 +109,39 @@ class Field:
         if aos.dtype != torch.int64 or aos.dim() != 2 or aos.shape[1] != self.N or not aos.is_cuda or not aos.is_contiguous():
             raise ValueError("expected a contiguous int64 device tensor of shape [n, %d]" % self.N)
         n = aos.shape[0]
-        out = torch.empty((self.N, n), dtype=torch.int64, device=aos.device)
-        _lib.check(self.lib.modarith_amd_aos_to_soa(aos.data_ptr(), out.data_ptr(), n, self.N, max(n, 1), _stream(self.device)), "aos_to_soa")
+        out = self.empty(n)
+        _lib.check(self.lib.modarith_amd_aos_to_soa(aos.data_ptr(), out.data_ptr(), n, self.N, max(self._ld(out), 1), _stream(self.device)), "aos_to_soa")
         return out
 
     def to_aos(self, soa: torch.Tensor) -> torch.Tensor:
         """limb-interleaved batch [N, n] -> element-major int64 [n, N], on the device."""
         n = self._chk(soa)
         out = torch.empty((n, self.N), dtype=torch.int64, device=soa.device)
-        _lib.check(self.lib.modarith_amd_soa_to_aos(soa.data_ptr(), out.data_ptr(), n, self.N, soa.stride(0) if n else 1, _stream(self.device)), "soa_to_aos")
+        _lib.check(self.lib.modarith_amd_soa_to_aos(soa.data_ptr(), out.data_ptr(), n, self.N, self._ld(soa), _stream(self.device)), "soa_to_aos")
         return out
 
     # ------------------------------------------------------------------ plumbing
+    def _ld(self, t: torch.Tensor) -> int:
+        """the limb stride argument of the C-ABI: the row stride of a flat batch, the tile size of a tiled one"""
+        if t.dim() == 3:
+            return t.shape[2]
+        return t.stride(0) if t.shape[1] else 1
+
     def _chk(self, *ts: torch.Tensor) -> int:
-        n = ts[0].shape[1]
+        t0 = ts[0]
+        if t0.dim() == 3:                                   # tiled [ntiles, N, tile]
+            nt, N, tile = t0.shape
+            if N != self.N or tile < 128 or tile & (tile - 1):
+                raise ValueError("tiled batches have shape [ntiles, %d, tile] with tile a power of two >= 128" % self.N)
+            for t in ts:
+                if t.dtype != torch.int64 or t.shape != t0.shape or not t.is_contiguous():
+                    raise ValueError("all operands of one call must be contiguous int64 tiled batches of one shape")
+                if not t.is_cuda:
+                    raise ValueError("batches must live in device memory")
+                if t.device != self.device:
+                    raise ValueError("batch on %s, field bound to %s (kernels launch on the field's device)" % (t.device, self.device))
+            return nt * tile
+        n = t0.shape[1]
         for t in ts:
             if t.dtype != torch.int64 or t.dim() != 2 or t.shape[0] != self.N or t.shape[1] != n:
                 raise ValueError("expected int64 tensors of shape [%d, n]" % self.N)
@@ -108,6 +155,8 @@ class Field:
         for t in ts:
             if t.stride(0) != ld:
                 raise ValueError("all operands of one call must share the limb stride")
+        if 1 < n and ld < n:
+            raise ValueError("a flat batch needs a limb stride >= n")
         return n
 
     def _call(self, fn: str, *args):
@@ -122,13 +171,13 @@ class Field:
     def _bin(self, fn, a, b, out):
         out = self._out(a, out)
         n = self._chk(a, b, out)
-        self._call(fn, a.data_ptr(), b.data_ptr(), out.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call(fn, a.data_ptr(), b.data_ptr(), out.data_ptr(), n, self._ld(a), _stream(self.device))
         return out
 
     def _un(self, fn, a, out):
         out = self._out(a, out)
         n = self._chk(a, out)
-        self._call(fn, a.data_ptr(), out.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call(fn, a.data_ptr(), out.data_ptr(), n, self._ld(a), _stream(self.device))
         return out
 
     def _ints(self, n: int) -> torch.Tensor:
@@ -153,72 +202,72 @@ class Field:
         out = self._out(a, out)
         n = self._chk(a, out)
         host = (_lib.ctypes.c_uint64 * self.N)(*[int(v) for v in b0])
-        self._call("modmuls", a.data_ptr(), _lib.ctypes.cast(host, _lib.ctypes.c_void_p), out.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("modmuls", a.data_ptr(), _lib.ctypes.cast(host, _lib.ctypes.c_void_p), out.data_ptr(), n, self._ld(a), _stream(self.device))
         return out
 
     def modmli(self, a, b: int, out=None):
         out = self._out(a, out)
         n = self._chk(a, out)
-        self._call("modmli", a.data_ptr(), int(b), out.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("modmli", a.data_ptr(), int(b), out.data_ptr(), n, self._ld(a), _stream(self.device))
         return out
 
     def modnsqr(self, a, k: int):
         n = self._chk(a)
-        self._call("modnsqr", a.data_ptr(), int(k), n, a.stride(0), _stream(self.device))
+        self._call("modnsqr", a.data_ptr(), int(k), n, self._ld(a), _stream(self.device))
         return a
 
     def modinv(self, x, h=None, out=None):
         out = self._out(x, out)
         n = self._chk(x, out) if h is None else self._chk(x, h, out)
-        self._call("modinv", x.data_ptr(), None if h is None else h.data_ptr(), out.data_ptr(), n, x.stride(0), _stream(self.device))
+        self._call("modinv", x.data_ptr(), None if h is None else h.data_ptr(), out.data_ptr(), n, self._ld(x), _stream(self.device))
         return out
 
     def modsqrt(self, x, h=None, out=None):
         out = self._out(x, out)
         n = self._chk(x, out) if h is None else self._chk(x, h, out)
-        self._call("modsqrt", x.data_ptr(), None if h is None else h.data_ptr(), out.data_ptr(), n, x.stride(0), _stream(self.device))
+        self._call("modsqrt", x.data_ptr(), None if h is None else h.data_ptr(), out.data_ptr(), n, self._ld(x), _stream(self.device))
         return out
 
     def modqr(self, h, x):
         """1 where x is a quadratic residue (or zero); h = optional progenitors modpro(x)."""
         n = self._chk(x) if h is None else self._chk(x, h)
         out = self._ints(n)
-        self._call("modqr", None if h is None else h.data_ptr(), x.data_ptr(), out.data_ptr(), n, x.stride(0), _stream(self.device))
+        self._call("modqr", None if h is None else h.data_ptr(), x.data_ptr(), out.data_ptr(), n, self._ld(x), _stream(self.device))
         return out
 
     def modfsb(self, a):
         """in place; returns the per-element flag (1 if the input was < p)."""
         n = self._chk(a)
         flag = self._ints(n)
-        self._call("modfsb", a.data_ptr(), flag.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("modfsb", a.data_ptr(), flag.data_ptr(), n, self._ld(a), _stream(self.device))
         return flag
 
     def flatten(self, a):
         n = self._chk(a)
         flag = self._ints(n)
-        self._call("flatten", a.data_ptr(), flag.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("flatten", a.data_ptr(), flag.data_ptr(), n, self._ld(a), _stream(self.device))
         return flag
 
     def modhaf(self, a):
         n = self._chk(a)
-        self._call("modhaf", a.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("modhaf", a.data_ptr(), n, self._ld(a), _stream(self.device))
         return a
 
     def modshl(self, k: int, a):
         n = self._chk(a)
-        self._call("modshl", int(k), a.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("modshl", int(k), a.data_ptr(), n, self._ld(a), _stream(self.device))
         return a
 
     def modshr(self, k: int, a):
         n = self._chk(a)
         out = self._ints(n)
-        self._call("modshr", int(k), a.data_ptr(), out.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("modshr", int(k), a.data_ptr(), out.data_ptr(), n, self._ld(a), _stream(self.device))
         return out
 
     def _pred(self, fn, a):
         n = self._chk(a)
         out = self._ints(n)
-        self._call(fn, a.data_ptr(), out.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call(fn, a.data_ptr(), out.data_ptr(), n, self._ld(a), _stream(self.device))
         return out
 
     def modis1(self, a): return self._pred("modis1", a)
@@ -232,27 +281,27 @@ class Field:
     def modcmp(self, a, b):
         n = self._chk(a, b)
         out = self._ints(n)
-        self._call("modcmp", a.data_ptr(), b.data_ptr(), out.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("modcmp", a.data_ptr(), b.data_ptr(), out.data_ptr(), n, self._ld(a), _stream(self.device))
         return out
 
     def modzer(self, n: int):
         a = self.empty(n)
-        self._call("modzer", a.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("modzer", a.data_ptr(), n, self._ld(a), _stream(self.device))
         return a
 
     def modone(self, n: int):
         a = self.empty(n)
-        self._call("modone", a.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("modone", a.data_ptr(), n, self._ld(a), _stream(self.device))
         return a
 
     def modint(self, x: int, n: int):
         a = self.empty(n)
-        self._call("modint", int(x), a.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("modint", int(x), a.data_ptr(), n, self._ld(a), _stream(self.device))
         return a
 
     def mod2r(self, r: int, n: int):
         a = self.empty(n)
-        self._call("mod2r", int(r), a.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("mod2r", int(r), a.data_ptr(), n, self._ld(a), _stream(self.device))
         return a
 
     def uniform(self, n: int, seed: int = 42, array: int = 0, first: int = 0, plus_p: bool = False, out=None):
@@ -262,7 +311,7 @@ class Field:
         a = out if out is not None else self.empty(n)
         if out is not None and self._chk(out) != n:
             raise ValueError("out must hold n elements")
-        self._call("moduniform", int(seed), int(array), int(first), int(bool(plus_p)), a.data_ptr(), n, a.stride(0) if n else 1, _stream(self.device))
+        self._call("moduniform", int(seed), int(array), int(first), int(bool(plus_p)), a.data_ptr(), n, self._ld(a), _stream(self.device))
         return a
 
     def _sel(self, d: torch.Tensor, n: int) -> torch.Tensor:
@@ -273,13 +322,13 @@ class Field:
     def modcmv(self, d, g, f):
         """f[j] = g[j] where d[j] == 1 (constant time); d: int32 [n]."""
         n = self._chk(g, f)
-        self._call("modcmv", self._sel(d, n).data_ptr(), g.data_ptr(), f.data_ptr(), n, g.stride(0), _stream(self.device))
+        self._call("modcmv", self._sel(d, n).data_ptr(), g.data_ptr(), f.data_ptr(), n, self._ld(g), _stream(self.device))
         return f
 
     def modcsw(self, d, g, f):
         """swap g[j], f[j] where d[j] == 1 (constant time)."""
         n = self._chk(g, f)
-        self._call("modcsw", self._sel(d, n).data_ptr(), g.data_ptr(), f.data_ptr(), n, g.stride(0), _stream(self.device))
+        self._call("modcsw", self._sel(d, n).data_ptr(), g.data_ptr(), f.data_ptr(), n, self._ld(g), _stream(self.device))
         return g, f
 
     def time_protocol(self, kind: str, x, y=None, outer: int = 1):
@@ -290,7 +339,7 @@ class Field:
         y = x if y is None else y
         z = torch.empty_like(x)
         n = self._chk(x, y, z)
-        self._call("time_protocol", k, x.data_ptr(), y.data_ptr(), z.data_ptr(), int(outer), n, x.stride(0), _stream(self.device))
+        self._call("time_protocol", k, x.data_ptr(), y.data_ptr(), z.data_ptr(), int(outer), n, self._ld(x), _stream(self.device))
         return z
 
     def modimp(self, b: torch.Tensor):
@@ -300,13 +349,13 @@ class Field:
         n = b.shape[0]
         a = self.empty(n)
         flag = self._ints(n)
-        self._call("modimp", b.data_ptr(), a.data_ptr(), flag.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("modimp", b.data_ptr(), a.data_ptr(), flag.data_ptr(), n, self._ld(a), _stream(self.device))
         return a, flag
 
     def modexp(self, a):
         n = self._chk(a)
         b = torch.empty((n, self.nbytes), dtype=torch.uint8, device=self.device)
-        self._call("modexp", a.data_ptr(), b.data_ptr(), n, a.stride(0), _stream(self.device))
+        self._call("modexp", a.data_ptr(), b.data_ptr(), n, self._ld(a), _stream(self.device))
         return b
 
 

@@ -9,7 +9,7 @@ newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1]      # gpu
 rows = list(csv.reader(open(newest(src + "/stats/*/*_kernel_stats.csv"))))
 with open("profiles/%s_bench_kernel_stats.csv" % tag, "w", newline="") as f:
     w = csv.writer(f)
-    w.writerow(["# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu (kernel names trimmed to 140 chars)"])
+    w.writerow(["# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu --no-others (kernel names trimmed to 140 chars)"])
     for r in rows:
         r[0] = r[0][:140]
         w.writerow(r)
