@@ -13,16 +13,20 @@ namespace ma {
 
 void set_error(const std::string& msg);
 int check_launch(const char* what);
-int max_blocks();          // grid cap for grid-stride streaming kernels (env MA_MAX_BLOCKS)
+int max_blocks();          // grid cap for grid-stride streaming kernels on flat batches (env MA_MAX_BLOCKS, 4096)
+int max_blocks_tiled();    // the same for tiled batches (env MA_MAX_BLOCKS_TILED, 65536)
 int ladder_block();        // workgroup size of the ladder kernel (env MA_LADDER_BLOCK)
 bool force_fast();         // env MA_FORCE_FAST=1: element-wise modmul/modsqr/nres/redc/modinv on the FAST product path (tests)
 bool force_exact();        // env MA_FORCE_EXACT=1: element-wise modmul/modsqr on the exact 128-bit products only (tests)
 bool ladder_split();       // env MA_LADDER_SPLIT=0: the batched ladders never take the split form (one inversion per lane)
 bool ladder_use_field();   // env MA_LADDER_IMPL=field: X25519 ladder on the 5x51 field.c-form arithmetic
 
-inline unsigned grid_for(size_t nthreads, int block = 256) {
+// tiled batches (kernels.h Ld) take a much larger cap: on tiles the streaming rate keeps rising with the number of
+// workgroups up to one 512-element chunk per workgroup (X25519 modmul 5.96 / 6.16 / 6.39 / 6.58 TB/s at 4096 / 8192 / 16384 /
+// 32768 workgroups, profiles/r03_tiled_exp_4_grid.log), whereas flat batches are insensitive to it
+inline unsigned grid_for(size_t nthreads, int block = 256, bool tiled = false) {
     size_t b = (nthreads + (size_t)block - 1) / (size_t)block;
-    size_t cap = (size_t)max_blocks();
+    size_t cap = (size_t)(tiled ? max_blocks_tiled() : max_blocks());
     if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (unsigned)b;

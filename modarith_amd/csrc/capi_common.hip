@@ -33,6 +33,10 @@ int max_blocks() {
     static int v = env_int("MA_MAX_BLOCKS", 256 * 16, 1, 1 << 24);
     return v;
 }
+int max_blocks_tiled() {
+    static int v = env_int("MA_MAX_BLOCKS_TILED", 1 << 16, 1, 1 << 24);
+    return v;
+}
 int ladder_block() {
     static int v = env_int("MA_LADDER_BLOCK", 64, 64, 256) / 64 * 64;    // the ladder kernels carry __launch_bounds__(256)
     return v;

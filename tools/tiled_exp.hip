@@ -15,9 +15,12 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 namespace ma {
 using P = EXP_P;
-template <int T>
+// SWZ 0: workgroup b takes chunk b (consecutive chunks go round-robin over the 8 XCDs); SWZ 1: XCD x (= b % 8) takes the
+// contiguous eighth [x * G/8, (x+1) * G/8) of the chunks of each grid-stride pass
+template <int T, int SWZ = 0>
 __global__ __launch_bounds__(BLOCK) void k_tiled(const spint* a, const spint* b, spint* c, size_t nthreads) {
-    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
+    const size_t blk = SWZ ? (size_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
+    for (size_t t = blk * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
         const size_t j = 2 * t, tile = j >> T, off = j & (((size_t)1 << T) - 1);
         const size_t base = ((tile * P::N) << T) + off;
         spint x[2][P::N], y[2][P::N], z[2][P::N];
@@ -31,6 +34,47 @@ __global__ __launch_bounds__(BLOCK) void k_tiled(const spint* a, const spint* b,
         });
         OpMulAuto<P>::apply(x[0], y[0], z[0]);
         OpMulAuto<P>::apply(x[1], y[1], z[1]);
+        static_for<0, P::N>([&](auto I) {
+            spint2 v; v.x = z[0][I]; v.y = z[1][I];
+            st_stream(reinterpret_cast<spint2*>(c + base + ((size_t)I << T)), v);
+        });
+    }
+}
+// one 2*BS-element chunk per workgroup of BS lanes (no grid-stride loop)
+template <int T, int BS>
+__global__ __launch_bounds__(BS) void k_tiled_bs(const spint* a, const spint* b, spint* c, size_t nthreads) {
+    const size_t t = (size_t)blockIdx.x * BS + threadIdx.x;
+    if (t >= nthreads) return;
+    const size_t j = 2 * t, tile = j >> T, off = j & (((size_t)1 << T) - 1);
+    const size_t base = ((tile * P::N) << T) + off;
+    spint x[2][P::N], y[2][P::N], z[2][P::N];
+    static_for<0, P::N>([&](auto I) {
+        spint2 v = ld_stream(reinterpret_cast<const spint2*>(a + base + ((size_t)I << T)));
+        x[0][I] = v.x; x[1][I] = v.y;
+    });
+    static_for<0, P::N>([&](auto I) {
+        spint2 v = ld_stream(reinterpret_cast<const spint2*>(b + base + ((size_t)I << T)));
+        y[0][I] = v.x; y[1][I] = v.y;
+    });
+    OpMulAuto<P>::apply(x[0], y[0], z[0]);
+    OpMulAuto<P>::apply(x[1], y[1], z[1]);
+    static_for<0, P::N>([&](auto I) {
+        spint2 v; v.x = z[0][I]; v.y = z[1][I];
+        st_stream(reinterpret_cast<spint2*>(c + base + ((size_t)I << T)), v);
+    });
+}
+template <int T, bool SQR>
+__global__ __launch_bounds__(BLOCK) void k_tiled_un(const spint* a, spint* c, size_t nthreads) {
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {
+        const size_t j = 2 * t, tile = j >> T, off = j & (((size_t)1 << T) - 1);
+        const size_t base = ((tile * P::N) << T) + off;
+        spint x[2][P::N], z[2][P::N];
+        static_for<0, P::N>([&](auto I) {
+            spint2 v = ld_stream(reinterpret_cast<const spint2*>(a + base + ((size_t)I << T)));
+            x[0][I] = v.x; x[1][I] = v.y;
+        });
+        if constexpr (SQR) { OpSqrAuto<P>::apply(x[0], z[0]); OpSqrAuto<P>::apply(x[1], z[1]); }
+        else { static_for<0, P::N>([&](auto I) { z[0][I] = x[0][I]; z[1][I] = x[1][I]; }); }
         static_for<0, P::N>([&](auto I) {
             spint2 v; v.x = z[0][I]; v.y = z[1][I];
             st_stream(reinterpret_cast<spint2*>(c + base + ((size_t)I << T)), v);
@@ -58,22 +102,22 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         return 24.0 * P::N * n / (ms / 10 * 1e-3) / 1e9;
     };
-    printf("%s  triple   flat   T=9   T=10   T=11   T=12   T=13   T=14   (GB/s)\n", P::NAME);
+    printf("%s  triple   mul: grid-stride g32768 | one chunk per workgroup: BS=64  128  256  512  1024 | T=13 BS=256  T=11 BS=256  (GB/s)\n", P::NAME);
     for (int k = 0; k < K; k++) {
         spint *a, *b, *c;
         CK(hipMalloc(&a, n * 8 * P::N)); CK(hipMalloc(&b, n * 8 * P::N)); CK(hipMalloc(&c, n * 8 * P::N));
         k_fill<<<4096, 256>>>(a, n * P::N, 1 + k); k_fill<<<4096, 256>>>(b, n * P::N, 100 + k);
         CK(hipDeviceSynchronize());
-        double r[7];
-        r[0] = tm([&] { k_binary<P, OpMulAuto<P>, 2><<<4096, BLOCK>>>(a, b, c, nt, n, n, n); });
-        r[1] = tm([&] { k_tiled<9><<<4096, BLOCK>>>(a, b, c, nt); });
-        r[2] = tm([&] { k_tiled<10><<<4096, BLOCK>>>(a, b, c, nt); });
-        r[3] = tm([&] { k_tiled<11><<<4096, BLOCK>>>(a, b, c, nt); });
-        r[4] = tm([&] { k_tiled<12><<<4096, BLOCK>>>(a, b, c, nt); });
-        r[5] = tm([&] { k_tiled<13><<<4096, BLOCK>>>(a, b, c, nt); });
-        r[6] = tm([&] { k_tiled<14><<<4096, BLOCK>>>(a, b, c, nt); });
-        double again = tm([&] { k_binary<P, OpMulAuto<P>, 2><<<4096, BLOCK>>>(a, b, c, nt, n, n, n); });
-        printf("%4d   %6.0f %6.0f %6.0f %6.0f %6.0f %6.0f %6.0f   (flat again %6.0f)\n", k, r[0], r[1], r[2], r[3], r[4], r[5], r[6], again);
+        double r[8];
+        r[0] = tm([&] { k_tiled<12><<<32768, BLOCK>>>(a, b, c, nt); });
+        r[1] = tm([&] { k_tiled_bs<12, 64><<<(unsigned)(nt / 64), 64>>>(a, b, c, nt); });
+        r[2] = tm([&] { k_tiled_bs<12, 128><<<(unsigned)(nt / 128), 128>>>(a, b, c, nt); });
+        r[3] = tm([&] { k_tiled_bs<12, 256><<<(unsigned)(nt / 256), 256>>>(a, b, c, nt); });
+        r[4] = tm([&] { k_tiled_bs<12, 512><<<(unsigned)(nt / 512), 512>>>(a, b, c, nt); });
+        r[5] = tm([&] { k_tiled_bs<12, 1024><<<(unsigned)(nt / 1024), 1024>>>(a, b, c, nt); });
+        r[6] = tm([&] { k_tiled_bs<13, 256><<<(unsigned)(nt / 256), 256>>>(a, b, c, nt); });
+        r[7] = tm([&] { k_tiled_bs<11, 256><<<(unsigned)(nt / 256), 256>>>(a, b, c, nt); });
+        printf("%4d   %6.0f | %6.0f %6.0f %6.0f %6.0f %6.0f | %6.0f %6.0f\n", k, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
         // keep the memory (do not free): the next triple lands elsewhere
     }
     return 0;
