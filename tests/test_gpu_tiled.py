@@ -125,3 +125,43 @@ def test_tiled_inputs_match_bulk_reference_digests(torch_cuda):
         A, B = T.to_tiled(to_dev(a)), T.to_tiled(to_dev(b))
         for op, r in (("modmul", T.modmul(A, B)), ("modsqr", T.modsqr(A)), ("redc", T.redc(A))):
             assert block_digests(to_np(T.to_flat(r)), g["block"]) == g["primes"][P]["edge"][op], (P, op)
+
+
+def test_tiled_grid_stride_passes_under_a_small_grid_cap(torch_cuda):
+    """with the default cap (65 536 workgroups) a tiled batch below 2^25 elements runs one chunk per workgroup; the
+    grid-stride loop over tiles is exercised here in a child process with MA_MAX_BLOCKS_TILED=7 (the cap is process-static):
+    every streaming kernel family on 5 tiles of 4096 + an odd partial tile, against the flat layout"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import ctypes, sys, torch
+sys.path.insert(0, %r)
+from modarith_amd import _lib
+from modarith_amd.field import Field
+lib = _lib.load()
+for P in ("X25519", "X448"):
+    F = Field(P)
+    tile, n = 4096, 5 * 4096 + 1237
+    a, b = F.uniform(6 * tile, seed=3, array=1), F.uniform(6 * tile, seed=3, array=2)
+    A, B = F.to_tiled(a, tile), F.to_tiled(b, tile)
+    C = torch.full_like(A, -1)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    f = lambda name: getattr(lib, "%%s_%%s_batch" %% (name, P))
+    assert f("modmul")(A.data_ptr(), B.data_ptr(), C.data_ptr(), n, tile, st) == 0
+    assert torch.equal(F.to_flat(C)[:, :n], F.modmul(a, b)[:, :n]), "modmul"
+    assert f("modsqr")(A.data_ptr(), C.data_ptr(), n, tile, st) == 0
+    assert torch.equal(F.to_flat(C)[:, :n], F.modsqr(a)[:, :n]), "modsqr"
+    assert f("modmli")(A.data_ptr(), 121665, C.data_ptr(), n, tile, st) == 0
+    assert torch.equal(F.to_flat(C)[:, :n], F.modmli(a, 121665)[:, :n]), "modmli"
+    assert f("modinv")(A.data_ptr(), None, C.data_ptr(), n, tile, st) == 0
+    assert torch.equal(F.to_flat(C)[:, :n], F.modinv(a)[:, :n]), "modinv"
+    out = torch.empty(6 * tile, dtype=torch.int32, device="cuda")
+    assert f("modis0")(A.data_ptr(), out.data_ptr(), n, tile, st) == 0
+    assert torch.equal(out[:n], F.modis0(a)[:n]), "modis0"
+print("tiled grid-stride ok")
+''' % root
+    env = dict(os.environ, MA_MAX_BLOCKS_TILED="7", MA_MAX_BLOCKS="5")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "tiled grid-stride ok" in p.stdout, p.stderr[-2000:]
