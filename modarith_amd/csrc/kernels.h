@@ -495,38 +495,49 @@ __global__ __launch_bounds__(BLOCK) void k_uniform(spint s0, size_t first, int p
 // simd/pseudo_cuda.py:1163-1231 runs the same dependent chains inside one thread): every lane runs the
 // serially dependent chain on its own operands, entirely in registers, and leaves redc(z).
 // KIND 0: `outer` x 200 x 5 modmul;  1: `outer` x 500 x 2 modsqr;  2: `outer` x 2 modinv.
-template <class P, int KIND, bool FAST = false>
+template <class F, class P, int KIND>
+MA_DEV void time_chain(spint* x, spint* y, spint* z, long outer) {
+    F::nres(x, x);
+    if constexpr (KIND == 0) {
+        F::nres(y, y);
+#pragma unroll 1
+        for (long i = 0; i < outer * 200; i++) {
+            F::modmul(x, y, z);
+            F::modmul(z, x, y);
+            F::modmul(y, z, x);
+            F::modmul(x, y, z);
+            F::modmul(z, x, y);
+        }
+    } else if constexpr (KIND == 1) {
+#pragma unroll 1
+        for (long i = 0; i < outer * 500; i++) {
+            F::modsqr(x, z);
+            F::modsqr(z, x);
+        }
+    } else {
+#pragma unroll 1
+        for (long i = 0; i < outer; i++) {
+            F::modinv(x, nullptr, z);
+            F::modinv(z, nullptr, x);
+        }
+    }
+    F::redc(z, z);
+}
+// POLICY 0: exact products; 1: split products, unguarded (MA_FORCE_FAST); 2: the wave vote of OpMulAuto, taken once on the
+// operands -- the chain then stays inside the limb contract by closure (every link is a field-function output)
+template <class P, int KIND, int POLICY = 0>
 __global__ __launch_bounds__(BLOCK) void k_time(const spint* xs, const spint* ys, spint* zs, long outer, size_t n, Ld ld) {
-    using F = Field<P, FAST>;
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
         spint x[1][P::N], y[1][P::N], z[1][P::N];
         load_soa<P, 1>(xs, ld, t, x);
-        F::nres(x[0], x[0]);
-        if constexpr (KIND == 0) {
-            load_soa<P, 1>(ys, ld, t, y);
-            F::nres(y[0], y[0]);
-#pragma unroll 1
-            for (long i = 0; i < outer * 200; i++) {
-                F::modmul(x[0], y[0], z[0]);
-                F::modmul(z[0], x[0], y[0]);
-                F::modmul(y[0], z[0], x[0]);
-                F::modmul(x[0], y[0], z[0]);
-                F::modmul(z[0], x[0], y[0]);
-            }
-        } else if constexpr (KIND == 1) {
-#pragma unroll 1
-            for (long i = 0; i < outer * 500; i++) {
-                F::modsqr(x[0], z[0]);
-                F::modsqr(z[0], x[0]);
-            }
-        } else {
-#pragma unroll 1
-            for (long i = 0; i < outer; i++) {
-                F::modinv(x[0], nullptr, z[0]);
-                F::modinv(z[0], nullptr, x[0]);
-            }
+        if constexpr (KIND == 0) load_soa<P, 1>(ys, ld, t, y);
+        else static_for<0, P::N>([&](auto I) { y[0][I] = 0; });
+        bool fast = POLICY == 1;
+        if constexpr (POLICY == 2 && P::SPLIT > 0) fast = __all(in_split_contract<P>(x[0]) && in_split_contract<P>(y[0]));
+        if constexpr (POLICY != 0 && P::SPLIT > 0) {
+            if (fast) { time_chain<Field<P, true>, P, KIND>(x[0], y[0], z[0], outer); store_soa<P, 1>(zs, ld, t, z); continue; }
         }
-        F::redc(z[0], z[0]);
+        time_chain<Field<P, false>, P, KIND>(x[0], y[0], z[0], outer);
         store_soa<P, 1>(zs, ld, t, z);
     }
 }
