@@ -41,6 +41,25 @@ def normalise_device(device, current=None) -> torch.device:
     return dev
 
 
+def tile_batch(t: torch.Tensor, tile: int = 4096) -> torch.Tensor:
+    """flat batch [N, n] -> tiled batch [n / tile, N, tile]: limb i of element j moves from buf[i*n + j] to
+    buf[((j // tile)*N + i)*tile + j % tile] (include/modarith_amd.h "TILED").  A copy made with torch ops; any device."""
+    if t.dim() != 2 or tile < 128 or tile & (tile - 1):
+        raise ValueError("expected a flat batch [N, n] and a power-of-two tile >= 128")
+    N, n = t.shape
+    if n % tile:
+        raise ValueError("n must be a multiple of the tile size")
+    return t.reshape(N, n // tile, tile).permute(1, 0, 2).contiguous()
+
+
+def flatten_batch(t: torch.Tensor) -> torch.Tensor:
+    """tiled batch [ntiles, N, tile] -> flat batch [N, n] (a copy); flat batches pass through"""
+    if t.dim() == 2:
+        return t
+    nt, N, tile = t.shape
+    return t.permute(1, 0, 2).reshape(N, nt * tile).contiguous()
+
+
 class Field:
     """Batched field arithmetic for one of the built primes (X25519, NIST256, X448)."""
 
@@ -71,18 +90,11 @@ class Field:
 
     def to_tiled(self, t: torch.Tensor, tile: Optional[int] = None) -> torch.Tensor:
         """flat [N, n] -> tiled [n / tile, N, tile] (a copy; torch ops only)"""
-        tile = tile or self.tile or 4096
-        N, n = t.shape
-        if n % tile:
-            raise ValueError("n must be a multiple of the tile size")
-        return t.reshape(N, n // tile, tile).permute(1, 0, 2).contiguous()
+        return tile_batch(t, tile or self.tile or 4096)
 
     def to_flat(self, t: torch.Tensor) -> torch.Tensor:
         """tiled [ntiles, N, tile] -> flat [N, n] (a copy); flat batches pass through"""
-        if t.dim() == 2:
-            return t
-        nt, N, tile = t.shape
-        return t.permute(1, 0, 2).reshape(N, nt * tile).contiguous()
+        return flatten_batch(t)
 
     def from_limbs(self, limbs: Sequence[Sequence[int]]) -> torch.Tensor:
         """list of per-element limb lists -> device batch [N, n] (tiled if this object creates tiled batches)."""

@@ -101,3 +101,23 @@ def test_device_is_normalised_to_an_indexed_form():
     assert normalise_device(2, current=cur) == torch.device("cuda:2")
     with pytest.raises(ValueError):
         normalise_device("cpu", current=cur)
+
+
+def test_tiled_layout_helpers_follow_the_documented_address_map():
+    """tile_batch / flatten_batch (torch ops, any device) against the address formula of include/modarith_amd.h:
+    limb i of element j at buf[((j // tile) * N + i) * tile + j % tile]"""
+    import torch
+    from modarith_amd.field import flatten_batch, tile_batch
+    N, tile, n = 5, 128, 3 * 128
+    flat = torch.arange(N * n, dtype=torch.int64).reshape(N, n)            # value = i * n + j
+    t = tile_batch(flat, tile)
+    assert t.shape == (3, N, tile) and t.is_contiguous()
+    buf = t.reshape(-1)
+    for i in (0, 2, 4):
+        for j in (0, 1, 127, 128, 200, n - 1):
+            assert int(buf[((j // tile) * N + i) * tile + j % tile]) == i * n + j
+    assert torch.equal(flatten_batch(t), flat) and flatten_batch(flat) is flat
+    with pytest.raises(ValueError):
+        tile_batch(flat, 100)
+    with pytest.raises(ValueError):
+        tile_batch(flat[:, :200], 128)
