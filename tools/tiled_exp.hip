@@ -15,6 +15,35 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 namespace ma {
 using P = EXP_P;
+#ifndef EXP_STORE
+#define EXP_STORE 0
+#endif
+// store flavours for the experiment: 0 = the product's non-temporal store; 1 = sc1; 2 = sc0 sc1; 3 = nt sc1; 4 = plain
+__device__ __forceinline__ void st_exp(spint2* p, spint2 v) {
+#if EXP_STORE == 0
+    st_stream(p, v);
+#elif EXP_STORE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif EXP_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#elif EXP_STORE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+#ifndef EXP_LOAD
+#define EXP_LOAD 0
+#endif
+__device__ __forceinline__ spint2 ld_exp(const spint2* p) {
+#if EXP_LOAD == 0
+    return ld_stream(p);
+#elif EXP_LOAD == 1
+    spint2 v; asm volatile("global_load_dwordx4 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v;
+#else
+    return *p;
+#endif
+}
 // SWZ 0: workgroup b takes chunk b (consecutive chunks go round-robin over the 8 XCDs); SWZ 1: XCD x (= b % 8) takes the
 // contiguous eighth [x * G/8, (x+1) * G/8) of the chunks of each grid-stride pass
 template <int T, int SWZ = 0>
@@ -60,7 +89,7 @@ __global__ __launch_bounds__(BS) void k_tiled_bs(const spint* a, const spint* b,
     OpMulAuto<P>::apply(x[1], y[1], z[1]);
     static_for<0, P::N>([&](auto I) {
         spint2 v; v.x = z[0][I]; v.y = z[1][I];
-        st_stream(reinterpret_cast<spint2*>(c + base + ((size_t)I << T)), v);
+        st_exp(reinterpret_cast<spint2*>(c + base + ((size_t)I << T)), v);
     });
 }
 template <int T, bool SQR>
