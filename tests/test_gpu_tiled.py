@@ -165,3 +165,25 @@ print("tiled grid-stride ok")
     env = dict(os.environ, MA_MAX_BLOCKS_TILED="7", MA_MAX_BLOCKS="5")
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "tiled grid-stride ok" in p.stdout, p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("P,kind", [("X25519", 0), ("X448", 2)])
+def test_headline_configuration_full_size_on_tiles_vs_oracle(oracle, torch_cuda, P, kind):
+    """the benchmarked configuration itself: 2^24 elements in tiles of 4096 (one 512-element chunk per workgroup), modmul,
+    EVERY element against the CPU oracle on all host cores"""
+    import os
+    torch = torch_cuda
+    from modarith_amd.field import Field
+    from tests.util import vp
+    T = Field(P, tile=4096)
+    n = 1 << 24
+    A, B = T.uniform(n, seed=42, array=0), T.uniform(n, seed=42, array=1)          # bench.py's operands (rank 0)
+    assert A.dim() == 3 and A.shape == (n // 4096, T.N, 4096)
+    if P != "X25519":
+        A, B = T.nres(A), T.nres(B)
+    C = T.modmul(A, B)
+    ha = np.ascontiguousarray(T.to_flat(A).cpu().numpy().view(np.uint64))
+    hb = np.ascontiguousarray(T.to_flat(B).cpu().numpy().view(np.uint64))
+    want = np.empty_like(ha)
+    assert oracle.lib.oracle_parallel(kind, vp(ha), vp(hb), vp(want), n, n, len(os.sched_getaffinity(0))) == 0
+    assert np.array_equal(T.to_flat(C).cpu().numpy().view(np.uint64), want), "%s modmul on tiles differs from the oracle at full size" % P
