@@ -35,7 +35,11 @@
  * modadd(z,z,z), modmul(z2,E,z2), rfc7748(alice,apk,apk)).  Partial overlap is not supported.
  * Results are bit-identical to the reference's field.c, including non-canonical (< 2p) limbs;
  * modpro/modinv use a different addition chain (the reference shells out to `addchain`), so their
- * limbs are only comparable after redc.
+ * limbs are only comparable after redc.  modinv (both forms, with or without a progenitor) returns the inverse in NORMALISED
+ * form nres(redc(1/x)): words that depend on the value alone.  modinv_<P>_batch shares one inversion between up to 64
+ * elements of a large batch (Montgomery's simultaneous inversion: 3 multiplications per element instead of ~265; zero
+ * values are kept out of the shared product by lane predication, modinv(0) = 0) -- the same words as one inversion per
+ * element, 20-30 x the rate.
  * Errors: the reference signals none.  Batched calls return 0 or a hipError_t value (launch/device
  * errors only); modarith_amd_last_error() describes the last failure on the calling thread.  Scalar
  * _ct calls abort() on a device error (their reference signatures have no way to report one).

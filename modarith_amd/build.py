@@ -56,6 +56,15 @@ _TIMES = {}
 _ROOT = os.path.dirname(HERE)
 
 
+def _unit_deps(obj: str):
+    """in-tree files the unit's last compile read (from its -MD depfile)"""
+    dep = obj[:-2] + ".d"
+    if not os.path.exists(dep):
+        return []
+    text = open(dep).read().replace("\\\n", " ")
+    return [f for f in sorted(set(text.split()[1:])) if os.path.abspath(f).startswith(_ROOT + os.sep)]
+
+
 def _unit_hash(obj: str, cmd) -> str | None:
     """hash of the command line and of every in-tree file the unit's last compile read (from its -MD depfile);
     None when the depfile is missing or names a file that no longer exists"""
@@ -86,8 +95,11 @@ def _compile(unit) -> str:
     t0 = time.time()
     subprocess.run(cmd + ["-MD", "-MF", obj[:-2] + ".d", "-o", obj], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
     _TIMES[obj_name] = time.time() - t0
+    # a source edited WHILE the unit compiled would be hashed in its new state against an object made from the old one: such a
+    # unit gets no hash and is compiled again by the next build
+    stale = any(os.path.exists(f) and os.path.getmtime(f) > t0 for f in _unit_deps(obj))
     with open(hfile, "w") as f:
-        f.write(_unit_hash(obj, cmd) or "-")
+        f.write("-" if stale else (_unit_hash(obj, cmd) or "-"))
     return obj
 
 

@@ -18,6 +18,7 @@ int max_blocks_tiled();    // the same for tiled batches (env MA_MAX_BLOCKS_TILE
 int ladder_block();        // workgroup size of the ladder kernel (env MA_LADDER_BLOCK)
 bool force_fast();         // env MA_FORCE_FAST=1: element-wise modmul/modsqr/nres/redc/modinv on the FAST product path (tests)
 bool force_exact();        // env MA_FORCE_EXACT=1: element-wise modmul/modsqr on the exact 128-bit products only (tests)
+bool inv_simul();          // env MA_INV_SIMUL=0: modinv_<P>_batch never shares an inversion between elements
 bool ladder_split();       // env MA_LADDER_SPLIT=0: the batched ladders never take the split form (one inversion per lane)
 bool ladder_use_field();   // env MA_LADDER_IMPL=field: X25519 ladder on the 5x51 field.c-form arithmetic
 

@@ -50,6 +50,10 @@ bool force_exact() {
     static bool v = [] { const char* s = getenv("MA_FORCE_EXACT"); return s && *s == '1'; }();
     return v;
 }
+bool inv_simul() {
+    static bool v = [] { const char* s = getenv("MA_INV_SIMUL"); return !(s && *s == '0'); }();
+    return v;
+}
 bool ladder_split() {
     static bool v = [] { const char* s = getenv("MA_LADDER_SPLIT"); return !(s && *s == '0'); }();
     return v;

@@ -162,7 +162,22 @@ template <class P, bool FAST = false> struct OpRedc { static MA_DEV void apply(c
 template <class P> struct ScalarOp<OpNresAuto<P>> { using type = OpNres<P, false>; };
 template <class P> struct ScalarOp<OpRedcAuto<P>> { using type = OpRedc<P, false>; };
 template <class P> struct OpCpy { static MA_DEV void apply(const spint* a, spint* c) { Field<P>::modcpy(a, c); } };
-template <class P, bool FAST = false> struct OpInv { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::modinv(a, nullptr, c); } };
+// modinv of the batched API returns the inverse in NORMALISED form nres(redc(1/a)): limbs that are a function of the value alone
+// (canonical limbs for the pseudo-Mersenne fields, the Montgomery form of the canonical value otherwise).  The reference's
+// modinv leaves whatever its addition chain leaves -- a chain this library does not share (the reference's comes from an
+// external tool), so its limbs were never comparable before redc -- and normalising makes the per-element kernel, the
+// progenitor form and the simultaneous-inversion kernel (k_inv_simul) return the same words for the same value.
+template <class F> MA_DEV void inv_normalise(spint* z) {
+    spint t[F::N];
+    F::redc(z, t);
+    F::nres(t, z);
+}
+template <class P, bool FAST = false> struct OpInv {
+    static MA_DEV void apply(const spint* a, spint* c) {
+        Field<P, FAST>::modinv(a, nullptr, c);
+        inv_normalise<Field<P, FAST>>(c);          // (1/a is a product of field-function outputs: inside the limb contract)
+    }
+};
 template <class P, bool FAST = false> struct OpSqrt { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::modsqrt(a, nullptr, c); } };
 template <class P, bool FAST = false> struct OpPro { static MA_DEV void apply(const spint* a, spint* c) { Field<P, FAST>::modpro(a, c); } };
 // the long chains (x^PE and what hangs on it: ~250-450 squarings + multiplications per element) with the same wave-uniform
@@ -288,9 +303,90 @@ __global__ __launch_bounds__(BLOCK) void k_inv_h(const spint* xs, const spint* h
         load_soa<P, 1>(hs, ldh, t, h);
         bool fast = false;
         if constexpr (P::SPLIT > 0) fast = __all(in_split_contract<P>(x[0]) && in_split_contract<P>(h[0]));
-        if (fast) Field<P, true>::modinv(x[0], h[0], z[0]); else Field<P, false>::modinv(x[0], h[0], z[0]);
+        if (fast) { Field<P, true>::modinv(x[0], h[0], z[0]); inv_normalise<Field<P, true>>(z[0]); }
+        else { Field<P, false>::modinv(x[0], h[0], z[0]); inv_normalise<Field<P, false>>(z[0]); }
         store_soa<P, 1>(zs, ldz, t, z);
     }
+}
+
+// z[j] = 1/x[j] for a whole batch with ONE inversion per `rounds` elements (Montgomery's simultaneous inversion).  modinv is
+// ~265 field multiplications (38 700 VALU instructions for 2^255-19); a batch does not owe one to every element.  Lane j of L
+// takes the elements {r * L + j : r < rounds} (every access of a wave is one coalesced row): forward, it multiplies them up,
+// leaving the prefix products c_r in cs (the output buffer itself, or scratch when the output aliases the input);
+// then it inverts the last product; backward, 1/x_r = inv * c_{r-1} and inv *= x_r.
+// No element may spoil the result of another, whatever its limbs.  Two kinds are kept out of the shared product by lane
+// predication (c_r = c_{r-1}), their verdicts travelling to the backward pass in bits 63 / 62 of the stored prefix's top limb
+// (free: prefixes are inside the limb contract and the path is taken for radix <= 60 only):
+//   * zero values -- tested on the PRODUCT c_{r-1} * x_r, a field-function output, where modis0 is exact whatever the
+//     representation of x_r (0, p, even 2p); their output is zero, as modinv(0) = 0 in the reference (pseudo.py:788-812);
+//   * elements with limbs outside the contract (fabricated; the reference's behaviour on them is its 64-bit wrap-around):
+//     they get an inversion of their own on the exact products in the backward pass -- exactly what the per-element
+//     kernel does for a wave that holds one -- paid by that wave only.
+// Everything that enters a product is therefore inside the contract: all products run on the split forms.  Outputs in
+// normalised form (inv_normalise): the same words as the per-element kernel for every input.
+template <class P>
+struct InvSimul {
+    using F0 = Field<P, false>;
+    using F1 = Field<P, (P::SPLIT > 0)>;
+    static constexpr spint ZERO = (spint)1 << 63, OOC = (spint)1 << 62;
+    static MA_DEV void load(const spint* xs, Ld ldx, size_t e, spint* x) {
+        spint t[1][P::N];
+        load_soa<P, 1>(xs, ldx, e, t);
+        static_for<0, P::N>([&](auto I) { x[I] = t[0][I]; });
+    }
+    static MA_DEV void run(const spint* xs, spint* zs, spint* cs, size_t n, size_t L, int rounds, Ld ldx, Ld ldz, Ld ldc, size_t j) {
+        spint c[P::N], x[P::N], t[1][P::N];
+        F1::modone(c);
+#pragma unroll 1
+        for (int r = 0; r < rounds; r++) {
+            const size_t e = (size_t)r * L + j;
+            if (e >= n) break;                                  // (e grows with r)
+            load(xs, ldx, e, x);
+            const bool ooc = !in_split_contract<P>(x);
+            F1::modmul(c, x, t[0]);                             // (discarded for an out-of-contract x)
+            const bool zero = !ooc && F1::modis0(t[0]) != 0;
+            const bool skip = ooc || zero;
+            static_for<0, P::N>([&](auto I) { c[I] = skip ? c[I] : t[0][I]; });
+            static_for<0, P::N>([&](auto I) { t[0][I] = c[I]; });
+            t[0][P::N - 1] |= (zero ? ZERO : (spint)0) | (ooc ? OOC : (spint)0);
+            store_soa<P, 1>(cs, ldc, e, t);
+        }
+        spint inv[P::N];
+        F1::modinv(c, nullptr, inv);
+#pragma unroll 1
+        for (int r = rounds - 1; r >= 0; r--) {
+            const size_t e = (size_t)r * L + j;
+            if (e >= n) continue;
+            load(xs, ldx, e, x);
+            const spint flags = cs[ldc.template off<P::N>(e) + (size_t)(P::N - 1) * ldc.ld];
+            const bool zero = (flags & ZERO) != 0, ooc = (flags & OOC) != 0;
+            spint zi[P::N];
+            if (r > 0) {
+                load_soa<P, 1>(cs, ldc, e - L, t);
+                t[0][P::N - 1] &= ~(ZERO | OOC);
+                F1::modmul(inv, t[0], zi);                      // inv * c_{r-1}
+                F1::modmul(inv, x, t[0]);
+                static_for<0, P::N>([&](auto I) { inv[I] = (zero || ooc) ? inv[I] : t[0][I]; });
+            } else {
+                static_for<0, P::N>([&](auto I) { zi[I] = inv[I]; });
+            }
+            inv_normalise<F1>(zi);
+            static_for<0, P::N>([&](auto I) { zi[I] = zero ? (spint)0 : zi[I]; });
+            if (__any(ooc)) {                                   // fabricated limbs somewhere in this wave: their own inversion, exact products
+                spint w[P::N];
+                F0::modinv(x, nullptr, w);
+                inv_normalise<F0>(w);
+                static_for<0, P::N>([&](auto I) { zi[I] = ooc ? w[I] : zi[I]; });
+            }
+            static_for<0, P::N>([&](auto I) { t[0][I] = zi[I]; });
+            store_soa<P, 1>(zs, ldz, e, t);
+        }
+    }
+};
+template <class P>
+__global__ __launch_bounds__(BLOCK) void k_inv_simul(const spint* xs, spint* zs, spint* cs, size_t n, size_t L, int rounds, Ld ldx, Ld ldz, Ld ldc) {
+    const size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j < L) InvSimul<P>::run(xs, zs, cs, n, L, rounds, ldx, ldz, ldc, j);
 }
 
 // r[j] = sqrt(x[j]) / qr(x[j]) with caller-supplied progenitors h[j] (pseudo.py:815-874)

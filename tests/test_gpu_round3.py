@@ -55,3 +55,63 @@ def test_mulgen_get_second_grid_stride_pass(name):
     # general kernel through 1M scalar multiplications: fine on the GPU, a second or two)
     wx, wy, ws = C.mul_get(e, C.gen(n))
     assert torch.equal(gx, wx) and torch.equal(gy, wy) and torch.equal(gs, ws)
+
+
+def _zero_forms(F):
+    """limb vectors whose VALUE is zero: 0, p (top limb unmasked) and 2p (outside the functions' domain [0, 2p), where
+    modis0 itself no longer sees a zero -- the shared product must still be protected from it)"""
+    fp = F.params
+    return [fp.to_limbs(0), fp.to_limbs(fp.p), fp.to_limbs(2 * fp.p)]
+
+
+@pytest.mark.parametrize("P", CORE + ["SECP256K1", "NIST384", "PM266M", "M607", "C2065", "SIDH751"])
+def test_simultaneous_inversion_equals_one_modinv_per_element(P):
+    """modinv_<P>_batch on a large batch shares one inversion between up to 64 elements (kernels.h k_inv_simul; fields of at
+    most 9 limbs and radix <= 60, the others keep one inversion per element).  Its words must be those of the per-element
+    kernel (both return the normalised form nres(redc(1/x))) for every element of the domain -- also for elements whose
+    value is zero in any representation (they must not poison their group; modinv(0) = 0), in place, and on tiles -- and a
+    fabricated out-of-contract element (whose own result is as undefined as in the reference) must leave every other
+    element of its group untouched."""
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from modarith_amd.field import Field
+    F = Field(P)
+    N = F.N
+    n = 3 * 16384 + 1237
+    x = F.nres(F.uniform(n, seed=11, array=3))
+    zf = _zero_forms(F)
+    idx = list(range(0, n, 997)) + [1, 2, 3, n - 1, 16384, 16385, 2 * 16384 + 5]
+    for k, j in enumerate(idx):
+        x[:, j] = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in zf[k % len(zf)]], dtype=torch.int64)
+
+    def per_element(v):
+        w = torch.empty_like(v)
+        for lo in range(0, v.shape[1], 8192):
+            hi = min(v.shape[1], lo + 8192)
+            w[:, lo:hi] = F.modinv(v[:, lo:hi].contiguous())
+        return w
+    want = per_element(x)
+    got = F.modinv(x)
+    assert torch.equal(got, want), P
+    # value check: x * (1/x) = 1 where x != 0 (mod p), 1/x = 0 where x = 0
+    z0 = torch.zeros(n, dtype=torch.bool, device="cuda")
+    z0[idx] = True
+    assert bool((F.modis0(got).bool() == z0).all())
+    one = F.redc(F.modmul(x, got))
+    assert torch.equal(one[:, ~z0], F.redc(F.modone(n))[:, ~z0])
+    # in place (prefix products go to scratch) and on tiles
+    y = x.clone()
+    F.modinv(y, out=y)
+    assert torch.equal(y, want)
+    m = (n // 4096) * 4096
+    T = Field(P, tile=4096)
+    assert torch.equal(T.to_flat(T.modinv(T.to_tiled(x[:, :m].contiguous()))), want[:, :m])
+    # normalised form: the words depend on the value only -- the progenitor form returns them too
+    h = F.modpro(x[:, :4096].contiguous())
+    assert torch.equal(F.modinv(x[:, :4096].contiguous(), h), want[:, :4096])
+    # fabricated limbs (outside the limb contract) in two elements: they get their own inversion on the exact products, as the
+    # per-element kernel gives a wave that holds one, and change nothing else -- all words equal again
+    bad = x.clone()
+    bad[0, 5000] = -1
+    bad[N - 1, 20000] = 1 << 62
+    assert torch.equal(F.modinv(bad), per_element(bad))
