@@ -136,6 +136,95 @@ static __global__ __launch_bounds__(BLOCK) void k_soa2aos(const spint* soa, spin
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK)
         for (int i = 0; i < nlimbs; i++) aos[t * (size_t)nlimbs + i] = soa[soa_off(L, nlimbs, t) + (size_t)i * L.ld];
 }
+// The same conversions through LDS, for 16-byte-aligned buffers, even strides and up to 14 limbs: a workgroup of 256 lanes moves
+// a chunk of 512 elements.  Both sides of the transposition then run as whole 16-byte-per-lane coalesced accesses -- the SoA rows
+// two elements per lane, the chunk's AoS image (512 * nlimbs consecutive words) as one linear stretch -- instead of one side
+// striding nlimbs words from lane to lane (soa->aos 2.8 -> TB/s class; tools/time_convert.py).  LDS image: sh[e * S + i] with
+// S = nlimbs | 1 words per element (an odd pitch keeps the strided side at two-way bank conflicts).
+constexpr int CONV_CHUNK = 512;
+template <bool TO_SOA>
+static __global__ __launch_bounds__(BLOCK) void k_convert_lds(const spint* src, spint* dst, size_t n, int nlimbs, Ld L) {
+    extern __shared__ spint sh[];
+    const int S = nlimbs | 1, t = threadIdx.x;
+    for (size_t c0 = (size_t)blockIdx.x * CONV_CHUNK; c0 < n; c0 += (size_t)gridDim.x * CONV_CHUNK) {
+        const size_t cnt = (n - c0 < (size_t)CONV_CHUNK) ? n - c0 : (size_t)CONV_CHUNK;
+        const size_t total = cnt * (size_t)nlimbs;                      // words of the chunk's AoS image
+        const spint* aos_in = src + c0 * (size_t)nlimbs;                // (TO_SOA)
+        spint* aos_out = dst + c0 * (size_t)nlimbs;                     // (!TO_SOA)
+        // ---- the SoA side: lane t holds elements 2t, 2t+1 of the chunk
+        const size_t j = c0 + 2 * (size_t)t;
+        const bool two = 2 * (size_t)t + 1 < cnt, one = 2 * (size_t)t < cnt;
+        const size_t so = soa_off(L, nlimbs, j);
+        if constexpr (!TO_SOA) {
+            if (two) {
+                for (int i = 0; i < nlimbs; i++) {
+                    const spint2 v = __builtin_nontemporal_load(reinterpret_cast<const spint2*>(src + so + (size_t)i * L.ld));
+                    sh[(2 * t) * S + i] = v.x;
+                    sh[(2 * t + 1) * S + i] = v.y;
+                }
+            } else if (one) {
+                for (int i = 0; i < nlimbs; i++) sh[(2 * t) * S + i] = src[so + (size_t)i * L.ld];
+            }
+        } else {
+            // ---- the AoS side, linear: lane t takes words 2t, 2t+1, then + 512, ...; (e, i) = divmod(w, nlimbs) kept incrementally
+            int e = (2 * t) / nlimbs, i = (2 * t) % nlimbs;
+            const int de = CONV_CHUNK / nlimbs, di = CONV_CHUNK % nlimbs;
+            for (size_t w = 2 * (size_t)t; w < total; w += CONV_CHUNK) {
+                int e1 = e, i1 = i + 1;
+                if (i1 == nlimbs) { i1 = 0; e1++; }
+                if (w + 1 < total) {
+                    const spint2 v = __builtin_nontemporal_load(reinterpret_cast<const spint2*>(aos_in + w));
+                    sh[e * S + i] = v.x;
+                    sh[e1 * S + i1] = v.y;
+                } else {
+                    sh[e * S + i] = aos_in[w];
+                }
+                e += de; i += di;
+                if (i >= nlimbs) { i -= nlimbs; e++; }
+            }
+        }
+        __syncthreads();
+        if constexpr (!TO_SOA) {
+            int e = (2 * t) / nlimbs, i = (2 * t) % nlimbs;
+            const int de = CONV_CHUNK / nlimbs, di = CONV_CHUNK % nlimbs;
+            for (size_t w = 2 * (size_t)t; w < total; w += CONV_CHUNK) {
+                int e1 = e, i1 = i + 1;
+                if (i1 == nlimbs) { i1 = 0; e1++; }
+                if (w + 1 < total) {
+                    spint2 v;
+                    v.x = sh[e * S + i];
+                    v.y = sh[e1 * S + i1];
+                    __builtin_nontemporal_store(v, reinterpret_cast<spint2*>(aos_out + w));
+                } else {
+                    aos_out[w] = sh[e * S + i];
+                }
+                e += de; i += di;
+                if (i >= nlimbs) { i -= nlimbs; e++; }
+            }
+        } else {
+            if (two) {
+                for (int i = 0; i < nlimbs; i++) {
+                    spint2 v;
+                    v.x = sh[(2 * t) * S + i];
+                    v.y = sh[(2 * t + 1) * S + i];
+                    __builtin_nontemporal_store(v, reinterpret_cast<spint2*>(dst + so + (size_t)i * L.ld));
+                }
+            } else if (one) {
+                for (int i = 0; i < nlimbs; i++) dst[so + (size_t)i * L.ld] = sh[(2 * t) * S + i];
+            }
+        }
+        __syncthreads();
+    }
+}
+static bool conv_fast_ok(const void* aos, const void* soa, int nlimbs, Ld L) {
+    return nlimbs <= 14 && L.ld % 2 == 0 && aligned16(aos) && aligned16(soa);
+}
+static unsigned conv_grid(size_t n, bool tiled) {
+    size_t b = (n + CONV_CHUNK - 1) / CONV_CHUNK;
+    const size_t cap = (size_t)(tiled ? max_blocks_tiled() : 4 * max_blocks());
+    return (unsigned)(b < cap ? b : cap);
+}
+
 // ld >= n: flat; ld < n: tiles of ld elements (a power of two >= 128)
 static bool conv_ld(size_t n, size_t ld, Ld* L) {
     if (ld >= n) { *L = Ld(ld); return true; }
@@ -198,14 +287,20 @@ int modarith_amd_aos_to_soa(const ma_spint* aos, ma_spint* soa, size_t n, int nl
     if (n == 0) return 0;
     Ld L;
     if (nlimbs < 1 || nlimbs > 64 || !conv_ld(n, ld, &L)) { set_error("aos_to_soa: need 1 <= nlimbs <= 64 and ld >= n (flat) or ld a power of two >= 128 (tiles)"); return (int)hipErrorInvalidValue; }
-    k_aos2soa<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(aos, soa, n, nlimbs, L);
+    if (conv_fast_ok(aos, soa, nlimbs, L))
+        k_convert_lds<true><<<conv_grid(n, L.s != 63), BLOCK, (size_t)CONV_CHUNK * (nlimbs | 1) * sizeof(spint), (hipStream_t)stream>>>(aos, soa, n, nlimbs, L);
+    else
+        k_aos2soa<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(aos, soa, n, nlimbs, L);
     return check_launch("aos_to_soa");
 }
 int modarith_amd_soa_to_aos(const ma_spint* soa, ma_spint* aos, size_t n, int nlimbs, size_t ld, void* stream) {
     if (n == 0) return 0;
     Ld L;
     if (nlimbs < 1 || nlimbs > 64 || !conv_ld(n, ld, &L)) { set_error("soa_to_aos: need 1 <= nlimbs <= 64 and ld >= n (flat) or ld a power of two >= 128 (tiles)"); return (int)hipErrorInvalidValue; }
-    k_soa2aos<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(soa, aos, n, nlimbs, L);
+    if (conv_fast_ok(aos, soa, nlimbs, L))
+        k_convert_lds<false><<<conv_grid(n, L.s != 63), BLOCK, (size_t)CONV_CHUNK * (nlimbs | 1) * sizeof(spint), (hipStream_t)stream>>>(soa, aos, n, nlimbs, L);
+    else
+        k_soa2aos<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(soa, aos, n, nlimbs, L);
     return check_launch("soa_to_aos");
 }
 

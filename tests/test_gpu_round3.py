@@ -115,3 +115,33 @@ def test_simultaneous_inversion_equals_one_modinv_per_element(P):
     bad[0, 5000] = -1
     bad[N - 1, 20000] = 1 << 62
     assert torch.equal(F.modinv(bad), per_element(bad))
+
+
+@pytest.mark.parametrize("P", ["X25519", "X448", "NIST521", "SIDH751", "C2065"])
+def test_lds_transposed_converters(P):
+    """element-major <-> limb-interleaved through the LDS-staged kernels (16-byte-aligned buffers, even stride, <= 14 limbs):
+    chunk boundaries (512 elements), a short and odd last chunk, a padded even stride, tiles of 128 and 4096 -- against
+    torch's own transposition; odd strides and unaligned views take the plain kernels and must agree too"""
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from modarith_amd.field import Field, tile_batch
+    F = Field(P)
+    N = F.N
+    g = torch.Generator(device="cuda").manual_seed(17)
+    for n in (2, 510, 512, 514, 3 * 512 + 77, 8192 + 6):
+        aos = torch.randint(-(1 << 62), 1 << 62, (n, N), dtype=torch.int64, device="cuda", generator=g)
+        soa = F.from_aos(aos)
+        assert torch.equal(soa, aos.t()), (P, n, "aos->soa")
+        assert torch.equal(F.to_aos(soa), aos), (P, n, "soa->aos")
+        wide = torch.zeros((N, n + 14), dtype=torch.int64, device="cuda")            # even padded stride: still the LDS kernels
+        wide[:, :n] = soa
+        assert torch.equal(F.to_aos(wide[:, :n]), aos)
+        odd = torch.zeros((N, n + 13), dtype=torch.int64, device="cuda")             # odd stride: the plain kernels
+        odd[:, :n] = soa
+        assert torch.equal(F.to_aos(odd[:, :n]), aos)
+    for tile, n in ((128, 5 * 128), (4096, 3 * 4096)):
+        T = Field(P, tile=tile)
+        aos = torch.randint(-(1 << 62), 1 << 62, (n, N), dtype=torch.int64, device="cuda", generator=g)
+        tiled = T.from_aos(aos)
+        assert tiled.dim() == 3 and torch.equal(tiled, tile_batch(aos.t().contiguous(), tile)), (P, tile)
+        assert torch.equal(T.to_aos(tiled), aos)
