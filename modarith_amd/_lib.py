@@ -182,6 +182,30 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+_plugins = {}
+
+
+def load_plugin(tag: str, path: str = None) -> ctypes.CDLL:
+    """Load the plug-in of a generated field (modarith_amd.generate): same entry points as a built-in prime, under
+    <fn>_<tag>_batch / <fn>_<tag>_ct.  The main library is loaded first; the plug-in's DT_NEEDED entry resolves to it."""
+    if tag in _plugins:
+        return _plugins[tag]
+    load()
+    if path is None:
+        from .generate import plugin_path
+        path = plugin_path(tag)
+    if not os.path.exists(path):
+        raise RuntimeError("modarith_amd: no plug-in for %r (%s) -- generate it with `python -m modarith_amd.generate 64 <prime>`. "
+                           "There is no CPU fallback." % (tag, path))
+    lib = ctypes.CDLL(path)
+    for fn, args in _SIG.items():
+        f = getattr(lib, "%s_%s_batch" % (fn, tag))
+        f.argtypes = args
+        f.restype = c_int
+    _plugins[tag] = lib
+    return lib
+
+
 class DeviceError(RuntimeError):
     pass
 

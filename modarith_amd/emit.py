@@ -183,6 +183,7 @@ def eval_chain(prog, x: int, p: int) -> int:
     return acc
 
 
+MAX_GENERATED_LIMBS = 16  # generator mode (modarith_amd.generate): limbs stay in VGPRs; the widest built-in field has 13
 MAX_UNROLLED_MULS = 24   # beyond this the progenitor is a square-and-multiply loop (general primes)
 
 

@@ -64,11 +64,20 @@ class Field:
     """Batched field arithmetic for one of the built primes (X25519, NIST256, X448)."""
 
     def __init__(self, prime: str, device: Optional[torch.device] = None, tile: Optional[int] = None):
-        if prime not in _lib.PRIMES:
-            raise ValueError("prime %r is not built; available: %s" % (prime, ", ".join(_lib.PRIMES)))
         self.lib = _lib.load()
+        self.flib = self.lib                   # the library that holds this prime's entry points
+        if prime in _lib.PRIMES:
+            self.params: FieldParams = derive(prime)
+        else:
+            # a field made by the generator mode (modarith_amd.generate): its kernels live in a plug-in next to the main library
+            from . import generate as _gen
+            if not os.path.exists(_gen.plugin_path(prime)):
+                raise ValueError("prime %r is neither built in (%s) nor generated (%s); generate it with Field.generate(...) or "
+                                 "`python -m modarith_amd.generate 64 <prime>`"
+                                 % (prime, ", ".join(_lib.PRIMES), ", ".join(m["tag"] for m in _gen.installed()) or "none"))
+            self.flib = _lib.load_plugin(prime)
+            self.params = _gen.params_of_plugin(prime)
         self.prime = prime
-        self.params: FieldParams = derive(prime)
         self.N = self.params.nlimbs
         self.radix = self.params.radix
         self.nbytes = self.params.nbytes
@@ -79,6 +88,14 @@ class Field:
         if tile is not None and (tile < 128 or tile & (tile - 1)):
             raise ValueError("tile must be a power of two >= 128")
         self.tile = tile
+
+    @classmethod
+    def generate(cls, prime: str, device: Optional[torch.device] = None, tile: Optional[int] = None, **kw) -> "Field":
+        """the generator mode in one call: `Field.generate("2**251-9")` is `python pseudo.py 64 2**251-9` followed by loading
+        what it built -- constants derived, kernels compiled for the prime (about ten seconds, reused afterwards), field bound.
+        Keywords as modarith_amd.generate.generate (family=, name=, radix=, force=)."""
+        from . import generate as _gen
+        return cls(_gen.generate(prime, **kw).tag, device, tile)
 
     # ------------------------------------------------------------------ buffers
     def empty(self, n: int) -> torch.Tensor:
@@ -172,7 +189,7 @@ class Field:
         return n
 
     def _call(self, fn: str, *args):
-        f = getattr(self.lib, "%s_%s_batch" % (fn, self.prime))
+        f = getattr(self.flib, "%s_%s_batch" % (fn, self.prime))
         with torch.cuda.device(self.device):          # the C-ABI launches on the calling thread's current device
             _lib.check(f(*args), "%s_%s_batch" % (fn, self.prime))
 

@@ -1,0 +1,232 @@
+"""Generator mode: a field for ANY prime the reference generators accept, built at run time.
+
+  python -m modarith_amd.generate 64 2**251-9               # the reference's own command-line shape
+  python -m modarith_amd.generate 64 BP256=0xa9fb57db...5377 --monty
+  python -m modarith_amd.generate --list
+
+This is the counterpart of `python pseudo.py 64 <prime>` / `python monty.py 64 <prime>` (pseudo.py:1461-1473,
+1552-1566; monty.py:2111-2135): where the reference writes a specialised field.c for the prime, this driver derives
+the same constants (modarith_amd.params), emits them as a `struct P_<TAG>` (modarith_amd.emit.header_text), and has
+hipcc instantiate the hand-written kernels of csrc/field.h + csrc/kernels.h for it -- one translation unit, about
+ten seconds -- into a plug-in `modarith_amd/plugins/libmodarith_amd_<TAG>.so` that exports the same C-ABI as a
+built-in prime: `<fn>_<TAG>_ct` (host pointers, the reference's signatures) and `<fn>_<TAG>_batch` (device
+pointers), declared by `MODARITH_AMD_DECLARE(<TAG>)` of include/modarith_amd.h.  The plug-in links against
+libmodarith_amd.so (launch geometry, error text, staging buffers); `Field("<TAG>")` loads it.
+
+Naming follows the generators' decoration rule (pseudo.py:1940-1944, monty.py:2510-2520): a named prime keeps its
+name; an unnamed pseudo-Mersenne 2^n - m is tagged `<n><m>` ("25519"); any other unnamed modulus must be given a
+name (`NAME=<expression>` or `name=`), as monty.py insists ("Modulus must have a name").  Only 64-bit words are
+built: the MI355X kernels hold u64 limbs (SURVEY 8 sizes); 16 / 32 are refused with the reason.
+
+There is no CPU path here either: the plug-in contains GPU kernels only, and a missing hipcc is an error.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+from dataclasses import dataclass
+from typing import List, Optional
+
+from . import emit
+from .params import NAMED, FieldParams, derive_monty, derive_pseudo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PLUGIN_DIR = os.environ.get("MA_PLUGIN_DIR", os.path.join(HERE, "plugins"))
+_TAG_RE = re.compile(r"^[A-Za-z0-9][A-Za-z0-9_]*$")
+
+
+# unnamed moduli the test-suite generates (tests/golden/field_<TAG>.json hold what the reference generators emit for them):
+# (argument as on the reference's command line, family) -- an unnamed pseudo-Mersenne, a three-limb one, a general 256-bit
+# prime (brainpoolP256r1) in full Montgomery form, and monty.py's PM shortcut for an unnamed 2^n - m
+EXAMPLES = (("2**251-9", "pseudo"), ("2**130-5", "pseudo"),
+            ("BP256=0xa9fb57dba1eea9bc3e660a909d838d726e3bf623d52620282013481d1f6e5377", "monty"), ("M2519=2**251-9", "monty"))
+
+
+class GenerateError(ValueError):
+    pass
+
+
+@dataclass
+class Generated:
+    tag: str                    # the <TAG> of the exported symbols
+    lib: str                    # path of the plug-in shared object
+    params: FieldParams
+    built: bool                 # False when an up-to-date plug-in was reused
+
+
+def _evaluate(expr: str) -> int:
+    """the modulus of a command-line argument: an expression that starts with a digit (pseudo.py:1554-1556), or
+    "00" + decimal for a group order (monty.py:2116-2118)"""
+    if not expr or not expr[0].isdigit():
+        raise GenerateError("%r: an unnamed modulus is a python expression that starts with a digit, e.g. 2**255-19" % (expr,))
+    if expr.startswith("00"):
+        return int(expr)
+    if not re.fullmatch(r"[0-9a-fA-FxX*+\-() ]+", expr):
+        raise GenerateError("%r: only integers, + - * ** and parentheses are evaluated" % (expr,))
+    return int(eval(expr, {"__builtins__": {}}))
+
+
+def resolve(prime: str, family: Optional[str] = None, name: Optional[str] = None, radix: Optional[int] = None) -> FieldParams:
+    """prime (a name of modarith_amd.params.NAMED, an expression, or NAME=expression) -> FieldParams with .name = TAG"""
+    if "=" in prime and name is None:
+        name, prime = prime.split("=", 1)
+    if prime in NAMED:
+        p, fam = NAMED[prime]
+        name = name or prime
+        family = family or fam
+    else:
+        p = _evaluate(prime)
+    n = p.bit_length()
+    fp = None
+    if family in (None, "pseudo"):
+        try:
+            fp = derive_pseudo(name or "_", p, radix)
+        except ValueError as e:
+            if family == "pseudo":
+                raise GenerateError("%s (pseudo.py:1563-1592)" % e) from None
+    if fp is None:
+        try:
+            fp = derive_monty(name or "_", p, radix)
+        except ValueError as e:
+            raise GenerateError("%s (monty.py:2131-2230)" % e) from None
+    if name is None:
+        if fp.family == "pseudo" or fp.pm:
+            name = "%d%d" % (n, (1 << n) - p)                   # the generators' own tag for an unnamed 2^n - m
+        else:
+            raise GenerateError("Modulus must have a name - unable to make one for you (monty.py:2517-2519): pass NAME=<expression>")
+    if not _TAG_RE.match(name):
+        raise GenerateError("%r cannot be part of a C identifier" % (name,))
+    fp.name = name
+    return fp
+
+
+def _flags() -> List[str]:
+    from .build import FLAGS
+    return list(FLAGS) + ["-I", os.path.join(HERE, "csrc", "generated"), "-I", os.path.join(HERE, "csrc")]
+
+
+def _key(fp: FieldParams, tag: str) -> str:
+    """what a plug-in was made from: the constants, the flags and every kernel source (path-independent, so a plug-in built in one
+    checkout is recognised as current in a copy of it)"""
+    from .build import FLAGS, _stamp
+    h = hashlib.sha256((" ".join(FLAGS) + "\n" + emit.header_text(fp) + "\n" + emit.capi_unit_text(tag) + "\n" + _stamp()).encode())
+    return h.hexdigest()
+
+
+def plugin_path(tag: str, plugin_dir: Optional[str] = None) -> str:
+    return os.path.join(plugin_dir or PLUGIN_DIR, "libmodarith_amd_%s.so" % tag)
+
+
+def generate(prime: str, wl: int = 64, family: Optional[str] = None, name: Optional[str] = None, radix: Optional[int] = None,
+             plugin_dir: Optional[str] = None, force: bool = False, verbose: bool = False) -> Generated:
+    """derive the constants of `prime`, emit them, compile the kernels for it; returns the plug-in to load.
+    An existing plug-in is reused when neither the constants nor any kernel source it was compiled from have changed."""
+    if wl != 64:
+        raise GenerateError("only 64-bit words are built for the GPU (u64 limbs, 128-bit column sums); the reference's 16- and "
+                            "32-bit forms have no counterpart here")
+    fp = resolve(prime, family, name, radix)
+    tag = fp.name
+    from . import _lib
+    if tag in _lib.PRIMES and NAMED.get(tag, (None,))[0] == fp.p and (family is None or NAMED[tag][1] == fp.family) and radix is None:
+        return Generated(tag, _lib.LIB_PATH, fp, False)         # a built-in prime: nothing to generate
+    if tag in _lib.PRIMES:
+        raise GenerateError("%s names a built-in field with other constants; choose another name" % tag)
+    if fp.nlimbs > emit.MAX_GENERATED_LIMBS:
+        raise GenerateError("%d limbs: the kernels keep every operand in registers and are built for at most %d limbs" % (fp.nlimbs, emit.MAX_GENERATED_LIMBS))
+    d = plugin_dir or PLUGIN_DIR
+    os.makedirs(d, exist_ok=True)
+    hdr, unit = os.path.join(d, "params_%s.h" % tag), os.path.join(d, "capi_%s.hip" % tag)
+    obj, lib, meta = os.path.join(d, "capi_%s.o" % tag), plugin_path(tag, d), os.path.join(d, "%s.json" % tag)
+    key = _key(fp, tag)
+    emit._write(hdr, emit.header_text(fp))
+    emit._write(unit, emit.capi_unit_text(tag).replace('"../capi_prime.inc"', '"capi_prime.inc"'))
+    from .build import ARCH, HIPCC
+    cmd = [HIPCC] + _flags() + ["-c", unit]
+    if not force and os.path.exists(lib) and os.path.exists(meta):
+        try:
+            if json.load(open(meta)).get("hash") == key:
+                return Generated(tag, lib, fp, False)
+        except (ValueError, OSError):
+            pass
+    if not os.path.exists(HIPCC):
+        raise GenerateError("%s not found: generating a field needs the ROCm compiler (there is no CPU path)" % HIPCC)
+    main = os.path.join(HERE, "libmodarith_amd.so")
+    if not os.path.exists(main):
+        raise GenerateError("%s is missing: build it first (python -m modarith_amd.build); plug-ins link against it" % main)
+    if verbose:
+        print("[modarith_amd] hipcc %s -> %s" % (os.path.basename(unit), os.path.basename(lib)), flush=True)
+    subprocess.run(cmd + ["-o", obj], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
+    rel = os.path.relpath(HERE, d)
+    subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, obj, "-L", HERE, "-l:libmodarith_amd.so",
+                           "-Wl,-rpath,$ORIGIN/" + rel, "-Wl,-rpath," + HERE])
+    json.dump({"tag": tag, "prime": prime, "p": hex(fp.p), "family": fp.family, "radix": fp.radix, "nlimbs": fp.nlimbs,
+               "hash": key}, open(meta, "w"), indent=1)
+    return Generated(tag, lib, fp, True)
+
+
+def installed(plugin_dir: Optional[str] = None) -> List[dict]:
+    """metadata of every plug-in whose shared object is present"""
+    d = plugin_dir or PLUGIN_DIR
+    out = []
+    if os.path.isdir(d):
+        for f in sorted(os.listdir(d)):
+            if f.endswith(".json") and os.path.exists(plugin_path(f[:-5], d)):
+                try:
+                    out.append(json.load(open(os.path.join(d, f))))
+                except ValueError:
+                    pass
+    return out
+
+
+def params_of_plugin(tag: str, plugin_dir: Optional[str] = None) -> FieldParams:
+    """FieldParams of an installed plug-in, re-derived from its recorded modulus / family / radix"""
+    d = plugin_dir or PLUGIN_DIR
+    meta = json.load(open(os.path.join(d, "%s.json" % tag)))
+    p = int(meta["p"], 16)
+    fp = (derive_pseudo if meta["family"] == "pseudo" else derive_monty)(tag, p, meta["radix"])
+    return fp
+
+
+def report(fp: FieldParams) -> str:
+    """the lines the reference generators print about their choice (pseudo.py:1600-1612, monty.py:2200-2230), for the CLI"""
+    L = ["Chosen radix is %d bits, using %d limbs with excess of %d bits" % (fp.radix, fp.nlimbs, fp.xcess)]
+    if fp.family == "pseudo":
+        L.append("pseudo-Mersenne 2^%d - %d: fold constant mm = %#x%s%s%s%s" % (fp.n, fp.m, fp.mm, ", overflow form" if fp.overflow else "",
+                                                                             ", tighter reduction" if fp.fred else "", ", EPM" if fp.epm else "",
+                                                                             ", carry_on" if fp.carry_on else ""))
+    else:
+        L.append("Montgomery form, R = 2^%d%s, ndash = %#x%s%s" % (fp.radix * (fp.nlimbs + (1 if fp.E else 0)), " (virtual limb)" if fp.E else "", fp.ndash,
+                                                                  ", trinomial" if fp.trin else "", ", exploitable pseudo-Mersenne (PM)" if fp.pm else ""))
+        L.append("prime limbs: " + " ".join(("%d" % v) if abs(v) < 10 else ("%#x" % v) for v in fp.ppw))
+    L.append("split products: %s; inversion chain: 2-adicity %d" % ("cut at bit %d" % emit.split_point(fp) if emit.split_point(fp) else "exact 128-bit products only", fp.pm1d2))
+    return "\n".join(L)
+
+
+def main(argv: List[str]) -> int:
+    args = [a for a in argv if not a.startswith("--")]
+    if "--list" in argv:
+        for m in installed():
+            print("%-12s %-6s %2d x %2d bits  %s" % (m["tag"], m["family"], m["nlimbs"], m["radix"], m["prime"]))
+        return 0
+    if len(args) != 2:
+        print("Syntax error")
+        print("Valid syntax - python -m modarith_amd.generate <word length> <prime> OR <prime name> OR <name>=<prime> [--pseudo|--monty] [--force]")
+        print("For example - python -m modarith_amd.generate 64 2**255-19")
+        return 2
+    fam = "pseudo" if "--pseudo" in argv else "monty" if "--monty" in argv else None
+    try:
+        g = generate(args[1], int(args[0]), family=fam, force="--force" in argv, verbose=True)
+    except GenerateError as e:
+        print(e)
+        return 2
+    print(report(g.params))
+    print("%s %s: C-ABI <fn>_%s_ct / <fn>_%s_batch (MODARITH_AMD_DECLARE(%s)); Field(%r)" % ("built" if g.built else "up to date:", g.lib, g.tag, g.tag, g.tag, g.tag))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

@@ -34,3 +34,20 @@ def limbs(hexlist):
 def oracle():
     from tests.oracle_binding import load_oracle
     return load_oracle()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def generated_fields():
+    """On a GPU box: the plug-ins of the generator mode's example moduli exist before any test binds a Field to one (a no-op when
+    they travelled with the tree and are current; otherwise one hipcc unit each, about ten seconds).  Not done on CPU-only runs:
+    the CPU suite tests generation in a scratch directory (tests/test_generate_cpu.py)."""
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        from modarith_amd import generate as gen
+        for arg, fam in gen.EXAMPLES:
+            gen.generate(arg, family=fam)
+    yield

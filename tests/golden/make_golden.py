@@ -945,7 +945,25 @@ def extras():
         print(name, fx["params"]["log"][0])
 
 
+def generated():
+    """the unnamed moduli of modarith_amd.generate.EXAMPLES, through the same recipe: what the reference's generators emit when
+    they are handed an expression instead of a name (pseudo.py:1552-1556, monty.py:2113-2121)"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from modarith_amd.generate import EXAMPLES, resolve
+    for k, (arg, fam) in enumerate(EXAMPLES):
+        tag = resolve(arg, fam).name
+        expr = arg.split("=", 1)[-1]
+        script = "pseudo.py" if fam == "pseudo" else "monty.py"
+        fx, _ = field_fixture(script, expr, 9000 + k, count=64, full_time=False, name=tag)
+        json.dump(fx, open(os.path.join(HERE, "field_%s.json" % tag), "w"), indent=0, separators=(",", ":"))
+        json.dump(sqrt_fixture(script, expr, 9100 + k, count=24, name=tag), open(os.path.join(HERE, "sqrt_%s.json" % tag), "w"), indent=0, separators=(",", ":"))
+        print(tag, fx["params"]["log"][0])
+
+
 def main():
+    if "--generated-only" in sys.argv:
+        generated()
+        return
     if "--extras-only" in sys.argv:
         extras()
         return

@@ -69,6 +69,8 @@ def main():
     from modarith_amd.params import reference_argv
     jobs = [("pseudo.py", "X25519", "X25519"), ("monty.py", "NIST256", "NIST256"), ("monty.py", "X448", "X448")]
     jobs += [reference_argv(n) + (n,) for n in EXTRA_PRIMES]
+    from modarith_amd.generate import EXAMPLES, resolve            # unnamed moduli of the generator mode (appended: seeds of the others stay)
+    jobs += [("pseudo.py" if fam == "pseudo" else "monty.py", arg.split("=", 1)[-1], resolve(arg, fam).name) for arg, fam in EXAMPLES]
     only = [a for a in sys.argv[1:] if not a.startswith("-")]
     for k, (script, arg, name) in enumerate(jobs):
         if only and name not in only:

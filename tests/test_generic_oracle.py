@@ -8,7 +8,9 @@ from tests.generic_oracle import Generic
 
 from modarith_amd.emit import BUILT_PRIMES
 
-ALL = list(BUILT_PRIMES)
+from modarith_amd import generate as _gen
+
+ALL = list(BUILT_PRIMES) + [_gen.resolve(arg, fam).name for arg, fam in _gen.EXAMPLES]     # + the generator mode's unnamed moduli
 
 
 @pytest.fixture(scope="module", params=ALL)

@@ -1,0 +1,93 @@
+"""Generator mode on the GPU (modarith_amd/generate.py): a field generated at run time computes what a built-in one does.
+The example moduli also run through every parametrised parity test of test_gpu_parity / test_gpu_round2 / test_gpu_round3
+(reference-generated vectors, generic oracle); here: the reference's self-test chain through the scalar entry points of the
+plug-ins, a modulus generated ON THIS BOX during the test, and 2^255-19 generated under its unnamed tag against the built-in
+X25519 kernels, limb for limb."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+from tests.util import derive_any, generated_tags, random_soa, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.mark.parametrize("P", generated_tags())
+def test_scalar_abi_reference_selftest_chain_on_plugins(torch_cuda, P):
+    """pseudo.py:1783-1796 / monty.py:2383-2396 through <fn>_<TAG>_ct of the plug-in (host pointers, reference signatures)"""
+    from modarith_amd import _lib
+    lib = _lib.load_plugin(P)
+    fp = derive_any(P)
+    U = ctypes.c_uint64 * fp.nlimbs
+    f = lambda name: getattr(lib, "%s_%s_ct" % (name, P))
+    rng = random.Random(199)
+    for _ in range(6):
+        x, y = rng.randrange(0, 2 * fp.p), rng.randrange(0, 2 * fp.p)
+        want = pow(((x - y) * (x + y)) ** 2 % fp.p, -1, fp.p)
+        ax, ay, at, az = U(*fp.to_limbs(x)), U(*fp.to_limbs(y)), U(), U()
+        f("nres")(ax, ax); f("nres")(ay, ay)
+        f("modadd")(ax, ay, at); f("modsub")(ax, ay, az)
+        f("modmul")(at, az, ax); f("modsqr")(ax, az)
+        f("modinv")(az, None, az)
+        f("modsqrt")(az, None, az); f("modsqr")(az, az)
+        f("modhaf")(az); f("modadd")(az, az, az)
+        f("modshl")(1, az); f("modshr")(1, az)
+        f("redc")(az, az)
+        assert fp.from_limbs(list(az)) == want
+
+
+def test_unnamed_25519_equals_the_builtin_x25519_kernels(torch_cuda, tmp_path, monkeypatch):
+    """`generate 64 2**255-19` -> tag 25519 (pseudo.py:1942): same constants as the built-in X25519, so every limb of every
+    function output must be the same, on canonical, < 2p and tiled batches (generated on this box, in a scratch directory)"""
+    from modarith_amd import generate as gen
+    from modarith_amd.field import Field
+    monkeypatch.setattr(gen, "PLUGIN_DIR", str(tmp_path))
+    F = Field.generate("2**255-19")
+    B = Field("X25519")
+    assert F.prime == "25519" and (F.N, F.radix, F.nbytes) == (B.N, B.radix, B.nbytes)
+    n = 3 * 4096
+    a, b = to_dev(random_soa("X25519", n, 11)), to_dev(random_soa("X25519", n, 12))
+    for op in ("modmul", "modadd", "modsub"):
+        assert np.array_equal(to_np(getattr(F, op)(a, b)), to_np(getattr(B, op)(a, b))), op
+    for op in ("modsqr", "modneg", "nres", "redc", "modpro"):
+        assert np.array_equal(to_np(getattr(F, op)(a)), to_np(getattr(B, op)(a))), op
+    assert np.array_equal(to_np(F.modinv(a)), to_np(B.modinv(a)))
+    assert np.array_equal(to_np(F.modmli(a, 121665)), to_np(B.modmli(a, 121665)))
+    ta, tb = F.to_tiled(a, 4096), F.to_tiled(b, 4096)
+    assert np.array_equal(to_np(F.to_flat(F.modmul(ta, tb))), to_np(B.modmul(a, b)))
+
+
+def test_a_modulus_generated_on_this_box(torch_cuda, tmp_path, monkeypatch):
+    """2^127 - 1 (three 43-bit limbs; no fixture, never built before): derive, compile, load, compute -- checked against plain
+    integer arithmetic after redc, with non-canonical (< 2p) inputs, and with the acceptance chain of the reference's self-test"""
+    from modarith_amd import generate as gen
+    from modarith_amd.field import Field
+    monkeypatch.setattr(gen, "PLUGIN_DIR", str(tmp_path))
+    p = 2**127 - 1
+    F = Field.generate("2**127-1")
+    assert F.prime == "1271" and F.params.p == p and gen.installed(str(tmp_path))[0]["tag"] == "1271"
+    rng = random.Random(5)
+    n = 4096 + 77
+    xs = [rng.randrange(0, 2 * p) for _ in range(n)]
+    ys = [rng.randrange(0, 2 * p) for _ in range(n)]
+    xs[:4] = [0, 1, p - 1, 2 * p - 1]
+    x, y = F.nres(F.from_ints(xs)), F.nres(F.from_ints(ys))
+    assert F.to_ints(F.redc(F.modmul(x, y))) == [(a * b) % p for a, b in zip(xs, ys)]
+    assert F.to_ints(F.redc(F.modsqr(x))) == [(a * a) % p for a in xs]
+    assert F.to_ints(F.redc(F.modadd(x, y))) == [(a + b) % p for a, b in zip(xs, ys)]
+    assert F.to_ints(F.redc(F.modsub(x, y))) == [(a - b) % p for a, b in zip(xs, ys)]
+    assert F.to_ints(F.redc(F.modmli(x, 121665))) == [(a * 121665) % p for a in xs]
+    assert F.to_ints(F.redc(F.modinv(x))) == [pow(a, p - 2, p) for a in xs]
+    t = F.modsqr(F.modmul(F.modadd(x, y), F.modsub(x, y)))
+    assert F.to_ints(F.redc(F.modinv(t))) == [pow(((a - b) * (a + b)) ** 2 % p, p - 2, p) for a, b in zip(xs, ys)]
+    by = F.modexp(x)                                               # big-endian bytes of the canonical value
+    assert [int.from_bytes(bytes(r), "big") for r in by.cpu().numpy()] == [a % p for a in xs]

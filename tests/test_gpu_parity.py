@@ -12,7 +12,7 @@ from tests.util import oracle_bin, oracle_mli, oracle_un, random_soa, to_dev, to
 
 pytestmark = pytest.mark.gpu
 ALL = ["X25519", "NIST256", "X448"]                      # BASELINE.json configs: golden vectors AND oracle batches
-EXTRA = list(__import__("modarith_amd.emit", fromlist=["EXTRA_PRIMES"]).EXTRA_PRIMES)   # further primes: golden vectors + generic oracle
+EXTRA = list(__import__("modarith_amd.emit", fromlist=["EXTRA_PRIMES"]).EXTRA_PRIMES) + __import__("tests.util", fromlist=["generated_tags"]).generated_tags()   # further primes: golden vectors + generic oracle
 
 
 @pytest.fixture(scope="module")
@@ -259,7 +259,7 @@ def test_scalar_abi_reference_selftest_chain(oracle, torch_cuda, P):
     == inverse(((x-y)(x+y))^2), through the scalar entry points with the reference's signatures."""
     import random
     from modarith_amd import _lib
-    from modarith_amd.params import derive
+    from tests.util import derive_any as derive
     lib = _lib.load()
     fp = derive(P)
     N = fp.nlimbs
@@ -368,12 +368,27 @@ def test_c_drop_in_example(torch_cuda, tmp_path):
     assert out[-1] == "batched: equal"
 
 
+def test_c_field_batch_example(torch_cuda, tmp_path):
+    """examples/field_batch_tiles.c: element-major host arrays -> tiles on the device -> the generators' acceptance chain batched
+    (modinv in place) -> back, from plain C through the C-ABI, checked there against the scalar entry points"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "field_batch_tiles")
+    subprocess.check_call(["gcc", "-O2", os.path.join(root, "examples", "field_batch_tiles.c"), "-I", os.path.join(root, "include"),
+                           "-L", os.path.join(root, "modarith_amd"), "-l:libmodarith_amd.so",
+                           "-Wl,-rpath," + os.path.join(root, "modarith_amd"), "-o", exe])
+    for n in ("21717", "70001"):                         # a partial last tile; a batch large enough for the shared inversions
+        p = subprocess.run([exe, n], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "equal to the scalar entry points" in p.stdout, p.stdout[-500:] + p.stderr[-500:]
+
+
 @pytest.mark.parametrize("P", EXTRA)
 def test_extra_primes_vs_generic_oracle(oracle, torch_cuda, P):
     """the further primes: seeded batches against the run-time generic oracle (oracle/field_generic.c, itself
     pinned to the reference's golden vectors by tests/test_generic_oracle.py)"""
     from modarith_amd.field import Field
-    from modarith_amd.params import derive
+    from tests.util import derive_any as derive
     from tests.generic_oracle import Generic
     G = Generic(oracle.lib, P)
     F = Field(P)

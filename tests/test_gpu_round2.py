@@ -23,7 +23,7 @@ from tests.util import oracle_bin, oracle_un, random_soa, to_dev, to_np, vp
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CORE = ["X25519", "NIST256", "X448"]
-EXTRA = list(__import__("modarith_amd.emit", fromlist=["EXTRA_PRIMES"]).EXTRA_PRIMES)
+EXTRA = list(__import__("modarith_amd.emit", fromlist=["EXTRA_PRIMES"]).EXTRA_PRIMES) + __import__("tests.util", fromlist=["generated_tags"]).generated_tags()
 FORCED_FAST = os.environ.get("MA_FORCE_FAST") == "1"      # unguarded split products: only defined inside the limb contract
 
 
@@ -180,7 +180,7 @@ def test_contract_edge_classes_vs_oracle(oracle, torch_cuda, P):
 def test_uniform_inputs_match_host_model(torch_cuda, P):
     """the benchmark's input recipe is regenerable on the host from (seed, array, j) alone"""
     from modarith_amd.field import Field
-    from modarith_amd.params import derive
+    from tests.util import derive_any as derive
     from tests.util import uniform_model
     F, fp = Field(P), derive(P)
     n = 1031

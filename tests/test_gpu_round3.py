@@ -4,7 +4,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 CORE = ["X25519", "NIST256", "X448"]
-EXTRA = list(__import__("modarith_amd.emit", fromlist=["EXTRA_PRIMES"]).EXTRA_PRIMES)
+EXTRA = list(__import__("modarith_amd.emit", fromlist=["EXTRA_PRIMES"]).EXTRA_PRIMES) + __import__("tests.util", fromlist=["generated_tags"]).generated_tags()
 
 
 class _GpuEdgeEngine:
@@ -32,7 +32,7 @@ def test_edge_protocol_gpu(P):
     import torch
     assert torch.cuda.is_available(), "these tests need the MI355X"
     from modarith_amd.field import Field
-    from modarith_amd.params import derive
+    from tests.util import derive_any as derive
     from tests import edge_protocol
     fp = derive(P)
     assert edge_protocol.run(_GpuEdgeEngine(Field(P), fp.nbytes), fp.p, fp.n, fp.nbytes) == []

@@ -6,10 +6,17 @@ import random
 import pytest
 
 from modarith_amd import emit
-from modarith_amd.params import derive
+from modarith_amd import generate as gen
+from modarith_amd.params import derive as _derive_named
 from tests.conftest import load_golden
 
-ALL = list(emit.BUILT_PRIMES)
+# the built-in primes, and the unnamed moduli of the generator mode (modarith_amd.generate.EXAMPLES) under their tags
+GENERATED = {gen.resolve(arg, fam).name: (arg, fam) for arg, fam in gen.EXAMPLES}
+ALL = list(emit.BUILT_PRIMES) + list(GENERATED)
+
+
+def derive(P):
+    return gen.resolve(*GENERATED[P]) if P in GENERATED else _derive_named(P)
 
 
 def _i(v):
@@ -59,7 +66,7 @@ def test_addition_chain_computes_progenitor(P):
         assert emit.eval_chain(prog, x, fp.p) == pow(x, fp.pe, fp.p)
     sq, mu = emit.chain_cost(prog)
     assert sq <= fp.pe.bit_length()               # squarings == bit length - 1: the leading run ladder is the main chain
-    if not P.endswith("Q") and P not in ("TWEEDLE", "SIDH434", "SIDH503", "SIDH610", "SIDH751", "MFP4", "MFP7", "MFP1973", "CSIDH512", "M607"):
+    if not P.endswith("Q") and P not in ("BP256", "TWEEDLE", "SIDH434", "SIDH503", "SIDH610", "SIDH751", "MFP4", "MFP7", "MFP1973", "CSIDH512", "M607"):
         assert mu <= 20                           # shaped primes: long runs of ones; general primes take the loop form
 
 

@@ -142,3 +142,21 @@ def block_digests(soa: np.ndarray, block: int = BULK_BLOCK):
     import hashlib
     n = soa.shape[1]
     return [hashlib.sha256(np.ascontiguousarray(soa[:, k:k + block]).astype("<u8").tobytes()).hexdigest()[:16] for k in range(0, n, block)]
+
+
+# ------------------------------------------------------------------ generator mode (modarith_amd/generate.py)
+def generated_tags():
+    """tags of the unnamed example moduli the generator mode builds plug-ins for (fixtures: tests/golden/field_<TAG>.json)"""
+    from modarith_amd import generate as gen
+    return [gen.resolve(arg, fam).name for arg, fam in gen.EXAMPLES]
+
+
+def derive_any(P: str):
+    """FieldParams of a built-in prime or of a generated example modulus, by tag"""
+    from modarith_amd import generate as gen
+    from modarith_amd.params import derive
+    for arg, fam in gen.EXAMPLES:
+        fp = gen.resolve(arg, fam)
+        if fp.name == P:
+            return fp
+    return derive(P)
