@@ -97,6 +97,10 @@ int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbi
  *   modhaf   pseudo.py:1084-1100  mod2r 1102-1112  modexp 1115-1127  modimp 1130-1146
  *   modsign  pseudo.py:1149-1158  modcmp 1161-1174
  *   generic=False modadd/modsub/modneg ("_lazy"): pseudo.py:294-302, 315-324, 337-346 with mp=2
+ *
+ * The same macro declares the entry points of a field made by the generator mode (python -m modarith_amd.generate 64 <prime>,
+ * the counterpart of running pseudo.py / monty.py on a prime of one's own): MODARITH_AMD_DECLARE(2519) for 2^251-9, whose
+ * definitions live in modarith_amd/plugins/libmodarith_amd_2519.so (link it next to libmodarith_amd.so).
  */
 #define MODARITH_AMD_DECLARE(P)                                                                                         \
     /* ---------------- scalar form: reference signatures, host pointers ---------------- */                            \

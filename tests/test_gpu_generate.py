@@ -91,3 +91,18 @@ def test_a_modulus_generated_on_this_box(torch_cuda, tmp_path, monkeypatch):
     assert F.to_ints(F.redc(F.modinv(t))) == [pow(((a - b) * (a + b)) ** 2 % p, p - 2, p) for a, b in zip(xs, ys)]
     by = F.modexp(x)                                               # big-endian bytes of the canonical value
     assert [int.from_bytes(bytes(r), "big") for r in by.cpu().numpy()] == [a % p for a in xs]
+
+
+def test_c_consumer_of_a_generated_field(torch_cuda, tmp_path):
+    """examples/generated_field.c: MODARITH_AMD_DECLARE(2519) + the plug-in on the link line, from plain C"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "generated_field")
+    plug, main = os.path.join(root, "modarith_amd", "plugins"), os.path.join(root, "modarith_amd")
+    subprocess.check_call(["gcc", "-O2", os.path.join(root, "examples", "generated_field.c"), "-I", os.path.join(root, "include"),
+                           "-L", plug, "-l:libmodarith_amd_2519.so", "-L", main, "-l:libmodarith_amd.so",
+                           "-Wl,-rpath," + plug, "-Wl,-rpath," + main, "-o", exe])
+    for n in ("1000", "70001"):                          # one inversion per element; inversions shared between elements
+        p = subprocess.run([exe, n], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "equal to the scalar entry points" in p.stdout, p.stdout[-500:] + p.stderr[-500:]
