@@ -106,3 +106,49 @@ def test_c_consumer_of_a_generated_field(torch_cuda, tmp_path):
     for n in ("1000", "70001"):                          # one inversion per element; inversions shared between elements
         p = subprocess.run([exe, n], capture_output=True, text=True, timeout=300)
         assert p.returncode == 0 and "equal to the scalar entry points" in p.stdout, p.stdout[-500:] + p.stderr[-500:]
+
+
+def test_more_than_2_32_elements_in_one_batch(torch_cuda):
+    """Maximum sizes: 288 GB of HBM hold batches whose ELEMENT index no longer fits 32 bits.  2^32 + 8192 elements of the
+    three-limb field 2^130 - 5 (103 GB per array, two arrays) through moduniform, modmul and modsqr in one launch each, flat
+    and tiled; then EVERY element again through launches of 2^26 elements on views of the same arrays (other base addresses, other
+    grid, same limb stride) -- equal bit for bit -- and windows around 0, 2^31, 2^32 and the end regenerated from (seed, j) alone
+    and recomputed as small batches of their own."""
+    torch = torch_cuda
+    from modarith_amd.field import Field
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    n = (1 << 32) + 8192
+    need = 2 * 3 * 8 * n + (8 << 30)
+    if free < need:
+        pytest.skip("needs %.0f GB of free HBM (free: %.0f GB)" % (need / 1e9, free / 1e9))
+    F = Field("1305")
+    a = F.uniform(n, seed=9, array=1)
+    c = F.modmul(a, a)
+    step = 1 << 26
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        assert torch.equal(F.modmul(a[:, s:e], a[:, s:e]), c[:, s:e]), "modmul chunk at %d" % s
+    F.modsqr(a, out=c)                                                     # same values by another kernel, over the same > 2^32 indices
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        assert torch.equal(F.modmul(a[:, s:e], a[:, s:e]), c[:, s:e]), "modsqr chunk at %d" % s
+    for first in (0, (1 << 31) - 64, (1 << 32) - 64, n - 128):
+        w = F.uniform(128, seed=9, array=1, first=first)
+        assert torch.equal(w, a[:, first:first + 128]), "moduniform window at %d" % first
+        assert torch.equal(F.modsqr(w), c[:, first:first + 128]), "window at %d" % first
+    # the tiled layout of the same batch: [n / 4096, 3, 4096] -- the address formula beyond 2^32 elements
+    del c
+    T = Field("1305", tile=4096)
+    ta = T.uniform(n, seed=9, array=1)
+    assert ta.dim() == 3
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        assert torch.equal(ta[s // 4096:e // 4096].permute(1, 0, 2).reshape(3, e - s), a[:, s:e]), "tiled moduniform chunk at %d" % s
+    del a
+    tc = T.modsqr(ta)
+    for first in (0, (1 << 31) - 4096, (1 << 32) - 4096, n - 4096):
+        w = F.uniform(4096, seed=9, array=1, first=first)
+        assert torch.equal(F.modsqr(w), tc[first // 4096]), "tiled window at %d" % first
+    del ta, tc
+    torch.cuda.empty_cache()
