@@ -2,6 +2,7 @@
 
   python -m modarith_amd.generate 64 2**251-9               # the reference's own command-line shape
   python -m modarith_amd.generate 64 BP256=0xa9fb57db...5377 --monty
+  python -m modarith_amd.generate 64 2**251-9 --time        # ... and run the time.c protocol on the GPU, as the generators do last
   python -m modarith_amd.generate --list
 
 This is the counterpart of `python pseudo.py 64 <prime>` / `python monty.py 64 <prime>` (pseudo.py:1461-1473,
@@ -206,6 +207,40 @@ def report(fp: FieldParams) -> str:
     return "\n".join(L)
 
 
+def time_report(tag: str, outer: int = 100000, lanes: int = 1 << 16) -> List[str]:
+    """What the generators do last: build time.c and run it (pseudo.py:1861-1925, monty.py:2440-2500) -- seed-42 operands,
+    `outer` x 1000 dependent modmul, the same number of modsqr, `outer` / 2 x 2... modinv, the 24-bit check word of each.  Here the
+    chains run on the GPU, one per lane (csrc/kernels.h k_time): the words are the reference's for outer = 100000 (its own depth);
+    the times are per dependent operation in one wave (latency-bound) and the rate with `lanes` chains in flight."""
+    import random
+    import time
+
+    import torch
+    from .field import Field
+    F = Field(tag)
+    fp = F.params
+    random.seed(42)                                              # pseudo.py:1862-1866
+    ra, rb, rs, ri = (random.randint(0, fp.p - 1) for _ in range(4))
+    mk = lambda v: [(v >> (fp.radix * i)) & ((1 << fp.radix) - 1) for i in range(fp.nlimbs)]      # makebig: every limb masked
+    out = []
+    for leg, x, y, nops in (("modmul", ra, rb, outer * 1000), ("modsqr", rs, None, outer * 1000), ("modinv", ri, None, max(1, outer // 2) * 2)):
+        o = outer if leg != "modinv" else max(1, outer // 2)
+        res = {}
+        for what, L in (("wave", 64), ("chip", lanes)):
+            xa = F.from_limbs([mk(x)]).expand(-1, L).contiguous()
+            ya = F.from_limbs([mk(y)]).expand(-1, L).contiguous() if y is not None else None
+            F.time_protocol(leg, xa, ya, 1)
+            torch.cuda.synchronize(F.device)
+            t0 = time.perf_counter()
+            z = F.time_protocol(leg, xa, ya, o)
+            torch.cuda.synchronize(F.device)
+            res[what] = time.perf_counter() - t0
+            word = int(z[0, 0].item()) & 0xFFFFFF
+        out.append("%s check 0x%06x Nanosecs= %d (one wave, per dependent call; %d calls)   %.3g %s/s with %d chains in flight"
+                   % (leg, word, round(res["wave"] / nops * 1e9), nops, lanes * nops / res["chip"], leg, lanes))
+    return out
+
+
 def main(argv: List[str]) -> int:
     args = [a for a in argv if not a.startswith("--")]
     if "--list" in argv:
@@ -214,7 +249,7 @@ def main(argv: List[str]) -> int:
         return 0
     if len(args) != 2:
         print("Syntax error")
-        print("Valid syntax - python -m modarith_amd.generate <word length> <prime> OR <prime name> OR <name>=<prime> [--pseudo|--monty] [--force]")
+        print("Valid syntax - python -m modarith_amd.generate <word length> <prime> OR <prime name> OR <name>=<prime> [--pseudo|--monty] [--force] [--time[=outer]]")
         print("For example - python -m modarith_amd.generate 64 2**255-19")
         return 2
     fam = "pseudo" if "--pseudo" in argv else "monty" if "--monty" in argv else None
@@ -224,6 +259,10 @@ def main(argv: List[str]) -> int:
         print(e)
         return 2
     print(report(g.params))
+    for a in argv:
+        if a == "--time" or a.startswith("--time="):
+            for line in time_report(g.tag, int(a.split("=", 1)[1]) if "=" in a else 100000):
+                print(line)
     print("%s %s: C-ABI <fn>_%s_ct / <fn>_%s_batch (MODARITH_AMD_DECLARE(%s)); Field(%r)" % ("built" if g.built else "up to date:", g.lib, g.tag, g.tag, g.tag, g.tag))
     return 0
 

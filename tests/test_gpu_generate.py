@@ -152,3 +152,28 @@ def test_more_than_2_32_elements_in_one_batch(torch_cuda):
         assert torch.equal(F.modsqr(w), tc[first // 4096]), "tiled window at %d" % first
     del ta, tc
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("P", generated_tags())
+def test_time_protocol_check_words_of_generated_fields(torch_cuda, P):
+    """the generators end by running time.c on the prime they were given: its dependent chains on the seed-42 operands
+    (pseudo.py:1235-1250, 1862-1866) per lane on the GPU; check words and redc'd limbs equal the reference's at depth 10^3 / 10^5,
+    and the command-line report (--time) prints the same words"""
+    from modarith_amd import generate as gen
+    from modarith_amd.field import Field
+    from tests.conftest import limbs, load_golden
+    F = Field(P)
+    fp = F.params
+    g = load_golden("field_%s.json" % P)["time"]
+    mk = lambda v: [(int(v, 16) >> (fp.radix * i)) & ((1 << fp.radix) - 1) for i in range(fp.nlimbs)]
+    lanes = 70
+    x, y, xs = F.from_limbs([mk(g["ra"])] * lanes), F.from_limbs([mk(g["rb"])] * lanes), F.from_limbs([mk(g["rs"])] * lanes)
+    for outer, tag in ((1, "1k"), (100, "100k")):
+        z = F.to_limbs(F.time_protocol("modmul", x, y, outer))
+        assert z == [limbs(g["modmul_z_" + tag])] * lanes
+        z = F.to_limbs(F.time_protocol("modsqr", xs, None, outer))
+        assert z == [limbs(g["modsqr_z_" + tag])] * lanes
+    rep = gen.time_report(P, outer=100, lanes=4096)
+    assert rep[0].startswith("modmul check 0x%06x " % int(g["modmul_check_100k"], 16)), rep
+    assert rep[1].startswith("modsqr check 0x%06x " % int(g["modsqr_check_100k"], 16)), rep
+    assert rep[2].startswith("modinv check 0x"), rep
