@@ -1,0 +1,261 @@
+"""Fused chains: a sequence of field.c calls per element compiled into ONE streaming kernel.
+
+A C caller of the reference writes `modadd(x,y,t); modsub(x,y,w); modmul(t,w,s); modsqr(s,s); modinv(s,NULL,z);`
+(the generators' acceptance chain, pseudo.py:1783-1796; the bodies of rfc7748.c:190-223, edwards.c:73-145) and the C
+compiler keeps every intermediate in registers -- field.c's functions are `static inline`.  Batched over HBM-resident
+arrays, the same five calls are five kernels and 520 bytes of traffic per element where 120 are needed (two arrays in,
+one out): on a memory-bound engine the round trips are the whole cost.  This module gives the batched caller what the C
+compiler gives the scalar one: the chain is written once with the reference's function names,
+
+    ch = Chain("X25519", "accept")             # any built-in prime or generated tag
+    x, y = ch.input(), ch.input()
+    s = ch.modsqr(ch.modmul(ch.modadd(x, y), ch.modsub(x, y)))
+    ch.output(ch.modinv(s))
+    f = ch.build()                              # one hipcc unit (seconds), cached
+    z, = f(xa, ya)                              # device batches, flat or tiled
+
+and hipcc instantiates the same `Field<P>` functions the library's kernels are made of, back to back, on registers:
+one load per input array, one store per output array, no LDS, no interpreter.  Limbs are those of the call-by-call
+sequence, bit for bit (the same functions on the same limbs; `modinv` returns the library's normalised form).  The
+product policy is the library's wave vote (csrc/kernels.h OpMulAuto), taken once on the inputs: inside the limb contract
+the whole chain runs the split products -- every intermediate is a field-function output and stays inside it -- otherwise
+the exact ones.  C-ABI of the built plug-in (modarith_amd/plugins/libmodarith_amd_chain_<name>_<TAG>.so):
+
+    int chain_<name>_<TAG>_batch(const void *const *in, void *const *out, size_t n, size_t ld, void *stream);
+
+Like the generator mode (modarith_amd/generate.py) this needs hipcc where the chain is built and has no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import json
+import os
+import re
+import subprocess
+from typing import List, Optional, Sequence
+
+from . import _lib, emit
+from . import generate as _gen
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_NAME_RE = re.compile(r"^[A-Za-z][A-Za-z0-9_]*$")
+# op -> (Field<P> function, operand count, takes an int immediate)
+_OPS = {"modmul": 2, "modadd": 2, "modsub": 2, "modsqr": 1, "modneg": 1, "nres": 1, "redc": 1, "modcpy": 1, "modinv": 1, "modmli": 1}
+MAX_OPS = 256
+
+
+class Val:
+    """one element-valued intermediate of a chain (an SSA value: written once)"""
+    def __init__(self, chain: "Chain", idx: int):
+        self.chain, self.idx = chain, idx
+
+
+class Chain:
+    def __init__(self, prime: str, name: str):
+        if not _NAME_RE.match(name):
+            raise ValueError("chain name %r cannot be part of a C identifier" % (name,))
+        if prime in _lib.PRIMES:
+            from .params import derive
+            self.params = derive(prime)
+            self.builtin = True
+        elif os.path.exists(_gen.plugin_path(prime)):
+            self.params = _gen.params_of_plugin(prime)
+            self.builtin = False
+        else:
+            raise ValueError("prime %r is neither built in nor generated (python -m modarith_amd.generate 64 <prime>)" % (prime,))
+        self.prime, self.name = prime, name
+        self.nin = 0
+        self.ops: List[tuple] = []          # (op, dst, a, b, imm)
+        self.outs: List[int] = []
+        self.nvals = 0
+
+    # ------------------------------------------------------------------ building
+    def _new(self) -> Val:
+        v = Val(self, self.nvals)
+        self.nvals += 1
+        return v
+
+    def input(self) -> Val:
+        if self.ops:
+            raise ValueError("declare every input before the first operation")
+        self.nin += 1
+        return self._new()
+
+    def inputs(self, k: int) -> List[Val]:
+        return [self.input() for _ in range(k)]
+
+    def _own(self, *vs: Val):
+        for v in vs:
+            if not isinstance(v, Val) or v.chain is not self:
+                raise ValueError("operands must be values of this chain")
+
+    def _op(self, op: str, a: Val, b: Optional[Val] = None, imm: int = 0) -> Val:
+        self._own(a, *([b] if b is not None else []))
+        if len(self.ops) >= MAX_OPS:
+            raise ValueError("chains are limited to %d operations" % MAX_OPS)
+        d = self._new()
+        self.ops.append((op, d.idx, a.idx, b.idx if b is not None else -1, int(imm)))
+        return d
+
+    def modmul(self, a, b): return self._op("modmul", a, b)
+    def modadd(self, a, b): return self._op("modadd", a, b)
+    def modsub(self, a, b): return self._op("modsub", a, b)
+    def modsqr(self, a): return self._op("modsqr", a)
+    def modneg(self, a): return self._op("modneg", a)
+    def nres(self, a): return self._op("nres", a)
+    def redc(self, a): return self._op("redc", a)
+    def modcpy(self, a): return self._op("modcpy", a)
+    def modinv(self, a): return self._op("modinv", a)
+
+    def modmli(self, a, k: int):
+        if not -(1 << 31) <= int(k) < (1 << 31):
+            raise ValueError("modmli takes a C int")
+        return self._op("modmli", a, imm=k)
+
+    def output(self, v: Val) -> None:
+        self._own(v)
+        self.outs.append(v.idx)
+
+    # ------------------------------------------------------------------ emission
+    @property
+    def symbol(self) -> str:
+        return "chain_%s_%s_batch" % (self.name, self.prime)
+
+    def traffic_bytes(self) -> int:
+        """HBM bytes per element of the fused kernel; the call-by-call sequence moves sum(8 N (operands + 1)) instead"""
+        return 8 * self.params.nlimbs * (self.nin + len(self.outs))
+
+    def unfused_traffic_bytes(self) -> int:
+        return sum(8 * self.params.nlimbs * (_OPS[o[0]] + 1) for o in self.ops)
+
+    def source(self) -> str:
+        if not self.nin or not self.outs:
+            raise ValueError("a chain needs at least one input and one output")
+        P, nv = self.prime, self.nvals
+        L = ["// GENERATED by modarith_amd/fuse.py -- do not edit.  Chain %r over %s: %d inputs, %d operations, %d outputs." % (self.name, P, self.nin, len(self.ops), len(self.outs)),
+             '#include "params_%s.h"' % P, '#include "modarith_amd.h"', '#include "capi_common.h"', '#include "kernels.h"', "",
+             "namespace {", "using namespace ma;", "using P = ma::P_%s;" % P, "constexpr int NIN = %d, NOUT = %d;" % (self.nin, len(self.outs)),
+             "constexpr bool HEAVY = %s;   // a chain with an inversion keeps one element per lane, as the library's k_unary_heavy does" % ("true" if any(o[0] == "modinv" for o in self.ops) else "false"),
+             "struct Args { const spint* in[NIN]; spint* out[NOUT]; };", "",
+             "// the chain on one element's registers; F = Field<P, FAST>",
+             "template <class F> MA_DEV void body(%s) {" % ", ".join(("const spint* v%d" if i < self.nin else "spint* v%d") % i for i in range(nv))]
+        for op, d, a, b, imm in self.ops:
+            if op == "modinv":
+                L.append("    F::modinv(v%d, nullptr, v%d); inv_normalise<F>(v%d);" % (a, d, d))
+            elif op == "modmli":
+                L.append("    F::modmli(v%d, %d, v%d);" % (a, imm, d))
+            elif _OPS[op] == 2:
+                L.append("    F::%s(v%d, v%d, v%d);" % (op, a, b, d))
+            else:
+                L.append("    F::%s(v%d, v%d);" % (op, a, d))
+        L += ["}", "",
+              "template <int EPT>", "__global__ __launch_bounds__(BLOCK) void k_chain(Args A, size_t nthreads, Ld L) {",
+              "    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {",
+              "        " + " ".join("spint v%d[EPT][P::N];" % i for i in range(nv))]
+        for i in range(self.nin):
+            L.append("        load_soa<P, EPT>(A.in[%d], L, t, v%d);" % (i, i))
+        L += ["        bool fast = false;",
+              "        if constexpr (P::SPLIT > 0) {",
+              "            bool ok = true;",
+              "            static_for<0, EPT>([&](auto E) { ok = ok && " + " && ".join("in_split_contract<P>(v%d[E])" % i for i in range(self.nin)) + "; });",
+              "            fast = __all(ok);",
+              "        }",
+              "        if (fast) {",
+              "            static_for<0, EPT>([&](auto E) { body<Field<P, true>>(%s); });" % ", ".join("v%d[E]" % i for i in range(nv)),
+              "        } else {",
+              "            static_for<0, EPT>([&](auto E) { body<Field<P, false>>(%s); });" % ", ".join("v%d[E]" % i for i in range(nv)),
+              "        }"]
+        for k, o in enumerate(self.outs):
+            L.append("        store_soa<P, EPT>(A.out[%d], L, t, v%d);" % (k, o))
+        L += ["    }", "}", "}  // namespace", "",
+              'extern "C" int %s(const void* const* in, void* const* out, size_t n, size_t ld, void* stream) {' % self.symbol,
+              "    if (n == 0) return 0;",
+              "    Ld L(ld);",
+              "    if (ld < n) {",
+              '        if (ld < 128 || (ld & (ld - 1)) != 0) { set_error("%s: a limb stride below n selects the tiled layout and must be a power of two >= 128"); return (int)hipErrorInvalidValue; }' % self.symbol,
+              "        L = Ld(ld, (unsigned)__builtin_ctzll((unsigned long long)ld));",
+              "    }",
+              "    Args A;",
+              "    bool al = ld % 2 == 0;",
+              "    for (int i = 0; i < NIN; i++) { A.in[i] = (const spint*)in[i]; al = al && aligned16(in[i]); }",
+              "    for (int i = 0; i < NOUT; i++) { A.out[i] = (spint*)out[i]; al = al && aligned16(out[i]); }",
+              "    hipStream_t s = (hipStream_t)stream;",
+              "    const bool tiled = L.s != 63;",
+              "    if (n >= 2 && al && !HEAVY) {",
+              "        size_t nt = n / 2;",
+              "        k_chain<2><<<grid_for(nt, BLOCK, tiled), BLOCK, 0, s>>>(A, nt, L);",
+              "        if (n & 1) {                                  // the odd element out: one lane on the 8-byte path, at its own address",
+              "            const size_t o = L.off<P::N>(n - 1);",
+              "            Args B;",
+              "            for (int i = 0; i < NIN; i++) B.in[i] = A.in[i] + o;",
+              "            for (int i = 0; i < NOUT; i++) B.out[i] = A.out[i] + o;",
+              "            k_chain<1><<<1, BLOCK, 0, s>>>(B, 1, Ld(L.ld));",
+              "        }",
+              "    } else {",
+              "        k_chain<1><<<grid_for(n, BLOCK, tiled), BLOCK, 0, s>>>(A, n, L);",
+              "    }",
+              '    return check_launch("%s");' % self.symbol,
+              "}", ""]
+        return "\n".join(L)
+
+    # ------------------------------------------------------------------ building the plug-in
+    def lib_path(self, plugin_dir: Optional[str] = None) -> str:
+        return os.path.join(plugin_dir or _gen.PLUGIN_DIR, "libmodarith_amd_chain_%s_%s.so" % (self.name, self.prime))
+
+    def build(self, plugin_dir: Optional[str] = None, force: bool = False, verbose: bool = False) -> "FusedChain":
+        from .build import ARCH, FLAGS, HIPCC, _stamp
+        d = plugin_dir or _gen.PLUGIN_DIR
+        os.makedirs(d, exist_ok=True)
+        src_text = self.source()
+        base = "chain_%s_%s" % (self.name, self.prime)
+        src, obj, meta = (os.path.join(d, base + e) for e in (".hip", ".o", ".json"))
+        lib = self.lib_path(d)
+        key = hashlib.sha256((" ".join(FLAGS) + "\n" + src_text + "\n" + emit.header_text(self.params) + "\n" + _stamp()).encode()).hexdigest()
+        fresh = False
+        if not force and os.path.exists(lib) and os.path.exists(meta):
+            try:
+                fresh = json.load(open(meta)).get("hash") == key
+            except (ValueError, OSError):
+                fresh = False
+        if not fresh:
+            if not os.path.exists(HIPCC):
+                raise RuntimeError("%s not found: fusing a chain needs the ROCm compiler (there is no CPU path)" % HIPCC)
+            emit._write(src, src_text)
+            inc = ["-I", os.path.join(HERE, "csrc", "generated"), "-I", os.path.join(HERE, "csrc"), "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", _gen.PLUGIN_DIR, "-I", d]
+            if verbose:
+                print("[modarith_amd] hipcc %s" % os.path.basename(src), flush=True)
+            subprocess.run([HIPCC] + list(FLAGS) + inc + ["-c", src, "-o", obj], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
+            subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, obj, "-L", HERE, "-l:libmodarith_amd.so",
+                                   "-Wl,-rpath,$ORIGIN/" + os.path.relpath(HERE, d), "-Wl,-rpath," + HERE])
+            json.dump({"chain": self.name, "prime": self.prime, "inputs": self.nin, "outputs": len(self.outs), "ops": [o[0] for o in self.ops],
+                       "symbol": self.symbol, "hash": key}, open(meta, "w"), indent=1)
+        return FusedChain(self, lib, built=not fresh)
+
+
+class FusedChain:
+    """a built chain: call it with one device batch per input (flat [N, n] or tiled [n / tile, N, tile], all the same shape)"""
+    def __init__(self, chain: Chain, lib: str, built: bool):
+        self.chain, self.path, self.built = chain, lib, built
+        _lib.load()
+        self.lib = ctypes.CDLL(lib)
+        self.fn = getattr(self.lib, chain.symbol)
+        self.fn.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
+        self.fn.restype = ctypes.c_int
+
+    def __call__(self, *inputs, out: Optional[Sequence] = None, device=None):
+        import torch
+        from .field import Field
+        ch = self.chain
+        if len(inputs) != ch.nin:
+            raise ValueError("chain %s takes %d inputs" % (ch.name, ch.nin))
+        F = Field(ch.prime, device if device is not None else inputs[0].device)
+        outs = list(out) if out is not None else [F._out(inputs[0], None) for _ in ch.outs]
+        if len(outs) != len(ch.outs):
+            raise ValueError("chain %s has %d outputs" % (ch.name, len(ch.outs)))
+        n = F._chk(*inputs, *outs)
+        ins = (ctypes.c_void_p * ch.nin)(*[t.data_ptr() for t in inputs])
+        ous = (ctypes.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+        with torch.cuda.device(F.device):
+            _lib.check(self.fn(ins, ous, n, F._ld(inputs[0]), torch.cuda.current_stream(F.device).cuda_stream), ch.symbol)
+        return tuple(outs)

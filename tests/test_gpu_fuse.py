@@ -1,0 +1,113 @@
+"""Fused chains on the GPU (modarith_amd/fuse.py): one kernel per chain, limbs equal to the call-by-call sequence of the
+batched API bit for bit -- and through it to the reference's, since every batched call is pinned to the golden vectors --
+on flat, tiled, unaligned, in-place and out-of-contract batches; values checked against plain integers after redc."""
+import random
+
+import numpy as np
+import pytest
+
+from tests.util import derive_any, random_soa, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _accept(P):
+    """the generators' acceptance chain (pseudo.py:1783-1796): z = 1 / ((x - y)(x + y))^2 on values already in internal form"""
+    from modarith_amd.fuse import Chain
+    ch = Chain(P, "accept")
+    x, y = ch.inputs(2)
+    s = ch.modsqr(ch.modmul(ch.modadd(x, y), ch.modsub(x, y)))
+    ch.output(ch.modinv(s))
+    return ch.build()
+
+
+def _accept_calls(F, x, y):
+    return F.modinv(F.modsqr(F.modmul(F.modadd(x, y), F.modsub(x, y))))
+
+
+def _rand(fp, n, seed):
+    rng = np.random.default_rng(seed)
+    out = rng.integers(0, 1 << fp.radix, size=(fp.nlimbs, n), dtype=np.uint64)
+    out[fp.nlimbs - 1] = rng.integers(0, 1 << (fp.n - fp.radix * (fp.nlimbs - 1)), size=n, dtype=np.uint64)
+    return np.ascontiguousarray(out)
+
+
+@pytest.mark.parametrize("P", ["X25519", "NIST256", "X448", "2519", "BP256"])
+def test_acceptance_chain_equals_the_call_sequence(torch_cuda, P):
+    torch = torch_cuda
+    from modarith_amd.field import Field
+    F, fp = Field(P), derive_any(P)
+    f = _accept(P)
+    n = 3 * 4096 + 1                                              # odd: the last element takes the 8-byte path where there is one
+    x, y = to_dev(_rand(fp, n, 1)), to_dev(_rand(fp, n, 2))
+    want = _accept_calls(F, x, y)
+    z, = f(x, y)
+    assert torch.equal(z, want)
+    # values: 1 / ((x - y)(x + y))^2 on the plain integers behind the internal form
+    m = 64
+    xi, yi = F.to_ints(F.redc(x[:, :m].contiguous())), F.to_ints(F.redc(y[:, :m].contiguous()))
+    got = F.to_ints(F.redc(z[:, :m].contiguous()))
+    assert got == [pow(((a - b) * (a + b)) ** 2 % fp.p, -1, fp.p) if ((a - b) * (a + b)) % fp.p else 0 for a, b in zip(xi, yi)]
+    # tiled batches, unaligned views (odd start: 8-byte path), in place
+    xt, yt = F.to_tiled(x[:, :3 * 4096].contiguous(), 4096), F.to_tiled(y[:, :3 * 4096].contiguous(), 4096)
+    zt, = f(xt, yt)
+    assert torch.equal(F.to_flat(zt), want[:, :3 * 4096])
+    zu, = f(x[:, 1:1000], y[:, 1:1000])
+    assert torch.equal(zu, want[:, 1:1000])
+    xc = x.clone()
+    f(xc, y, out=[xc])
+    assert torch.equal(xc, want)
+
+
+def test_two_outputs_and_small_constants(torch_cuda):
+    """a ladder-step-shaped chain (rfc7748.c:194-209: sums, differences, products, a multiplication by a small constant) with two
+    results, one element pair per lane, two elements per lane on aligned batches"""
+    torch = torch_cuda
+    from modarith_amd.field import Field
+    from modarith_amd.fuse import Chain
+    for P in ("X25519", "X448"):
+        F, fp = Field(P), derive_any(P)
+        ch = Chain(P, "step")
+        a, b = ch.inputs(2)
+        A, B = ch.modadd(a, b), ch.modsub(a, b)
+        AA, BB = ch.modsqr(A), ch.modsqr(B)
+        E = ch.modsub(AA, BB)
+        ch.output(ch.modmul(AA, BB))
+        ch.output(ch.modmul(E, ch.modadd(AA, ch.modmli(E, 121665))))
+        f = ch.build()
+        n = 1 << 16
+        x, y = to_dev(_rand(fp, n, 5)), to_dev(_rand(fp, n, 6))
+        o1, o2 = f(x, y)
+        sA, sB = F.modadd(x, y), F.modsub(x, y)
+        sAA, sBB = F.modsqr(sA), F.modsqr(sB)
+        sE = F.modsub(sAA, sBB)
+        assert torch.equal(o1, F.modmul(sAA, sBB))
+        assert torch.equal(o2, F.modmul(sE, F.modadd(sAA, F.modmli(sE, 121665))))
+
+
+def test_out_of_contract_limbs_take_the_exact_products(torch_cuda):
+    """fabricated limbs (up to 2^64 - 1) in a few lanes: the vote fails for their waves, the chain runs the exact 128-bit products
+    there and the split ones elsewhere -- the same words as the call-by-call sequence, whose first multiplication votes the same way"""
+    torch = torch_cuda
+    from modarith_amd.field import Field
+    from modarith_amd.fuse import Chain
+    F, fp = Field("X25519"), derive_any("X25519")
+    ch = Chain("X25519", "mulsqr")
+    a, b = ch.inputs(2)
+    ch.output(ch.modsqr(ch.modmul(a, b)))
+    f = ch.build()
+    n = 1 << 14
+    x, y = _rand(fp, n, 7), _rand(fp, n, 8)
+    rng = np.random.default_rng(9)
+    for j in list(range(0, n, 997)) + list(range(4096, 4096 + 256)):
+        x[:, j] = rng.integers(0, 1 << 64, size=fp.nlimbs, dtype=np.uint64)
+    x, y = to_dev(x), to_dev(y)
+    z, = f(x, y)
+    assert torch.equal(z, F.modsqr(F.modmul(x, y)))
