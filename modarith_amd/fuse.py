@@ -118,6 +118,9 @@ class Chain:
         self.outs.append(v.idx)
 
     # ------------------------------------------------------------------ emission
+    def default_ept(self) -> int:
+        return 1 if any(o[0] == "modinv" for o in self.ops) else 2
+
     @property
     def symbol(self) -> str:
         return "chain_%s_%s_batch" % (self.name, self.prime)
@@ -129,14 +132,15 @@ class Chain:
     def unfused_traffic_bytes(self) -> int:
         return sum(8 * self.params.nlimbs * (_OPS[o[0]] + 1) for o in self.ops)
 
-    def source(self) -> str:
+    def source(self, ept: Optional[int] = None, policy: str = "vote") -> str:
+        """ept: elements per lane on aligned batches (2 = 16-byte accesses, 1 = 8-byte); None = the measured default"""
         if not self.nin or not self.outs:
             raise ValueError("a chain needs at least one input and one output")
         P, nv = self.prime, self.nvals
         L = ["// GENERATED by modarith_amd/fuse.py -- do not edit.  Chain %r over %s: %d inputs, %d operations, %d outputs." % (self.name, P, self.nin, len(self.ops), len(self.outs)),
              '#include "params_%s.h"' % P, '#include "modarith_amd.h"', '#include "capi_common.h"', '#include "kernels.h"', "",
              "namespace {", "using namespace ma;", "using P = ma::P_%s;" % P, "constexpr int NIN = %d, NOUT = %d;" % (self.nin, len(self.outs)),
-             "constexpr bool HEAVY = %s;   // a chain with an inversion keeps one element per lane, as the library's k_unary_heavy does" % ("true" if any(o[0] == "modinv" for o in self.ops) else "false"),
+             "constexpr bool HEAVY = %s;   // one element per lane (8-byte accesses) on every batch: chains with an inversion, as the library's k_unary_heavy" % ("true" if (ept or self.default_ept()) == 1 else "false"),
              "struct Args { const spint* in[NIN]; spint* out[NOUT]; };", "",
              "// the chain on one element's registers; F = Field<P, FAST>",
              "template <class F> MA_DEV void body(%s) {" % ", ".join(("const spint* v%d" if i < self.nin else "spint* v%d") % i for i in range(nv))]
@@ -150,24 +154,23 @@ class Chain:
             else:
                 L.append("    F::%s(v%d, v%d);" % (op, a, d))
         L += ["}", "",
-              "template <int EPT>", "__global__ __launch_bounds__(BLOCK) void k_chain(Args A, size_t nthreads, Ld L) {",
-              "    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {",
+              "template <int EPT>", "__global__ __launch_bounds__(BLOCK) void k_chain(Args A, size_t nthreads, Ld L) {"]
+        votel = ["bool fast = %s;" % ("true" if policy == "fast" else "false"),
+                 "if constexpr (P::SPLIT > 0 && %s) {" % ("true" if policy == "vote" else "false"),
+                 "    bool ok = true;",
+                 "    static_for<0, EPT>([&](auto E) { ok = ok && " + " && ".join("in_split_contract<P>(v%d[E])" % i for i in range(self.nin)) + "; });",
+                 "    fast = __all(ok);",
+                 "}",
+                 "if (fast) {",
+                 "    static_for<0, EPT>([&](auto E) { body<Field<P, true>>(%s); });" % ", ".join("v%d[E]" % i for i in range(nv)),
+                 "} else {",
+                 "    static_for<0, EPT>([&](auto E) { body<Field<P, false>>(%s); });" % ", ".join("v%d[E]" % i for i in range(nv)),
+                 "}"]
+        L += ["    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {",
               "        " + " ".join("spint v%d[EPT][P::N];" % i for i in range(nv))]
-        for i in range(self.nin):
-            L.append("        load_soa<P, EPT>(A.in[%d], L, t, v%d);" % (i, i))
-        L += ["        bool fast = false;",
-              "        if constexpr (P::SPLIT > 0) {",
-              "            bool ok = true;",
-              "            static_for<0, EPT>([&](auto E) { ok = ok && " + " && ".join("in_split_contract<P>(v%d[E])" % i for i in range(self.nin)) + "; });",
-              "            fast = __all(ok);",
-              "        }",
-              "        if (fast) {",
-              "            static_for<0, EPT>([&](auto E) { body<Field<P, true>>(%s); });" % ", ".join("v%d[E]" % i for i in range(nv)),
-              "        } else {",
-              "            static_for<0, EPT>([&](auto E) { body<Field<P, false>>(%s); });" % ", ".join("v%d[E]" % i for i in range(nv)),
-              "        }"]
-        for k, o in enumerate(self.outs):
-            L.append("        store_soa<P, EPT>(A.out[%d], L, t, v%d);" % (k, o))
+        L += ["        load_soa<P, EPT>(A.in[%d], L, t, v%d);" % (i, i) for i in range(self.nin)]
+        L += ["        " + l for l in votel]
+        L += ["        store_soa<P, EPT>(A.out[%d], L, t, v%d);" % (k, o) for k, o in enumerate(self.outs)]
         L += ["    }", "}", "}  // namespace", "",
               'extern "C" int %s(const void* const* in, void* const* out, size_t n, size_t ld, void* stream) {' % self.symbol,
               "    if (n == 0) return 0;",
@@ -203,11 +206,11 @@ class Chain:
     def lib_path(self, plugin_dir: Optional[str] = None) -> str:
         return os.path.join(plugin_dir or _gen.PLUGIN_DIR, "libmodarith_amd_chain_%s_%s.so" % (self.name, self.prime))
 
-    def build(self, plugin_dir: Optional[str] = None, force: bool = False, verbose: bool = False) -> "FusedChain":
+    def build(self, plugin_dir: Optional[str] = None, force: bool = False, verbose: bool = False, ept: Optional[int] = None, policy: str = "vote") -> "FusedChain":
         from .build import ARCH, FLAGS, HIPCC, _stamp
         d = plugin_dir or _gen.PLUGIN_DIR
         os.makedirs(d, exist_ok=True)
-        src_text = self.source()
+        src_text = self.source(ept, policy)
         base = "chain_%s_%s" % (self.name, self.prime)
         src, obj, meta = (os.path.join(d, base + e) for e in (".hip", ".o", ".json"))
         lib = self.lib_path(d)
@@ -242,6 +245,7 @@ class FusedChain:
         self.fn = getattr(self.lib, chain.symbol)
         self.fn.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
         self.fn.restype = ctypes.c_int
+        self._fields = {}
 
     def __call__(self, *inputs, out: Optional[Sequence] = None, device=None):
         import torch
@@ -249,7 +253,10 @@ class FusedChain:
         ch = self.chain
         if len(inputs) != ch.nin:
             raise ValueError("chain %s takes %d inputs" % (ch.name, ch.nin))
-        F = Field(ch.prime, device if device is not None else inputs[0].device)
+        dev = device if device is not None else inputs[0].device
+        F = self._fields.get(dev)
+        if F is None:                                  # binding a Field derives the prime's constants: once per device, not per call
+            F = self._fields[dev] = Field(ch.prime, dev)
         outs = list(out) if out is not None else [F._out(inputs[0], None) for _ in ch.outs]
         if len(outs) != len(ch.outs):
             raise ValueError("chain %s has %d outputs" % (ch.name, len(ch.outs)))
