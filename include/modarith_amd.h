@@ -281,9 +281,11 @@ int rfc7748_X448_base_batch(const char *bk, char *bv, size_t n, void *stream);
  * 9-entry table (two of them for mul2) lives in a caller-provided device workspace of
  * ecn_*_mul_workspace_bytes(n) bytes.
  * add, dbl and mul run the reference's formulas (edwards.c:73-145, weierstrass.c:68-281) from the bit-exact field calls
- * in the reference's order; the reference-derived fixtures pin these results as AFFINE values (the curve templates
- * cannot be built here without a stand-in for addchain), the projective limbs are checked against the restated
- * templates in oracle/ ("affine-pinned").  set/get/affine/cmp involve modpro and are comparable as affine coordinates.  ecnXXXmul2 (a joint sparse form
+ * in the reference's order, and their PROJECTIVE LIMBS equal the reference's: the reference's own edwards.c / weierstrass.c,
+ * built in the build container from its files without the functions that need the external addchain tool, produced the
+ * fixtures tests/golden/curveref_<CURVE>.json (gen, mul, dbl, add, sub, neg, cof, the special cases; eleven curves), which the
+ * kernels and the oracle reproduce limb for limb.  set/get/affine involve modpro and are comparable as affine coordinates
+ * (big-integer model, survey-captured reference outputs).  ecnXXXmul2 (a joint sparse form
  * with data-dependent branches in the reference, edwards.c:404-431, 486-510) is two interleaved fixed-window
  * multiplications sharing their doublings here, constant-time: same point, another projective representative.
  * Input points must have limbs below 2^(Radix+2) -- true of every point these functions or the reference's
