@@ -529,6 +529,29 @@ def main():
                        "all_lanes_ops_per_s": (1 << 18) * nops / res["all_lanes"], "lanes": 1 << 18}
         others["time_c_protocol_gpu_X25519"] = tc
 
+    # Fused chains (modarith_amd/fuse.py): a sequence of field.c calls per element as ONE streaming kernel on
+    # registers, against the same calls through the batched API, on the timed region's own operands.  z = ((a + b)(a - b))^2:
+    # four calls, 440 B per element call by call, 120 B fused.  The chain's plug-in is built by __graft_entry__.build() and
+    # travels with the tree (rebuilt here in seconds if it is not current); equal limbs are asserted.
+    if not args.no_others and single:
+        try:
+            from modarith_amd.fuse import bench_chain
+            ch = bench_chain("X25519")
+            fz = ch.build()
+            t1, t2, zc = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+            def calls():
+                F.modadd(a, b, out=t1); F.modsub(a, b, out=t2); F.modmul(t1, t2, out=t1); F.modsqr(t1, out=zc)
+            ms_f, ms_c = rate(lambda: fz(a, b, out=[c])), rate(calls)
+            assert torch.equal(c, zc), "fused chain differs from the call-by-call sequence"
+            others["fused_chain_X25519"] = {"chain": "modsqr(modmul(modadd(a,b), modsub(a,b)))", "elements": n, "fused_ms": ms_f, "calls_ms": ms_c,
+                                            "speedup": ms_c / ms_f, "fused_bytes_per_element": ch.traffic_bytes(), "calls_bytes_per_element": ch.unfused_traffic_bytes(),
+                                            "fused_GBps": ch.traffic_bytes() * n / (ms_f * 1e-3) / 1e9, "field_ops_per_s_per_gpu": 4 * n / (ms_f * 1e-3),
+                                            "limbs_equal_to_call_sequence": True}
+            del t1, t2, zc
+            F.modmul(a, b, out=c)                              # the verifier below checks c = a * b
+        except Exception as ex:                                # a missing compiler on the box must not cost the headline line
+            others["fused_chain_X25519"] = {"skipped": repr(ex)[:200]}
+
     ladder = None
     my_lt = None
     if not args.no_ladder:

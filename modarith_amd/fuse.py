@@ -23,6 +23,10 @@ the exact ones.  C-ABI of the built plug-in (modarith_amd/plugins/libmodarith_am
 
     int chain_<name>_<TAG>_batch(const void *const *in, void *const *out, size_t n, size_t ld, void *stream);
 
+(`in`: the element batches, then one int32 array per selector of modcmv / modcsw.)  Operations: modmul modsqr modadd modsub modneg
+modmli nres redc modcpy modinv modpro modsqrt modnsqr modhaf modcmv modcsw and the generic=False forms modadd_lazy modsub_lazy
+modneg_lazy (one level of laziness between reductions, which is how rfc7748.c uses them).
+
 Like the generator mode (modarith_amd/generate.py) this needs hipcc where the chain is built and has no CPU path.
 """
 from __future__ import annotations
@@ -41,12 +45,21 @@ from . import generate as _gen
 HERE = os.path.dirname(os.path.abspath(__file__))
 _NAME_RE = re.compile(r"^[A-Za-z][A-Za-z0-9_]*$")
 # op -> (Field<P> function, operand count, takes an int immediate)
-_OPS = {"modmul": 2, "modadd": 2, "modsub": 2, "modsqr": 1, "modneg": 1, "nres": 1, "redc": 1, "modcpy": 1, "modinv": 1, "modmli": 1}
+_OPS = {"modmul": 2, "modadd": 2, "modsub": 2, "modsqr": 1, "modneg": 1, "nres": 1, "redc": 1, "modcpy": 1, "modinv": 1, "modmli": 1,
+        "modadd_lazy": 2, "modsub_lazy": 2, "modneg_lazy": 1, "modnsqr": 1, "modpro": 1, "modsqrt": 1, "modhaf": 1, "modcmv": 2, "modcsw": 2}
+_HEAVY = ("modinv", "modpro", "modsqrt")          # long exponentiation chains: one element per lane
+_LAZY = ("modadd_lazy", "modsub_lazy", "modneg_lazy")
 MAX_OPS = 256
 
 
 class Val:
     """one element-valued intermediate of a chain (an SSA value: written once)"""
+    def __init__(self, chain: "Chain", idx: int):
+        self.chain, self.idx = chain, idx
+
+
+class Sel:
+    """a per-element int selector input of a chain"""
     def __init__(self, chain: "Chain", idx: int):
         self.chain, self.idx = chain, idx
 
@@ -66,6 +79,8 @@ class Chain:
             raise ValueError("prime %r is neither built in nor generated (python -m modarith_amd.generate 64 <prime>)" % (prime,))
         self.prime, self.name = prime, name
         self.nin = 0
+        self.nsel = 0                       # per-element int selectors (modcmv / modcsw): int32 arrays after the element inputs
+        self.lazy = set()                   # values produced by a generic=False operation
         self.ops: List[tuple] = []          # (op, dst, a, b, imm)
         self.outs: List[int] = []
         self.nvals = 0
@@ -113,13 +128,59 @@ class Chain:
             raise ValueError("modmli takes a C int")
         return self._op("modmli", a, imm=k)
 
+    # generic=False forms (pseudo.py:294-302, 315-324, 337-346: what rfc7748.c:20 asks for).  Their results carry up to two extra bits;
+    # one level of them keeps the limb contract the split products rely on, a lazy sum of lazy sums need not -- refused here
+    def _lazy(self, op, a, b=None):
+        for v in (a, b):
+            if v is not None and v.idx in self.lazy:
+                raise ValueError("%s of a value that is itself a generic=False result: reduce in between (modadd / modsub / modmul ...)" % op)
+        d = self._op(op, a, b)
+        self.lazy.add(d.idx)
+        return d
+
+    def modadd_lazy(self, a, b): return self._lazy("modadd_lazy", a, b)
+    def modsub_lazy(self, a, b): return self._lazy("modsub_lazy", a, b)
+    def modneg_lazy(self, a): return self._lazy("modneg_lazy", a)
+    def modpro(self, a): return self._op("modpro", a)
+    def modsqrt(self, a): return self._op("modsqrt", a)
+    def modhaf(self, a): return self._op("modhaf", a)
+
+    def modnsqr(self, a, k: int):
+        if not 0 <= int(k) <= 100000:
+            raise ValueError("modnsqr count out of range")
+        return self._op("modnsqr", a, imm=k)
+
+    def selector(self) -> "Sel":
+        """a per-element int input (0 / 1), as the `int b` of modcmv / modcsw: an int32 array, passed after the element inputs"""
+        if self.ops:
+            raise ValueError("declare every input before the first operation")
+        self.nsel += 1
+        return Sel(self, self.nsel - 1)
+
+    def _sel(self, d):
+        if not isinstance(d, Sel) or d.chain is not self:
+            raise ValueError("the selector must come from this chain's selector()")
+        return d.idx
+
+    def modcmv(self, d, g, f):
+        """f' = d ? g : f  (constant time: lane-predicated selects, pseudo.py:1017-1048)"""
+        return self._op("modcmv", g, f, imm=self._sel(d))
+
+    def modcsw(self, d, g, f):
+        """(g', f') = d ? (f, g) : (g, f)  (pseudo.py:979-1014)"""
+        k = self._sel(d)
+        self._own(g, f)
+        g2, f2 = self._new(), self._new()
+        self.ops.append(("modcsw", g2.idx, g.idx, f.idx, k, f2.idx))
+        return g2, f2
+
     def output(self, v: Val) -> None:
         self._own(v)
         self.outs.append(v.idx)
 
     # ------------------------------------------------------------------ emission
     def default_ept(self) -> int:
-        return 1 if any(o[0] == "modinv" for o in self.ops) else 2
+        return 1 if any(o[0] in _HEAVY for o in self.ops) else 2
 
     @property
     def symbol(self) -> str:
@@ -127,10 +188,10 @@ class Chain:
 
     def traffic_bytes(self) -> int:
         """HBM bytes per element of the fused kernel; the call-by-call sequence moves sum(8 N (operands + 1)) instead"""
-        return 8 * self.params.nlimbs * (self.nin + len(self.outs))
+        return 8 * self.params.nlimbs * (self.nin + len(self.outs)) + 4 * self.nsel
 
     def unfused_traffic_bytes(self) -> int:
-        return sum(8 * self.params.nlimbs * (_OPS[o[0]] + 1) for o in self.ops)
+        return sum(8 * self.params.nlimbs * (_OPS[o[0]] + (2 if o[0] == "modcsw" else 1)) + (4 if o[0] in ("modcmv", "modcsw") else 0) for o in self.ops)
 
     def source(self, ept: Optional[int] = None, policy: str = "vote") -> str:
         """ept: elements per lane on aligned batches (2 = 16-byte accesses, 1 = 8-byte); None = the measured default"""
@@ -141,11 +202,23 @@ class Chain:
              '#include "params_%s.h"' % P, '#include "modarith_amd.h"', '#include "capi_common.h"', '#include "kernels.h"', "",
              "namespace {", "using namespace ma;", "using P = ma::P_%s;" % P, "constexpr int NIN = %d, NOUT = %d;" % (self.nin, len(self.outs)),
              "constexpr bool HEAVY = %s;   // one element per lane (8-byte accesses) on every batch: chains with an inversion, as the library's k_unary_heavy" % ("true" if (ept or self.default_ept()) == 1 else "false"),
-             "struct Args { const spint* in[NIN]; spint* out[NOUT]; };", "",
+             "constexpr int NSEL = %d;" % self.nsel,
+             "struct Args { const spint* in[NIN]; spint* out[NOUT]; const int* sel[NSEL > 0 ? NSEL : 1]; };", "",
              "// the chain on one element's registers; F = Field<P, FAST>",
-             "template <class F> MA_DEV void body(%s) {" % ", ".join(("const spint* v%d" if i < self.nin else "spint* v%d") % i for i in range(nv))]
-        for op, d, a, b, imm in self.ops:
-            if op == "modinv":
+             "template <class F> MA_DEV void body(%s) {" % ", ".join([("const spint* v%d" if i < self.nin else "spint* v%d") % i for i in range(nv)] + ["int s%d" % k for k in range(self.nsel)])]
+        for o in self.ops:
+            op, d, a, b, imm = o[:5]
+            if op == "modcsw":
+                L.append("    F::modcpy(v%d, v%d); F::modcpy(v%d, v%d); F::modcsw(s%d, v%d, v%d);" % (a, d, b, o[5], imm, d, o[5]))
+            elif op == "modcmv":
+                L.append("    F::modcpy(v%d, v%d); F::modcmv(s%d, v%d, v%d);" % (b, d, imm, a, d))
+            elif op == "modnsqr":
+                L.append("    F::modcpy(v%d, v%d); F::modnsqr(v%d, %d);" % (a, d, d, imm))
+            elif op == "modhaf":
+                L.append("    F::modcpy(v%d, v%d); F::modhaf(v%d);" % (a, d, d))
+            elif op == "modsqrt":
+                L.append("    F::modsqrt(v%d, nullptr, v%d);" % (a, d))
+            elif op == "modinv":
                 L.append("    F::modinv(v%d, nullptr, v%d); inv_normalise<F>(v%d);" % (a, d, d))
             elif op == "modmli":
                 L.append("    F::modmli(v%d, %d, v%d);" % (a, imm, d))
@@ -162,17 +235,19 @@ class Chain:
                  "    fast = __all(ok);",
                  "}",
                  "if (fast) {",
-                 "    static_for<0, EPT>([&](auto E) { body<Field<P, true>>(%s); });" % ", ".join("v%d[E]" % i for i in range(nv)),
+                 "    static_for<0, EPT>([&](auto E) { body<Field<P, true>>(%s); });" % ", ".join(["v%d[E]" % i for i in range(nv)] + ["s%d[E]" % k for k in range(self.nsel)]),
                  "} else {",
-                 "    static_for<0, EPT>([&](auto E) { body<Field<P, false>>(%s); });" % ", ".join("v%d[E]" % i for i in range(nv)),
+                 "    static_for<0, EPT>([&](auto E) { body<Field<P, false>>(%s); });" % ", ".join(["v%d[E]" % i for i in range(nv)] + ["s%d[E]" % k for k in range(self.nsel)]),
                  "}"]
         L += ["    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * BLOCK) {",
               "        " + " ".join("spint v%d[EPT][P::N];" % i for i in range(nv))]
         L += ["        load_soa<P, EPT>(A.in[%d], L, t, v%d);" % (i, i) for i in range(self.nin)]
+        L += ["        int s%d[EPT]; static_for<0, EPT>([&](auto E) { s%d[E] = A.sel[%d][(size_t)EPT * t + E]; });" % (k, k, k) for k in range(self.nsel)]
         L += ["        " + l for l in votel]
         L += ["        store_soa<P, EPT>(A.out[%d], L, t, v%d);" % (k, o) for k, o in enumerate(self.outs)]
         L += ["    }", "}", "}  // namespace", "",
               'extern "C" int %s(const void* const* in, void* const* out, size_t n, size_t ld, void* stream) {' % self.symbol,
+              "    // in[0 .. NIN): element batches; in[NIN .. NIN + NSEL): int32 selector arrays, one entry per element",
               "    if (n == 0) return 0;",
               "    Ld L(ld);",
               "    if (ld < n) {",
@@ -183,6 +258,7 @@ class Chain:
               "    bool al = ld % 2 == 0;",
               "    for (int i = 0; i < NIN; i++) { A.in[i] = (const spint*)in[i]; al = al && aligned16(in[i]); }",
               "    for (int i = 0; i < NOUT; i++) { A.out[i] = (spint*)out[i]; al = al && aligned16(out[i]); }",
+              "    for (int i = 0; i < NSEL; i++) A.sel[i] = (const int*)in[NIN + i];",
               "    hipStream_t s = (hipStream_t)stream;",
               "    const bool tiled = L.s != 63;",
               "    if (n >= 2 && al && !HEAVY) {",
@@ -193,6 +269,7 @@ class Chain:
               "            Args B;",
               "            for (int i = 0; i < NIN; i++) B.in[i] = A.in[i] + o;",
               "            for (int i = 0; i < NOUT; i++) B.out[i] = A.out[i] + o;",
+              "            for (int i = 0; i < NSEL; i++) B.sel[i] = A.sel[i] + (n - 1);",
               "            k_chain<1><<<1, BLOCK, 0, s>>>(B, 1, Ld(L.ld));",
               "        }",
               "    } else {",
@@ -251,8 +328,9 @@ class FusedChain:
         import torch
         from .field import Field
         ch = self.chain
-        if len(inputs) != ch.nin:
-            raise ValueError("chain %s takes %d inputs" % (ch.name, ch.nin))
+        if len(inputs) != ch.nin + ch.nsel:
+            raise ValueError("chain %s takes %d element batches followed by %d int32 selector arrays" % (ch.name, ch.nin, ch.nsel))
+        inputs, sels = inputs[:ch.nin], inputs[ch.nin:]
         dev = device if device is not None else inputs[0].device
         F = self._fields.get(dev)
         if F is None:                                  # binding a Field derives the prime's constants: once per device, not per call
@@ -261,8 +339,19 @@ class FusedChain:
         if len(outs) != len(ch.outs):
             raise ValueError("chain %s has %d outputs" % (ch.name, len(ch.outs)))
         n = F._chk(*inputs, *outs)
-        ins = (ctypes.c_void_p * ch.nin)(*[t.data_ptr() for t in inputs])
+        for d in sels:
+            if d.dtype != torch.int32 or d.numel() != n or not d.is_cuda or not d.is_contiguous() or d.device != F.device:
+                raise ValueError("selectors are contiguous int32 device tensors with one 0/1 entry per element")
+        ins = (ctypes.c_void_p * (ch.nin + ch.nsel))(*[t.data_ptr() for t in list(inputs) + list(sels)])
         ous = (ctypes.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
         with torch.cuda.device(F.device):
             _lib.check(self.fn(ins, ous, n, F._ld(inputs[0]), torch.cuda.current_stream(F.device).cuda_stream), ch.symbol)
         return tuple(outs)
+
+
+def bench_chain(prime: str = "X25519") -> Chain:
+    """the chain bench.py times beside the headline and __graft_entry__.build() pre-builds: z = ((a + b)(a - b))^2, four calls"""
+    ch = Chain(prime, "bench_prod")
+    u, v = ch.inputs(2)
+    ch.output(ch.modsqr(ch.modmul(ch.modadd(u, v), ch.modsub(u, v))))
+    return ch

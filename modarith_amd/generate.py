@@ -177,9 +177,11 @@ def installed(plugin_dir: Optional[str] = None) -> List[dict]:
         for f in sorted(os.listdir(d)):
             if f.endswith(".json") and os.path.exists(plugin_path(f[:-5], d)):
                 try:
-                    out.append(json.load(open(os.path.join(d, f))))
+                    m = json.load(open(os.path.join(d, f)))
                 except ValueError:
-                    pass
+                    continue
+                if "tag" in m:                         # (the directory also holds the plug-ins of fused chains, modarith_amd/fuse.py)
+                    out.append(m)
     return out
 
 

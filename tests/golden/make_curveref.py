@@ -5,7 +5,8 @@ called).  For every curve of curve.py's list: the generator's limbs, and chained
     P (limbs, Z != 1 after the first) , e, f  ->  M = e*P (ecnXXXmul), D = 2M (dbl), A = M + D (add), S = A - D (sub),
     N = -A (neg), C = cof(A), R = e*M + f*D (mul2), isinf flags
 
-plus the special cases P + P through add, P + (-P), multiplication by 0 and 1, and operations on the point at infinity.
+plus the special cases P + P through add, P + (-P), multiplication by 0 and 1, operations on the point at infinity, and
+ecnXXXset from both coordinates (on- and off-curve input).
 Inputs and outputs are the struct's raw limbs, so the oracle's restatement and the HIP kernels are compared with the reference
 limb for limb (tests/test_curveref_oracle.py, tests/test_gpu_curveref.py).   python tests/golden/make_curveref.py [CURVE ...]
 """
@@ -84,6 +85,19 @@ def fixture(curve, seed, records):
     X = cp(O); f("add")(ref(G), ref(X)); sp["inf+gen"] = H(X)
     X = cp(O); f("mul")(bytes(rng.randrange(256) for _ in range(nb)), ref(X)); sp["mul_inf"] = H(X)
     fx["special"] = sp
+    # ecnXXXset with BOTH coordinates (edwards.c:243-270, weierstrass.c:366-388): modimp, nres, the curve equation, modcmp -- no
+    # square root, so the reference's own function runs.  Inputs: the affine points of the big-integer fixtures (edwards_*.json /
+    # weierstrass_*.json "set_xy", on and off the curve)
+    kind = "edwards" if curve.startswith(("ED", "NUMS256E")) else "weierstrass"
+    aff = json.load(open(os.path.join(HERE, "%s_%s.json" % (kind, curve))))
+    f("set").argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, PP]
+    f("set").restype = None
+    sx = []
+    for r in aff["set_xy"]:
+        X = Pt(); f("set")(0, bytes.fromhex(r["x"]), bytes.fromhex(r["y"]), ref(X))
+        sx.append({"x": r["x"], "y": r["y"], "P": H(X), "isinf": f("isinf")(ref(X))})
+        assert f("isinf")(ref(X)) == (0 if r["valid"] else 1), "the big-integer model and the reference disagree on a point's validity"
+    fx["set_xy"] = sx
     return fx
 
 

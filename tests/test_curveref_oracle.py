@@ -73,3 +73,12 @@ def test_special_cases(cx):
     G = point(Pt, g["gen"])
     X = Pt.from_buffer_copy(bytes(G)); f("add")(ref(O), ref(X)); assert rows(X) == sp["gen+inf"]
     X = Pt.from_buffer_copy(bytes(O)); f("add")(ref(G), ref(X)); assert rows(X) == sp["inf+gen"]
+
+
+def test_set_from_both_coordinates(cx):
+    """ecnXXXset(s, x, y): big-endian coordinates in, limbs out (or the point at infinity for off-curve input)"""
+    name, C, o, Pt, g = cx
+    for r in g["set_xy"]:
+        p = Pt()
+        o.ecn(C, "set")(0, bytes.fromhex(r["x"]), bytes.fromhex(r["y"]), ctypes.byref(p))
+        assert rows(p) == r["P"] and o.ecn(C, "isinf")(ctypes.byref(p)) == r["isinf"], (name, r["x"])

@@ -83,3 +83,12 @@ def test_special_cases(cx):
     G = batch(torch, [g["gen"]] * 2)
     assert unbatch(W.add(O, G.clone())) == [sp["gen+inf"]] * 2
     assert unbatch(W.add(G, O.clone())) == [sp["inf+gen"]] * 2
+
+
+def test_set_from_both_coordinates(cx):
+    """ecnXXXset(s, x, y): big-endian coordinates in, limbs out (or the point at infinity for off-curve input)"""
+    name, W, g, torch = cx
+    recs = g["set_xy"]
+    P = W.set(None, scalars(torch, [r["x"] for r in recs]), scalars(torch, [r["y"] for r in recs]))
+    assert unbatch(P) == [r["P"] for r in recs]
+    assert W.isinf(P).cpu().tolist() == [r["isinf"] for r in recs]

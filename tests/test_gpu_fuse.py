@@ -111,3 +111,71 @@ def test_out_of_contract_limbs_take_the_exact_products(torch_cuda):
     x, y = to_dev(x), to_dev(y)
     z, = f(x, y)
     assert torch.equal(z, F.modsqr(F.modmul(x, y)))
+
+
+def test_a_ladder_step_with_selectors_and_lazy_forms(torch_cuda):
+    """one Montgomery-ladder step as the reference writes it (rfc7748.c:190-223: modcsw on the scalar bit, generic=False sums,
+    5 multiplications, 4 squarings, a24) as ONE kernel: five element batches and a per-element swap bit in, four batches out --
+    equal to the same 22 calls of the batched API, limb for limb; the fused step moves 364 bytes per element, the calls 2 288"""
+    torch = torch_cuda
+    from modarith_amd.field import Field
+    from modarith_amd.fuse import Chain
+    for P, a24 in (("X25519", 121665), ("X448", 39081)):
+        F, fp = Field(P), derive_any(P)
+        ch = Chain(P, "ladderstep")
+        x1, x2, z2, x3, z3 = ch.inputs(5)
+        sw = ch.selector()
+        x2, x3 = ch.modcsw(sw, x2, x3)
+        z2, z3 = ch.modcsw(sw, z2, z3)
+        A, B, C, D = ch.modadd_lazy(x2, z2), ch.modsub_lazy(x2, z2), ch.modadd_lazy(x3, z3), ch.modsub_lazy(x3, z3)
+        AA, BB, DA, CB = ch.modsqr(A), ch.modsqr(B), ch.modmul(D, A), ch.modmul(C, B)
+        E = ch.modsub_lazy(AA, BB)
+        for v in (ch.modmul(AA, BB), ch.modmul(E, ch.modadd_lazy(AA, ch.modmli(E, a24))),
+                  ch.modsqr(ch.modadd_lazy(DA, CB)), ch.modmul(x1, ch.modsqr(ch.modsub_lazy(DA, CB)))):
+            ch.output(v)
+        with pytest.raises(ValueError, match="generic=False result"):
+            ch.modadd_lazy(A, B)
+        f = ch.build()
+        n = 2 * 4096 + 3
+        t = [to_dev(_rand(fp, n, 20 + i)) for i in range(5)]
+        bit = torch.randint(0, 2, (n,), dtype=torch.int32, device="cuda")
+        got = f(*t, bit)
+        X1, X2, Z2, X3, Z3 = [x.clone() for x in t]
+        F.modcsw(bit, X2, X3); F.modcsw(bit, Z2, Z3)
+        sA, sB, sC, sD = F.modadd_lazy(X2, Z2), F.modsub_lazy(X2, Z2), F.modadd_lazy(X3, Z3), F.modsub_lazy(X3, Z3)
+        sAA, sBB, sDA, sCB = F.modsqr(sA), F.modsqr(sB), F.modmul(sD, sA), F.modmul(sC, sB)
+        sE = F.modsub_lazy(sAA, sBB)
+        want = (F.modmul(sAA, sBB), F.modmul(sE, F.modadd_lazy(sAA, F.modmli(sE, a24))),
+                F.modsqr(F.modadd_lazy(sDA, sCB)), F.modmul(X1, F.modsqr(F.modsub_lazy(sDA, sCB))))
+        for k in range(4):
+            assert torch.equal(got[k], want[k]), (P, k)
+        assert ch.traffic_bytes() == 9 * 8 * fp.nlimbs + 4
+
+
+def test_remaining_operations(torch_cuda):
+    """modcmv, modnsqr, modhaf, modneg, modpro, modsqrt, nres / redc inside a chain against the same calls"""
+    torch = torch_cuda
+    from modarith_amd.field import Field
+    from modarith_amd.fuse import Chain
+    P = "NIST256"
+    F, fp = Field(P), derive_any(P)
+    ch = Chain(P, "misc")
+    a, b = ch.inputs(2)
+    d = ch.selector()
+    m = ch.modcmv(d, a, b)                     # d ? a : b
+    q = ch.modnsqr(ch.nres(m), 3)
+    h = ch.modneg(ch.modhaf(q))
+    ch.output(ch.redc(h))
+    ch.output(ch.modsqrt(ch.modsqr(a)))
+    ch.output(ch.modpro(b))
+    f = ch.build()
+    n = 4096 + 5
+    x, y = to_dev(_rand(fp, n, 31)), to_dev(_rand(fp, n, 32))
+    sel = torch.randint(0, 2, (n,), dtype=torch.int32, device="cuda")
+    o1, o2, o3 = f(x, y, sel)
+    mm = y.clone(); F.modcmv(sel, x, mm)
+    qq = F.nres(mm); F.modnsqr(qq, 3)
+    hh = qq.clone(); F.modhaf(hh)
+    assert torch.equal(o1, F.redc(F.modneg(hh)))
+    assert torch.equal(o2, F.modsqrt(F.modsqr(x)))
+    assert torch.equal(o3, F.modpro(y))
