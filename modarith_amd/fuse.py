@@ -193,7 +193,7 @@ class Chain:
     def unfused_traffic_bytes(self) -> int:
         return sum(8 * self.params.nlimbs * (_OPS[o[0]] + (2 if o[0] == "modcsw" else 1)) + (4 if o[0] in ("modcmv", "modcsw") else 0) for o in self.ops)
 
-    def source(self, ept: Optional[int] = None, policy: str = "vote") -> str:
+    def source(self, ept: Optional[int] = None, policy: str = "vote", waves: int = 0) -> str:
         """ept: elements per lane on aligned batches (2 = 16-byte accesses, 1 = 8-byte); None = the measured default"""
         if not self.nin or not self.outs:
             raise ValueError("a chain needs at least one input and one output")
@@ -227,7 +227,7 @@ class Chain:
             else:
                 L.append("    F::%s(v%d, v%d);" % (op, a, d))
         L += ["}", "",
-              "template <int EPT>", "__global__ __launch_bounds__(BLOCK) void k_chain(Args A, size_t nthreads, Ld L) {"]
+              "template <int EPT>", "__global__ __launch_bounds__(BLOCK) %svoid k_chain(Args A, size_t nthreads, Ld L) {" % ("__attribute__((amdgpu_waves_per_eu(%d, %d))) " % (waves, waves) if waves else "")]
         votel = ["bool fast = %s;" % ("true" if policy == "fast" else "false"),
                  "if constexpr (P::SPLIT > 0 && %s) {" % ("true" if policy == "vote" else "false"),
                  "    bool ok = true;",
@@ -283,11 +283,11 @@ class Chain:
     def lib_path(self, plugin_dir: Optional[str] = None) -> str:
         return os.path.join(plugin_dir or _gen.PLUGIN_DIR, "libmodarith_amd_chain_%s_%s.so" % (self.name, self.prime))
 
-    def build(self, plugin_dir: Optional[str] = None, force: bool = False, verbose: bool = False, ept: Optional[int] = None, policy: str = "vote") -> "FusedChain":
+    def build(self, plugin_dir: Optional[str] = None, force: bool = False, verbose: bool = False, ept: Optional[int] = None, policy: str = "vote", waves: int = 0) -> "FusedChain":
         from .build import ARCH, FLAGS, HIPCC, _stamp
         d = plugin_dir or _gen.PLUGIN_DIR
         os.makedirs(d, exist_ok=True)
-        src_text = self.source(ept, policy)
+        src_text = self.source(ept, policy, waves)
         base = "chain_%s_%s" % (self.name, self.prime)
         src, obj, meta = (os.path.join(d, base + e) for e in (".hip", ".o", ".json"))
         lib = self.lib_path(d)
@@ -305,11 +305,16 @@ class Chain:
             inc = ["-I", os.path.join(HERE, "csrc", "generated"), "-I", os.path.join(HERE, "csrc"), "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", _gen.PLUGIN_DIR, "-I", d]
             if verbose:
                 print("[modarith_amd] hipcc %s" % os.path.basename(src), flush=True)
-            subprocess.run([HIPCC] + list(FLAGS) + inc + ["-c", src, "-o", obj], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
-            subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, obj, "-L", HERE, "-l:libmodarith_amd.so",
+            tmp = ".%d.tmp" % os.getpid()              # process-private names, moved into place when complete (see generate.py)
+            subprocess.run([HIPCC] + list(FLAGS) + inc + ["-c", src, "-o", obj + tmp], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
+            subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib + tmp, obj + tmp, "-L", HERE, "-l:libmodarith_amd.so",
                                    "-Wl,-rpath,$ORIGIN/" + os.path.relpath(HERE, d), "-Wl,-rpath," + HERE])
-            json.dump({"chain": self.name, "prime": self.prime, "inputs": self.nin, "outputs": len(self.outs), "ops": [o[0] for o in self.ops],
-                       "symbol": self.symbol, "hash": key}, open(meta, "w"), indent=1)
+            with open(meta + tmp, "w") as f:
+                json.dump({"chain": self.name, "prime": self.prime, "inputs": self.nin, "selectors": self.nsel, "outputs": len(self.outs),
+                           "ops": [o[0] for o in self.ops], "symbol": self.symbol, "hash": key}, f, indent=1)
+            os.replace(obj + tmp, obj)
+            os.replace(lib + tmp, lib)
+            os.replace(meta + tmp, meta)
         return FusedChain(self, lib, built=not fresh)
 
 

@@ -160,12 +160,18 @@ def generate(prime: str, wl: int = 64, family: Optional[str] = None, name: Optio
         raise GenerateError("%s is missing: build it first (python -m modarith_amd.build); plug-ins link against it" % main)
     if verbose:
         print("[modarith_amd] hipcc %s -> %s" % (os.path.basename(unit), os.path.basename(lib)), flush=True)
-    subprocess.run(cmd + ["-o", obj], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
+    # object, library and metadata are written under process-private names and moved into place: another process (a second rank,
+    # a parallel test worker) generating or loading the same plug-in never sees a half-written file
+    tmp = ".%d.tmp" % os.getpid()
+    subprocess.run(cmd + ["-o", obj + tmp], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
     rel = os.path.relpath(HERE, d)
-    subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, obj, "-L", HERE, "-l:libmodarith_amd.so",
+    subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib + tmp, obj + tmp, "-L", HERE, "-l:libmodarith_amd.so",
                            "-Wl,-rpath,$ORIGIN/" + rel, "-Wl,-rpath," + HERE])
-    json.dump({"tag": tag, "prime": prime, "p": hex(fp.p), "family": fp.family, "radix": fp.radix, "nlimbs": fp.nlimbs,
-               "hash": key}, open(meta, "w"), indent=1)
+    with open(meta + tmp, "w") as f:
+        json.dump({"tag": tag, "prime": prime, "p": hex(fp.p), "family": fp.family, "radix": fp.radix, "nlimbs": fp.nlimbs, "hash": key}, f, indent=1)
+    os.replace(obj + tmp, obj)
+    os.replace(lib + tmp, lib)
+    os.replace(meta + tmp, meta)
     return Generated(tag, lib, fp, True)
 
 

@@ -29,7 +29,7 @@ for P in ("X25519", "NIST256", "X448"):
     # 1: products of sums: z = ((x + y)(x - y))^2  (4 calls, 440 / 704 B per element call by call; 120 / 192 fused)
     ch = Chain(P, "t_prod"); a, b = ch.inputs(2)
     ch.output(ch.modsqr(ch.modmul(ch.modadd(a, b), ch.modsub(a, b))))
-    f1 = ch.build(ept=int(os.environ["EPT"]) if "EPT" in os.environ else None, policy=os.environ.get("POLICY", "vote"))
+    f1 = ch.build(ept=int(os.environ["EPT"]) if "EPT" in os.environ else None, policy=os.environ.get("POLICY", "vote"), waves=int(os.environ.get("WAVES", "0")))
     t1, t2 = F.empty(n), F.empty(n)
     def calls1():
         F.modadd(x, y, out=t1); F.modsub(x, y, out=t2); F.modmul(t1, t2, out=t1); F.modsqr(t1, out=o1)
@@ -43,7 +43,7 @@ for P in ("X25519", "NIST256", "X448"):
     AA, BB = ch.modsqr(A), ch.modsqr(B)
     E = ch.modsub(AA, BB)
     ch.output(ch.modmul(AA, BB)); ch.output(ch.modmul(E, ch.modadd(AA, ch.modmli(E, 121665))))
-    f2 = ch.build(ept=int(os.environ["EPT"]) if "EPT" in os.environ else None, policy=os.environ.get("POLICY", "vote"))
+    f2 = ch.build(ept=int(os.environ["EPT"]) if "EPT" in os.environ else None, policy=os.environ.get("POLICY", "vote"), waves=int(os.environ.get("WAVES", "0")))
     t3, t4, p1, p2 = F.empty(n), F.empty(n), F.empty(n), F.empty(n)
     def calls2():
         F.modadd(x, y, out=t1); F.modsub(x, y, out=t2); F.modsqr(t1, out=t1); F.modsqr(t2, out=t2)
