@@ -87,6 +87,26 @@ UTIL_FUNCS = ("modarith_amd_abi_version", "modarith_amd_last_error", "modarith_a
               "modarith_amd_field_info")
 
 
+def _declare_curve(lib, C: str) -> None:
+    """argtypes / restypes of the batched curve entry points ecn_<C>_*_batch of `lib` (the main library or a curve plug-in)"""
+    g = lambda f: getattr(lib, "ecn_%s_%s" % (C, f))
+    g("mul_workspace_bytes").argtypes = [c_size_t]
+    g("mul_workspace_bytes").restype = c_size_t
+    g("mul_batch").argtypes = [_P, _P, c_size_t, c_size_t, _P, c_size_t, _P]
+    g("mul2_batch").argtypes = [_P, _P, _P, _P, _P, c_size_t, c_size_t, _P, c_size_t, _P]
+    g("ran_batch").argtypes = [c_int, _P, c_size_t, c_size_t, _P]
+    for f in ("add", "sub", "cpy"):
+        g(f + "_batch").argtypes = [_P, _P, c_size_t, c_size_t, _P]
+    for f in ("dbl", "neg", "inf", "gen", "cof", "affine"):
+        g(f + "_batch").argtypes = [_P, c_size_t, c_size_t, _P]
+    g("cmp_batch").argtypes = [_P, _P, _P, c_size_t, c_size_t, _P]
+    g("isinf_batch").argtypes = [_P, _P, c_size_t, c_size_t, _P]
+    g("set_batch").argtypes = [_P, _P, _P, _P, c_size_t, c_size_t, _P]
+    g("get_batch").argtypes = [_P, _P, _P, _P, c_size_t, c_size_t, _P]
+    for f in ED_BATCH_FUNCS:
+        g(f + "_batch").restype = c_int
+
+
 def load() -> ctypes.CDLL:
     """Load the HIP library or raise: the engine has no CPU path."""
     global _lib
@@ -116,23 +136,7 @@ def load() -> ctypes.CDLL:
         h.argtypes = [_P, _P, _P, c_size_t, _P, c_size_t, _P]
         h.restype = c_int
     for C in CURVES:
-        nl, nb = CURVES[C]
-        g = lambda f: getattr(lib, "ecn_%s_%s" % (C, f))
-        g("mul_workspace_bytes").argtypes = [c_size_t]
-        g("mul_workspace_bytes").restype = c_size_t
-        g("mul_batch").argtypes = [_P, _P, c_size_t, c_size_t, _P, c_size_t, _P]
-        g("mul2_batch").argtypes = [_P, _P, _P, _P, _P, c_size_t, c_size_t, _P, c_size_t, _P]
-        g("ran_batch").argtypes = [c_int, _P, c_size_t, c_size_t, _P]
-        for f in ("add", "sub", "cpy"):
-            g(f + "_batch").argtypes = [_P, _P, c_size_t, c_size_t, _P]
-        for f in ("dbl", "neg", "inf", "gen", "cof", "affine"):
-            g(f + "_batch").argtypes = [_P, c_size_t, c_size_t, _P]
-        g("cmp_batch").argtypes = [_P, _P, _P, c_size_t, c_size_t, _P]
-        g("isinf_batch").argtypes = [_P, _P, c_size_t, c_size_t, _P]
-        g("set_batch").argtypes = [_P, _P, _P, _P, c_size_t, c_size_t, _P]
-        g("get_batch").argtypes = [_P, _P, _P, _P, c_size_t, c_size_t, _P]
-        for f in ED_BATCH_FUNCS:
-            g(f + "_batch").restype = c_int
+        _declare_curve(lib, C)
     for c in FUSED_CURVES:
         f = getattr(lib, "ecn_%s_mul_get_batch" % c)
         f.argtypes = [_P, _P, _P, _P, _P, c_size_t, c_size_t, _P, c_size_t, _P]
@@ -204,6 +208,32 @@ def load_plugin(tag: str, path: str = None) -> ctypes.CDLL:
         f.restype = c_int
     _plugins[tag] = lib
     return lib
+
+
+_curve_plugins = {}
+
+
+def load_curve_plugin(name: str, path: str = None):
+    """Load the plug-in of a generated curve (modarith_amd.generate.generate_curve); returns (CDLL, Nlimbs, Nbytes)"""
+    low = name.lower()
+    if low in _curve_plugins:
+        return _curve_plugins[low]
+    load()
+    import json
+    from .generate import PLUGIN_DIR, curve_plugin_path
+    path = path or curve_plugin_path(low)
+    meta = os.path.join(os.path.dirname(path), "curve_%s.json" % name.upper())
+    if not (os.path.exists(path) and os.path.exists(meta)):
+        raise RuntimeError("modarith_amd: no plug-in for curve %r (%s) -- generate it with modarith_amd.generate.generate_curve(...). "
+                           "There is no CPU fallback." % (name, path))
+    m = json.load(open(meta))
+    field = m["field"]
+    if field not in PRIMES:
+        load_plugin(field)                 # the curve's field is itself a plug-in
+    lib = ctypes.CDLL(path)
+    _declare_curve(lib, low)
+    _curve_plugins[low] = (lib, m["nlimbs"], m["nbytes"])
+    return _curve_plugins[low]
 
 
 class DeviceError(RuntimeError):

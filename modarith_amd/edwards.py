@@ -7,6 +7,8 @@ the reference's `char *` arguments.  Methods keep the reference's names and argu
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -26,10 +28,18 @@ class Edwards:
 
     def __init__(self, curve: str, device: Optional[torch.device] = None):
         self.name = curve.lower()
-        if self.name not in _lib.CURVES:
-            raise ValueError("curve %r is not built; available: %s" % (curve, ", ".join(_lib.CURVES)))
-        self.lib = _lib.load()
-        self.N, self.nbytes = _lib.CURVES[self.name]
+        if self.name in _lib.CURVES:
+            self.lib = _lib.load()
+            self.N, self.nbytes = _lib.CURVES[self.name]
+            self._field = None
+        else:
+            # a curve made by modarith_amd.generate.generate_curve (the counterpart of adding a curve to curve.py's table)
+            from . import generate as _gen
+            if not os.path.exists(_gen.curve_plugin_path(self.name)):
+                raise ValueError("curve %r is neither built in (%s) nor generated (%s); see modarith_amd.generate.generate_curve"
+                                 % (curve, ", ".join(_lib.CURVES), ", ".join(m["curve"] for m in _gen.installed_curves()) or "none"))
+            self.lib, self.N, self.nbytes = _lib.load_curve_plugin(self.name)
+            self._field = next(m["field"] for m in _gen.installed_curves() if m["curve"].lower() == self.name)
         from .field import normalise_device
         self.device = normalise_device(device)
         self._ws = None
@@ -109,7 +119,7 @@ class Edwards:
         from .field import Field
         self._chk(P)
         up = self.name.upper()
-        fname = (curves.CURVES[up] if up in curves.CURVES else curves.W_CURVES[up]).field
+        fname = self._field or (curves.CURVES[up] if up in curves.CURVES else curves.W_CURVES[up]).field
         F = Field(fname, device=self.device)
         return F.modlimbs(P[0]) & F.modlimbs(P[1]) & F.modlimbs(P[2])
 

@@ -376,7 +376,12 @@ def curve_header_text(name: str) -> str:
     """constants of one Edwards curve as `struct C_<NAME>` (counterpart of curve.py's curve.c: COF,
     CONSTANT_A, CONSTANT_B or constant_b[], constant_x[], constant_y[]; curve.py:244-298)."""
     from .curves import curve
-    c = curve(name)
+    return curve_header_text_of(curve(name))
+
+
+def curve_header_text_of(c) -> str:
+    """the same for any EdwardsCurve object with its field parameters attached (c.fp): the built-in table, or a curve of the
+    caller's own (modarith_amd.generate.generate_curve, the counterpart of curve.py's "Insert your own!")"""
     N = c.fp.nlimbs
     L = ["// GENERATED by modarith_amd/emit.py from modarith_amd/curves.py -- do not edit.",
          "// Edwards curve %s: %d*x^2 + y^2 = 1 + d*x^2*y^2 over the %s field" % (c.name, c.a, c.field),
@@ -427,7 +432,10 @@ def wcurve_header_text(name: str) -> str:
     """constants of one short-Weierstrass curve (curve.py's curve.c: CONSTANT_A, constant_b[], constant_b3[],
     constant_x[], constant_y[]; curve.py:244-298)"""
     from .curves import wcurve
-    c = wcurve(name)
+    return wcurve_header_text_of(wcurve(name))
+
+
+def wcurve_header_text_of(c) -> str:
     L = ["// GENERATED by modarith_amd/emit.py from modarith_amd/curves.py -- do not edit.",
          "// Weierstrass curve %s: y^2 = x^3 %+d*x + b over the %s field" % (c.name, c.a, c.field),
          "#pragma once",

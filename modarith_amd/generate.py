@@ -175,6 +175,130 @@ def generate(prime: str, wl: int = 64, family: Optional[str] = None, name: Optio
     return Generated(tag, lib, fp, True)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# curves of one's own: the counterpart of curve.py's table ("More curves can be added here", curve.py:73-203)
+@dataclass
+class GeneratedCurve:
+    name: str                   # upper-case name; symbols ecn_<lower>_*
+    kind: str                   # "edwards" | "weierstrass"
+    field: str                  # tag of the field (built-in or generated)
+    lib: str
+    nlimbs: int
+    nbytes: int
+    built: bool
+
+
+def curve_plugin_path(name: str, plugin_dir: Optional[str] = None) -> str:
+    return os.path.join(plugin_dir or PLUGIN_DIR, "libmodarith_amd_curve_%s.so" % name.lower())
+
+
+def generate_curve(name: str, kind: str, field: str, a: int, b: int, order: int, gx: int, gy: int, cof: int = 0,
+                   plugin_dir: Optional[str] = None, force: bool = False, verbose: bool = False) -> GeneratedCurve:
+    """The curve layer (curve.h: ecn_<name>_mul / mul2 / add / dbl / set / get ..., scalar and batched) for a curve that is not in
+    curve.py's table.  kind "edwards": a x^2 + y^2 = 1 + b x^2 y^2 with a = +-1 (edwards.c; cof = log2 of the cofactor);
+    kind "weierstrass": y^2 = x^3 + a x + b with a = -3 or 0 and prime order (weierstrass.c).  `field`: a built-in prime name or the
+    tag of a generated field (generate() first).  One hipcc unit (the scalar-multiplication kernels take about a minute to
+    compile); the plug-in exports what MODARITH_AMD_DECLARE_EDWARDS(<lower-case name>, Nlimbs) declares."""
+    from . import _lib, curves
+    from .params import derive
+    if kind not in ("edwards", "weierstrass"):
+        raise GenerateError("kind must be 'edwards' or 'weierstrass'")
+    if not _TAG_RE.match(name) or not name[0].isalpha():
+        raise GenerateError("%r cannot be part of a C identifier" % (name,))
+    up, low = name.upper(), name.lower()
+    if low in _lib.CURVES:
+        raise GenerateError("%s is a built-in curve" % up)
+    d = plugin_dir or PLUGIN_DIR
+    if field in _lib.PRIMES:
+        fp = derive(field)
+    elif os.path.exists(os.path.join(d, "%s.json" % field)):
+        fp = params_of_plugin(field, d)
+    elif os.path.exists(os.path.join(PLUGIN_DIR, "%s.json" % field)):
+        fp = params_of_plugin(field)
+    else:
+        raise GenerateError("field %r is neither built in nor generated: run generate() for it first" % (field,))
+    p = fp.p
+    # the checks curve.py leaves to its user: the generator is on the curve, the order annihilates it
+    if kind == "edwards":
+        if a not in (1, -1):
+            raise GenerateError("edwards.c handles a = 1 and a = -1")
+        if gy and (a * gx * gx + gy * gy - 1 - b * gx * gx * gy * gy) % p:
+            raise GenerateError("the generator is not on the curve")
+        c = curves.EdwardsCurve(up, field, a, b, cof, order, gx, gy, fp)
+        hdr_text = emit.curve_header_text_of(c)
+        cls, inc = "ma::Edwards<ma::C_%s>" % up, "edwards.h"
+    else:
+        if a not in (-3, 0):
+            raise GenerateError("weierstrass.c handles a = -3 and a = 0")
+        if gy and (gy * gy - gx ** 3 - a * gx - b) % p:
+            raise GenerateError("the generator is not on the curve")
+        c = curves.WeierstrassCurve(up, field, a, b, order, gx, gy, fp)
+        hdr_text = emit.wcurve_header_text_of(c)
+        cls, inc = "ma::Weierstrass<ma::C_%s>" % up, "weierstrass.h"
+    unit_text = ("// GENERATED by modarith_amd/generate.py -- do not edit.  C-ABI of the curve layer for %s (%s over %s); body: csrc/capi_curve.inc\n"
+                 '#include "modarith_amd.h"\nextern "C" {\nMODARITH_AMD_DECLARE_EDWARDS(%s, %d)\n}\n#include "curve_%s.h"\n#include "%s"\n'
+                 "#define MA_CURVE_CLASS %s\n#define MA_CNAME %s\n#include \"capi_curve.inc\"\n" % (up, kind, field, low, fp.nlimbs, up, inc, cls, low))
+    os.makedirs(d, exist_ok=True)
+    hdr, unit = os.path.join(d, "curve_%s.h" % up), os.path.join(d, "capi_curve_%s.hip" % up)
+    obj, lib, meta = os.path.join(d, "capi_curve_%s.o" % up), curve_plugin_path(up, d), os.path.join(d, "curve_%s.json" % up)
+    from .build import ARCH, FLAGS, HIPCC, _stamp
+    key = hashlib.sha256((" ".join(FLAGS) + "\n" + hdr_text + "\n" + unit_text + "\n" + emit.header_text(fp) + "\n" + _stamp()).encode()).hexdigest()
+    out = GeneratedCurve(up, kind, field, lib, fp.nlimbs, fp.nbytes, False)
+    if not force and os.path.exists(lib) and os.path.exists(meta):
+        try:
+            if json.load(open(meta)).get("hash") == key:
+                return out
+        except (ValueError, OSError):
+            pass
+    if not os.path.exists(HIPCC):
+        raise GenerateError("%s not found: generating a curve needs the ROCm compiler (there is no CPU path)" % HIPCC)
+    emit._write(hdr, hdr_text)
+    emit._write(unit, unit_text)
+    if verbose:
+        print("[modarith_amd] hipcc %s -> %s" % (os.path.basename(unit), os.path.basename(lib)), flush=True)
+    tmp = ".%d.tmp" % os.getpid()
+    inc_dirs = ["-I", os.path.join(HERE, "csrc", "generated"), "-I", os.path.join(HERE, "csrc"), "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", PLUGIN_DIR, "-I", d]
+    subprocess.run([HIPCC] + list(FLAGS) + inc_dirs + ["-c", unit, "-o", obj + tmp], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
+    subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib + tmp, obj + tmp, "-L", HERE, "-l:libmodarith_amd.so",
+                           "-Wl,-rpath,$ORIGIN/" + os.path.relpath(HERE, d), "-Wl,-rpath," + HERE])
+    with open(meta + tmp, "w") as f:
+        json.dump({"curve": up, "kind": kind, "field": field, "a": a, "b": hex(b) if b >= 0 else "-" + hex(-b), "order": hex(order), "cof": cof,
+                   "gx": hex(gx), "gy": hex(gy), "nlimbs": fp.nlimbs, "nbytes": fp.nbytes, "hash": key}, f, indent=1)
+    os.replace(obj + tmp, obj)
+    os.replace(lib + tmp, lib)
+    os.replace(meta + tmp, meta)
+    out.built = True
+    return out
+
+
+def installed_curves(plugin_dir: Optional[str] = None) -> List[dict]:
+    d = plugin_dir or PLUGIN_DIR
+    out = []
+    if os.path.isdir(d):
+        for f in sorted(os.listdir(d)):
+            if f.startswith("curve_") and f.endswith(".json") and os.path.exists(curve_plugin_path(f[6:-5], d)):
+                try:
+                    out.append(json.load(open(os.path.join(d, f))))
+                except ValueError:
+                    pass
+    return out
+
+
+# curves the test-suite generates: Curve1174 (Bernstein-Hamburg-Krasnova-Lange: x^2 + y^2 = 1 - 1174 x^2 y^2 over 2^251 - 9, the generated
+# field 2519) and NIST P-224 (a = -3 over the built-in NIST224 field) -- neither is in curve.py's table; the reference's own
+# edwards.c / weierstrass.c, given the same definitions the way curve.py asks its user to insert them, produced
+# tests/golden/curveref_CURVE1174.json / curveref_NIST224.json
+EXAMPLE_CURVES = (
+    dict(name="CURVE1174", kind="edwards", field="2519", a=1, b=-1174, cof=2,
+         order=2**249 - 11332719920821432534773113288178349711,
+         gx=1582619097725911541954547006453739763381091388846394833492296309729998839514,
+         gy=3037538013604154504764115728651437646519513534305223422754827055689195992590),
+    dict(name="NIST224", kind="weierstrass", field="NIST224", a=-3, b=0xb4050a850c04b3abf54132565044b0b7d7bfd8ba270b39432355ffb4,
+         order=0xffffffffffffffffffffffffffff16a2e0b8f03e13dd29455c5c2a3d,
+         gx=0xb70e0cbd6bb4bf7f321390b94a03c1d356c21122343280d6115c1d21, gy=0xbd376388b5f723fb4c22dfe6cd4375a05a07476444d5819985007e34),
+)
+
+
 def installed(plugin_dir: Optional[str] = None) -> List[dict]:
     """metadata of every plug-in whose shared object is present"""
     d = plugin_dir or PLUGIN_DIR

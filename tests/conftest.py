@@ -50,4 +50,6 @@ def generated_fields():
         from modarith_amd import generate as gen
         for arg, fam in gen.EXAMPLES:
             gen.generate(arg, family=fam)
+        for c in gen.EXAMPLE_CURVES:
+            gen.generate_curve(**c)
     yield

@@ -20,8 +20,11 @@ import refgen  # noqa: E402
 REF = refgen.REF
 
 
-def build(curve: str):
-    """-> (CDLL, prefix 'ecn_<curve>_', Nlimbs, Nbytes, radix, scratch dir)"""
+def build(curve: str, custom: dict = None):
+    """-> (CDLL, prefix 'ecn_<curve>_', Nlimbs, Nbytes, radix, scratch dir, small_x)
+    custom: a curve that is not in curve.py's table, given the way curve.py asks its user to insert one ("More curves can be added
+    here", curve.py:73-203) -- the variables that block assigns: p, q, cof, prime_type ('pseudo' | 'monty'), curve_type ('edwards' |
+    'weierstrass'), A, B, X, Y -- plus field_arg, the prime as the field generator takes it on its command line."""
     scratch = tempfile.mkdtemp(prefix="curveref_")
     for f in ("edwards.c", "weierstrass.c", "curve.h", "testcurve.c"):
         shutil.copy(os.path.join(REF, f), scratch)
@@ -37,10 +40,16 @@ def build(curve: str):
     try:
         for node in tree.body:
             seg = ast.get_source_segment(src, node) or ""
+            if custom is not None and isinstance(node, ast.If) and "This curve not supported" in seg:
+                assert ns["p"] == 0, "%s is in curve.py's table" % curve
+                ns.update(p=custom["p"], q=custom["q"], cof=custom["cof"], A=custom["A"], B=custom["B"], X=custom["X"], Y=custom["Y"],
+                          prime_type=ns["PSEUDO"] if custom["prime_type"] == "pseudo" else ns["MONTY"],
+                          curve_type=ns["EDWARDS"] if custom["curve_type"] == "edwards" else ns["WEIERSTRASS"])
+                continue
             if "subprocess.run" in seg and "radix=" in seg.replace(" ", ""):
                 # `radix = subprocess.run("python3 pseudo.py 64 <curve>").returncode`: run that generator through refgen instead
                 script = "pseudo.py" if ns["prime_type"] == ns["PSEUDO"] else "monty.py"
-                g = refgen.load(script, 64, curve)
+                g = refgen.load(script, 64, custom["field_arg"] if custom is not None else curve)
                 ns["radix"] = g["base"]
                 open(os.path.join(scratch, "field.c"), "w").write(refgen.emit_c(g, makestatic=False))
                 field_done = True

@@ -19,8 +19,47 @@ import curveref  # noqa: E402
 CURVES = ("ED25519", "ED448", "NUMS256E", "ED248", "ED376", "ED500", "NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W")
 
 
-def fixture(curve, seed, records):
-    lib, pre, N, nb, radix, _, small_x = curveref.build(curve)
+def custom_curves():
+    """modarith_amd.generate.EXAMPLE_CURVES in curve.py's vocabulary"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from modarith_amd.generate import EXAMPLE_CURVES, resolve, EXAMPLES
+    from modarith_amd.params import NAMED, derive
+    out = {}
+    for c in EXAMPLE_CURVES:
+        if c["field"] in NAMED:
+            fp, arg = derive(c["field"]), c["field"]
+        else:
+            arg, fam = next((a, f) for a, f in EXAMPLES if resolve(a, f).name == c["field"])
+            fp, arg = resolve(arg, fam), arg.split("=", 1)[-1]
+        out[c["name"]] = dict(p=fp.p, q=c["order"], cof=c.get("cof", 0), prime_type=fp.family, curve_type=c["kind"], A=c["a"], B=c["b"], X=c["gx"], Y=c["gy"], field_arg=arg)
+    return out
+
+
+def affine_multiples(cu, count):
+    """[G, 2G, ...] as affine (x, y) by plain integer arithmetic, for the ecnXXXset inputs of a custom curve"""
+    p, a, b = cu["p"], cu["A"], cu["B"]
+    G = (cu["X"], cu["Y"])
+    if cu["curve_type"] == "edwards":
+        def add(P, Q):
+            t = b * P[0] * Q[0] * P[1] * Q[1] % p
+            return ((P[0] * Q[1] + P[1] * Q[0]) * pow(1 + t, -1, p) % p, (P[1] * Q[1] - a * P[0] * Q[0]) * pow(1 - t, -1, p) % p)
+    else:
+        def add(P, Q):
+            if P == Q:
+                m = (3 * P[0] * P[0] + a) * pow(2 * P[1], -1, p) % p
+            else:
+                m = (Q[1] - P[1]) * pow(Q[0] - P[0], -1, p) % p
+            x = (m * m - P[0] - Q[0]) % p
+            return (x, (m * (P[0] - x) - P[1]) % p)
+    out, P = [], G
+    for _ in range(count):
+        out.append(P)
+        P = add(P, G)
+    return out
+
+
+def fixture(curve, seed, records, custom=None):
+    lib, pre, N, nb, radix, _, small_x = curveref.build(curve, custom)
 
     class Pt(ctypes.Structure):
         _fields_ = [("x", ctypes.c_uint64 * N), ("y", ctypes.c_uint64 * N), ("z", ctypes.c_uint64 * N)]
@@ -88,8 +127,14 @@ def fixture(curve, seed, records):
     # ecnXXXset with BOTH coordinates (edwards.c:243-270, weierstrass.c:366-388): modimp, nres, the curve equation, modcmp -- no
     # square root, so the reference's own function runs.  Inputs: the affine points of the big-integer fixtures (edwards_*.json /
     # weierstrass_*.json "set_xy", on and off the curve)
-    kind = "edwards" if curve.startswith(("ED", "NUMS256E")) else "weierstrass"
-    aff = json.load(open(os.path.join(HERE, "%s_%s.json" % (kind, curve))))
+    if custom is None:
+        kind = "edwards" if curve.startswith(("ED", "NUMS256E")) else "weierstrass"
+        aff = json.load(open(os.path.join(HERE, "%s_%s.json" % (kind, curve))))
+    else:
+        pts = affine_multiples(custom, 6)
+        hx = lambda v: v.to_bytes(nb, "big").hex()
+        aff = {"set_xy": [{"x": hx(x), "y": hx(y), "valid": 1} for x, y in pts] + [{"x": hx(pts[1][0]), "y": hx((pts[1][1] + 1) % custom["p"]), "valid": 0}]}
+        fx["custom"] = {k: (hex(v) if isinstance(v, int) and abs(v) > 1 << 32 else v) for k, v in custom.items()}
     f("set").argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, PP]
     f("set").restype = None
     sx = []
@@ -109,6 +154,13 @@ def main():
         fx = fixture(c, 12000 + k, 10 if fx_small(c) else 6)
         json.dump(fx, open(os.path.join(HERE, "curveref_%s.json" % c), "w"), indent=0, separators=(",", ":"))
         print(c, len(fx["records"]), "records; gen x limb 0:", fx["gen"][0][0])
+    # curves that are not in curve.py's table (modarith_amd.generate.EXAMPLE_CURVES), inserted the way curve.py asks its user to
+    for k, (c, cu) in enumerate(custom_curves().items()):
+        if only and c not in only:
+            continue
+        fx = fixture(c, 13000 + k, 8, custom=cu)
+        json.dump(fx, open(os.path.join(HERE, "curveref_%s.json" % c), "w"), indent=0, separators=(",", ":"))
+        print(c, len(fx["records"]), "records (custom curve); gen x limb 0:", fx["gen"][0][0])
 
 
 def fx_small(c):

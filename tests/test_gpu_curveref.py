@@ -9,7 +9,9 @@ import pytest
 from tests.conftest import load_golden
 
 pytestmark = pytest.mark.gpu
-CURVES = ["ED25519", "ED448", "NUMS256E", "ED248", "ED376", "ED500", "NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W"]
+CURVES = ["ED25519", "ED448", "NUMS256E", "ED248", "ED376", "ED500", "NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W",
+          # generated curves (modarith_amd.generate.EXAMPLE_CURVES; fixtures from the reference's code given the same definitions)
+          "CURVE1174", "NIST224"]
 SMALL_X = {"NUMS256E", "ED248", "ED376", "ED500", "NUMS256W"}
 
 
@@ -92,3 +94,61 @@ def test_set_from_both_coordinates(cx):
     P = W.set(None, scalars(torch, [r["x"] for r in recs]), scalars(torch, [r["y"] for r in recs]))
     assert unbatch(P) == [r["P"] for r in recs]
     assert W.isinf(P).cpu().tolist() == [r["isinf"] for r in recs]
+
+
+@pytest.mark.parametrize("name", ["CURVE1174", "NIST224"])
+def test_generated_curve_affine_results(name):
+    """a curve that is not in curve.py's table, end to end: key generation e -> affine e*G through gen / mul / get, a double
+    multiplication through mul2 / get, compression and decompression through get / set -- against plain integer arithmetic on
+    the curve's equation (the projective limbs are covered by the reference-run fixture above)"""
+    import random
+    import torch
+    from modarith_amd import generate as gen
+    from modarith_amd.edwards import Curve
+    c = next(x for x in gen.EXAMPLE_CURVES if x["name"] == name)
+    W = Curve(name)
+    from modarith_amd.generate import params_of_plugin
+    from modarith_amd.params import NAMED, derive
+    p = (derive(c["field"]) if c["field"] in NAMED else params_of_plugin(c["field"])).p
+    a, b, G = c["a"], c["b"], (c["gx"], c["gy"])
+    if c["kind"] == "edwards":
+        O = (0, 1)
+        def add(P, Q):
+            t = b * P[0] * Q[0] * P[1] * Q[1] % p
+            return ((P[0] * Q[1] + P[1] * Q[0]) * pow(1 + t, -1, p) % p, (P[1] * Q[1] - a * P[0] * Q[0]) * pow(1 - t, -1, p) % p)
+    else:
+        O = None
+        def add(P, Q):
+            if P is None: return Q
+            if Q is None: return P
+            if P[0] == Q[0] and (P[1] + Q[1]) % p == 0: return None
+            m = ((3 * P[0] * P[0] + a) * pow(2 * P[1], -1, p) if P == Q else (Q[1] - P[1]) * pow(Q[0] - P[0], -1, p)) % p
+            x = (m * m - P[0] - Q[0]) % p
+            return (x, (m * (P[0] - x) - P[1]) % p)
+    def mul(k, P):
+        R = O
+        while k:
+            if k & 1: R = add(R, P)
+            P = add(P, P); k >>= 1
+        return R
+    rng = random.Random(41)
+    n, nb = 33, W.nbytes
+    es = [rng.randrange(1, c["order"]) for _ in range(n)]
+    fs = [rng.randrange(1, c["order"]) for _ in range(n)]
+    es[0], es[1] = 1, c["order"] - 1
+    rec = lambda ks: torch.tensor([list(k.to_bytes(nb, "big")) for k in ks], dtype=torch.uint8, device="cuda")
+    def affine(Pt):
+        x, y, _ = W.get(Pt.clone())
+        return [(int.from_bytes(bytes(u), "big"), int.from_bytes(bytes(v), "big")) for u, v in zip(x.cpu().numpy(), y.cpu().numpy())]
+    E = W.mul(rec(es), W.gen(n))
+    want = [mul(e, G) for e in es]
+    assert affine(E) == want
+    Q = W.mul(rec(fs), W.gen(n))                                   # second base points
+    R = W.mul2(rec(es), E.clone(), rec(fs), Q.clone())               # e*(eG) + f*(fG)
+    assert affine(R) == [mul((e * e + f * f) % c["order"], G) for e, f in zip(es, fs)]
+    assert W.isinf(W.mul(rec([c["order"]] * 2), W.gen(2))).cpu().tolist() == [1, 1]
+    # compression: x and the sign of y  ->  the same point
+    xb, yb, _ = W.get(E.clone())
+    sgn = torch.tensor([w[1] & 1 for w in want], dtype=torch.int32, device="cuda")
+    back = W.set(sgn, xb, None)
+    assert affine(back) == want
