@@ -88,3 +88,30 @@ def test_field_refuses_an_ungenerated_prime():
     from modarith_amd.field import Field
     with pytest.raises(ValueError, match="neither built in"):
         Field("NOSUCH")
+
+
+def test_generate_curve_refusals_and_cross_compile(tmp_path):
+    """a curve that is not in curve.py's table (NIST P-224 over the built-in NIST224 field): the checks curve.py leaves to its
+    user, then one hipcc unit whose plug-in exports the whole batched and scalar curve API"""
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libmodarith_amd.so not built")
+    c = dict(next(x for x in gen.EXAMPLE_CURVES if x["name"] == "NIST224"))
+    with pytest.raises(gen.GenerateError, match="not on the curve"):
+        gen.generate_curve(**dict(c, gy=c["gy"] + 1), plugin_dir=str(tmp_path))
+    with pytest.raises(gen.GenerateError, match="a = -3 and a = 0"):
+        gen.generate_curve(**dict(c, a=2), plugin_dir=str(tmp_path))
+    with pytest.raises(gen.GenerateError, match="built-in curve"):
+        gen.generate_curve(**dict(c, name="NIST256"), plugin_dir=str(tmp_path))
+    with pytest.raises(gen.GenerateError, match="neither built in nor generated"):
+        gen.generate_curve(**dict(c, field="NOSUCH"), plugin_dir=str(tmp_path))
+    with pytest.raises(gen.GenerateError, match="a = 1 and a = -1"):
+        gen.generate_curve(**dict(c, kind="edwards", a=-3), plugin_dir=str(tmp_path))
+    g = gen.generate_curve(**c, plugin_dir=str(tmp_path))
+    assert g.built and (g.nlimbs, g.nbytes) == (4, 28)
+    lib, nl, nb = _lib.load_curve_plugin("NIST224", g.lib)
+    for fn in _lib.ED_BATCH_FUNCS:
+        assert hasattr(lib, "ecn_nist224_%s_batch" % fn), fn
+    for fn in _lib.ED_SCALAR_FUNCS:
+        assert hasattr(lib, "ecn_nist224_%s" % fn), fn
+    assert not gen.generate_curve(**c, plugin_dir=str(tmp_path)).built
+    assert [m["curve"] for m in gen.installed_curves(str(tmp_path))] == ["NIST224"]
