@@ -287,7 +287,8 @@ int rfc7748_X448_base_batch(const char *bk, char *bv, size_t n, void *stream);
  * kernels and the oracle reproduce limb for limb.  set/get/affine involve modpro and are comparable as affine coordinates
  * (big-integer model, survey-captured reference outputs).  ecnXXXmul2 (a joint sparse form
  * with data-dependent branches in the reference, edwards.c:404-431, 486-510) is two interleaved fixed-window
- * multiplications sharing their doublings here, constant-time: same point, another projective representative.
+ * multiplications sharing their doublings here, constant-time: same point, another projective representative;
+ * ecn_*_mul2_exact_batch walks the reference's joint sparse form itself and returns the reference's limbs (variable time).
  * Input points must have limbs below 2^(Radix+2) -- true of every point these functions or the reference's
  * produce; the field-level functions above have no such condition. */
 #define MODARITH_AMD_DECLARE_EDWARDS(c, NL)                                                                             \
@@ -314,6 +315,10 @@ int rfc7748_X448_base_batch(const char *bk, char *bv, size_t n, void *stream);
     /* R = eP + fQ (edwards.c:486-510); same workspace size as mul; R may be P or Q */                                 \
     int ecn_##c##_mul2_batch(const char *e, const ma_spint *P, const char *f, const ma_spint *Q, ma_spint *R, size_t n, \
                              size_t ld, void *workspace, size_t workspace_bytes, void *stream);                         \
+    /* the same R = eP + fQ by the reference's own walk over its joint sparse form (variable time, as the reference's):    \
+       the reference's projective limbs, where mul2_batch gives another representative of the same point */           \
+    int ecn_##c##_mul2_exact_batch(const char *e, const ma_spint *P, const char *f, const ma_spint *Q, ma_spint *R,    \
+                                   size_t n, size_t ld, void *workspace, size_t workspace_bytes, void *stream);         \
     int ecn_##c##_ran_batch(int r, ma_spint *P, size_t n, size_t ld, void *stream);                                     \
     int ecn_##c##_add_batch(const ma_spint *Q, ma_spint *P, size_t n, size_t ld, void *stream);                         \
     int ecn_##c##_sub_batch(const ma_spint *Q, ma_spint *P, size_t n, size_t ld, void *stream);                         \

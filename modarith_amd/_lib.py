@@ -20,7 +20,7 @@ PRIMES = ("X25519", "NIST256", "X448",
           "PM383M", "PM266M", "PM336M", "C41417M", "PM512M", "M607")
 LADDERS = ("X25519", "X448")
 CURVES = {"ed25519": (5, 32), "ed448": (8, 56), "nist256": (5, 32), "nist384": (7, 48), "nist521": (9, 66), "secp256k1": (5, 32), "nums256w": (5, 32), "nums256e": (5, 32), "ed248": (5, 32), "ed376": (7, 48), "ed500": (9, 64)}       # curve -> (Nlimbs, Nbytes)
-ED_BATCH_FUNCS = ("mul", "mul2", "ran", "add", "sub", "cpy", "dbl", "neg", "inf", "gen", "cof", "affine", "cmp", "isinf", "set", "get")
+ED_BATCH_FUNCS = ("mul", "mul2", "mul2_exact", "ran", "add", "sub", "cpy", "dbl", "neg", "inf", "gen", "cof", "affine", "cmp", "isinf", "set", "get")
 FUSED_CURVES = ("ed25519", "ed448", "nist256", "secp256k1")       # fused mul + get kernels (csrc/ed26.h, csrc/ed28.h, csrc/wn26.h)
 FUSED2_CURVES = ("ed25519", "ed448", "nist256", "secp256k1")        # fused mul2 + get
 FUSEDG_CURVES = ("nist256", "secp256k1", "ed25519", "ed448")             # fused gen + mul + get (fixed-base tables; csrc/wn26.h, ed26.h, ed28.h *_mulgen_get_one)
@@ -94,6 +94,7 @@ def _declare_curve(lib, C: str) -> None:
     g("mul_workspace_bytes").restype = c_size_t
     g("mul_batch").argtypes = [_P, _P, c_size_t, c_size_t, _P, c_size_t, _P]
     g("mul2_batch").argtypes = [_P, _P, _P, _P, _P, c_size_t, c_size_t, _P, c_size_t, _P]
+    g("mul2_exact_batch").argtypes = [_P, _P, _P, _P, _P, c_size_t, c_size_t, _P, c_size_t, _P]
     g("ran_batch").argtypes = [c_int, _P, c_size_t, c_size_t, _P]
     for f in ("add", "sub", "cpy"):
         g(f + "_batch").argtypes = [_P, _P, c_size_t, c_size_t, _P]

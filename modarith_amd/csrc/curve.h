@@ -225,6 +225,57 @@ struct CurveOps {
         }
     }
 
+    // R = e*P + f*Q with the REFERENCE'S OWN walk (edwards.c:404-431 dnaf, 486-510; weierstrass.c:545-569): the joint sparse form
+    // w[k] = (bit_k(3e) - bit_k(e)) + 3 (bit_k(3f) - bit_k(f)) in {-4..4}, table W = {O, P, Q-P, Q, Q+P}, R = O, and from the first
+    // non-zero digit down to k = 1: R = 2R, then R += W[w] or R -= W[-w].  Same field calls in the same order, hence the reference's
+    // projective limbs -- and, like the reference ("not constant time"), a walk that depends on the scalars: lanes of a wave start
+    // at different digits and skip different additions, so the wave pays for the union of their paths (about 2.5 x mul2 above).
+    // The digits are produced from the top by shifting e, 3e, f, 3f left one bit per step; no digit array is stored.
+    static MA_DEV void mul2_exact(const spint* ew, const Point& p, const spint* fw, const Point& q, Point& r, const Table& W) {
+        constexpr int NX = NW + 1;                        // 3e needs two more bits than e
+        constexpr int TOP = 8 * NB + 7;                   // index of the highest digit (edwards.c:497)
+        Point T;
+        Crv::inf(T); W.put(0, T);
+        W.put(1, p);
+        W.put(3, q);
+        cpy(q, T); sub(p, T); W.put(2, T);                // Q - P
+        cpy(q, T); Crv::add(p, T); W.put(4, T);           // Q + P
+        spint a[NX], a3[NX], b[NX], b3[NX];
+        static_for<0, NX>([&](auto K) { a[K] = K < NW ? ew[K < NW ? K : 0] : 0; b[K] = K < NW ? fw[K < NW ? K : 0] : 0; });
+        {   // 3x = x + 2x over NX words
+            spint ca = 0, cb = 0;
+            static_for<0, NX>([&](auto K) {
+                const spint ta = (a[K] << 1) | (K > 0 ? a[K > 0 ? K - 1 : 0] >> 63 : 0);
+                const spint tb = (b[K] << 1) | (K > 0 ? b[K > 0 ? K - 1 : 0] >> 63 : 0);
+                const spint sa = a[K] + ta, sa2 = sa + ca;
+                ca = (spint)(sa < ta) | (spint)(sa2 < sa);
+                a3[K] = sa2;
+                const spint sb = b[K] + tb, sb2 = sb + cb;
+                cb = (spint)(sb < tb) | (spint)(sb2 < sb);
+                b3[K] = sb2;
+            });
+        }
+        constexpr int S = NX * 64 - 1 - TOP;              // left-align: digit TOP in bit 63 of the top word
+        shl_words<S, NX>(a); shl_words<S, NX>(a3); shl_words<S, NX>(b); shl_words<S, NX>(b3);
+        Crv::inf(r);
+        bool started = false;
+#pragma unroll 1
+        for (int i = TOP; i >= 1; i--) {
+            const int j = ((int)(a3[NX - 1] >> 63) - (int)(a[NX - 1] >> 63)) + 3 * ((int)(b3[NX - 1] >> 63) - (int)(b[NX - 1] >> 63));
+            shl_words<1, NX>(a); shl_words<1, NX>(a3); shl_words<1, NX>(b); shl_words<1, NX>(b3);
+            if (!started) {
+                if (j == 0) continue;                     // "ignore leading zeros" (edwards.c:498)
+                started = true;
+            }
+            Crv::dbl(r);
+            if (j != 0) {
+                W.get(j < 0 ? -j : j, T);
+                if (j < 0) Crv::neg(T);                   // ecnXXXsub = copy, negate, add (edwards.c:114-119)
+                Crv::add(T, r);
+            }
+        }
+    }
+
     // ---- SoA load / store of a point batch: P[(c*N + i)*ld + j]
     static MA_DEV void load(const spint* Pb, size_t ld, size_t j, Point& p) {
         static_for<0, N>([&](auto I) {
@@ -277,6 +328,25 @@ __global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul2(const unsigned char*
         E::load(Pb, ld, t, p);
         E::load(Qb, ld, t, q);
         E::mul2(ew, p, fw, q, r, W);
+        E::store(Rb, ld, t, r);
+    }
+}
+
+template <class Crv>
+__global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul2x(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, spint* Rb,
+                                                 size_t n, size_t ld, spint* ws) {
+    using E = Crv;
+    const size_t lanes = (size_t)gridDim.x * blockDim.x;
+    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    typename E::Table W{ws + lane, lanes};
+    for (size_t t = lane; t < n; t += lanes) {
+        spint ew[E::NW], fw[E::NW];
+        load_be_record<typename E::P>(e, t, ew);
+        load_be_record<typename E::P>(f, t, fw);
+        typename E::Point p, q, r;
+        E::load(Pb, ld, t, p);
+        E::load(Qb, ld, t, q);
+        E::mul2_exact(ew, p, fw, q, r, W);
         E::store(Rb, ld, t, r);
     }
 }

@@ -222,12 +222,14 @@ class Edwards:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def mul2(self, e, P, f, Q):
-        """R = e*P + f*Q (ecnXXXmul2, edwards.c:486-510); returns a new batch"""
+    def mul2(self, e, P, f, Q, exact: bool = False):
+        """R = e*P + f*Q (ecnXXXmul2, edwards.c:486-510); returns a new batch.  Default: two fixed-window multiplications sharing
+        their doublings (constant time, no lane divergence) -- the reference's point in another projective representative.
+        exact=True: the reference's own walk over its joint sparse form -- the reference's limbs, variable time, about 2.5 x slower."""
         n = self._chk(P, Q)
         R = torch.empty_like(P)
         ws = self._workspace(n)
-        self._call("mul2", self._scalars(e, n), P.data_ptr(), self._scalars(f, n), Q.data_ptr(), R.data_ptr(), n, n,
+        self._call("mul2_exact" if exact else "mul2", self._scalars(e, n), P.data_ptr(), self._scalars(f, n), Q.data_ptr(), R.data_ptr(), n, n,
                    ws.data_ptr(), ws.numel(), _stream(self.device))
         return R
 

@@ -1,7 +1,7 @@
 """The batched curve kernels (csrc/curve.h, edwards.h, weierstrass.h) against the projective limbs the REFERENCE'S OWN
 edwards.c / weierstrass.c produce (tests/golden/curveref_<CURVE>.json; tests/golden/make_curveref.py): raw limbs in, raw limbs
-out, limb for limb -- mul, dbl, add, sub, neg, cof, isinf, the generator, the special cases; mul2 by value (see there) -- for all
-eleven curves.
+out, limb for limb -- mul, dbl, add, sub, neg, cof, mul2 in its exact form, isinf, the generator, the special cases; the default
+(constant-time) mul2 by value (see there) -- for all eleven curves and the two generated ones.
 Every record of a fixture is one lane of one batch, so the kernels run them side by side."""
 import numpy as np
 import pytest
@@ -67,6 +67,7 @@ def test_records_limb_for_limb(cx):
     # kernel runs two fixed-window multiplications that share their doublings -- constant time, no lane divergence -- and reaches the
     # same POINT in another projective representative (csrc/curve.h mul2; include/modarith_amd.h says so).  Compared by value with
     # the reference's limbs (ecnXXXcmp: cross-multiplication, no inversion); the oracle reproduces the reference's limbs themselves
+    assert unbatch(W.mul2(e, M.clone(), f, D.clone(), exact=True)) == col("R"), "mul2 (the reference's own walk: its limbs)"
     R2 = W.mul2(e, M.clone(), f, D.clone())
     assert W.cmp(R2, batch(torch, col("R"))).cpu().tolist() == [1] * len(R), "mul2"
     Z = W.add(N, A.clone())
@@ -152,3 +153,43 @@ def test_generated_curve_affine_results(name):
     sgn = torch.tensor([w[1] & 1 for w in want], dtype=torch.int32, device="cuda")
     back = W.set(sgn, xb, None)
     assert affine(back) == want
+
+
+@pytest.mark.parametrize("name", ["ED25519", "ED448", "NIST256", "NIST521"])
+def test_exact_mul2_against_the_oracle_on_mixed_waves(oracle, name):
+    """mul2(exact=True) on lanes whose walks differ -- full-size scalars next to tiny ones (1, 2, 3, 2^k), whose joint sparse forms
+    start hundreds of digits later -- against the oracle's mul2, which reproduces the reference's limbs (tests/test_curveref_oracle.py)"""
+    import ctypes
+    import random
+    import torch
+    from modarith_amd.edwards import Curve
+    W = Curve(name)
+    C = name.lower()
+    Pt, nb = oracle.ed[C]
+    rng = random.Random(77)
+    n = 192
+    es = [rng.randrange(1, 1 << (8 * nb - 8)) for _ in range(n)]
+    fs = [rng.randrange(1, 1 << (8 * nb - 8)) for _ in range(n)]
+    for j, v in enumerate((1, 2, 3, 5, 1 << 20, (1 << 64) - 1)):
+        es[7 * j + 1] = v
+        fs[7 * j + 2] = v
+        es[7 * j + 3], fs[7 * j + 3] = v, v + 1
+    es[100], fs[100] = 1, 0
+    es[101], fs[101] = 0, 1
+    rec = lambda ks: torch.tensor([list(k.to_bytes(nb, "big")) for k in ks], dtype=torch.uint8, device="cuda")
+    k0 = rec([rng.randrange(1, 1 << 200) for _ in range(n)])
+    P = W.mul(k0, W.gen(n))
+    Q = W.dbl(W.mul(rec([rng.randrange(1, 1 << 200) for _ in range(n)]), W.gen(n)))
+    R = W.mul2(rec(es), P.clone(), rec(fs), Q.clone(), exact=True)
+    got = R.cpu().numpy().view(np.uint64)
+    hp, hq = P.cpu().numpy().view(np.uint64), Q.cpu().numpy().view(np.uint64)
+    for j in range(n):
+        p, q, r = Pt(), Pt(), Pt()
+        for c, nm in enumerate("xyz"):
+            for i in range(W.N):
+                getattr(p, nm)[i] = int(hp[c, i, j]); getattr(q, nm)[i] = int(hq[c, i, j])
+        oracle.ecn(C, "mul2")(es[j].to_bytes(nb, "big"), ctypes.byref(p), fs[j].to_bytes(nb, "big"), ctypes.byref(q), ctypes.byref(r))
+        for c, nm in enumerate("xyz"):
+            assert [int(v) for v in got[c, :, j]] == list(getattr(r, nm)), (name, j, nm)
+    # and the default form reaches the same points
+    assert W.cmp(W.mul2(rec(es), P.clone(), rec(fs), Q.clone()), R).cpu().tolist() == [1] * n
