@@ -360,3 +360,83 @@ def bench_chain(prime: str = "X25519") -> Chain:
     u, v = ch.inputs(2)
     ch.output(ch.modsqr(ch.modmul(ch.modadd(u, v), ch.modsub(u, v))))
     return ch
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# command line: a chain written as text, for consumers that do not otherwise touch Python
+#   python -m modarith_amd.fuse X25519 accept "in x, y; t = modadd(x, y); w = modsub(x, y); s = modsqr(modmul(t, w)); out modinv(s)"
+def parse(prime: str, name: str, text: str) -> Chain:
+    """statements separated by ';':  `in a, b`  (element inputs, in order) | `sel d` (int32 selector inputs) | `v = f(args)` |
+    `g2, f2 = modcsw(d, g, f)` | `out expr, ...`.  Expressions nest: modsqr(modmul(a, b)).  Integers are accepted where the
+    function takes one (modmli, modnsqr).  Function names are the chain's methods, i.e. field.c's."""
+    import ast
+    ch = Chain(prime, name)
+    env = {}
+
+    def ev(node):
+        if isinstance(node, ast.Name):
+            if node.id not in env:
+                raise ValueError("unknown value %r" % node.id)
+            return env[node.id]
+        if isinstance(node, ast.Constant) and isinstance(node.value, int):
+            return node.value
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, ast.USub) and isinstance(node.operand, ast.Constant):
+            return -node.operand.value
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and not node.keywords:
+            fn = node.func.id
+            if fn not in _OPS or not hasattr(ch, fn):
+                raise ValueError("unknown operation %r (available: %s)" % (fn, ", ".join(sorted(_OPS))))
+            return getattr(ch, fn)(*[ev(a) for a in node.args])
+        raise ValueError("cannot parse %r" % ast.unparse(node))
+
+    for st in [t.strip() for t in text.split(";") if t.strip()]:
+        head, _, rest = st.partition(" ")
+        if head == "in":
+            for nm in [t.strip() for t in rest.split(",")]:
+                env[nm] = ch.input()
+        elif head == "sel":
+            for nm in [t.strip() for t in rest.split(",")]:
+                env[nm] = ch.selector()
+        elif head == "out":
+            for node in ast.parse("(%s,)" % rest, mode="eval").body.elts:
+                ch.output(ev(node))
+        else:
+            node = ast.parse(st).body[0]
+            if not isinstance(node, ast.Assign) or len(node.targets) != 1:
+                raise ValueError("expected `name = expression`: %r" % st)
+            val = ev(node.value)
+            tgt = node.targets[0]
+            if isinstance(tgt, ast.Tuple):
+                if not isinstance(val, tuple) or len(val) != len(tgt.elts):
+                    raise ValueError("%r does not produce %d values" % (st, len(tgt.elts)))
+                for t, v in zip(tgt.elts, val):
+                    env[t.id] = v
+            else:
+                env[tgt.id] = val
+    return ch
+
+
+def main(argv: List[str]) -> int:
+    args = [a for a in argv if not a.startswith("--")]
+    if len(args) != 3:
+        print('usage: python -m modarith_amd.fuse <prime or tag> <name> "in a, b; t = modadd(a, b); out modsqr(t)" [--force] [--source]')
+        return 2
+    try:
+        ch = parse(*args)
+        if "--source" in argv:
+            print(ch.source())
+            return 0
+        f = ch.build(force="--force" in argv, verbose=True)
+    except ValueError as e:
+        print(e)
+        return 2
+    print("%s %s" % ("built" if f.built else "up to date:", f.path))
+    print("int %s(const void *const *in /* %d element batches%s */, void *const *out /* %d */, size_t n, size_t ld, void *stream);"
+          % (ch.symbol, ch.nin, (", then %d int32 selector arrays" % ch.nsel) if ch.nsel else "", len(ch.outs)))
+    print("HBM bytes per element: %d fused, %d call by call" % (ch.traffic_bytes(), ch.unfused_traffic_bytes()))
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(main(sys.argv[1:]))

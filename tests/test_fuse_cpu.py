@@ -59,3 +59,17 @@ def test_chain_cross_compiles_and_exports(tmp_path):
     assert f.built and os.path.exists(f.path) and hasattr(f.lib, "chain_twoout_NIST256_batch")
     assert "HEAVY = false" in ch.source()
     assert not ch.build(plugin_dir=str(tmp_path)).built          # cached by content
+
+
+def test_text_front_end():
+    """python -m modarith_amd.fuse <prime> <name> "<statements>": the same chain as the builder calls"""
+    from modarith_amd.fuse import parse
+    a = _accept("X25519").source()
+    b = parse("X25519", "accept", "in x, y; t = modadd(x, y); w = modsub(x, y); s = modsqr(modmul(t, w)); out modinv(s)").source()
+    assert a == b
+    c = parse("X448", "sw", "in g, f; sel d; g2, f2 = modcsw(d, g, f); out modmli(g2, 39081), f2")
+    assert (c.nin, c.nsel, len(c.outs)) == (2, 1, 2) and "F::modcsw(s0, v2, v3);" in c.source() and "F::modmli(v2, 39081, v4);" in c.source()
+    for bad, msg in (("in x; out nosuch(x)", "unknown operation"), ("in x; out y", "unknown value"), ("in x; x + 1", "expected"),
+                     ("in x; a, b = modsqr(x); out a", "does not produce")):
+        with pytest.raises(ValueError, match=msg):
+            parse("X25519", "bad", bad)
