@@ -6,6 +6,7 @@
                   in-range values: the product policies must agree bit for bit (checksums compared across three child processes: MA_FORCE_EXACT=1, MA_FORCE_FAST=1, default)
   soak.py curves  2^13 .. 2^16 random scalars x random points for each of the eleven curves, fused ecn mul on the GPU against the CPU oracle,
                   projective limbs compared
+  soak.py mul2    2^10 .. 2^12 (scalar pair, point pair) records per curve through Curve.mul2(exact=True) against the oracle's mul2, projective limbs
   soak.py fused   2^18 .. 2^20 random (scalar, projective point) pairs per fused curve (ED25519, ED448, NIST256, SECP256K1): mul_get against mul + get and
                   mul2_get against mul2 + get (the two-call forms are the ones `soak.py curves` pins to the oracle), the generator forms mulgen_get / mulgen2_get against
                   those, rfc7748 on the base point against the ladder; bytes compared
@@ -105,6 +106,42 @@ def curves():
     return rc
 
 
+def mul2_exact():
+    """Curve.mul2(exact=True) -- the reference's joint-sparse-form walk, lanes diverging -- against the oracle's mul2 (which
+    reproduces the reference's limbs, tests/test_curveref_oracle.py): 2^12 (2^10 for the widest fields) pairs per curve, projective limbs"""
+    import ctypes, numpy as np, torch
+    from modarith_amd.edwards import Curve
+    from tests.oracle_binding import load_oracle
+    o = load_oracle(build=not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")))
+    rc = 0
+    for name, lg in (("ED25519", 12), ("NIST256", 12), ("SECP256K1", 12), ("NUMS256W", 12), ("NUMS256E", 12), ("ED248", 12), ("ED448", 11), ("NIST384", 11),
+                     ("ED376", 11), ("NIST521", 10), ("ED500", 10)):
+        n = 1 << lg
+        C = Curve(name)
+        c = name.lower()
+        Pt, nb = o.ed[c]
+        g = torch.Generator(device="cuda").manual_seed(91)
+        rnd = lambda: torch.randint(0, 256, (n, C.nbytes), dtype=torch.uint8, device="cuda", generator=g)
+        P, Q = C.mul(rnd(), C.gen(n)), C.dbl(C.mul(rnd(), C.gen(n)))
+        e, f = rnd(), rnd()
+        e[:64, :-2] = 0                               # short scalars: their walks start hundreds of digits later than their neighbours'
+        f[32:96, :-1] = 0
+        R = C.mul2(e, P, f, Q, exact=True).cpu().numpy().view(np.uint64)
+        hp, hq, he, hf = P.cpu().numpy().view(np.uint64), Q.cpu().numpy().view(np.uint64), e.cpu().numpy(), f.cpu().numpy()
+        fn = o.ecn(c, "mul2")
+        bad = 0
+        for j in range(n):
+            p, q, r = Pt(), Pt(), Pt()
+            for k, nm in enumerate("xyz"):
+                for i in range(C.N):
+                    getattr(p, nm)[i] = int(hp[k, i, j]); getattr(q, nm)[i] = int(hq[k, i, j])
+            fn(bytes(he[j]), ctypes.byref(p), bytes(hf[j]), ctypes.byref(q), ctypes.byref(r))
+            bad += any([int(v) for v in R[k, :, j]] != list(getattr(r, nm)) for k, nm in enumerate("xyz"))
+        print("mul2 soak %-9s 2^%d double multiplications (exact form), projective limbs vs oracle: %s" % (name, lg, "EQUAL" if not bad else "%d MISMATCHES" % bad), flush=True)
+        rc |= 1 if bad else 0
+    return rc
+
+
 def fused():
     import torch
     from modarith_amd.edwards import Curve
@@ -155,6 +192,8 @@ if __name__ == "__main__":
         field_child(sys.argv[2])
     elif mode == "field":
         sys.exit(field())
+    elif mode == "mul2":
+        sys.exit(mul2_exact())
     elif mode == "fused":
         sys.exit(fused())
     else:
