@@ -179,3 +179,32 @@ def test_remaining_operations(torch_cuda):
     assert torch.equal(o1, F.redc(F.modneg(hh)))
     assert torch.equal(o2, F.modsqrt(F.modsqr(x)))
     assert torch.equal(o3, F.modpro(y))
+
+
+def test_fused_chain_and_generated_field_under_graph_capture(torch_cuda):
+    """a fused chain and the kernels of a generated field are plain launches on the caller's stream: captured into a hipGraph on a
+    side stream, replayed on fresh inputs (a launch-bound inner loop becomes one graph launch)"""
+    torch = torch_cuda
+    from modarith_amd.field import Field
+    from modarith_amd.fuse import Chain
+    F, fp = Field("2519"), derive_any("2519")
+    ch = Chain("2519", "graphed")
+    u, v = ch.inputs(2)
+    ch.output(ch.modmul(ch.modadd(u, v), ch.modsub(u, v)))
+    f = ch.build()
+    n = 4096
+    x, y = to_dev(_rand(fp, n, 41)), to_dev(_rand(fp, n, 42))
+    z, w = torch.empty_like(x), torch.empty_like(x)
+    f(x, y, out=[z]); F.modsqr(z, out=w)                      # warm-up outside the capture (code objects, Field binding)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            f(x, y, out=[z])
+            F.modsqr(z, out=w)
+    torch.cuda.current_stream().wait_stream(side)
+    x.copy_(to_dev(_rand(fp, n, 43))); y.copy_(to_dev(_rand(fp, n, 44)))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(w, F.modsqr(F.modmul(F.modadd(x, y), F.modsub(x, y))))
