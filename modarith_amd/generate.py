@@ -3,6 +3,7 @@
   python -m modarith_amd.generate 64 2**251-9               # the reference's own command-line shape
   python -m modarith_amd.generate 64 BP256=0xa9fb57db...5377 --monty
   python -m modarith_amd.generate 64 2**251-9 --time        # ... and run the time.c protocol on the GPU, as the generators do last
+  python -m modarith_amd.generate curve NIST224 weierstrass NIST224 -3 0xb405...ffb4 0xffff...2a3d 0xb70e...1d21 0xbd37...7e34
   python -m modarith_amd.generate --list
 
 This is the counterpart of `python pseudo.py 64 <prime>` / `python monty.py 64 <prime>` (pseudo.py:1461-1473,
@@ -378,6 +379,22 @@ def main(argv: List[str]) -> int:
     if "--list" in argv:
         for m in installed():
             print("%-12s %-6s %2d x %2d bits  %s" % (m["tag"], m["family"], m["nlimbs"], m["radix"], m["prime"]))
+        for m in installed_curves():
+            print("%-12s %-11s over %-8s a = %d, b = %s" % (m["curve"], m["kind"], m["field"], m["a"], m["b"]))
+        return 0
+    if args and args[0] == "curve":
+        # python -m modarith_amd.generate curve <NAME> edwards|weierstrass <field> <a> <b> <order> <gx> <gy> [cof]   (integers: any python literal)
+        if len(args) not in (9, 10):
+            print("Valid syntax - python -m modarith_amd.generate curve <name> edwards|weierstrass <field> <a> <b> <order> <gx> <gy> [log2 cofactor]")
+            return 2
+        try:
+            nums = [int(v, 0) for v in args[4:]]
+            g = generate_curve(args[1], args[2], args[3], nums[0], nums[1], nums[2], nums[3], nums[4], nums[5] if len(nums) > 5 else 0,
+                               force="--force" in argv, verbose=True)
+        except (GenerateError, ValueError) as e:
+            print(e)
+            return 2
+        print("%s %s: C-ABI ecn_%s_* (MODARITH_AMD_DECLARE_EDWARDS(%s, %d)); Curve(%r)" % ("built" if g.built else "up to date:", g.lib, g.name.lower(), g.name.lower(), g.nlimbs, g.name))
         return 0
     if len(args) != 2:
         print("Syntax error")

@@ -79,6 +79,8 @@ def test_cli(tmp_path):
     assert p.returncode == 2 and "64-bit" in p.stdout
     p = subprocess.run([sys.executable, "-m", "modarith_amd.generate", "64"], capture_output=True, text=True, cwd=root, env=env)
     assert p.returncode == 2 and "Syntax error" in p.stdout
+    p = subprocess.run([sys.executable, "-m", "modarith_amd.generate", "curve", "X", "edwards", "X25519", "2", "3", "5", "7", "11"], capture_output=True, text=True, cwd=root, env=env)
+    assert p.returncode == 2 and "a = 1 and a = -1" in p.stdout
     p = subprocess.run([sys.executable, "-m", "modarith_amd.generate", "64", "X448"], capture_output=True, text=True, cwd=root, env=env)
     assert p.returncode == 0 and "Chosen radix is 56 bits, using 8 limbs" in p.stdout and "up to date" in p.stdout
 
