@@ -35,9 +35,9 @@ UNITS = ([(u, u, []) for u in ["capi_common", "capi_ED25519F", "capi_ED25519F2",
          + [("generated/capi_%s" % p, "capi_%s" % p, []) for p in emit.EXTRA_PRIMES])
 # longest first, so the pool does not finish on a long tail: measured compile seconds of the slow units (8 jobs on 8 cores; the
 # rest take 10-30 s each)
-_COST = {"capi_SIDH751": 135, "capi_NIST521W_part2": 127, "capi_NIST521W_part1": 87, "capi_ED500_part2": 73, "capi_ED448G": 65,
-         "capi_SIDH610": 62, "capi_NIST384": 61, "capi_X448": 47, "capi_ED448F": 43, "capi_SIDH503": 37, "capi_ED448F2": 36,
-         "capi_ED500_part3": 36, "capi_ED500_part1": 27, "capi_NIST384W_part2": 26, "capi_NIST256G": 24}
+_COST = {"capi_SIDH751": 180, "capi_NIST521W_part2": 170, "capi_ED500_part2": 143, "capi_SIDH610": 105, "capi_NIST521W_part1": 91, "capi_CSIDH512": 90,
+         "capi_ED448G": 80, "capi_NIST384": 61, "capi_X448": 47, "capi_ED448F": 43, "capi_SIDH503": 37, "capi_ED448F2": 36,
+         "capi_ED500_part3": 37, "capi_NIST384W_part2": 35, "capi_NIST521W_part3": 32, "capi_ED500_part1": 27, "capi_NIST256G": 24}
 UNITS.sort(key=lambda t: -_COST.get(t[1], 25 if ("-DMA_CURVE_PART=1" in t[2] or "-DMA_CURVE_PART=2" in t[2]) else 15))
 
 
