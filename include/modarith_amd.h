@@ -288,7 +288,8 @@ int rfc7748_X448_base_batch(const char *bk, char *bv, size_t n, void *stream);
  * (big-integer model, survey-captured reference outputs).  ecnXXXmul2 (a joint sparse form
  * with data-dependent branches in the reference, edwards.c:404-431, 486-510) is two interleaved fixed-window
  * multiplications sharing their doublings here, constant-time: same point, another projective representative;
- * ecn_*_mul2_exact_batch walks the reference's joint sparse form itself and returns the reference's limbs (variable time).
+ * ecn_*_mul2_exact_batch walks the reference's joint sparse form itself and returns the reference's limbs (variable time);
+ * the scalar ecn_*_mul2 (one element, nothing to keep in step) takes that form.
  * Input points must have limbs below 2^(Radix+2) -- true of every point these functions or the reference's
  * produce; the field-level functions above have no such condition. */
 #define MODARITH_AMD_DECLARE_EDWARDS(c, NL)                                                                             \

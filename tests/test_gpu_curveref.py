@@ -193,3 +193,32 @@ def test_exact_mul2_against_the_oracle_on_mixed_waves(oracle, name):
             assert [int(v) for v in got[c, :, j]] == list(getattr(r, nm)), (name, j, nm)
     # and the default form reaches the same points
     assert W.cmp(W.mul2(rec(es), P.clone(), rec(fs), Q.clone()), R).cpu().tolist() == [1] * n
+
+
+@pytest.mark.parametrize("name", ["ED25519", "NIST256", "ED448"])
+def test_scalar_entry_points_return_the_references_limbs(name):
+    """the scalar API (host pointers, curve.h's own signatures): mul, dbl, add and mul2 on the fixture's records, limb for limb --
+    the scalar mul2 takes the reference's own walk (one element: nothing to keep in step)"""
+    import ctypes
+    from modarith_amd import _lib
+    lib = _lib.load()
+    g = load_golden("curveref_%s.json" % name)
+    N, nb, c = g["N"], g["Nbytes"], name.lower()
+
+    class Pt(ctypes.Structure):
+        _fields_ = [("x", ctypes.c_uint64 * N), ("y", ctypes.c_uint64 * N), ("z", ctypes.c_uint64 * N)]
+    def point(rows):
+        p = Pt()
+        for k, row in zip("xyz", rows):
+            for i, v in enumerate(row):
+                getattr(p, k)[i] = int(v, 16)
+        return p
+    rows = lambda p: [[hex(v) for v in getattr(p, k)] for k in "xyz"]
+    f = lambda fn: getattr(lib, "ecn_%s_%s" % (c, fn))
+    ref = ctypes.byref
+    for r in g["records"][:4]:
+        e, fb = bytes.fromhex(r["e"]), bytes.fromhex(r["f"])
+        M = point(r["P"]); f("mul")(e, ref(M)); assert rows(M) == r["M"]
+        D = point(r["M"]); f("dbl")(ref(D)); assert rows(D) == r["D"]
+        A = point(r["M"]); f("add")(ref(D), ref(A)); assert rows(A) == r["A"]
+        R = Pt(); f("mul2")(e, ref(M), fb, ref(D), ref(R)); assert rows(R) == r["R"], "scalar mul2"
