@@ -71,6 +71,11 @@ class Field:
         else:
             # a field made by the generator mode (modarith_amd.generate): its kernels live in a plug-in next to the main library
             from . import generate as _gen
+            if not os.path.exists(_gen.plugin_path(prime)) and (prime[:1].isdigit() or "=" in prime):
+                try:                                   # an expression ("2**251-9", "NAME=0x...") names the field by its tag
+                    prime = _gen.resolve(prime).name
+                except _gen.GenerateError:
+                    pass
             if not os.path.exists(_gen.plugin_path(prime)):
                 raise ValueError("prime %r is neither built in (%s) nor generated (%s); generate it with Field.generate(...) or "
                                  "`python -m modarith_amd.generate 64 <prime>`"

@@ -75,6 +75,7 @@ def test_a_modulus_generated_on_this_box(torch_cuda, tmp_path, monkeypatch):
     p = 2**127 - 1
     F = Field.generate("2**127-1")
     assert F.prime == "1271" and F.params.p == p and gen.installed(str(tmp_path))[0]["tag"] == "1271"
+    assert Field("2**127-1").prime == "1271"                          # an expression binds the generated field of that tag
     rng = random.Random(5)
     n = 4096 + 77
     xs = [rng.randrange(0, 2 * p) for _ in range(n)]
