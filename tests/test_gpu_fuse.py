@@ -208,3 +208,19 @@ def test_fused_chain_and_generated_field_under_graph_capture(torch_cuda):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(w, F.modsqr(F.modmul(F.modadd(x, y), F.modsub(x, y))))
+
+
+def test_c_consumer_of_a_fused_chain(torch_cuda, tmp_path):
+    """examples/fused_chain.c: the chain's C entry point next to the four batched calls, from plain C"""
+    import os
+    import subprocess
+    from modarith_amd.fuse import bench_chain
+    bench_chain("X25519").build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fused_chain")
+    plug, main = os.path.join(root, "modarith_amd", "plugins"), os.path.join(root, "modarith_amd")
+    subprocess.check_call(["gcc", "-O2", os.path.join(root, "examples", "fused_chain.c"), "-I", os.path.join(root, "include"),
+                           "-L", plug, "-l:libmodarith_amd_chain_bench_prod_X25519.so", "-L", main, "-l:libmodarith_amd.so",
+                           "-Wl,-rpath," + plug, "-Wl,-rpath," + main, "-o", exe])
+    p = subprocess.run([exe, "100001"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "limb for limb" in p.stdout, p.stdout[-500:] + p.stderr[-500:]
