@@ -245,7 +245,9 @@ class Chain:
         L += ["        int s%d[EPT]; static_for<0, EPT>([&](auto E) { s%d[E] = A.sel[%d][(size_t)EPT * t + E]; });" % (k, k, k) for k in range(self.nsel)]
         L += ["        " + l for l in votel]
         L += ["        store_soa<P, EPT>(A.out[%d], L, t, v%d);" % (k, o) for k, o in enumerate(self.outs)]
-        L += ["    }", "}", "}  // namespace", "",
+        L += ["    }", "}"]
+        L += self._aos_kernel(votel)
+        L += ["}  // namespace", "",
               'extern "C" int %s(const void* const* in, void* const* out, size_t n, size_t ld, void* stream) {' % self.symbol,
               "    // in[0 .. NIN): element batches; in[NIN .. NIN + NSEL): int32 selector arrays, one entry per element",
               "    if (n == 0) return 0;",
@@ -277,7 +279,103 @@ class Chain:
               "    }",
               '    return check_launch("%s");' % self.symbol,
               "}", ""]
+        L += self._aos_entry()
         return "\n".join(L)
+
+    @property
+    def aos_symbol(self) -> str:
+        return "chain_%s_%s_aos" % (self.name, self.prime)
+
+    def _aos_kernel(self, votel: List[str]) -> List[str]:
+        """The same chain over ELEMENT-MAJOR arrays (`spint x[n][Nlimbs]`, how the scalar callers of field.c hold their elements): a
+        workgroup of 256 lanes takes a chunk of 512 elements; each array's chunk is one linear stretch of 512 N words, moved with
+        16-byte-per-lane coalesced accesses and transposed through LDS (pitch N | 1 words: two-way bank conflicts at most) into the
+        lanes' registers -- elements 2t, 2t+1 -- and back.  The layout conversions on either side of a chain (aos_to_soa before,
+        soa_to_aos after: 160 bytes of HBM traffic per element and array) disappear into the kernel."""
+        nv, N = self.nvals, self.params.nlimbs
+        if N > 14:                                    # 512 (N | 1) words of LDS per workgroup: 64 KB hold up to 14 limbs (as k_convert_lds)
+            return []
+        L = ["", "// ---- element-major I/O: x[n][N] in, x[n][N] out, transposed through LDS (the pattern of capi_common.hip k_convert_lds)",
+             "constexpr int CH = 512, SP = P::N | 1;",
+             "static __device__ __forceinline__ void aos_in(const spint* aos, size_t cnt, spint* sh, spint (*v)[P::N]) {",
+             "    const int t = threadIdx.x;",
+             "    const size_t total = cnt * (size_t)P::N;",
+             "    int e = (2 * t) / P::N, i = (2 * t) % P::N;",
+             "    constexpr int de = CH / P::N, di = CH % P::N;",
+             "    __syncthreads();                                  // the previous user of sh is done",
+             "    for (size_t w = 2 * (size_t)t; w < total; w += CH) {",
+             "        int e1 = e, i1 = i + 1;",
+             "        if (i1 == P::N) { i1 = 0; e1++; }",
+             "        if (w + 1 < total) {",
+             "            const spint2 x = __builtin_nontemporal_load(reinterpret_cast<const spint2*>(aos + w));",
+             "            sh[e * SP + i] = x.x; sh[e1 * SP + i1] = x.y;",
+             "        } else {",
+             "            sh[e * SP + i] = aos[w];",
+             "        }",
+             "        e += de; i += di;",
+             "        if (i >= P::N) { i -= P::N; e++; }",
+             "    }",
+             "    __syncthreads();",
+             "    static_for<0, 2>([&](auto E) {",
+             "        const bool live = 2 * (size_t)t + E < cnt;         // lanes beyond the chunk's end compute on zeros (inside the limb contract)",
+             "        static_for<0, P::N>([&](auto I) { v[E][I] = live ? sh[(2 * t + E) * SP + I] : 0; });",
+             "    });",
+             "}",
+             "static __device__ __forceinline__ void aos_out(spint* aos, size_t cnt, spint* sh, spint (*v)[P::N]) {",
+             "    const int t = threadIdx.x;",
+             "    const size_t total = cnt * (size_t)P::N;",
+             "    __syncthreads();",
+             "    static_for<0, 2>([&](auto E) { static_for<0, P::N>([&](auto I) { sh[(2 * t + E) * SP + I] = v[E][I]; }); });",
+             "    __syncthreads();",
+             "    int e = (2 * t) / P::N, i = (2 * t) % P::N;",
+             "    constexpr int de = CH / P::N, di = CH % P::N;",
+             "    for (size_t w = 2 * (size_t)t; w < total; w += CH) {",
+             "        int e1 = e, i1 = i + 1;",
+             "        if (i1 == P::N) { i1 = 0; e1++; }",
+             "        if (w + 1 < total) {",
+             "            spint2 x; x.x = sh[e * SP + i]; x.y = sh[e1 * SP + i1];",
+             "            __builtin_nontemporal_store(x, reinterpret_cast<spint2*>(aos + w));",
+             "        } else {",
+             "            aos[w] = sh[e * SP + i];",
+             "        }",
+             "        e += de; i += di;",
+             "        if (i >= P::N) { i -= P::N; e++; }",
+             "    }",
+             "}",
+             "__global__ __launch_bounds__(BLOCK) void k_chain_aos(Args A, size_t n) {",
+             "    __shared__ spint sh[CH * SP];",
+             "    constexpr int EPT = 2;",
+             "    const int t = threadIdx.x;",
+             "    (void)t;",
+             "    for (size_t c0 = (size_t)blockIdx.x * CH; c0 < n; c0 += (size_t)gridDim.x * CH) {",
+             "        const size_t cnt = (n - c0 < (size_t)CH) ? n - c0 : (size_t)CH;",
+             "        " + " ".join("spint v%d[EPT][P::N];" % i for i in range(nv))]
+        L += ["        aos_in(A.in[%d] + c0 * (size_t)P::N, cnt, sh, v%d);" % (i, i) for i in range(self.nin)]
+        L += ["        int s%d[EPT]; static_for<0, EPT>([&](auto E) { s%d[E] = (2 * (size_t)t + E < cnt) ? A.sel[%d][c0 + 2 * (size_t)t + E] : 0; });" % (k, k, k) for k in range(self.nsel)]
+        L += ["        " + l for l in votel]
+        L += ["        aos_out(A.out[%d] + c0 * (size_t)P::N, cnt, sh, v%d);" % (k, o) for k, o in enumerate(self.outs)]
+        L += ["    }", "}"]
+        return L
+
+    def _aos_entry(self) -> List[str]:
+        if self.params.nlimbs > 14:
+            return ['extern "C" int %s(const void* const*, void* const*, size_t, void*) {' % self.aos_symbol,
+                    '    set_error("%s: element-major I/O is built for fields of up to 14 limbs; convert with modarith_amd_aos_to_soa");' % self.aos_symbol,
+                    "    return (int)hipErrorInvalidValue;", "}", ""]
+        return ['extern "C" int %s(const void* const* in, void* const* out, size_t n, void* stream) {' % self.aos_symbol,
+                "    // element-major arrays spint x[n][Nlimbs] (16-byte aligned); in[NIN ..): int32 selector arrays as in the _batch form",
+                "    if (n == 0) return 0;",
+                "    Args A;",
+                "    bool al = true;",
+                "    for (int i = 0; i < NIN; i++) { A.in[i] = (const spint*)in[i]; al = al && aligned16(in[i]); }",
+                "    for (int i = 0; i < NOUT; i++) { A.out[i] = (spint*)out[i]; al = al && aligned16(out[i]); }",
+                "    for (int i = 0; i < NSEL; i++) A.sel[i] = (const int*)in[NIN + i];",
+                '    if (!al) { set_error("%s: element-major arrays must be 16-byte aligned"); return (int)hipErrorInvalidValue; }' % self.aos_symbol,
+                "    const size_t chunks = (n + CH - 1) / CH;",
+                "    const size_t cap = (size_t)max_blocks_tiled();",
+                "    k_chain_aos<<<(unsigned)(chunks < cap ? chunks : cap), BLOCK, 0, (hipStream_t)stream>>>(A, n);",
+                '    return check_launch("%s");' % self.aos_symbol,
+                "}", ""]
 
     # ------------------------------------------------------------------ building the plug-in
     def lib_path(self, plugin_dir: Optional[str] = None) -> str:
@@ -328,6 +426,32 @@ class FusedChain:
         self.fn.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
         self.fn.restype = ctypes.c_int
         self._fields = {}
+
+    def aos(self, *inputs, out: Optional[Sequence] = None):
+        """the same chain over element-major device arrays int64 [n, Nlimbs] (`spint x[n][Nlimbs]`, how CPU callers of field.c hold
+        elements): no aos_to_soa / soa_to_aos passes around it; selectors follow the element arrays as in __call__"""
+        import torch
+        ch = self.chain
+        N = ch.params.nlimbs
+        if len(inputs) != ch.nin + ch.nsel:
+            raise ValueError("chain %s takes %d element arrays followed by %d int32 selector arrays" % (ch.name, ch.nin, ch.nsel))
+        elems, sels = inputs[:ch.nin], inputs[ch.nin:]
+        n = elems[0].shape[0]
+        outs = list(out) if out is not None else [torch.empty_like(elems[0]) for _ in ch.outs]
+        for t in list(elems) + outs:
+            if t.dtype != torch.int64 or t.dim() != 2 or tuple(t.shape) != (n, N) or not t.is_cuda or not t.is_contiguous():
+                raise ValueError("expected contiguous int64 device tensors of shape [n, %d]" % N)
+        for d in sels:
+            if d.dtype != torch.int32 or d.numel() != n or not d.is_cuda or not d.is_contiguous():
+                raise ValueError("selectors are contiguous int32 device tensors with one 0/1 entry per element")
+        fn = getattr(self.lib, ch.aos_symbol)
+        fn.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_void_p]
+        fn.restype = ctypes.c_int
+        ins = (ctypes.c_void_p * (ch.nin + ch.nsel))(*[t.data_ptr() for t in list(elems) + list(sels)])
+        ous = (ctypes.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+        with torch.cuda.device(elems[0].device):
+            _lib.check(fn(ins, ous, n, torch.cuda.current_stream(elems[0].device).cuda_stream), ch.aos_symbol)
+        return tuple(outs)
 
     def __call__(self, *inputs, out: Optional[Sequence] = None, device=None):
         import torch

@@ -224,3 +224,33 @@ def test_c_consumer_of_a_fused_chain(torch_cuda, tmp_path):
                            "-Wl,-rpath," + plug, "-Wl,-rpath," + main, "-o", exe])
     p = subprocess.run([exe, "100001"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "limb for limb" in p.stdout, p.stdout[-500:] + p.stderr[-500:]
+
+
+@pytest.mark.parametrize("P", ["X25519", "X448", "1305"])
+def test_element_major_io(torch_cuda, P):
+    """FusedChain.aos: the chain over element-major arrays x[n][Nlimbs] (how the scalar callers of field.c hold elements), transposed
+    through LDS inside the kernel -- equal to aos_to_soa, the chain, soa_to_aos; whole chunks, a ragged tail, fewer elements than one
+    chunk, a selector, an inversion"""
+    torch = torch_cuda
+    from modarith_amd.field import Field
+    from modarith_amd.fuse import Chain
+    F, fp = Field(P), derive_any(P)
+    ch = Chain(P, "aosio")
+    a, b = ch.inputs(2)
+    d = ch.selector()
+    g, h = ch.modcsw(d, a, b)
+    ch.output(ch.modmul(ch.modadd(g, h), ch.modsub(g, h)))
+    ch.output(ch.modinv(h))
+    f = ch.build()
+    for n in (3 * 512, 2 * 512 + 77, 5, 1):
+        x, y = to_dev(_rand(fp, n, 50 + n % 7)), to_dev(_rand(fp, n, 60 + n % 7))
+        sel = torch.randint(0, 2, (n,), dtype=torch.int32, device="cuda")
+        want = f(x, y, sel)
+        xa, ya = F.to_aos(x), F.to_aos(y)
+        got = f.aos(xa, ya, sel)
+        for k in range(2):
+            assert torch.equal(F.from_aos(got[k]), want[k]), (P, n, k)
+        xin = xa.clone()
+        f.aos(xa, ya, sel, out=[xa, ya])                      # in place on the element-major arrays
+        assert torch.equal(xa, got[0]) and torch.equal(ya, got[1])
+        del xin

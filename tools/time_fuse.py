@@ -52,6 +52,22 @@ for P in ("X25519", "NIST256", "X448"):
     assert torch.equal(o1, p1) and torch.equal(o2, p2)
     res["%s ladder-step doubling (9 calls, 2 results)" % P] = {"fused_ms": ms_f, "calls_ms": ms_c, "speedup": ms_c / ms_f, "fused_GBps": ch.traffic_bytes() * n / ms_f / 1e6,
                                                              "fused_bytes_per_element": ch.traffic_bytes(), "calls_bytes_per_element": ch.unfused_traffic_bytes()}
-    del x, y, o1, o2, t1, t2, t3, t4, p1, p2
+    # 3: the same two chains for a consumer that holds ELEMENT-MAJOR arrays x[n][N] (field.c's scalar callers): FusedChain.aos
+    # against aos_to_soa x 2, the fused chain, soa_to_aos -- and against the converters around the call-by-call sequence
+    xa, ya = F.to_aos(x), F.to_aos(y)
+    za = torch.empty_like(xa)
+    def conv_fused():
+        u, v = F.from_aos(xa), F.from_aos(ya)
+        r, = f1(u, v)
+        return F.to_aos(r)
+    def conv_calls():
+        u, v = F.from_aos(xa), F.from_aos(ya)
+        F.modadd(u, v, out=t1); F.modsub(u, v, out=t2); F.modmul(t1, t2, out=t1); F.modsqr(t1, out=o1)
+        return F.to_aos(o1)
+    ms_a, ms_cf, ms_cc = timed(lambda: f1.aos(xa, ya, out=[za])), timed(conv_fused), timed(conv_calls)
+    assert torch.equal(za, conv_calls())
+    res["%s ((x+y)(x-y))^2, element-major in and out" % P] = {"aos_chain_ms": ms_a, "converters_plus_fused_ms": ms_cf, "converters_plus_calls_ms": ms_cc,
+                                                             "speedup_over_converters_plus_calls": ms_cc / ms_a, "GBps": 3 * 8 * N * n / ms_a / 1e6}
+    del x, y, o1, o2, t1, t2, t3, t4, p1, p2, xa, ya, za
     torch.cuda.empty_cache()
 print(json.dumps({"n": n, "layout": "tiles of 4096", "device": torch.cuda.get_device_name(0), "chains": res}, indent=1))
