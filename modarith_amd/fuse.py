@@ -22,6 +22,7 @@ the whole chain runs the split products -- every intermediate is a field-functio
 the exact ones.  C-ABI of the built plug-in (modarith_amd/plugins/libmodarith_amd_chain_<name>_<TAG>.so):
 
     int chain_<name>_<TAG>_batch(const void *const *in, void *const *out, size_t n, size_t ld, void *stream);
+    int chain_<name>_<TAG>_aos(const void *const *in, void *const *out, size_t n, void *stream);     /* element-major x[n][Nlimbs] */
 
 (`in`: the element batches, then one int32 array per selector of modcmv / modcsw.)  Operations: modmul modsqr modadd modsub modneg
 modmli nres redc modcpy modinv modpro modsqrt modnsqr modhaf modcmv modcsw and the generic=False forms modadd_lazy modsub_lazy
@@ -557,6 +558,7 @@ def main(argv: List[str]) -> int:
     print("%s %s" % ("built" if f.built else "up to date:", f.path))
     print("int %s(const void *const *in /* %d element batches%s */, void *const *out /* %d */, size_t n, size_t ld, void *stream);"
           % (ch.symbol, ch.nin, (", then %d int32 selector arrays" % ch.nsel) if ch.nsel else "", len(ch.outs)))
+    print("int %s(const void *const *in, void *const *out, size_t n, void *stream);   /* the same over element-major arrays x[n][Nlimbs] */" % ch.aos_symbol)
     print("HBM bytes per element: %d fused, %d call by call" % (ch.traffic_bytes(), ch.unfused_traffic_bytes()))
     return 0
 
