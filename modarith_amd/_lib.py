@@ -117,6 +117,12 @@ def load() -> ctypes.CDLL:
         raise RuntimeError(
             "modarith_amd: %s is missing -- build it with `python -m modarith_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    try:
+        # torch-rocm ships its own HIP runtime: when this process is going to use torch as well, that runtime must be the first one
+        # loaded -- with the library's copy first, HIP calls made through the library report "no ROCm-capable device"
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for P in PRIMES:
         for fn, args in _SIG.items():

@@ -322,6 +322,31 @@ class Chain:
              "        static_for<0, P::N>([&](auto I) { v[E][I] = live ? sh[(2 * t + E) * SP + I] : 0; });",
              "    });",
              "}",
+             "static __device__ __forceinline__ void aos_load(const spint* aos, size_t cnt, spint* sh) {",
+             "    const int t = threadIdx.x;",
+             "    const size_t total = cnt * (size_t)P::N;",
+             "    int e = (2 * t) / P::N, i = (2 * t) % P::N;",
+             "    constexpr int de = CH / P::N, di = CH % P::N;",
+             "    for (size_t w = 2 * (size_t)t; w < total; w += CH) {",
+             "        int e1 = e, i1 = i + 1;",
+             "        if (i1 == P::N) { i1 = 0; e1++; }",
+             "        if (w + 1 < total) {",
+             "            const spint2 x = __builtin_nontemporal_load(reinterpret_cast<const spint2*>(aos + w));",
+             "            sh[e * SP + i] = x.x; sh[e1 * SP + i1] = x.y;",
+             "        } else {",
+             "            sh[e * SP + i] = aos[w];",
+             "        }",
+             "        e += de; i += di;",
+             "        if (i >= P::N) { i -= P::N; e++; }",
+             "    }",
+             "}",
+             "static __device__ __forceinline__ void aos_regs(size_t cnt, const spint* sh, spint (*v)[P::N]) {",
+             "    const int t = threadIdx.x;",
+             "    static_for<0, 2>([&](auto E) {",
+             "        const bool live = 2 * (size_t)t + E < cnt;",
+             "        static_for<0, P::N>([&](auto I) { v[E][I] = live ? sh[(2 * t + E) * SP + I] : 0; });",
+             "    });",
+             "}",
              "static __device__ __forceinline__ void aos_out(spint* aos, size_t cnt, spint* sh, spint (*v)[P::N]) {",
              "    const int t = threadIdx.x;",
              "    const size_t total = cnt * (size_t)P::N;",
@@ -351,7 +376,16 @@ class Chain:
              "    for (size_t c0 = (size_t)blockIdx.x * CH; c0 < n; c0 += (size_t)gridDim.x * CH) {",
              "        const size_t cnt = (n - c0 < (size_t)CH) ? n - c0 : (size_t)CH;",
              "        " + " ".join("spint v%d[EPT][P::N];" % i for i in range(nv))]
-        L += ["        aos_in(A.in[%d] + c0 * (size_t)P::N, cnt, sh, v%d);" % (i, i) for i in range(self.nin)]
+        if getattr(self, "aos_multi", self.nin * 512 * (N | 1) * 8 <= 65536):
+            # one LDS image per input array while they fit 64 KB: every array's loads are issued before the first barrier
+            # (measured against one shared image, tools/aos_exp.py: X25519 0.577 -> 0.517 ms, X448 1.089 -> 1.038 ms)
+            L = [l.replace("__shared__ spint sh[CH * SP];", "__shared__ spint sh[%d * CH * SP];" % self.nin) for l in L]
+            L += ["        __syncthreads();"]
+            L += ["        aos_load(A.in[%d] + c0 * (size_t)P::N, cnt, sh + %d * CH * SP);" % (i, i) for i in range(self.nin)]
+            L += ["        __syncthreads();"]
+            L += ["        aos_regs(cnt, sh + %d * CH * SP, v%d);" % (i, i) for i in range(self.nin)]
+        else:
+            L += ["        aos_in(A.in[%d] + c0 * (size_t)P::N, cnt, sh, v%d);" % (i, i) for i in range(self.nin)]
         L += ["        int s%d[EPT]; static_for<0, EPT>([&](auto E) { s%d[E] = (2 * (size_t)t + E < cnt) ? A.sel[%d][c0 + 2 * (size_t)t + E] : 0; });" % (k, k, k) for k in range(self.nsel)]
         L += ["        " + l for l in votel]
         L += ["        aos_out(A.out[%d] + c0 * (size_t)P::N, cnt, sh, v%d);" % (k, o) for k, o in enumerate(self.outs)]
