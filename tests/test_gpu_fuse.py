@@ -254,3 +254,33 @@ def test_element_major_io(torch_cuda, P):
         f.aos(xa, ya, sel, out=[xa, ya])                      # in place on the element-major arrays
         assert torch.equal(xa, got[0]) and torch.equal(ya, got[1])
         del xin
+
+
+def test_element_major_io_five_inputs(torch_cuda):
+    """more input arrays than LDS images fit (five 5-limb arrays: one shared image, barriers between the arrays): the ladder step of
+    test_a_ladder_step_with_selectors_and_lazy_forms over element-major arrays"""
+    torch = torch_cuda
+    from modarith_amd.field import Field
+    from modarith_amd.fuse import Chain
+    P, a24 = "X25519", 121665
+    F, fp = Field(P), derive_any(P)
+    ch = Chain(P, "ladderstep")
+    x1, x2, z2, x3, z3 = ch.inputs(5)
+    sw = ch.selector()
+    x2, x3 = ch.modcsw(sw, x2, x3)
+    z2, z3 = ch.modcsw(sw, z2, z3)
+    A, B, C, D = ch.modadd_lazy(x2, z2), ch.modsub_lazy(x2, z2), ch.modadd_lazy(x3, z3), ch.modsub_lazy(x3, z3)
+    AA, BB, DA, CB = ch.modsqr(A), ch.modsqr(B), ch.modmul(D, A), ch.modmul(C, B)
+    E = ch.modsub_lazy(AA, BB)
+    for v in (ch.modmul(AA, BB), ch.modmul(E, ch.modadd_lazy(AA, ch.modmli(E, a24))),
+              ch.modsqr(ch.modadd_lazy(DA, CB)), ch.modmul(x1, ch.modsqr(ch.modsub_lazy(DA, CB)))):
+        ch.output(v)
+    f = ch.build()
+    assert "sh[CH * SP]" in ch.source()                           # the shared image
+    n = 3 * 512 + 201
+    t = [to_dev(_rand(fp, n, 70 + i)) for i in range(5)]
+    bit = torch.randint(0, 2, (n,), dtype=torch.int32, device="cuda")
+    want = f(*t, bit)
+    got = f.aos(*[F.to_aos(x) for x in t], bit)
+    for k in range(4):
+        assert torch.equal(F.from_aos(got[k]), want[k]), k
