@@ -284,3 +284,21 @@ def test_element_major_io_five_inputs(torch_cuda):
     got = f.aos(*[F.to_aos(x) for x in t], bit)
     for k in range(4):
         assert torch.equal(F.from_aos(got[k]), want[k]), k
+
+
+def test_empty_and_single_element_batches(torch_cuda):
+    """n = 0 is a no-op (as every batched entry point), n = 1 takes the 8-byte path; both layouts"""
+    torch = torch_cuda
+    from modarith_amd.field import Field
+    from modarith_amd.fuse import bench_chain
+    F, fp = Field("X25519"), derive_any("X25519")
+    f = bench_chain("X25519").build()
+    x, y = to_dev(_rand(fp, 1, 81)), to_dev(_rand(fp, 1, 82))
+    z, = f(x, y)
+    assert torch.equal(z, F.modsqr(F.modmul(F.modadd(x, y), F.modsub(x, y))))
+    za, = f.aos(F.to_aos(x), F.to_aos(y))
+    assert torch.equal(F.from_aos(za), z)
+    e = torch.empty((5, 0), dtype=torch.int64, device="cuda")
+    assert f(e, e)[0].shape == (5, 0)
+    ea = torch.empty((0, 5), dtype=torch.int64, device="cuda")
+    assert f.aos(ea, ea)[0].shape == (0, 5)
