@@ -397,7 +397,7 @@ def rfc7748(curve: str, bk: torch.Tensor, bu: torch.Tensor, out: Optional[torch.
     """Batched `rfc7748(bk, bu, bv)` (reference rfc7748.c:156): uint8 [n, Nbytes] RFC little-endian
     records in device memory -> uint8 [n, Nbytes].  `out` may be `bu`."""
     if curve not in _lib.LADDERS:
-        raise ValueError("curve must be one of %s" % (_lib.LADDERS,))
+        return _rfc7748_generated(curve, bk, bu, out)
     lib = _lib.load()
     nb = 32 if curve == "X25519" else 56
     for t in (bk, bu):
@@ -424,6 +424,44 @@ def rfc7748(curve: str, bk: torch.Tensor, bu: torch.Tensor, out: Optional[torch.
         else:
             f = getattr(lib, "rfc7748_%s_batch" % curve)
             _lib.check(f(bk.data_ptr(), bu.data_ptr(), out.data_ptr(), n, st), "rfc7748_%s_batch" % curve)
+    return out
+
+
+_ladder_plugins = {}
+
+
+def _rfc7748_generated(curve: str, bk: torch.Tensor, bu: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
+    """rfc7748() of a Montgomery curve made by modarith_amd.generate.generate_ladder (the #ifdef block a user of rfc7748.c adds for
+    a curve of their own, rfc7748.c:118-132)"""
+    import ctypes
+    import json
+    from . import generate as _gen
+    if curve not in _ladder_plugins:
+        path = _gen.ladder_plugin_path(curve)
+        meta = os.path.join(os.path.dirname(path), "ladder_%s.json" % curve)
+        if not (os.path.exists(path) and os.path.exists(meta)):
+            raise ValueError("curve must be one of %s or a ladder generated with modarith_amd.generate.generate_ladder" % (_lib.LADDERS,))
+        m = json.load(open(meta))
+        _lib.load()
+        if m["field"] not in _lib.PRIMES:
+            _lib.load_plugin(m["field"])
+        lib = ctypes.CDLL(path)
+        f = getattr(lib, "rfc7748_%s_batch" % curve)
+        f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p]
+        f.restype = ctypes.c_int
+        _ladder_plugins[curve] = (lib, f, m["nbytes"])
+    _, f, nb = _ladder_plugins[curve]
+    for t in (bk, bu):
+        if t.dtype != torch.uint8 or t.dim() != 2 or t.shape[1] != nb or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError("expected contiguous uint8 device tensors [n, %d]" % nb)
+    if bk.shape[0] != bu.shape[0] or bk.device != bu.device:
+        raise ValueError("bk and bu must hold the same number of records on the same device")
+    if out is None:
+        out = torch.empty_like(bu)
+    elif out.dtype != torch.uint8 or out.shape != bu.shape or not out.is_contiguous() or out.device != bu.device:
+        raise ValueError("out must be a contiguous uint8 tensor of shape %s on %s" % (tuple(bu.shape), bu.device))
+    with torch.cuda.device(bu.device):
+        _lib.check(f(bk.data_ptr(), bu.data_ptr(), out.data_ptr(), bk.shape[0], torch.cuda.current_stream().cuda_stream), "rfc7748_%s_batch" % curve)
     return out
 
 

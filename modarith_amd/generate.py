@@ -272,6 +272,102 @@ def generate_curve(name: str, kind: str, field: str, a: int, b: int, order: int,
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Montgomery ladders of one's own: rfc7748.c describes its curve in an #ifdef block (A24, COF, GENERATOR, TWIST_SECURE; rfc7748.c:118-132)
+# and is otherwise generic over the pasted field; this is that block for a curve other than X25519 / X448
+def ladder_plugin_path(name: str, plugin_dir: Optional[str] = None) -> str:
+    return os.path.join(plugin_dir or PLUGIN_DIR, "libmodarith_amd_ladder_%s.so" % name)
+
+
+def generate_ladder(name: str, field: str, a24: int, cof: int, twist_secure: bool = True, plugin_dir: Optional[str] = None,
+                    force: bool = False, verbose: bool = False) -> str:
+    """`rfc7748_<name>(bk, bu, bv)` and `rfc7748_<name>_batch(bk, bu, bv, n, stream)` for the Montgomery curve
+    v^2 = u^3 + A u^2 + u with (A - 2) / 4 = a24 over a built-in or generated field, cofactor 2^cof (2 or 3): the reference's
+    rfc7748() call for call on the bit-exact field (csrc/ladder.h k_rfc7748: clamp, 5 M + 4 S + a24 per bit, generic=False sums,
+    modpro + modinv, little-endian Nbytes records).  Only the TWIST_SECURE branch of rfc7748.c:224-227 is built; records move as
+    64-bit words, so Nbytes must be a multiple of 8.  Returns the plug-in's path."""
+    from . import _lib
+    from .params import derive
+    if not _TAG_RE.match(name) or name in _lib.LADDERS:
+        raise GenerateError("%r: not a usable name (X25519 and X448 are built in)" % (name,))
+    if not twist_secure:
+        raise GenerateError("only the TWIST_SECURE form of rfc7748() is built (rfc7748.c:224-227); the point-validation branch is not")
+    if cof not in (2, 3):
+        raise GenerateError("COF is 2 or 3 (rfc7748.c:122)")
+    if not 0 < a24 < (1 << 28):
+        raise GenerateError("A24 must be a small positive integer: it is the `int` of modmli (rfc7748.c:209)")
+    d = plugin_dir or PLUGIN_DIR
+    if field in _lib.PRIMES:
+        fp = derive(field)
+    elif os.path.exists(os.path.join(d, "%s.json" % field)):
+        fp = params_of_plugin(field, d)
+    elif os.path.exists(os.path.join(PLUGIN_DIR, "%s.json" % field)):
+        fp = params_of_plugin(field)
+    else:
+        raise GenerateError("field %r is neither built in nor generated: run generate() for it first" % (field,))
+    if fp.nbytes % 8:
+        raise GenerateError("%d-byte records: the ladder kernel moves records as 64-bit words" % fp.nbytes)
+    sym = "rfc7748_%s" % name
+    unit_text = "\n".join([
+        "// GENERATED by modarith_amd/generate.py -- do not edit.  rfc7748() for the Montgomery curve %s: A24 = %d, COF = %d, over %s" % (name, a24, cof, field),
+        '#include "params_%s.h"' % field, '#include "modarith_amd.h"', '#include "capi_common.h"', '#include "kernels.h"', '#include "ladder.h"', "",
+        "namespace {", "using namespace ma;", "using P = ma::P_%s;" % field, "constexpr int NB = P::NBYTES;", "}", "",
+        'extern "C" int %s_batch(const char* bk, const char* bu, char* bv, size_t n, void* st) {' % sym,
+        "    if (n == 0) return 0;",
+        "    if ((reinterpret_cast<uintptr_t>(bk) | reinterpret_cast<uintptr_t>(bu) | reinterpret_cast<uintptr_t>(bv)) & 7u) {",
+        '        set_error("%s: byte records must be 8-byte aligned");' % sym,
+        "        return (int)hipErrorInvalidValue;",
+        "    }",
+        "    const int block = ladder_block();",
+        "    k_rfc7748<P, %d, %d><<<grid_for(n, block), block, 0, (hipStream_t)st>>>(" % (a24, cof),
+        "        reinterpret_cast<const spint*>(bk), reinterpret_cast<const spint*>(bu), reinterpret_cast<spint*>(bv), n);",
+        '    return check_launch("%s");' % sym,
+        "}",
+        "// the reference's own signature (rfc7748.c:156), host pointers: one record through the staging buffer",
+        'extern "C" void %s(const char* bk, const char* bu, char* bv) {' % sym,
+        "    std::lock_guard<std::mutex> lock(staging().mu);",
+        "    char* d = reinterpret_cast<char*>(staging().get());",
+        "    char *dk = d, *du = d + 64 * ((NB + 63) / 64), *dv = du + 64 * ((NB + 63) / 64);",
+        '    hipError_t e = hipMemcpy(dk, bk, NB, hipMemcpyHostToDevice); if (e != hipSuccess) die("hipMemcpy", e);',
+        '    e = hipMemcpy(du, bu, NB, hipMemcpyHostToDevice); if (e != hipSuccess) die("hipMemcpy", e);',
+        '    if (%s_batch(dk, du, dv, 1, nullptr) != 0) die("%s", hipErrorLaunchFailure);' % (sym, sym),
+        '    e = hipMemcpy(bv, dv, NB, hipMemcpyDeviceToHost); if (e != hipSuccess) die("hipMemcpy", e);',
+        "}", ""])
+    os.makedirs(d, exist_ok=True)
+    unit, obj = os.path.join(d, "capi_ladder_%s.hip" % name), os.path.join(d, "capi_ladder_%s.o" % name)
+    lib, meta = ladder_plugin_path(name, d), os.path.join(d, "ladder_%s.json" % name)
+    from .build import ARCH, FLAGS, HIPCC, _stamp
+    key = hashlib.sha256((" ".join(FLAGS) + "\n" + unit_text + "\n" + emit.header_text(fp) + "\n" + _stamp()).encode()).hexdigest()
+    if not force and os.path.exists(lib) and os.path.exists(meta):
+        try:
+            if json.load(open(meta)).get("hash") == key:
+                return lib
+        except (ValueError, OSError):
+            pass
+    if not os.path.exists(HIPCC):
+        raise GenerateError("%s not found: generating a ladder needs the ROCm compiler (there is no CPU path)" % HIPCC)
+    emit._write(unit, unit_text)
+    if verbose:
+        print("[modarith_amd] hipcc %s -> %s" % (os.path.basename(unit), os.path.basename(lib)), flush=True)
+    tmp = ".%d.tmp" % os.getpid()
+    inc_dirs = ["-I", os.path.join(HERE, "csrc", "generated"), "-I", os.path.join(HERE, "csrc"), "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", PLUGIN_DIR, "-I", d]
+    subprocess.run([HIPCC] + list(FLAGS) + inc_dirs + ["-c", unit, "-o", obj + tmp], check=True, timeout=int(os.environ.get("MA_BUILD_TIMEOUT", "1500")))
+    subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib + tmp, obj + tmp, "-L", HERE, "-l:libmodarith_amd.so",
+                           "-Wl,-rpath,$ORIGIN/" + os.path.relpath(HERE, d), "-Wl,-rpath," + HERE])
+    with open(meta + tmp, "w") as f:
+        json.dump({"ladder": name, "field": field, "a24": a24, "cof": cof, "nbytes": fp.nbytes, "nbits": fp.n, "hash": key}, f, indent=1)
+    os.replace(obj + tmp, obj)
+    os.replace(lib + tmp, lib)
+    os.replace(meta + tmp, meta)
+    return lib
+
+
+# ladders the test-suite generates: M-383 (Aranha-Barreto-Pereira-Ricardini: v^2 = u^3 + 2065150 u^2 + u over 2^383 - 187, the
+# built-in PM383 field; base point u = 12) and a ladder over the GENERATED field 2^251 - 9 (A = 49382: a test curve -- the ladder
+# is algebra on (A - 2) / 4 and is checked against plain integer arithmetic, whatever the curve's group looks like)
+EXAMPLE_LADDERS = (dict(name="M383", field="PM383", a24=516287, cof=3), dict(name="T2519", field="2519", a24=12345, cof=3))
+
+
 def installed_curves(plugin_dir: Optional[str] = None) -> List[dict]:
     d = plugin_dir or PLUGIN_DIR
     out = []

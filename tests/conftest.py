@@ -52,4 +52,6 @@ def generated_fields():
             gen.generate(arg, family=fam)
         for c in gen.EXAMPLE_CURVES:
             gen.generate_curve(**c)
+        for c in gen.EXAMPLE_LADDERS:
+            gen.generate_ladder(**c)
     yield

@@ -117,3 +117,20 @@ def test_generate_curve_refusals_and_cross_compile(tmp_path):
         assert hasattr(lib, "ecn_nist224_%s" % fn), fn
     assert not gen.generate_curve(**c, plugin_dir=str(tmp_path)).built
     assert [m["curve"] for m in gen.installed_curves(str(tmp_path))] == ["NIST224"]
+
+
+def test_generate_ladder_refusals_and_cross_compile(tmp_path):
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libmodarith_amd.so not built")
+    with pytest.raises(gen.GenerateError, match="TWIST_SECURE"):
+        gen.generate_ladder("M383", "PM383", 516287, 3, twist_secure=False, plugin_dir=str(tmp_path))
+    with pytest.raises(gen.GenerateError, match="COF is 2 or 3"):
+        gen.generate_ladder("M383", "PM383", 516287, 4, plugin_dir=str(tmp_path))
+    with pytest.raises(gen.GenerateError, match="64-bit words"):
+        gen.generate_ladder("M224", "NIST224", 1234, 3, plugin_dir=str(tmp_path))        # 28-byte records
+    with pytest.raises(gen.GenerateError, match="built in"):
+        gen.generate_ladder("X25519", "X25519", 121665, 3, plugin_dir=str(tmp_path))
+    lib = gen.generate_ladder("M383", "PM383", 516287, 3, plugin_dir=str(tmp_path))
+    h = ctypes.CDLL(lib)
+    assert hasattr(h, "rfc7748_M383") and hasattr(h, "rfc7748_M383_batch")
+    assert gen.generate_ladder("M383", "PM383", 516287, 3, plugin_dir=str(tmp_path)) == lib

@@ -178,3 +178,61 @@ def test_time_protocol_check_words_of_generated_fields(torch_cuda, P):
     assert rep[0].startswith("modmul check 0x%06x " % int(g["modmul_check_100k"], 16)), rep
     assert rep[1].startswith("modsqr check 0x%06x " % int(g["modsqr_check_100k"], 16)), rep
     assert rep[2].startswith("modinv check 0x"), rep
+
+
+@pytest.mark.parametrize("name", ["M383", "T2519"])
+def test_generated_montgomery_ladder(torch_cuda, name):
+    """rfc7748() for a Montgomery curve other than X25519 / X448 (the #ifdef block a user of rfc7748.c adds, rfc7748.c:118-132): M-383
+    over the built-in PM383 field and a ladder over the GENERATED field 2^251-9 -- batched and through the scalar entry point --
+    against RFC 7748 section 5 in plain integers: clamping, masking of u, non-canonical u, u = 0, the base point, a DH exchange"""
+    import ctypes
+    import json
+    import os
+    import random
+    torch = torch_cuda
+    from modarith_amd import generate as gen
+    from modarith_amd.field import rfc7748
+    c = next(x for x in gen.EXAMPLE_LADDERS if x["name"] == name)
+    m = json.load(open(os.path.join(gen.PLUGIN_DIR, "ladder_%s.json" % name)))
+    nb, bits, a24, cof = m["nbytes"], m["nbits"], c["a24"], c["cof"]
+    p = derive_any(c["field"]).p
+
+    def model(k, u):
+        k = int.from_bytes(k, "little"); u = int.from_bytes(u, "little")
+        k &= ~((1 << cof) - 1); k &= (1 << bits) - 1; k |= 1 << (bits - 1)
+        u = (u & ((1 << bits) - 1)) % p
+        x1, x2, z2, x3, z3, swap = u, 1, 0, u, 1, 0
+        for t in range(bits - 1, -1, -1):
+            kt = (k >> t) & 1
+            swap ^= kt
+            if swap: x2, x3, z2, z3 = x3, x2, z3, z2
+            swap = kt
+            A, B, C, D = (x2 + z2) % p, (x2 - z2) % p, (x3 + z3) % p, (x3 - z3) % p
+            AA, BB, DA, CB = A * A % p, B * B % p, D * A % p, C * B % p
+            E = (AA - BB) % p
+            x3, z3 = (DA + CB) ** 2 % p, x1 * (DA - CB) ** 2 % p
+            x2, z2 = AA * BB % p, E * (AA + a24 * E) % p
+        if swap: x2, z2 = x3, z3
+        return (x2 * pow(z2, p - 2, p) % p).to_bytes(nb, "little")
+
+    rng = random.Random(5)
+    n = 70
+    ks = [bytes(rng.randrange(256) for _ in range(nb)) for _ in range(n)]
+    us = [bytes(rng.randrange(256) for _ in range(nb)) for _ in range(n)]
+    us[0] = (12).to_bytes(nb, "little")                        # M-383's base point
+    us[1] = (0).to_bytes(nb, "little")
+    us[2] = (p + 5).to_bytes(nb, "little") if p + 5 < 1 << (8 * nb) else us[2]      # non-canonical u
+    us[3] = b"\xff" * nb                                        # bits above Nbits are masked
+    dev = lambda rows: torch.tensor([list(r) for r in rows], dtype=torch.uint8, device="cuda")
+    got = rfc7748(name, dev(ks), dev(us)).cpu().numpy()
+    assert [bytes(r) for r in got] == [model(k, u) for k, u in zip(ks, us)]
+    # Diffie-Hellman on the curve: both sides reach the same bytes; and the scalar entry point (the reference's signature)
+    base = dev([us[0]] * 2)
+    pk = rfc7748(name, dev(ks[:2]), base)
+    s1 = rfc7748(name, dev([ks[0]]), pk[1:2].contiguous())
+    s2 = rfc7748(name, dev([ks[1]]), pk[0:1].contiguous())
+    assert torch.equal(s1, s2)
+    lib = ctypes.CDLL(gen.ladder_plugin_path(name))
+    out = ctypes.create_string_buffer(nb)
+    getattr(lib, "rfc7748_%s" % name)(ks[5], us[5], out)
+    assert out.raw == model(ks[5], us[5])
