@@ -477,6 +477,23 @@ def main(argv: List[str]) -> int:
             print("%-12s %-6s %2d x %2d bits  %s" % (m["tag"], m["family"], m["nlimbs"], m["radix"], m["prime"]))
         for m in installed_curves():
             print("%-12s %-11s over %-8s a = %d, b = %s" % (m["curve"], m["kind"], m["field"], m["a"], m["b"]))
+        d = PLUGIN_DIR
+        for f in sorted(os.listdir(d)) if os.path.isdir(d) else []:
+            if f.startswith("ladder_") and f.endswith(".json") and os.path.exists(ladder_plugin_path(f[7:-5])):
+                m = json.load(open(os.path.join(d, f)))
+                print("%-12s ladder      over %-8s A24 = %d, COF = %d" % (m["ladder"], m["field"], m["a24"], m["cof"]))
+        return 0
+    if args and args[0] == "ladder":
+        # python -m modarith_amd.generate ladder <name> <field> <A24> <COF>
+        if len(args) != 5:
+            print("Valid syntax - python -m modarith_amd.generate ladder <name> <field> <A24> <COF>")
+            return 2
+        try:
+            lib = generate_ladder(args[1], args[2], int(args[3], 0), int(args[4], 0), force="--force" in argv, verbose=True)
+        except (GenerateError, ValueError) as e:
+            print(e)
+            return 2
+        print("%s: void rfc7748_%s(const char *bk, const char *bu, char *bv); int rfc7748_%s_batch(bk, bu, bv, n, stream); rfc7748(%r, ...)" % (lib, args[1], args[1], args[1]))
         return 0
     if args and args[0] == "curve":
         # python -m modarith_amd.generate curve <NAME> edwards|weierstrass <field> <a> <b> <order> <gx> <gy> [cof]   (integers: any python literal)
