@@ -704,9 +704,22 @@ def main():
                             "kernel_ms": {"min": min(kms), "mean": sum(kms) / len(kms), "max": max(kms)}},
             "dist": dist_info,
         }
-        print(json.dumps(out))
+        line = json.dumps(out)
+    # The JSON line must be the LAST thing on stdout.  RCCL writes a version banner ("RCCL version : ...", five lines) to the C
+    # stdout of rank 0 when the communicator is made; redirected to a file or a pipe that buffer is flushed at exit -- after a line
+    # printed from Python.  So: every rank flushes its C and Python streams, the ranks meet, the process group is torn down, the
+    # streams are flushed again, and only then rank 0 prints the line.
+    import ctypes
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+        sys.stdout.flush()
+        libc.fflush(None)
+    if rank == 0:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
