@@ -199,6 +199,48 @@ def valu_roofline(scalars_per_s_per_gpu):
             "mad_only_ceiling_scalars_per_s": 1024 * 2.4e9 * 64 / (5.0 * mad)}
 
 
+def measure_traffic(timeout_s=240):
+    """HBM bytes per launch of the headline kernel, measured in THIS run: two child processes -- started before this process touches
+    the GPU -- run this same script for a few launches under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes
+    with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes; the program itself after `--`), and their
+    counter_collection.csv is read back.  gfx950 correction of that section: FETCH_SIZE reports half the bytes of a 16-B-per-lane
+    coalesced streaming read -> doubled; WRITE_SIZE is exact; both in KiB.  Any failure (no rocprofv3, a refused counter) returns
+    None and the caller falls back to the committed summary of the same passes (profiles/traffic_modmul_X25519.json)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    kern = "k_binary<ma::P_X25519, ma::OpMulAuto<ma::P_X25519"
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp", MA_BENCH_PLACEMENTS="1", MA_BENCH_CHILD="1")
+    base = tempfile.mkdtemp(prefix="ma_traffic_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(base, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", "python3", os.path.abspath(__file__),
+                   "--steps", "5", "--warmup", "2", "--no-cpu", "--no-ladder", "--no-others", "--no-verify", "--no-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0])) if kern in row["Kernel_Name"] and row.get("Counter_Name", counter) == counter]
+            if not vals:
+                return None
+            out[counter] = (sum(vals) / len(vals), len(vals))
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    fk, wk = out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
+    return {"hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024, "hbm_read_bytes_per_launch": 2 * fk * 1024, "hbm_write_bytes_per_launch": wk * 1024,
+            "launches_sampled": min(out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]),
+            "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this script (FETCH_SIZE doubled per the gfx950 correction)"}
+
+
 def launch_ranks(n_ranks, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, through
     torch.distributed.run (the command the driver uses for N>1), relay their output and return their exit code.
@@ -223,6 +265,7 @@ def main():
     ap.add_argument("--no-ladder", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-others", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure the headline kernel's HBM traffic with rocprofv3 child passes (N=1 only; the committed summary is quoted instead)")
     ap.add_argument("--no-verify", action="store_true", help="skip the per-rank spot check of the timed outputs against the CPU oracle")
     ap.add_argument("--launch-check", action="store_true",
                     help="only check the rank launch: gloo group over the N ranks, no GPU work (tests/test_bench_launch.py)")
@@ -230,6 +273,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    # N = 1: the PMC passes for roofline.traffic run as children BEFORE this process initialises the GPU (nothing that has touched
+    # HIP is ever replaced or re-executed; the children are ordinary subprocesses and the timed region below starts after they end)
+    live_traffic = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_traffic and not args.launch_check
+            and os.environ.get("MA_BENCH_CHILD") != "1" and os.environ.get("MA_BENCH_TRAFFIC", "1") != "0"):
+        live_traffic = measure_traffic()
 
     import torch
     import torch.distributed as dist
@@ -666,7 +715,9 @@ def main():
         # the same build: a property of the kernel and the batch size, so it is only quoted for the profiled size
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_modmul_X25519.json")
-        if os.path.exists(tpath):
+        if live_traffic is not None:              # (the children inherit this process's environment: same batch size and layout)
+            traffic, traffic_source = live_traffic["hbm_bytes_per_launch"], live_traffic["source"] + " (%d launches)" % live_traffic["launches_sampled"]
+        elif os.path.exists(tpath):
             tdoc = json.load(open(tpath))
             if tdoc.get("algorithmic_bytes_per_launch") == BYTES_PER_MODMUL * n:
                 traffic = tdoc.get("hbm_bytes_per_launch")

@@ -17,6 +17,9 @@ def _run(args, env_extra):
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
+    # the JSON line is the LAST line of stdout, whatever the libraries underneath print (RCCL's version banner is written to the C
+    # stdout buffer when the communicator is made and would otherwise surface at exit, after the line)
+    assert p.stdout.strip().splitlines()[-1] == lines[0], p.stdout[-1500:]
     return json.loads(lines[0])
 
 
@@ -36,10 +39,13 @@ def test_bench_line_contract():
     assert d["verified_against_oracle"]["all_ranks_equal_oracle"] is True and len(d["ranks"]) == 1
     assert d["roofline"]["frac_median_placement"] <= d["roofline"]["frac"] * 1.15 and d["value_median_placement"] > 0
     assert len(d["config"]["placement_probe_GBps"]) == 4
+    # roofline.traffic is measured in the run itself: rocprofv3 --pmc child passes before the parent touches the GPU
+    assert "measured in this run" in r["traffic_source"], r["traffic_source"]
+    assert 0.99 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05
 
 
 def test_bench_rccl_path_one_rank():
-    d = _run(["--steps", "10", "--warmup", "3", "--no-cpu", "--no-others"], {"MA_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29533"})
+    d = _run(["--steps", "10", "--warmup", "3", "--no-cpu", "--no-others", "--no-traffic"], {"MA_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29533"})
     assert d["n_gpus"] == 1 and d["x25519"]["gather_ms"] is not None and d["x25519"]["gather_ms"] > 0
 
 

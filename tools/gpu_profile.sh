@@ -12,9 +12,9 @@ cd /tmp && export TMPDIR=/tmp
 export MA_BENCH_PLACEMENTS=1
 # (--no-others: the side figures launch the same kernel symbol on other data sets and on the other HBM layout; without them the
 # per-kernel average of --stats covers the headline launches only)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu --no-others > $OUT/bench_under_rocprof.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-ladder --no-others > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-ladder --no-others > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu --no-others --no-traffic > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-ladder --no-others --no-traffic > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-ladder --no-others --no-traffic > $OUT/pmc_write.log 2>&1
 cd $R
 unset MA_BENCH_PLACEMENTS
 python3 bench.py > $OUT/bench_plain.log 2>&1
