@@ -200,8 +200,8 @@ def valu_roofline(scalars_per_s_per_gpu):
 
 
 def measure_traffic(timeout_s=240):
-    """HBM bytes per launch of the headline kernel, measured in THIS run: two child processes -- started before this process touches
-    the GPU -- run this same script for a few launches under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes
+    """HBM bytes per launch of the headline kernel, measured in THIS run: two child processes -- started after this process's own
+    timed regions -- run this same script for a few launches under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes
     with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes; the program itself after `--`), and their
     counter_collection.csv is read back.  gfx950 correction of that section: FETCH_SIZE reports half the bytes of a 16-B-per-lane
     coalesced streaming read -> doubled; WRITE_SIZE is exact; both in KiB.  Any failure (no rocprofv3, a refused counter) returns
@@ -273,12 +273,6 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
-    # N = 1: the PMC passes for roofline.traffic run as children BEFORE this process initialises the GPU (nothing that has touched
-    # HIP is ever replaced or re-executed; the children are ordinary subprocesses and the timed region below starts after they end)
-    live_traffic = None
-    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_traffic and not args.launch_check
-            and os.environ.get("MA_BENCH_CHILD") != "1" and os.environ.get("MA_BENCH_TRAFFIC", "1") != "0"):
-        live_traffic = measure_traffic()
 
     import torch
     import torch.distributed as dist
@@ -705,6 +699,14 @@ def main():
         dist.all_gather_object(ranks, mine)
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                      "distinct_devices": len({(r["pci_bus_id"], r["uuid"], r["device_index"]) for r in ranks})}
+
+    # N = 1: the PMC passes for roofline.traffic, as child processes AFTER every timed region of this process (they are ordinary
+    # subprocesses -- nothing that has touched HIP is replaced or re-executed -- and cannot disturb the placement or the timing of
+    # the launches measured above)
+    live_traffic = None
+    if (world == 1 and args.gpus == 1 and not args.no_traffic and os.environ.get("MA_BENCH_CHILD") != "1"
+            and os.environ.get("MA_BENCH_TRAFFIC", "1") != "0"):
+        live_traffic = measure_traffic()
 
     if rank == 0:
         cpu = None

@@ -39,7 +39,7 @@ def test_bench_line_contract():
     assert d["verified_against_oracle"]["all_ranks_equal_oracle"] is True and len(d["ranks"]) == 1
     assert d["roofline"]["frac_median_placement"] <= d["roofline"]["frac"] * 1.15 and d["value_median_placement"] > 0
     assert len(d["config"]["placement_probe_GBps"]) == 4
-    # roofline.traffic is measured in the run itself: rocprofv3 --pmc child passes before the parent touches the GPU
+    # roofline.traffic is measured in the run itself: rocprofv3 --pmc child passes after the parent's timed regions
     assert "measured in this run" in r["traffic_source"], r["traffic_source"]
     assert 0.99 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05
 
