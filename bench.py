@@ -24,6 +24,7 @@ import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -161,23 +162,32 @@ def cpu_baseline(a_host, b_host, min_seconds=6.0):
     }
 
 
-def valu_roofline(scalars_per_s_per_gpu):
-    """VALU-issue roofline of the X25519 ladder kernels.  The instruction counts per scalar multiplication come from the
-    committed PMC summary (profiles/, SQ_INSTS_VALU of one pass / scalars; round 3: the ladder kernel k_x25519_fe26_xz plus
-    the batched finish k_fe_finish<Fe26>); the rate is the one measured in THIS run.
+def valu_roofline(scalars_per_s_per_gpu, curve="X25519"):
+    """VALU-issue roofline of the ladder kernels.  The instruction counts per scalar multiplication come from the
+    committed PMC summary (profiles/, SQ_INSTS_VALU of one pass / scalars; round 3: the ladder kernel k_x25519_fe26_xz /
+    k_x448_fe28_xz plus the batched finish k_fe_finish<Fe26 / Fe28>); the rate is the one measured in THIS run.
       achieved = scalars/s x wave-instructions per scalar (= per-lane instructions / 64 lanes)      [wave-instr/s]
       peak     = 1024 SIMDs x 2.4 GHz / cost,  cost = (5.0 x mad + 2.5 x (instr - mad)) / instr     [wave-instr/s]
     5.0 / 2.5 cycles per wave-instruction per SIMD: measured issue costs of v_mad_u64_u32 and of simple 32-bit ALU
     instructions (profiles/r01_valubench.log); 2.4 GHz is the nominal peak clock, so frac is a lower bound when the
     part clocks lower under this load (the PMC file records the clock seen during its pass)."""
-    for tag in ("r03", "r02", "r01g"):
+    for tag in ("r04", "r03", "r02", "r01g"):
         path = os.path.join(ROOT, "profiles", "%s_valu_pmc.json" % tag)
         if os.path.exists(path):
             break
     else:
         return None
     doc = json.load(open(path))
-    if "k_x25519_fe26_xz" in doc and "k_fe_finish_fe26" in doc:
+    if curve == "X448":
+        k, f = doc.get("k_x448_fe28_xz"), doc.get("k_fe_finish_fe28")
+        if not (k and f):
+            return None
+        instr = k["SQ_INSTS_VALU"] * 64.0 / k["scalars"] + f["SQ_INSTS_VALU"] * 64.0 / f["scalars"]
+        # multiply-adds per scalar from the ISA (tools/ct_audit.py's disassembly of capi_X448.o): 448 steps x 1354 v_mad_u64_u32 (2874 VALU
+        # instructions per step = the counter's 1 288 178 per scalar); finish: 3 multiplications (256 each) + 1/32 of an inversion (447 S x 136 + 13 M x 256)
+        mad = k.get("mad_per_scalar", 448 * 1354) + f.get("mad_per_scalar", 3 * 256 + (447 * 136 + 13 * 256) / 32.0)
+        kernels = "k_x448_fe28_xz + k_fe_finish<Fe28,16,7>"
+    elif "k_x25519_fe26_xz" in doc and "k_fe_finish_fe26" in doc:
         k, f = doc["k_x25519_fe26_xz"], doc["k_fe_finish_fe26"]
         instr = k["SQ_INSTS_VALU"] * 64.0 / k["scalars"] + f["SQ_INSTS_VALU"] * 64.0 / f["scalars"]
         # multiply-adds per scalar from the ISA: 255 steps x 739; finish: 4 multiplications (101 each) + 1/32 of an inversion
@@ -205,7 +215,11 @@ def measure_traffic(timeout_s=240):
     with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes; the program itself after `--`), and their
     counter_collection.csv is read back.  gfx950 correction of that section: FETCH_SIZE reports half the bytes of a 16-B-per-lane
     coalesced streaming read -> doubled; WRITE_SIZE is exact; both in KiB.  Any failure (no rocprofv3, a refused counter) returns
-    None and the caller falls back to the committed summary of the same passes (profiles/traffic_modmul_X25519.json)."""
+    a dict with only "failed": <reason>; the caller then quotes the committed summary of the same passes
+    (profiles/traffic_modmul_X25519.json) and says in traffic_source that the live measurement failed and why.
+    The program after `--` is the REAL interpreter binary of this process (os.path.realpath(sys.executable)): a `python3`
+    resolved through PATH may be a shim or wrapper script -- an exec hop after the profiler's preload has initialised the GPU,
+    which this pool forbids -- or another interpreter without torch."""
     import csv
     import glob
     import shutil
@@ -213,7 +227,8 @@ def measure_traffic(timeout_s=240):
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None
+        return {"failed": "rocprofv3 not found"}
+    py = os.path.realpath(sys.executable)
     kern = "k_binary<ma::P_X25519, ma::OpMulAuto<ma::P_X25519"
     out = {}
     env = dict(os.environ, TMPDIR="/tmp", MA_BENCH_PLACEMENTS="1", MA_BENCH_CHILD="1")
@@ -221,18 +236,18 @@ def measure_traffic(timeout_s=240):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(base, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", "python3", os.path.abspath(__file__),
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", py, os.path.abspath(__file__),
                    "--steps", "5", "--warmup", "2", "--no-cpu", "--no-ladder", "--no-others", "--no-verify", "--no-traffic"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
             files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
             if r.returncode != 0 or not files:
-                return None
+                return {"failed": "%s pass: exit code %d, %d counter file(s)" % (counter, r.returncode, len(files))}
             vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0])) if kern in row["Kernel_Name"] and row.get("Counter_Name", counter) == counter]
             if not vals:
-                return None
+                return {"failed": "%s pass: no row of the headline kernel in the counter file" % counter}
             out[counter] = (sum(vals) / len(vals), len(vals))
-    except Exception:
-        return None
+    except Exception as ex:
+        return {"failed": "%s: %s" % (type(ex).__name__, str(ex)[:120])}
     finally:
         shutil.rmtree(base, ignore_errors=True)
     fk, wk = out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
@@ -267,6 +282,9 @@ def main():
     ap.add_argument("--no-others", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="do not measure the headline kernel's HBM traffic with rocprofv3 child passes (N=1 only; the committed summary is quoted instead)")
     ap.add_argument("--no-verify", action="store_true", help="skip the per-rank spot check of the timed outputs against the CPU oracle")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="x25519 block: weak = 2^MA_BENCH_LOG2_LADDER records per GPU (default); strong = BASELINE.json configs[4] literally, "
+                         "2^MA_BENCH_LOG2_LADDER_TOTAL (26) records divided over the N ranks.  The headline modmul line is weak either way.")
     ap.add_argument("--launch-check", action="store_true",
                     help="only check the rank launch: gloo group over the N ranks, no GPU work (tests/test_bench_launch.py)")
     args = ap.parse_args()
@@ -380,6 +398,22 @@ def main():
     value = world * n * args.steps / dt
     achieved = BYTES_PER_MODMUL * n / (kern_ms * 1e-3) / 1e9
 
+    # SURVEY 8(d) "report median": per-launch durations of a SEPARATE pass of the same launches on the same buffers (one event
+    # between consecutive launches; the timed region above keeps the contract's single bracket and is not touched)
+    nl = max(20, min(args.steps, 100))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nl + 1)]
+    torch.cuda.synchronize()
+    for i in range(nl):
+        evs[i].record()
+        F.modmul(a, b, out=c)
+    evs[nl].record()
+    torch.cuda.synchronize()
+    per_launch = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nl))
+    launch_stats = {"launches": nl, "median_ms": per_launch[nl // 2] if nl % 2 else 0.5 * (per_launch[nl // 2 - 1] + per_launch[nl // 2]),
+                    "min_ms": per_launch[0], "max_ms": per_launch[-1], "p10_ms": per_launch[nl // 10], "p90_ms": per_launch[(9 * nl) // 10]}
+    launch_stats["median_GBps"] = BYTES_PER_MODMUL * n / (launch_stats["median_ms"] * 1e-3) / 1e9
+    launch_stats["frac_of_hbm_peak_median"] = launch_stats["median_GBps"] / HBM_PEAK_GBS
+
     # size-independent correctness guard inside the bench: a*b == b*a and (a*b) canonical form is stable
     chk = F.modmul(b, a)
     assert torch.equal(chk, c), "modmul is not commutative bit-for-bit: kernel bug"
@@ -437,6 +471,15 @@ def main():
                                                                               "kernel_ms": ms, "frac_of_hbm_peak": BYTES_PER_MODMUL * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                                               "note": "same operand values, same kernel, the other HBM layout; one placement (no probe)"}
         del ao, bo, co
+        # what a caller gets who writes Field("X25519") and nothing else (no tile argument): the object's default layout
+        Fd = Field("X25519", dev)
+        ad, bd = Fd.uniform(n, seed=SEED, array=AID + 0), Fd.uniform(n, seed=SEED, array=AID + 1)
+        cd = torch.empty_like(ad)
+        ms = rate(lambda: Fd.modmul(ad, bd, out=cd))
+        assert torch.equal(Fd.to_flat(cd), F.to_flat(c)), "the default-layout batch disagrees"
+        data_sets["default_caller"] = {"default_caller_GBps": BYTES_PER_MODMUL * n / (ms * 1e-3) / 1e9, "kernel_ms": ms, "frac_of_hbm_peak": BYTES_PER_MODMUL * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "layout": "tiled, tile = %d" % ad.shape[2] if ad.dim() == 3 else "flat", "note": "Field('X25519').uniform(n) / .modmul(): no layout argument given"}
+        del ad, bd, cd
 
     # the other single-GPU configs of BASELINE.json (configs[2], configs[3]) with the same protocol, short runs:
     # parity for them is in tests/; these are side figures, not the headline
@@ -581,24 +624,32 @@ def main():
             from modarith_amd.fuse import bench_chain
             ch = bench_chain("X25519")
             fz = ch.build()
-            t1, t2, zc = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+            t1, t2, zc, zf = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
             def calls():
                 F.modadd(a, b, out=t1); F.modsub(a, b, out=t2); F.modmul(t1, t2, out=t1); F.modsqr(t1, out=zc)
-            ms_f, ms_c = rate(lambda: fz(a, b, out=[c])), rate(calls)
-            assert torch.equal(c, zc), "fused chain differs from the call-by-call sequence"
+            ms_f, ms_c = rate(lambda: fz(a, b, out=[zf])), rate(calls)       # the chain writes its OWN buffer: c stays a * b for the verifier
+            chain_equal = bool(torch.equal(zf, zc))
             others["fused_chain_X25519"] = {"chain": "modsqr(modmul(modadd(a,b), modsub(a,b)))", "elements": n, "fused_ms": ms_f, "calls_ms": ms_c,
                                             "speedup": ms_c / ms_f, "fused_bytes_per_element": ch.traffic_bytes(), "calls_bytes_per_element": ch.unfused_traffic_bytes(),
                                             "fused_GBps": ch.traffic_bytes() * n / (ms_f * 1e-3) / 1e9, "field_ops_per_s_per_gpu": 4 * n / (ms_f * 1e-3),
-                                            "limbs_equal_to_call_sequence": True}
-            del t1, t2, zc
-            F.modmul(a, b, out=c)                              # the verifier below checks c = a * b
-        except Exception as ex:                                # a missing compiler on the box must not cost the headline line
+                                            "frac_of_hbm_peak": ch.traffic_bytes() * n / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "limbs_equal_to_call_sequence": chain_equal}
+            del t1, t2, zc, zf
+        except (RuntimeError, OSError, subprocess.CalledProcessError, ValueError) as ex:   # a missing compiler on the box must not cost the headline line
             others["fused_chain_X25519"] = {"skipped": repr(ex)[:200]}
+            chain_equal = True
+        assert chain_equal, "fused chain differs from the call-by-call sequence"
 
     ladder = None
     my_lt = None
+    x448 = None
     if not args.no_ladder:
-        m = 1 << LOG2_LADDER
+        if args.scaling == "strong":
+            # BASELINE.json configs[4] literally: 2^26 records in total, contiguous shards of 2^26 / N per rank
+            total = 1 << int(os.environ.get("MA_BENCH_LOG2_LADDER_TOTAL", "26"))
+            m = total // world + (1 if rank < total % world else 0)
+        else:
+            m = 1 << LOG2_LADDER
         k = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)
         u = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)
         o = torch.empty_like(u)
@@ -612,24 +663,29 @@ def main():
         lt = (time.perf_counter() - t0) / reps
         my_lt = lt
         gather_ms = None
+        m_all = m
         if use_dist:
             from modarith_amd.dist import gather_records
             payload = o if backend == "nccl" else o.cpu()
+            tt = torch.tensor([m], dtype=torch.int64, device=cdev)
+            dist.all_reduce(tt)
+            m_all = int(tt[0])
             barrier()
             t0 = time.perf_counter()
-            allv = gather_records(payload, world * m, dst=0)   # the only collective: final result gather (RCCL over xGMI)
+            allv = gather_records(payload, m_all, dst=0)       # the only collective: final result gather (RCCL over xGMI)
             barrier()
             gather_ms = (time.perf_counter() - t0) * 1e3
             if rank == 0:
-                assert allv.shape[0] == world * m and torch.equal(allv[:m].to(o.device), o)
+                assert allv.shape[0] == m_all and torch.equal(allv[:m].to(o.device), o)
             del allv
             lt, gather_ms = max_over_ranks([lt, gather_ms])
-        ladder = {"value": world * m / lt, "unit": "X25519 scalar-mults/s", "scalars_per_gpu": m, "ms_per_pass": lt * 1e3,
+        ladder = {"value": m_all / lt, "unit": "X25519 scalar-mults/s", "scalars_per_gpu": m, "scalars_total": m_all, "ms_per_pass": lt * 1e3,
+                  "scaling": args.scaling,
                   "gather_ms": gather_ms, "io_bytes_per_scalar": 96,
-                  "gather_GBps": (world * m * 32 / (gather_ms * 1e-3) / 1e9) if gather_ms else None,
-                  "gather_payload_bytes": world * m * 32 if gather_ms else None,
+                  "gather_GBps": (m_all * 32 / (gather_ms * 1e-3) / 1e9) if gather_ms else None,
+                  "gather_payload_bytes": m_all * 32 if gather_ms else None,
                   "bound": "VALU 32-bit integer multiply-add issue (not HBM)",
-                  "roofline": valu_roofline(m / lt)}
+                  "roofline": valu_roofline(m / my_lt)}
         if single:
             # public-key generation: the same function on the base point u = 9 (rfc7748.c:297-333), fixed-base kernel
             from modarith_amd.field import rfc7748_base
@@ -641,7 +697,46 @@ def main():
             assert torch.equal(pk[:4096], rfc7748("X25519", k[:4096].contiguous(), ub)), "fixed-base public keys differ from the ladder on u = 9"
             del pk, ub
             ladder["base_point_public_keys_per_s_per_gpu"] = m / tb
-
+            # SURVEY 8(d) "include H2D/D2H separately for C5": the reference's own GPU harness holds its records on the HOST
+            # (simd/rfc7748_simt.cu:257-270 cudaMemcpy in, 302-312 cudaMemcpy out).  Pinned host buffers, C ABI only
+            # (modarith_amd/hostio.py): the two transfer legs alone, the three legs one after the other, and the pipelined form
+            # (three streams, two device slots, chunks of 2^20 records) whose bytes are compared with the device-resident result.
+            from modarith_amd import _lib as mlib
+            from modarith_amd.hostio import PinnedBytes, ladder_host
+            L = mlib.load()
+            hk, hu, hv = PinnedBytes(m, 32), PinnedBytes(m, 32), PinnedBytes(m, 32)
+            hk.array[:] = k.cpu().numpy(); hu.array[:] = u.cpu().numpy()
+            def leg(fn, reps=3):
+                fn(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps
+            def h2d():
+                mlib.check(L.modarith_amd_memcpy_h2d(k.data_ptr(), hk.ptr, m * 32, None), "h2d"); mlib.check(L.modarith_amd_memcpy_h2d(u.data_ptr(), hu.ptr, m * 32, None), "h2d")
+                mlib.check(L.modarith_amd_sync(None), "sync")
+            def d2h():
+                mlib.check(L.modarith_amd_memcpy_d2h(hv.ptr, o.data_ptr(), m * 32, None), "d2h"); mlib.check(L.modarith_amd_sync(None), "sync")
+            t_in, t_out = leg(h2d), leg(d2h)
+            t_pipe = leg(lambda: ladder_host("X25519", hk, hu, hv, chunk=1 << 20), reps=2)
+            import numpy as np
+            assert np.array_equal(hv.array, o.cpu().numpy()), "host-resident (pipelined) ladder differs from the device-resident one"
+            ladder["host_resident"] = {"h2d_ms": t_in * 1e3, "d2h_ms": t_out * 1e3, "h2d_bytes": m * 64, "d2h_bytes": m * 32,
+                                       "h2d_GBps": m * 64 / t_in / 1e9, "d2h_GBps": m * 32 / t_out / 1e9,
+                                       "end_to_end_serial_per_s": m / (t_in + lt + t_out), "end_to_end_pipelined_per_s": m / t_pipe,
+                                       "pipelined_ms": t_pipe * 1e3, "chunk_records": 1 << 20, "device_resident_per_s": m / lt,
+                                       "pipelined_over_device_resident": lt / t_pipe,
+                                       "note": "pinned host records in, pinned host results out (simd/rfc7748_simt.cu:257-312 shape); pipelined bytes equal the device-resident result"}
+            hk.close(); hu.close(); hv.close()
+            # the other curve of rfc7748.c (120-132): X448, 56-byte records, 2^MA_BENCH_LOG2_X448 (21) of them
+            m4 = 1 << int(os.environ.get("MA_BENCH_LOG2_X448", "21"))
+            k4 = torch.randint(0, 256, (m4, 56), dtype=torch.uint8, device=dev, generator=gen)
+            u4 = torch.randint(0, 256, (m4, 56), dtype=torch.uint8, device=dev, generator=gen)
+            o4 = torch.empty_like(u4)
+            t4 = leg(lambda: rfc7748("X448", k4, u4, out=o4), reps=2)
+            x448 = {"value": m4 / t4, "unit": "X448 scalar-mults/s", "scalars_per_gpu": m4, "ms_per_pass": t4 * 1e3, "io_bytes_per_scalar": 168,
+                    "bound": "VALU 32-bit integer multiply-add issue (not HBM)", "roofline": valu_roofline(m4 / t4, "X448")}
     # EVERY rank spot-checks its own timed outputs against the CPU oracle (checker only, outside every timed
     # region): first / last 4096 and a strided sample of the modmul batch and of the ladder records.  The verdicts are
     # AND-reduced over the ranks, so that one N-GPU line says whether all N devices computed the reference's results.
@@ -691,7 +786,7 @@ def main():
             "pci_bus_id": ("%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), bus, getattr(props, "pci_device_id", 0))) if bus is not None else None,
             "uuid": str(getattr(props, "uuid", "")) or None,
             "modmul_per_s": n * args.steps / my_dt, "kernel_ms": my_kern_ms, "hbm_GBps": BYTES_PER_MODMUL * n / (my_kern_ms * 1e-3) / 1e9,
-            "x25519_per_s": (k.shape[0] / my_lt) if my_lt else None, "verified_against_oracle": my_ok}
+            "x25519_per_s": (k.shape[0] / my_lt) if my_lt else None, "x25519_records": k.shape[0] if my_lt else None, "verified_against_oracle": my_ok}
     ranks = [mine]
     dist_info = None
     if use_dist:
@@ -717,13 +812,16 @@ def main():
         # the same build: a property of the kernel and the batch size, so it is only quoted for the profiled size
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_modmul_X25519.json")
-        if live_traffic is not None:              # (the children inherit this process's environment: same batch size and layout)
+        live_failed = live_traffic.get("failed") if live_traffic else None
+        if live_traffic is not None and not live_failed:   # (the children inherit this process's environment: same batch size and layout)
             traffic, traffic_source = live_traffic["hbm_bytes_per_launch"], live_traffic["source"] + " (%d launches)" % live_traffic["launches_sampled"]
         elif os.path.exists(tpath):
             tdoc = json.load(open(tpath))
             if tdoc.get("algorithmic_bytes_per_launch") == BYTES_PER_MODMUL * n:
                 traffic = tdoc.get("hbm_bytes_per_launch")
                 traffic_source = "profiles/traffic_modmul_X25519.json (rocprofv3 --pmc passes, tag %s)" % tdoc.get("tag")
+                if live_failed:
+                    traffic_source += "; the live measurement of this run FAILED (%s)" % live_failed
         per_rank = [r["modmul_per_s"] for r in ranks]
         kms = [r["kernel_ms"] for r in ranks]
         med = sorted(probe_rates)[len(probe_rates) // 2] if probe_rates else None      # upper median of the probe rates
@@ -749,6 +847,10 @@ def main():
                          "frac_first_placement": (probe_rates[0] / HBM_PEAK_GBS) if probe_rates else None},
             "cpu_baseline": cpu,
             "x25519": ladder,
+            "x448": x448,
+            # per-launch durations of a separate pass of the same launches (SURVEY 8(d) "report median"); ms_per_step above is the contract's mean
+            "ms_per_step_median": launch_stats["median_ms"], "ms_per_step_min": launch_stats["min_ms"], "ms_per_step_max": launch_stats["max_ms"],
+            "launch_stats": launch_stats,
             "data_sets": data_sets,
             "other_configs": others,
             "verified_against_oracle": verified,

@@ -15,15 +15,16 @@
 #include "modarith_amd.h"
 
 #define Nlimbs 5
-#define TILE 4096
 #define CK(call) do { if ((call) != 0) { printf("%s failed: %s\n", #call, modarith_amd_last_error()); return 1; } } while (0)
 
 static uint64_t rnd_state = 88172645463325252ull;
 static uint64_t rnd(void) { rnd_state ^= rnd_state << 13; rnd_state ^= rnd_state >> 7; rnd_state ^= rnd_state << 17; return rnd_state; }
 
 int main(int argc, char **argv) {
-    size_t n = argc > 1 ? (size_t)atol(argv[1]) : (size_t)5 * TILE + 1237;      /* odd, with a partial last tile */
-    size_t ntiles = (n + TILE - 1) / TILE, words = ntiles * Nlimbs * TILE;
+    size_t n = argc > 1 ? (size_t)atol(argv[1]) : (size_t)5 * 4096 + 1237;      /* odd, with a partial last tile */
+    /* the layout is the library's recommendation for this batch size: tiles of 4096 from two whole tiles on (flat rows
+     * below), and the buffer size that goes with it -- a caller never hard-codes either */
+    const size_t TILE = modarith_amd_recommended_ld(n), words = modarith_amd_batch_words(n, Nlimbs, TILE);
     if (modarith_amd_device_count() < 1) { puts("no GPU"); return 2; }
     ma_spint (*x)[Nlimbs] = malloc(n * sizeof *x), (*y)[Nlimbs] = malloc(n * sizeof *y), (*z)[Nlimbs] = malloc(n * sizeof *z);
     for (size_t j = 0; j < n; j++)
@@ -62,7 +63,7 @@ int main(int argc, char **argv) {
         modinv_X25519_ct(w, NULL, w); redc_X25519_ct(w, w);
         if (memcmp(w, z[j], sizeof w) != 0) { bad++; printf("element %zu differs\n", j); }
     }
-    printf("batched chain over %zu elements in tiles of %d: %s\n", n, TILE, bad ? "MISMATCH" : "equal to the scalar entry points");
+    printf("batched chain over %zu elements, limb stride %zu (%s): %s\n", n, TILE, TILE < n ? "tiles" : "flat rows", bad ? "MISMATCH" : "equal to the scalar entry points");
     modarith_amd_free(dx_aos); modarith_amd_free(dy_aos); modarith_amd_free(dx); modarith_amd_free(dy); modarith_amd_free(dt); modarith_amd_free(dz);
     free(x); free(y); free(z);
     return bad != 0;

@@ -79,6 +79,16 @@ int modarith_amd_host_free(void *hptr);
 /* element-major (spint x[n][nlimbs], how CPU callers hold arrays of elements) <-> SoA (flat or tiled, by ld as above); any limb count */
 int modarith_amd_aos_to_soa(const ma_spint *aos, ma_spint *soa, size_t n, int nlimbs, size_t ld, void *stream);
 int modarith_amd_soa_to_aos(const ma_spint *soa, ma_spint *aos, size_t n, int nlimbs, size_t ld, void *stream);
+/* layout helpers: the limb stride a caller without a layout of its own should use for a batch of n elements (tiles of 4096 once
+ * the batch holds two of them, else flat rows: the TILED note above), and the number of 64-bit words a batch of n elements of
+ * nlimbs limbs occupies with stride ld (flat: nlimbs*ld; tiled: ceil(n/ld) whole tiles) */
+size_t modarith_amd_recommended_ld(size_t n);
+size_t modarith_amd_batch_words(size_t n, int nlimbs, size_t ld);
+/* the library's stream-ordered scratch (the split form of rfc7748_<C>_batch, in-place modinv_<P>_batch) caches up to 1.25 GiB per
+ * device between calls; scratch_trim gives what is cached beyond keep_bytes on the current device back to the driver */
+int modarith_amd_scratch_trim(size_t keep_bytes);
+/* diagnostic: the name of the kernel family this thread's last batched call launched ("rfc7748(split)", "rfc7748(field form)", ...) */
+const char *modarith_amd_last_launch(void);
 /* per-prime macro block of field.c (pseudo.py:1403-1407): returns 0 if `prime` is unknown */
 int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbits, int *nbytes, int *montgomery);
 

@@ -84,7 +84,8 @@ UTIL_FUNCS = ("modarith_amd_abi_version", "modarith_amd_last_error", "modarith_a
               "modarith_amd_set_device", "modarith_amd_malloc", "modarith_amd_free", "modarith_amd_memcpy_h2d",
               "modarith_amd_memcpy_d2h", "modarith_amd_sync", "modarith_amd_aos_to_soa", "modarith_amd_soa_to_aos",
               "modarith_amd_stream_create", "modarith_amd_stream_destroy", "modarith_amd_stream_wait", "modarith_amd_host_alloc", "modarith_amd_host_free",
-              "modarith_amd_field_info")
+              "modarith_amd_field_info", "modarith_amd_recommended_ld", "modarith_amd_batch_words", "modarith_amd_scratch_trim",
+              "modarith_amd_last_launch")
 
 
 def _declare_curve(lib, C: str) -> None:
@@ -189,6 +190,13 @@ def load() -> ctypes.CDLL:
     lib.modarith_amd_stream_wait.argtypes = [_P, _P]
     lib.modarith_amd_host_alloc.argtypes = [ctypes.POINTER(c_void_p), c_size_t]
     lib.modarith_amd_host_free.argtypes = [_P]
+    lib.modarith_amd_recommended_ld.argtypes = [c_size_t]
+    lib.modarith_amd_recommended_ld.restype = c_size_t
+    lib.modarith_amd_batch_words.argtypes = [c_size_t, c_int, c_size_t]
+    lib.modarith_amd_batch_words.restype = c_size_t
+    lib.modarith_amd_scratch_trim.argtypes = [c_size_t]
+    lib.modarith_amd_scratch_trim.restype = c_int
+    lib.modarith_amd_last_launch.restype = c_char_p
     _lib = lib
     return lib
 

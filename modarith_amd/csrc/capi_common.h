@@ -20,6 +20,7 @@ bool force_fast();         // env MA_FORCE_FAST=1: element-wise modmul/modsqr/nr
 bool force_exact();        // env MA_FORCE_EXACT=1: element-wise modmul/modsqr on the exact 128-bit products only (tests)
 bool inv_simul();          // env MA_INV_SIMUL=0: modinv_<P>_batch never shares an inversion between elements
 bool ladder_split();       // env MA_LADDER_SPLIT=0: the batched ladders never take the split form (one inversion per lane)
+int scratch_trim(size_t keep_bytes);   // give the current device's cached scratch beyond keep_bytes back to the driver
 bool ladder_use_field();   // env MA_LADDER_IMPL=field: X25519 ladder on the 5x51 field.c-form arithmetic
 
 // tiled batches (kernels.h Ld) take a much larger cap: on tiles the streaming rate keeps rising with the number of

@@ -8,10 +8,12 @@
 namespace ma {
 
 static thread_local std::string g_err;
+static thread_local const char* g_last_launch = "";
 
 void set_error(const std::string& msg) { g_err = msg; }
 
 int check_launch(const char* what) {
+    g_last_launch = what;                      // string literals only: modarith_amd_last_launch()
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -78,31 +80,39 @@ unsigned char* Staging::get() {
 // first use, that keeps what it has handed out once (release threshold = max), so that a resident caller pays for the
 // workspace of its largest batch once and not per call.  nullptr when pools are unavailable: callers then take the
 // self-contained kernels.
+static std::mutex g_pool_mu;
+static hipMemPool_t g_pools[Staging::MAX_DEVICES] = {};
+static bool g_pool_failed[Staging::MAX_DEVICES] = {};
+// what the pool keeps cached between calls: enough for the split ladder of a 2^24-record batch (1.2 GiB) -- beyond that, freed
+// blocks go back to the driver at the next synchronisation; modarith_amd_scratch_trim() releases on demand
+static constexpr uint64_t POOL_KEEP_BYTES = (uint64_t)1280 << 20;
 void* scratch_alloc(size_t bytes, hipStream_t s) {
-    static std::mutex mu;
-    static hipMemPool_t pools[Staging::MAX_DEVICES] = {};
-    static bool failed[Staging::MAX_DEVICES] = {};
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= Staging::MAX_DEVICES) return nullptr;
+    // never allocate while a capture is in progress that this call could invalidate: on the stream itself, or -- for the legacy
+    // default stream (s == nullptr), which a global-mode capture of another thread's stream also covers -- anywhere in the process
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
     hipMemPool_t pool = nullptr;
     {
-        std::lock_guard<std::mutex> lock(mu);
-        if (!pools[d] && !failed[d]) {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        if (!g_pools[d] && !g_pool_failed[d]) {
             hipMemPoolProps props = {};
             props.allocType = hipMemAllocationTypePinned;
             props.handleTypes = hipMemHandleTypeNone;
             props.location.type = hipMemLocationTypeDevice;
             props.location.id = d;
-            if (hipMemPoolCreate(&pools[d], &props) == hipSuccess) {
-                uint64_t keep = ~(uint64_t)0;
-                (void)hipMemPoolSetAttribute(pools[d], hipMemPoolAttrReleaseThreshold, &keep);
+            if (hipMemPoolCreate(&g_pools[d], &props) == hipSuccess) {
+                uint64_t keep = POOL_KEEP_BYTES;
+                (void)hipMemPoolSetAttribute(g_pools[d], hipMemPoolAttrReleaseThreshold, &keep);
             } else {
-                pools[d] = nullptr;
-                failed[d] = true;
+                g_pools[d] = nullptr;
+                g_pool_failed[d] = true;
                 (void)hipGetLastError();
             }
         }
-        pool = pools[d];
+        pool = g_pools[d];
     }
     if (!pool) return nullptr;
     void* p = nullptr;
@@ -111,6 +121,18 @@ void* scratch_alloc(size_t bytes, hipStream_t s) {
         return nullptr;
     }
     return p;
+}
+// give cached scratch of the current device back to the driver, keeping at most keep_bytes
+int scratch_trim(size_t keep_bytes) {
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return (int)e;
+    if (d < 0 || d >= Staging::MAX_DEVICES) return (int)hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (!g_pools[d]) return 0;
+    e = hipMemPoolTrimTo(g_pools[d], keep_bytes);
+    if (e != hipSuccess) { set_error(std::string("hipMemPoolTrimTo: ") + hipGetErrorString(e)); return (int)e; }
+    return 0;
 }
 void scratch_free(void* p, hipStream_t s) {
     if (p) (void)hipFreeAsync(p, s);
@@ -249,6 +271,16 @@ extern "C" {
 
 int modarith_amd_abi_version(void) { return MODARITH_AMD_ABI; }
 const char* modarith_amd_last_error(void) { return g_err.c_str(); }
+const char* modarith_amd_last_launch(void) { return g_last_launch; }
+int modarith_amd_scratch_trim(size_t keep_bytes) { return scratch_trim(keep_bytes); }
+// the limb stride a caller without a layout of its own should use (include/modarith_amd.h, TILED): tiles of 4096 elements once
+// the batch holds two of them, flat rows below
+size_t modarith_amd_recommended_ld(size_t n) { return n >= 2 * (size_t)4096 ? (size_t)4096 : n; }
+size_t modarith_amd_batch_words(size_t n, int nlimbs, size_t ld) {
+    if (nlimbs < 1 || ld == 0) return 0;
+    if (ld >= n) return (size_t)nlimbs * ld;                       // flat
+    return (n + ld - 1) / ld * ld * (size_t)nlimbs;               // whole tiles
+}
 int modarith_amd_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

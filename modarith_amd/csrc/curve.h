@@ -3,20 +3,30 @@
 // curve class K that supplies the formulas (add, dbl, neg, inf, isinf, affine, setxy, gen, cof), plus the
 // batched kernels of the curve API (curve.h:13-29).  One point per lane, coordinates in VGPRs, built from the
 // bit-exact Field<P> functions in the reference's order.  The 9-entry window table of ecnXXXmul does not fit the
-// register file (9 x 3 x N limbs); it lives in a per-lane slot of a global workspace laid out
-// [entry][coord][limb][lane] (coalesced; sized to the resident grid so it stays in the 256 MiB Infinity Cache) and
-// is scanned in full on every lookup: the table index never forms an address, selection is lane-predicated modcmv.
+// register file (9 x 3 x N limbs); it lives in the wave's slab of a global workspace laid out
+// [wave][entry][coord][limb][lane] (coalesced 512-byte rows; sized to the resident grid so it stays in the 256 MiB
+// Infinity Cache) and is scanned in full on every lookup: the table index never forms an address, selection is
+// lane-predicated modcmv.  The recoded scalar digits live in LDS (one byte per window per lane).
 #pragma once
 #include "field.h"
 #include "kernels.h"
 
 namespace ma {
 
-template <class Crv, class P_>
+// scalar(i): i again, pinned into an SGPR.  The window counters of the multiplication loops are wave-uniform, but feed the LDS address of
+// the window's digit, so the compiler may keep them in a VGPR and close the loop with a carry-out vote (v_subrev_co + s_cbranch_vccz):
+// harmless, yet indistinguishable in the ISA from a branch on lane data (tools/ct_audit.py).  Pinned, the loop closes on s_cmp / SCC.
+MA_DEV int scalar(int i) {
+    asm volatile("" : "+s"(i));
+    return i;
+}
+template <class Crv, class P_, class F_ = Field<P_, true>>
 struct CurveOps {
     using P = P_;
-    using F = Field<P, true>;   // FAST product path where the driver proved it (P::SPLIT > 0), else exact
-    static constexpr int N = P::N;
+    using F = F_;               // Field<P, true>: FAST product path where the driver proved it (P::SPLIT > 0), else exact; or a resident form (fh51.h)
+    using limb_t = typename F::limb_t;
+    static constexpr int N = P::N;             // limbs of a coordinate in HBM and in the window tables
+    static constexpr int NL = F::NL;           // words of a coordinate in registers
     static constexpr int NB = P::NBYTES;
     static constexpr int NW = (NB + 7) / 8;          // 64-bit words of a scalar / coordinate record
     static constexpr int PADB = 8 * NW - NB;         // unused top bytes of the top word (6 for the 66-byte NIST521 records)
@@ -32,7 +42,7 @@ struct CurveOps {
             v[k] = x;
         });
     }
-    struct Point { spint x[N], y[N], z[N]; };
+    struct Point { limb_t x[NL], y[NL], z[NL]; };
 
     static MA_DEV void cpy(const Point& q, Point& p) { F::modcpy(q.x, p.x); F::modcpy(q.y, p.y); F::modcpy(q.z, p.z); }
     static MA_DEV void ran(int r, Point& p) {                                       // edwards.c:55-63
@@ -49,7 +59,7 @@ struct CurveOps {
     }
     // edwards.c:208-218 / weierstrass.c:320-330
     static MA_DEV int cmp(const Point& p, const Point& q) {
-        spint a[N], b[N];
+        limb_t a[NL], b[NL];
         F::modmul(p.x, q.z, a);
         F::modmul(q.x, p.z, b);
         int eq = F::modcmp(a, b);
@@ -58,26 +68,42 @@ struct CurveOps {
         return eq & F::modcmp(a, b);
     }
 
-    // ---- window tables in the global workspace: slot of this lane, entry k (mul: one 9-entry table; mul2: two)
+    // ---- window tables in the global workspace.  Every wave (= workgroup of the scalar-multiplication kernels) owns one slab
+    // [entry][coord][limb][64 lanes]: the slab base is wave-uniform (SGPRs), a lane adds 8 * lane, and entry / coordinate / limb
+    // are compile-time or loop-uniform offsets -- the loads of a table scan need no per-lane address arithmetic (one
+    // global_load_dwordx2 v, v_lane, s[base] offset:imm per limb), and each is one contiguous 512-byte row.
+    static constexpr size_t ENTRY_WORDS = (size_t)3 * N * 64;            // one table entry of one wave
+    static constexpr size_t TABLE_WORDS = 2 * 9 * 3 * N;                 // per lane: room for the two tables of mul2
+    static constexpr size_t SLAB_WORDS = 64 * TABLE_WORDS;               // per wave
     struct Table {
-        spint* base;       // workspace + lane
-        size_t stride;     // total lanes
+        spint* base;       // slab of this wave (table of mul, or first / second table of mul2): wave-uniform
+        unsigned lane;     // 0..63
+        // here(): the lane offset as a value born at this access -- otherwise the row addresses (an entry of an 8- or 9-limb curve
+        // spans 12-14 KB, beyond one base register's +-4 KB immediate range) are loop-invariant, get hoisted to the top of the
+        // kernel and live (and spill) through the whole multiplication; recomputed they cost two instructions per access
+        MA_DEV unsigned here() const {
+            unsigned l = lane;
+            asm volatile("" : "+v"(l));
+            return l;
+        }
         MA_DEV void put(int k, const Point& w) const {
+            spint* q = base + (size_t)k * ENTRY_WORDS + here();
             static_for<0, N>([&](auto I) {
-                base[((size_t)(k * 3 + 0) * N + I) * stride] = w.x[I];
-                base[((size_t)(k * 3 + 1) * N + I) * stride] = w.y[I];
-                base[((size_t)(k * 3 + 2) * N + I) * stride] = w.z[I];
+                q[(0 * N + I) * 64] = F::pack(w.x, I);
+                q[(1 * N + I) * 64] = F::pack(w.y, I);
+                q[(2 * N + I) * 64] = F::pack(w.z, I);
             });
         }
         MA_DEV void get(int k, Point& w) const {
+            const spint* q = base + (size_t)k * ENTRY_WORDS + here();
             static_for<0, N>([&](auto I) {
-                w.x[I] = base[((size_t)(k * 3 + 0) * N + I) * stride];
-                w.y[I] = base[((size_t)(k * 3 + 1) * N + I) * stride];
-                w.z[I] = base[((size_t)(k * 3 + 2) * N + I) * stride];
+                F::unpack(q[(0 * N + I) * 64], w.x, I);
+                F::unpack(q[(1 * N + I) * 64], w.y, I);
+                F::unpack(q[(2 * N + I) * 64], w.z, I);
             });
         }
+        MA_DEV Table second() const { return Table{base + 9 * ENTRY_WORDS, lane}; }
     };
-    static constexpr size_t TABLE_WORDS = 2 * 9 * 3 * N;   // per lane: room for the two tables of mul2
 
     // constant-time lookup of sign(b) * W[|b|] (edwards.c:381-401): every entry is read
     static MA_DEV void select(int b, const Table& W, Point& p) {
@@ -110,80 +136,50 @@ struct CurveOps {
         Crv::inf(T);
         W.put(0, T);
         W.put(1, p);
+        // p is read back from W[1] where an odd entry needs it: no point stays live across a formula it is not part of
 #pragma unroll 1
         for (int k = 2; k <= 8; k++) {
-            if (k & 1) { W.get(k - 1, T); Crv::add(p, T); }
+            if (k & 1) { Point P1; W.get(k - 1, T); W.get(1, P1); Crv::add(P1, T); }
             else       { W.get(k >> 1, T); Crv::dbl(T); }
             W.put(k, T);
         }
     }
 
-    // Signed 4-bit recoding of a scalar (edwards.c:452-467), produced digit by digit from the top: the scalar stays
-    // left-aligned in NW words (nib), the carries c_0 = 0, c_{j+1} = (nibble_j + c_j > 7) are computed once into a bit
-    // mask (car), so no per-lane digit array is needed.  top() is the digit w[2*NB] (the final carry), next() then
-    // returns w[2*NB-1], ..., w[0].
-    struct Recoder {
-        spint nib[NW], car[NW];
-        unsigned cout;
-        int consumed;
-        MA_DEV int top(const spint* ew) {
-            // left-aligned (a no-op shift when Nbytes is a multiple of 8): the padding nibbles at the bottom are zero,
-            // produce no carry and are never reached by the 2*NB digits
-            static_for<0, NW>([&](auto K) { nib[K] = ew[K]; car[K] = 0; });
-            shl_words<8 * PADB, NW>(nib);
-            unsigned c = 0;
-            static_for<0, NW>([&](auto K) {
-                spint word = nib[K], cw = 0;
+    // Signed 4-bit recoding of a scalar (edwards.c:452-467): w_j = nibble_j + c_j - 16 c_{j+1}, c_0 = 0, c_{j+1} = (nibble_j + c_j > 7),
+    // j = 0 .. 2*NB-1, and w_{2*NB} = the final carry.  The digits are written once, before the point is touched, into the lane's
+    // column of an LDS array dg[j * 64] (one byte each, 2*NB+1 of them: 4-8.5 KB per wave) and read back one per window with a
+    // ds_read_i8 -- no scalar words or carry masks stay in registers during the multiplication.  Each lane reads only what it wrote
+    // itself (the kernels run one wave per workgroup), so no barrier is involved.
+    static constexpr int NDIG = 2 * NB + 1;
+    static MA_DEV void recode(const spint* ew, signed char* dg) {
+        unsigned c = 0;
+        static_for<0, NW>([&](auto K) {
+            constexpr int cnt = (2 * NB - 16 * K) < 16 ? (2 * NB - 16 * K) : 16;
+            spint word = ew[K];
+            signed char* d = dg + (size_t)(16 * K) * 64;
 #pragma unroll 1
-                for (int j = 0; j < 16; j++) {
-                    cw |= (spint)c << j;
-                    unsigned v = (unsigned)(word & 15) + c;
-                    c = v > 7 ? 1u : 0u;
-                    word >>= 4;
-                }
-                car[K] = cw;              // bit j = carry INTO nibble 16K + j
-            });
-            // car left-aligned: the carry into the current nibble in bit 63 of car[NW-1]; the carry OUT of the current
-            // nibble is the carry into the one above, i.e. the bit consumed in the previous step
-            static_for<0, NW>([&](auto K) { car[K] <<= 48; });   // 16 carry bits per word -> top of the word
-            cout = c;
-            consumed = 0;
-            return (int)c;
-        }
-        MA_DEV int next() {
-            const unsigned nb4 = (unsigned)(nib[NW - 1] >> 60);
-            const unsigned cin = (unsigned)(car[NW - 1] >> 63);
-            static_for<0, NW>([&](auto KK) {
-                constexpr int k = NW - 1 - KK;
-                nib[k] <<= 4;
-                if constexpr (k > 0) nib[k] |= nib[k - 1] >> 60;
-            });
-            car[NW - 1] <<= 1;
-            consumed++;
-            if ((consumed & 15) == 0) {          // 16 digits consumed: the next carry word moves up
-                static_for<0, NW - 1>([&](auto KK) {
-                    constexpr int k = NW - 1 - KK;
-                    car[k] = car[k - 1];
-                });
+            for (int j = 0; j < cnt; j++) {
+                const unsigned v = (unsigned)(word & 15) + c;
+                c = v > 7 ? 1u : 0u;
+                d[j * 64] = (signed char)((int)v - (int)(c << 4));
+                word >>= 4;
             }
-            const int digit = (int)(nb4 + cin) - (int)(cout << 4);
-            cout = cin;
-            return digit;
-        }
-    };
+        });
+        dg[(size_t)(2 * NB) * 64] = (signed char)c;
+    }
 
-    // P = e*P, signed 4-bit fixed window (edwards.c:435-482).  ew = the scalar as NW little-endian 64-bit words.
-    static MA_DEV void mul(const spint* ew, Point& p, const Table& W) {
-        Point Q;
-        Crv::inf(Q);
+    // P = e*P, signed 4-bit fixed window (edwards.c:435-482).  dg = the recoded scalar (recode() above).  The table lookup of a
+    // window comes after its four doublings (the order does not matter to either), so the looked-up point is not live across them.
+    static MA_DEV void mul(const signed char* dg, Point& p, const Table& W) {
         build_table(p, W);
-        Recoder rc;
-        select(rc.top(ew), W, p);
+        select((int)dg[(size_t)(2 * NB) * 64], W, p);
 #pragma unroll 1
         for (int i = 2 * NB - 1; i >= 0; i--) {
-            select(rc.next(), W, Q);
+            i = scalar(i);
 #pragma unroll 1
             for (int r = 0; r < 4; r++) Crv::dbl(p);
+            Point Q;
+            select((int)dg[(size_t)i * 64], W, Q);
             Crv::add(Q, p);
         }
     }
@@ -193,34 +189,24 @@ struct CurveOps {
     // multiplications sharing their doublings -- tables {0..8}P and {0..8}Q in the workspace, per window four
     // doublings and two complete additions -- so every lane runs the same 2*NB windows and the multiplication is
     // constant-time as well.  Same point as the reference's, another projective representative.
-    static MA_DEV void mul2(const spint* ew, const Point& p, const spint* fw, const Point& q, Point& r, const Table& W) {
-        // the two halves (table, lookup, addition) run through loops of two rolled iterations, so the instruction
-        // stream holds one copy of add / dbl / select, as in mul; t is wave-uniform
-        const size_t second = (size_t)9 * 3 * N * W.stride;
-        Point T;
-#pragma unroll 1
-        for (int t = 0; t < 2; t++) {
-            cpy(p, T);
-            if (t) cpy(q, T);
-            build_table(T, Table{W.base + (size_t)t * second, W.stride});
-        }
-        Recoder re, rf;
-        const int top_e = re.top(ew), top_f = rf.top(fw);
+    // de / df = the recoded scalars (two digit columns in LDS).
+    static MA_DEV void mul2(const signed char* de, const signed char* df, Point& r, const Table& W) {
+        // the tables {0..8}P (W) and {0..8}Q (W.second()) are built by the caller, one point loaded at a time (k_ed_mul2); the two
+        // halves (lookup, addition) run through a loop of two rolled iterations, so the instruction stream holds one copy of
+        // add / dbl / select, as in mul; t is wave-uniform
         Crv::inf(r);
 #pragma unroll 1
-        for (int t = 0; t < 2; t++) {
-            select(t ? top_f : top_e, Table{W.base + (size_t)t * second, W.stride}, T);
-            Crv::add(T, r);                      // first pass adds to the neutral element
-        }
+        for (int i = 2 * NB; i >= 0; i--) {
+            i = scalar(i);
+            if (i != 2 * NB) {
 #pragma unroll 1
-        for (int i = 2 * NB - 1; i >= 0; i--) {
-#pragma unroll 1
-            for (int k = 0; k < 4; k++) Crv::dbl(r);
-            const int de = re.next(), df = rf.next();
+                for (int k = 0; k < 4; k++) Crv::dbl(r);
+            }
 #pragma unroll 1
             for (int t = 0; t < 2; t++) {
-                select(t ? df : de, Table{W.base + (size_t)t * second, W.stride}, T);
-                Crv::add(T, r);
+                Point T;
+                select((int)(t ? df : de)[(size_t)i * 64], t ? W.second() : W, T);
+                Crv::add(T, r);                  // the first pass adds to the neutral element
             }
         }
     }
@@ -230,16 +216,13 @@ struct CurveOps {
     // non-zero digit down to k = 1: R = 2R, then R += W[w] or R -= W[-w].  Same field calls in the same order, hence the reference's
     // projective limbs -- and, like the reference ("not constant time"), a walk that depends on the scalars: lanes of a wave start
     // at different digits and skip different additions, so the wave pays for the union of their paths (measured: 4-18 % slower than mul2 above, tools/time_mul2.py).
-    // The digits are produced from the top by shifting e, 3e, f, 3f left one bit per step; no digit array is stored.
-    static MA_DEV void mul2_exact(const spint* ew, const Point& p, const spint* fw, const Point& q, Point& r, const Table& W) {
+    // jsf_digits() produces the digits from the top by shifting e, 3e, f, 3f left one bit per step and packs them, biased by 4, two
+    // per byte into the lane's LDS column (4*NB+4 bytes) BEFORE any point is loaded: the four multi-word shift registers (up to 72
+    // VGPRs for the 521-bit field) are dead by the time the walk starts.
+    static constexpr int JSF_TOP = 8 * NB + 7;                    // index of the highest digit (edwards.c:497)
+    static constexpr int JSF_BYTES = (JSF_TOP + 1) / 2;
+    static MA_DEV void jsf_digits(const spint* ew, const spint* fw, unsigned char* dj) {
         constexpr int NX = NW + 1;                        // 3e needs two more bits than e
-        constexpr int TOP = 8 * NB + 7;                   // index of the highest digit (edwards.c:497)
-        Point T;
-        Crv::inf(T); W.put(0, T);
-        W.put(1, p);
-        W.put(3, q);
-        cpy(q, T); sub(p, T); W.put(2, T);                // Q - P
-        cpy(q, T); Crv::add(p, T); W.put(4, T);           // Q + P
         spint a[NX], a3[NX], b[NX], b3[NX];
         static_for<0, NX>([&](auto K) { a[K] = K < NW ? ew[K < NW ? K : 0] : 0; b[K] = K < NW ? fw[K < NW ? K : 0] : 0; });
         {   // 3x = x + 2x over NX words
@@ -255,14 +238,42 @@ struct CurveOps {
                 b3[K] = sb2;
             });
         }
-        constexpr int S = NX * 64 - 1 - TOP;              // left-align: digit TOP in bit 63 of the top word
+        constexpr int S = NX * 64 - 1 - JSF_TOP;          // left-align: digit TOP in bit 63 of the top word
         shl_words<S, NX>(a); shl_words<S, NX>(a3); shl_words<S, NX>(b); shl_words<S, NX>(b3);
+#pragma unroll 1
+        for (int q = 0; q < JSF_BYTES; q++) {             // digits TOP-2q and TOP-2q-1 (the last byte's low half is digit 0: unused)
+            unsigned byte = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int j = ((int)(a3[NX - 1] >> 63) - (int)(a[NX - 1] >> 63)) + 3 * ((int)(b3[NX - 1] >> 63) - (int)(b[NX - 1] >> 63));
+                shl_words<1, NX>(a); shl_words<1, NX>(a3); shl_words<1, NX>(b); shl_words<1, NX>(b3);
+                byte = (byte << 4) | (unsigned)(j + 4);
+            }
+            dj[(size_t)q * 64] = (unsigned char)byte;
+        }
+    }
+    static MA_DEV void mul2_exact(const unsigned char* dj, const Point& p, const Point& q, Point& r, const Table& W) {
+        Point T;
+        Crv::inf(T); W.put(0, T);
+        W.put(1, p);
+        W.put(3, q);
+        // W[2] = Q - P (ecnXXXsub = copy, negate, add: edwards.c:114-119), W[4] = Q + P: one rolled loop, one copy of add
+#pragma unroll 1
+        for (int t = 0; t < 2; t++) {
+            Point w;
+            W.get(1, w);
+            if (t == 0) Crv::neg(w);
+            W.get(3, T);
+            Crv::add(w, T);
+            W.put(2 + 2 * t, T);
+        }
         Crv::inf(r);
         bool started = false;
 #pragma unroll 1
-        for (int i = TOP; i >= 1; i--) {
-            const int j = ((int)(a3[NX - 1] >> 63) - (int)(a[NX - 1] >> 63)) + 3 * ((int)(b3[NX - 1] >> 63) - (int)(b[NX - 1] >> 63));
-            shl_words<1, NX>(a); shl_words<1, NX>(a3); shl_words<1, NX>(b); shl_words<1, NX>(b3);
+        for (int i = JSF_TOP; i >= 1; i--) {
+            const int pos = JSF_TOP - i;
+            const unsigned byte = dj[(size_t)(pos >> 1) * 64];
+            const int j = (int)((pos & 1) ? (byte & 15u) : (byte >> 4)) - 4;
             if (!started) {
                 if (j == 0) continue;                     // "ignore leading zeros" (edwards.c:498)
                 started = true;
@@ -278,17 +289,21 @@ struct CurveOps {
 
     // ---- SoA load / store of a point batch: P[(c*N + i)*ld + j]
     static MA_DEV void load(const spint* Pb, size_t ld, size_t j, Point& p) {
+        spint x[N], y[N], z[N];
         static_for<0, N>([&](auto I) {
-            p.x[I] = Pb[((size_t)(0 * N + I)) * ld + j];
-            p.y[I] = Pb[((size_t)(1 * N + I)) * ld + j];
-            p.z[I] = Pb[((size_t)(2 * N + I)) * ld + j];
+            x[I] = Pb[((size_t)(0 * N + I)) * ld + j];
+            y[I] = Pb[((size_t)(1 * N + I)) * ld + j];
+            z[I] = Pb[((size_t)(2 * N + I)) * ld + j];
         });
+        F::from_limbs(x, p.x); F::from_limbs(y, p.y); F::from_limbs(z, p.z);
     }
     static MA_DEV void store(spint* Pb, size_t ld, size_t j, const Point& p) {
+        spint x[N], y[N], z[N];
+        F::to_limbs(p.x, x); F::to_limbs(p.y, y); F::to_limbs(p.z, z);
         static_for<0, N>([&](auto I) {
-            Pb[((size_t)(0 * N + I)) * ld + j] = p.x[I];
-            Pb[((size_t)(1 * N + I)) * ld + j] = p.y[I];
-            Pb[((size_t)(2 * N + I)) * ld + j] = p.z[I];
+            Pb[((size_t)(0 * N + I)) * ld + j] = x[I];
+            Pb[((size_t)(1 * N + I)) * ld + j] = y[I];
+            Pb[((size_t)(2 * N + I)) * ld + j] = z[I];
         });
     }
 };
@@ -296,20 +311,30 @@ struct CurveOps {
 // ---------------------------------------------------------------- kernels
 // resident waves per SIMD the scalar-multiplication kernels are register-budgeted for (256 VGPRs each); three waves at
 // 170 VGPRs measured the same throughput, one wave at 512 VGPRs 20 % less
+#ifndef MA_MUL_WPS
 #define MA_MUL_WPS 2
+#endif
+// One wave per workgroup; the workgroup's LDS holds the recoded scalars of its 64 lanes (CurveOps::recode), the workspace slab
+// blockIdx.x its window tables.
 template <class Crv>
 __global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul(const unsigned char* e, spint* Pb, size_t n, size_t ld, spint* ws) {
     using E = Crv;
-    const size_t lanes = (size_t)gridDim.x * blockDim.x;
-    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    typename E::Table W{ws + lane, lanes};
-    for (size_t t = lane; t < n; t += lanes) {
-        spint ew[E::NW];
-        load_be_record<typename E::P>(e, t, ew);         // big-endian byte record -> little-endian words
+    __shared__ signed char digs[E::NDIG * 64];
+    const typename E::Table W{ws + (size_t)blockIdx.x * E::SLAB_WORDS, threadIdx.x};
+    signed char* dg = digs + threadIdx.x;
+    // base: the wave's first element of this pass, wave-uniform (SGPRs); a lane's element index base + lane is formed where it is used
+    // (W.here(): the lane number as a fresh value), so no 64-bit index or address stays in VGPRs across the multiplication
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
+        if (base + W.here() >= n) continue;
+        {
+            spint ew[E::NW];
+            load_be_record<typename E::P>(e, base + W.here(), ew);         // big-endian byte record -> little-endian words
+            E::recode(ew, dg);
+        }
         typename E::Point p;
-        E::load(Pb, ld, t, p);
-        E::mul(ew, p, W);
-        E::store(Pb, ld, t, p);
+        E::load(Pb, ld, base + W.here(), p);
+        E::mul(dg, p, W);
+        E::store(Pb, ld, base + W.here(), p);
     }
 }
 
@@ -317,18 +342,28 @@ template <class Crv>
 __global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul2(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, spint* Rb,
                                                 size_t n, size_t ld, spint* ws) {
     using E = Crv;
-    const size_t lanes = (size_t)gridDim.x * blockDim.x;
-    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    typename E::Table W{ws + lane, lanes};
-    for (size_t t = lane; t < n; t += lanes) {
-        spint ew[E::NW], fw[E::NW];
-        load_be_record<typename E::P>(e, t, ew);
-        load_be_record<typename E::P>(f, t, fw);
-        typename E::Point p, q, r;
-        E::load(Pb, ld, t, p);
-        E::load(Qb, ld, t, q);
-        E::mul2(ew, p, fw, q, r, W);
-        E::store(Rb, ld, t, r);
+    __shared__ signed char digs[2 * E::NDIG * 64];
+    const typename E::Table W{ws + (size_t)blockIdx.x * E::SLAB_WORDS, threadIdx.x};
+    signed char* de = digs + threadIdx.x;
+    signed char* df = de + E::NDIG * 64;
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
+        if (base + W.here() >= n) continue;
+        {
+            spint ew[E::NW];
+            load_be_record<typename E::P>(e, base + W.here(), ew);
+            E::recode(ew, de);
+            load_be_record<typename E::P>(f, base + W.here(), ew);
+            E::recode(ew, df);
+        }
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {                        // one point at a time: load, build its table, forget
+            typename E::Point p;
+            E::load(h ? Qb : Pb, ld, base + W.here(), p);
+            E::build_table(p, h ? W.second() : W);
+        }
+        typename E::Point r;
+        E::mul2(de, df, r, W);
+        E::store(Rb, ld, base + W.here(), r);
     }
 }
 
@@ -336,18 +371,22 @@ template <class Crv>
 __global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul2x(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, spint* Rb,
                                                  size_t n, size_t ld, spint* ws) {
     using E = Crv;
-    const size_t lanes = (size_t)gridDim.x * blockDim.x;
-    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    typename E::Table W{ws + lane, lanes};
-    for (size_t t = lane; t < n; t += lanes) {
-        spint ew[E::NW], fw[E::NW];
-        load_be_record<typename E::P>(e, t, ew);
-        load_be_record<typename E::P>(f, t, fw);
+    __shared__ unsigned char digs[E::JSF_BYTES * 64];
+    const typename E::Table W{ws + (size_t)blockIdx.x * E::SLAB_WORDS, threadIdx.x};
+    unsigned char* dj = digs + threadIdx.x;
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
+        if (base + W.here() >= n) continue;
+        {
+            spint ew[E::NW], fw[E::NW];
+            load_be_record<typename E::P>(e, base + W.here(), ew);
+            load_be_record<typename E::P>(f, base + W.here(), fw);
+            E::jsf_digits(ew, fw, dj);
+        }
         typename E::Point p, q, r;
-        E::load(Pb, ld, t, p);
-        E::load(Qb, ld, t, q);
-        E::mul2_exact(ew, p, fw, q, r, W);
-        E::store(Rb, ld, t, r);
+        E::load(Pb, ld, base + W.here(), p);
+        E::load(Qb, ld, base + W.here(), q);
+        E::mul2_exact(dj, p, q, r, W);
+        E::store(Rb, ld, base + W.here(), r);
     }
 }
 

@@ -9,25 +9,28 @@
 
 namespace ma {
 
-template <class C>
-struct Edwards : CurveOps<Edwards<C>, typename C::FieldParams> {
-    using Base = CurveOps<Edwards<C>, typename C::FieldParams>;
+template <class C, class F_ = Field<typename C::FieldParams, true>>
+struct Edwards : CurveOps<Edwards<C, F_>, typename C::FieldParams, F_> {
+    using Base = CurveOps<Edwards<C, F_>, typename C::FieldParams, F_>;
     using P = typename C::FieldParams;
-    using F = Field<P, true>;
+    using F = F_;
     using Point = typename Base::Point;
+    using limb_t = typename F::limb_t;
     using Base::cmv;
     using Base::cpy;
-    static constexpr int N = P::N;
+    static constexpr int N = P::N, NL = F::NL;
     static constexpr bool HAS_Y_ONLY_SET = true;    // ecnXXXset accepts y + sign of x (edwards.c:362-365)
     static constexpr bool SELECT_FROM_NEUTRAL = true;    // curve.h select(): start the table scan from the neutral element
 
     // e <- d*e  with the sign handling of edwards.c:81-98
-    static MA_DEV void bterm(spint* e) {
+    static MA_DEV void bterm(limb_t* e) {
         if constexpr (C::B_SMALL) {
             F::modmli(e, C::B_INT > 0 ? C::B_INT : -C::B_INT, e);
         } else {
-            spint b[N];
-            static_for<0, N>([&](auto I) { b[I] = C::b(I); });
+            spint bl[N];
+            limb_t b[NL];
+            static_for<0, N>([&](auto I) { bl[I] = C::b(I); });
+            F::from_limbs(bl, b);
             F::modmul(e, b, e);
         }
     }
@@ -38,7 +41,7 @@ struct Edwards : CurveOps<Edwards<C>, typename C::FieldParams> {
     static MA_DEV int isinf(const Point& p) { return F::modis0(p.x) & F::modcmp(p.y, p.z); }  // edwards.c:179-183
     // P += Q (edwards.c:73-111)
     static MA_DEV void add(const Point& q, Point& p) {
-        spint A[N], B[N], Cc[N], D[N], E[N], Ff[N], G[N];
+        limb_t A[NL], B[NL], Cc[NL], D[NL], E[NL], Ff[NL], G[NL];
         F::modmul(q.z, p.z, A);
         F::modsqr(A, B);
         F::modmul(q.x, p.x, Cc);
@@ -61,7 +64,7 @@ struct Edwards : CurveOps<Edwards<C>, typename C::FieldParams> {
     }
     // P = 2P (edwards.c:123-145)
     static MA_DEV void dbl(Point& p) {
-        spint B[N], Cc[N], D[N], E[N], Ff[N], H[N], J[N];
+        limb_t B[NL], Cc[NL], D[NL], E[NL], Ff[NL], H[NL], J[NL];
         F::modadd(p.x, p.y, B);
         F::modsqr(B, B);
         F::modsqr(p.x, Cc);
@@ -154,8 +157,13 @@ struct Edwards : CurveOps<Edwards<C>, typename C::FieldParams> {
             F::modint(C::SMALL_X, gx);
             setxy<1>(0, gx, nullptr, p);
         } else {
+            // ecnXXXset(0, x, y) on the generator's own coordinates: the on-curve test of setxy<0> is a fact about the constants
+            // (checked where they are emitted and by tests/test_gpu_curveref.py against the reference's ecnXXXgen limbs), so what
+            // is left of edwards.c:347-366 is the copy -- a constant store
             static_for<0, N>([&](auto I) { gx[I] = C::gx(I); gy[I] = C::gy(I); });
-            setxy<0>(0, gx, gy, p);
+            F::modcpy(gx, p.x);
+            F::modcpy(gy, p.y);
+            F::modone(p.z);
         }
     }
 

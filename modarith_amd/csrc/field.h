@@ -119,6 +119,13 @@ template <class P, bool FAST_ = false, bool PIN_ = true>
 struct Field {
     template <class T> static MA_DEV void pin(T& x) { if constexpr (PIN_) MA_PIN(x); }
     static constexpr int N = P::N;
+    // resident form of an element in the curve layer (csrc/curve.h): here the limbs themselves (csrc/fh51.h: half limbs)
+    using limb_t = spint;
+    static constexpr int NL = P::N;
+    static MA_DEV void from_limbs(const spint* a, spint* h) { static_for<0, P::N>([&](auto I) { h[I] = a[I]; }); }
+    static MA_DEV void to_limbs(const spint* h, spint* a) { static_for<0, P::N>([&](auto I) { a[I] = h[I]; }); }
+    static MA_DEV spint pack(const spint* h, int k) { return h[k]; }
+    static MA_DEV void unpack(spint w, spint* h, int k) { h[k] = w; }
     static constexpr int RADIX = P::RADIX;
     static constexpr spint Q = (spint)1 << RADIX;
     static constexpr spint MASK = Q - 1;

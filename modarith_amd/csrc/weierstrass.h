@@ -256,8 +256,13 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
             F::modint(C::SMALL_X, gx);
             setxy<1>(0, gx, nullptr, p);
         } else {
+            // ecnXXXset(0, x, y) on the generator's own coordinates: the on-curve test of setxy<0> is a fact about the constants
+            // (checked where they are emitted and by tests/test_gpu_curveref.py against the reference's ecnXXXgen limbs), so what
+            // is left of weierstrass.c:417-428 is the copy -- a constant store
             static_for<0, N>([&](auto I) { gx[I] = C::gx(I); gy[I] = C::gy(I); });
-            setxy<0>(0, gx, gy, p);
+            F::modcpy(gx, p.x);
+            F::modcpy(gy, p.y);
+            F::modone(p.z);
         }
     }
 };

@@ -63,7 +63,9 @@ def flatten_batch(t: torch.Tensor) -> torch.Tensor:
 class Field:
     """Batched field arithmetic for one of the built primes (X25519, NIST256, X448)."""
 
-    def __init__(self, prime: str, device: Optional[torch.device] = None, tile: Optional[int] = None):
+    DEFAULT_TILE = 4096            # = modarith_amd_recommended_ld(n) for n >= 2 * 4096 (include/modarith_amd.h "TILED")
+
+    def __init__(self, prime: str, device: Optional[torch.device] = None, tile: Optional[int] = DEFAULT_TILE):
         self.lib = _lib.load()
         self.flib = self.lib                   # the library that holds this prime's entry points
         if prime in _lib.PRIMES:
@@ -87,9 +89,13 @@ class Field:
         self.radix = self.params.radix
         self.nbytes = self.params.nbytes
         self.device = normalise_device(device)
-        # Layout of the batches this object CREATES (empty / uniform / from_limbs / modimp ...): None = flat [N, n];
-        # tile = 2^k >= 128 (4096 recommended) = tiled [n / tile, N, tile] (include/modarith_amd.h "TILED"; n a multiple of
-        # tile).  Every method ACCEPTS both forms, whatever this is set to.
+        # Layout of the batches this object CREATES (empty / uniform / from_limbs / modimp ...): tile = 2^k >= 128 (default
+        # 4096, the recommended stride) = tiled [n / tile, N, tile] for every batch of at least two whole tiles (include/
+        # modarith_amd.h "TILED": the fast layout, 0.82 against 0.70 of the HBM peak for flat rows); smaller batches, and sizes
+        # that are not a multiple of the tile, are flat [N, n] (see creates_tiled).  tile = None or 0: always flat (the n-lane
+        # form of the reference's SIMD layout; what the curve and byte-record APIs take).  Every method ACCEPTS both forms,
+        # whatever this is set to; to_flat / to_tiled convert.
+        tile = tile or None
         if tile is not None and (tile < 128 or tile & (tile - 1)):
             raise ValueError("tile must be a power of two >= 128")
         self.tile = tile
@@ -103,10 +109,14 @@ class Field:
         return cls(_gen.generate(prime, **kw).tag, device, tile)
 
     # ------------------------------------------------------------------ buffers
+    def creates_tiled(self, n: int) -> bool:
+        """whether a batch of n elements made by this object is tiled: at least two whole tiles and nothing left over (a
+        torch tensor of whole tiles cannot say how many elements of a partial last tile are meant; such sizes stay flat --
+        the C ABI itself takes ceil(n / ld) tiles with an explicit n)"""
+        return bool(self.tile) and n >= 2 * self.tile and n % self.tile == 0
+
     def empty(self, n: int) -> torch.Tensor:
-        if self.tile and n > self.tile:
-            if n % self.tile:
-                raise ValueError("tiled batches hold a whole number of tiles (n = %d, tile = %d)" % (n, self.tile))
+        if self.creates_tiled(n):
             return torch.empty((n // self.tile, self.N, self.tile), dtype=torch.int64, device=self.device)
         return torch.empty((self.N, n), dtype=torch.int64, device=self.device)
 
@@ -122,7 +132,7 @@ class Field:
         """list of per-element limb lists -> device batch [N, n] (tiled if this object creates tiled batches)."""
         arr = np.array(limbs, dtype=np.uint64).reshape(len(limbs), self.N).T.copy()
         t = torch.from_numpy(arr.view(np.int64)).to(self.device)
-        if self.tile and t.shape[1] > self.tile and t.shape[1] % self.tile == 0:
+        if self.creates_tiled(t.shape[1]):
             t = self.to_tiled(t)
         return t
 
@@ -414,7 +424,7 @@ def rfc7748(curve: str, bk: torch.Tensor, bu: torch.Tensor, out: Optional[torch.
     n = bk.shape[0]
     with torch.cuda.device(bu.device):
         st = torch.cuda.current_stream().cuda_stream
-        if n >= 8192 and os.environ.get("MA_LADDER_SPLIT") != "0":
+        if n >= 8192 and os.environ.get("MA_LADDER_SPLIT") != "0" and os.environ.get("MA_LADDER_IMPL") != "field":
             # split form (include/modarith_amd.h): ladders, then one inversion per up to 32 records; the scratch comes from
             # torch's caching allocator (stream-ordered, reused across calls, legal under graph capture)
             nbytes = getattr(lib, "rfc7748_%s_batch_workspace_bytes" % curve)(n)

@@ -121,3 +121,86 @@ def map_host(prime: str, fn: str, a: PinnedArray, b: Optional[PinnedArray], out:
                 lib.modarith_amd_free(d)
         for s in (up, run, down):
             lib.modarith_amd_stream_destroy(s)
+
+
+class PinnedBytes:
+    """page-locked host array [n, nbytes] of uint8 (contiguous byte records, the layout of rfc7748's bk / bu / bv:
+    simd/rfc7748_simt.cu:165-168), owned by the library's allocator"""
+
+    def __init__(self, n: int, nbytes: int):
+        self.lib = _lib.load()
+        self.ptr = c_void_p()
+        self.nbytes = n * nbytes
+        _lib.check(self.lib.modarith_amd_host_alloc(ctypes.byref(self.ptr), max(self.nbytes, 8)), "host_alloc")
+        buf = (ctypes.c_uint8 * (n * nbytes)).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=np.uint8).reshape(n, nbytes)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            _lib.check(self.lib.modarith_amd_host_free(self.ptr), "host_free")
+            self.ptr = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ladder_host(curve: str, bk: PinnedBytes, bu: PinnedBytes, bv: PinnedBytes, chunk: int = 1 << 20) -> None:
+    """bv[j] = rfc7748(bk[j], bu[j]) for HOST-resident records -- the shape of the reference's own GPU harness
+    (simd/rfc7748_simt.cu:257-312: cudaMemcpy in, launch, cudaMemcpy out), pipelined: three streams, two device slots, the
+    upload of chunk i+1 and the download of chunk i-1 run under the ladders of chunk i.  The ladder is VALU-bound (2^20
+    X25519 records take ~9 ms, their 64 MiB of input ~1.2 ms of link time), so the link disappears behind the kernels.
+    C ABI only (rfc7748_<C>_batch_ws with a caller-owned workspace per slot)."""
+    lib = _lib.load()
+    if curve not in _lib.LADDERS:
+        raise ValueError("curve must be one of %s" % (_lib.LADDERS,))
+    n, nb = bk.array.shape
+    if bu.array.shape != (n, nb) or bv.array.shape != (n, nb):
+        raise ValueError("bk, bu, bv must share the shape [n, Nbytes]")
+    if n == 0:
+        return
+    f = getattr(lib, "rfc7748_%s_batch_ws" % curve)
+    chunk = max(1, min(chunk, n))
+    wsb = int(getattr(lib, "rfc7748_%s_batch_workspace_bytes" % curve)(chunk))
+    up, run, down = c_void_p(), c_void_p(), c_void_p()
+    for s in (up, run, down):
+        _lib.check(lib.modarith_amd_stream_create(ctypes.byref(s)), "stream_create")
+    slots = []
+    try:
+        for _ in range(2):
+            bufs = []
+            for size in (chunk * nb, chunk * nb, chunk * nb, max(wsb, 8)):
+                d = c_void_p()
+                _lib.check(lib.modarith_amd_malloc(ctypes.byref(d), size), "malloc")
+                bufs.append(d)
+            slots.append(bufs)
+
+        def download(off, cnt, dv):
+            _lib.check(lib.modarith_amd_stream_wait(down, run), "stream_wait")
+            _lib.check(lib.modarith_amd_memcpy_d2h(bv.ptr.value + off * nb, dv, cnt * nb, down), "d2h")
+
+        pending = None
+        for i, off in enumerate(range(0, n, chunk)):
+            cnt = min(chunk, n - off)
+            dk, du, dv, ws = slots[i % 2]
+            _lib.check(lib.modarith_amd_stream_wait(up, down), "stream_wait")      # slot i%2: chunk i-2's download is the newest on `down`
+            _lib.check(lib.modarith_amd_memcpy_h2d(dk, bk.ptr.value + off * nb, cnt * nb, up), "h2d")
+            _lib.check(lib.modarith_amd_memcpy_h2d(du, bu.ptr.value + off * nb, cnt * nb, up), "h2d")
+            if pending is not None:
+                download(*pending)
+            _lib.check(lib.modarith_amd_stream_wait(run, up), "stream_wait")
+            _lib.check(f(dk, du, dv, cnt, ws, max(wsb, 8), run), "rfc7748_%s_batch_ws" % curve)
+            pending = (off, cnt, dv)
+        download(*pending)
+        _lib.check(lib.modarith_amd_sync(down), "sync")
+    finally:
+        for s in (up, run, down):
+            lib.modarith_amd_sync(s)
+        for bufs in slots:
+            for d in bufs:
+                lib.modarith_amd_free(d)
+        for s in (up, run, down):
+            lib.modarith_amd_stream_destroy(s)

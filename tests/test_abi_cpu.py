@@ -121,3 +121,27 @@ def test_tiled_layout_helpers_follow_the_documented_address_map():
         tile_batch(flat, 100)
     with pytest.raises(ValueError):
         tile_batch(flat[:, :200], 128)
+
+
+def test_recommended_layout_helpers(lib):
+    """modarith_amd_recommended_ld / modarith_amd_batch_words (pure host functions): tiles of 4096 from two whole tiles on,
+    flat rows below; the word count of a batch in either form -- and Field's own default follows the same recommendation"""
+    rec, words = lib.modarith_amd_recommended_ld, lib.modarith_amd_batch_words
+    assert rec(0) == 0 and rec(1) == 1 and rec(4096) == 4096 and rec(8191) == 8191
+    assert rec(8192) == 4096 and rec(8193) == 4096 and rec(1 << 24) == 4096
+    assert words(100, 5, 100) == 500 and words(100, 5, 128) == 640            # flat: nlimbs * ld
+    assert words(8192, 5, 4096) == 2 * 5 * 4096                               # two whole tiles
+    assert words(8193, 5, 4096) == 3 * 5 * 4096                               # a partial last tile is a whole tile of storage
+    assert words(1 << 24, 8, 4096) == 8 << 24
+    assert words(10, 0, 10) == 0 and words(10, 5, 0) == 0
+    from modarith_amd.field import Field
+    assert Field.DEFAULT_TILE == rec(1 << 24)
+    F = Field.__new__(Field)                                                  # layout rule only: no device needed
+    F.tile = Field.DEFAULT_TILE
+    assert [F.creates_tiled(n) for n in (1, 4096, 8191, 8192, 8193, 12288, 1 << 24)] == [False, False, False, True, False, True, True]
+    F.tile = None
+    assert not F.creates_tiled(1 << 24)
+
+
+def test_last_launch_and_scratch_trim_are_callable_without_a_gpu(lib):
+    assert lib.modarith_amd_last_launch() in (b"",) or isinstance(lib.modarith_amd_last_launch(), bytes)

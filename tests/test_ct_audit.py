@@ -1,0 +1,45 @@
+"""tools/ct_audit.py as a test (no GPU): every conditional branch in the gfx950 code of the kernels that carry the reference's
+constant-time contract (modcsw / modcmv pseudo.py:979-1048, the ladders, ecnXXXmul edwards.c:382-401, 435-482) is classified
+from the disassembly; a branch on lane data, or more exec-mask branches than the reviewed allow-list (tools/ct_allowlist.json)
+names, fails.  The classifier itself is checked on hand-made instruction streams."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ct_audit  # noqa: E402
+
+
+def test_classifier_on_hand_made_streams():
+    uniform_loop = ["s_mov_b32 s4, 0", "v_add_u32_e32 v1, v2, v3", "s_add_i32 s4, s4, 1", "s_cmp_lg_u32 s4, 8", "s_cbranch_scc1 65530"]
+    a = ct_audit.audit_function(uniform_loop)
+    assert (a["scc_uniform"], a["scc_lane_data"], a["unknown"]) == (1, 0, 0)
+    vote = ["v_cmp_gt_u32_e32 vcc, v1, v2", "s_cbranch_vccnz 12"]                       # a wave vote on lane values
+    a = ct_audit.audit_function(vote)
+    assert a["vcc_lane_data"] == 1
+    vote2 = ["v_cmp_eq_u32_e64 s[6:7], v1, v2", "s_and_b64 vcc, exec, s[6:7]", "s_cbranch_vccz 12"]
+    assert ct_audit.audit_function(vote2)["vcc_lane_data"] == 1
+    structurizer = ["s_mov_b64 s[50:51], 0", "s_andn2_b64 vcc, exec, s[50:51]", "v_mad_u64_u32 v[2:3], s[50:51], v3, 19, v[4:5]", "s_cbranch_vccnz 61396"]
+    a = ct_audit.audit_function(structurizer)                                            # vcc = exec & ~0: the compiler's uniform branch
+    assert (a["vcc_uniform"], a["vcc_lane_data"]) == (1, 0)
+    firstlane = ["v_readfirstlane_b32 s5, v9", "s_cmp_eq_u32 s5, 0", "s_cbranch_scc0 40"]   # a uniform branch on what lane 0 holds
+    assert ct_audit.audit_function(firstlane)["scc_lane_data"] == 1
+    carry = ["v_subrev_co_u32_e32 v54, vcc, 1, v54", "s_and_b64 vcc, exec, vcc", "s_cbranch_vccz 100"]   # counter kept in a VGPR
+    assert ct_audit.audit_function(carry)["vcc_lane_data"] == 1
+    div = ["v_cmp_lt_u64_e32 vcc, s[2:3], v[0:1]", "s_and_saveexec_b64 s[4:5], vcc", "s_cbranch_execz 55"]
+    assert ct_audit.audit_function(div)["exec"] == 1
+
+
+def test_audited_kernels_have_no_data_dependent_branch():
+    bdir = os.path.join(ROOT, "modarith_amd", "build")
+    if not os.path.exists(os.path.join(bdir, "capi_X25519.o")):
+        pytest.skip("no built objects (run __graft_entry__.build())")
+    rows, problems = ct_audit.run()
+    names = " ".join(r["kernel"] for r in rows)
+    for must in ("k_cond<ma::P_X25519", "k_x25519_fe26_xz", "k_x448_fe28_xz", "k_fe_finish<ma::Fe26", "k_ed_mul<ma::Edwards<ma::C_ED25519", "k_ed_mul<ma::Edwards<ma::C_ED448",
+                 "k_ed_mul<ma::Weierstrass<ma::C_NIST256", "k_ed_mul2<ma::Edwards<ma::C_ED25519"):
+        assert must in names, "audited kernel missing from the build: " + must
+    assert not problems, "\n".join(problems)
+    assert all(r["scc_lane_data"] == 0 and r["vcc_lane_data"] == 0 and r["unknown"] == 0 for r in rows)

@@ -16,7 +16,7 @@ def test_bulk_digests_gpu(P):
     import torch
     assert torch.cuda.is_available(), "these tests need the MI355X"
     from modarith_amd.field import Field
-    F = Field(P)
+    F = Field(P, tile=None)          # flat batches: the digests are taken over rows [N, n]
     g = load_golden("bulk_digests.json")
     n, blk = g["n"], g["block"]
     for cls in BULK_CLASSES:

@@ -123,7 +123,7 @@ def test_more_than_2_32_elements_in_one_batch(torch_cuda):
     need = 2 * 3 * 8 * n + (8 << 30)
     if free < need:
         pytest.skip("needs %.0f GB of free HBM (free: %.0f GB)" % (need / 1e9, free / 1e9))
-    F = Field("1305")
+    F = Field("1305", tile=None)
     a = F.uniform(n, seed=9, array=1)
     c = F.modmul(a, a)
     step = 1 << 26

@@ -24,7 +24,7 @@ def torch_cuda():
 def test_every_field_function_on_tiles(torch_cuda, P, tile):
     torch = torch_cuda
     from modarith_amd.field import Field
-    F, T = Field(P), Field(P, tile=tile)
+    F, T = Field(P, tile=None), Field(P, tile=tile)
     n = 3 * tile
     a, b = F.uniform(n, seed=7, array=1, plus_p=True), F.uniform(n, seed=7, array=2)
     A, B = T.to_tiled(a), T.to_tiled(b)
@@ -91,7 +91,7 @@ def test_partial_last_tile_and_odd_n_through_the_c_abi(torch_cuda, P):
     torch = torch_cuda
     from modarith_amd import _lib
     from modarith_amd.field import Field
-    lib, F = _lib.load(), Field(P)
+    lib, F = _lib.load(), Field(P, tile=None)
     tile, n = 256, 2 * 256 + 77
     a, b = F.uniform(3 * tile, seed=9, array=1), F.uniform(3 * tile, seed=9, array=2)
     A, B = F.to_tiled(a, tile), F.to_tiled(b, tile)
@@ -142,7 +142,7 @@ from modarith_amd import _lib
 from modarith_amd.field import Field
 lib = _lib.load()
 for P in ("X25519", "X448"):
-    F = Field(P)
+    F = Field(P, tile=None)
     tile, n = 4096, 5 * 4096 + 1237
     a, b = F.uniform(6 * tile, seed=3, array=1), F.uniform(6 * tile, seed=3, array=2)
     A, B = F.to_tiled(a, tile), F.to_tiled(b, tile)

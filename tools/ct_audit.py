@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Mechanical constant-time guard for the kernels that carry the reference's constant-time contract (pseudo.py:979-1048
+modcsw / modcmv; edwards.c:382-401 select; the ladders of rfc7748.c:156-256; the fixed-window ecnXXXmul of edwards.c:435-482).
+
+  python tools/ct_audit.py [--json out.json] [--verbose]
+
+Disassembles the gfx950 code objects of modarith_amd/build/*.o, finds every conditional branch of the audited kernels and
+classifies what its condition is made of, by tracing the condition register back through the instruction stream:
+
+  scc   s_cbranch_scc0/1: the s_cmp / s_bitcmp / s_add that set SCC, and the producers of its SGPR operands.
+        uniform   = loop counters, kernel arguments, constants (s_mov / s_add / s_load from the kernarg segment ...)
+        lane-data = an operand that came out of the vector unit (v_readfirstlane / v_readlane / a v_cmp mask): a wave-level
+                    decision on what the lanes hold -- a data-dependent branch
+  vcc   s_cbranch_vccz/nz: the instruction that wrote VCC.  s_and / s_andn2 / s_or of EXEC with an SGPR pair that holds a
+        constant or an s_cselect of SCC is the compiler's way of branching on a uniform condition (uniform); a v_cmp is a vote
+        on lane data (lane-data)
+  exec  s_cbranch_execz/nz: divergence -- some lanes skip a region.  Constant-time only if the lane mask depends on the lane
+        index and the batch size alone (the `t < n` guard and the grid-stride back-edge); cannot be told apart mechanically,
+        so the NUMBER of such branches per kernel is pinned in the allow-list with the reviewed reason.
+
+tools/ct_allowlist.json holds, per kernel pattern, the allowed count of exec branches and of lane-data branches (0 unless a
+documented exception) with the justification; tests/test_ct_audit.py fails when a kernel exceeds its entry or an audited kernel
+has no entry -- a regression (e.g. the compiler turning a predicated table scan into `if (eq) load`) cannot slip in silently.
+No GPU needed.
+"""
+import fnmatch
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALLOW = os.path.join(ROOT, "tools", "ct_allowlist.json")
+# (object glob, demangled-name substring) of the audited kernels
+AUDITED = [
+    ("capi_X25519.o", "k_cond<"), ("capi_NIST256.o", "k_cond<"), ("capi_X448.o", "k_cond<"),
+    ("capi_X25519.o", "k_x25519_fe26_xz"), ("capi_X25519.o", "k_x25519_fe26("), ("capi_X448.o", "k_x448_fe28_xz"), ("capi_X448.o", "k_x448_fe28("),
+    ("capi_X25519.o", "k_fe_finish<"), ("capi_X448.o", "k_fe_finish<"),
+    ("capi_X25519.o", "k_rfc7748<"), ("capi_X448.o", "k_rfc7748<"),
+    ("capi_*_part1.o", "k_ed_mul<"), ("capi_*_part2.o", "k_ed_mul2<"),
+]
+
+
+def disassemble(obj):
+    """{mangled symbol: [(address, instruction text)]} of the gfx950 code object inside a host object"""
+    with tempfile.TemporaryDirectory() as tmp:
+        fb, co = os.path.join(tmp, "fb.bin"), os.path.join(tmp, "k.co")
+        if subprocess.run([LLVM + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fb], capture_output=True).returncode:
+            return {}
+        if subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fb, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co],
+                          capture_output=True).returncode:
+            return {}
+        text = subprocess.run([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+    funcs, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+            continue
+        if cur is not None and line.startswith("\t"):
+            body, _, cm = line.partition("//")
+            m = re.match(r"\s*([0-9A-Fa-f]+):", cm)
+            cur.append((int(m.group(1), 16) if m else None, body.strip()))
+    return funcs
+
+
+def _regs(tok):
+    """registers named by an operand token: 's4' -> {('s',4)}, 's[4:5]' -> {('s',4),('s',5)}, 'vcc' -> {('vcc',0)}"""
+    tok = tok.strip().rstrip(",")
+    m = re.match(r"^s\[(\d+):(\d+)\]$", tok)
+    if m:
+        return {("s", i) for i in range(int(m.group(1)), int(m.group(2)) + 1)}
+    m = re.match(r"^s(\d+)$", tok)
+    if m:
+        return {("s", int(m.group(1)))}
+    if tok in ("vcc", "vcc_lo", "vcc_hi"):
+        return {("vcc", 0)}
+    return set()
+
+
+def _split(ins):
+    parts = ins.split(None, 1)
+    ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+    return parts[0], ops
+
+
+# scalar instructions that do NOT write SCC (everything else in the SALU does: compares, arithmetic, logic, shifts)
+NOT_SCC = ("s_cselect", "s_mul_i32", "s_mul_hi", "s_mov", "s_load", "s_waitcnt", "s_nop", "s_cbranch", "s_branch", "s_buffer", "s_movk", "s_cmov", "s_barrier", "s_endpgm", "s_sleep",
+           "s_setprio", "s_getpc", "s_setpc", "s_swappc", "s_sext", "s_pack", "s_brev", "s_bcnt", "s_ff", "s_flbit", "s_bitset", "s_getreg", "s_setreg", "s_memtime", "s_memrealtime",
+           "s_dcache", "s_icache", "s_store", "s_scratch", "s_atc", "s_code_end", "s_trap", "s_sendmsg", "s_inst_prefetch", "s_clause", "s_version", "s_ttrace", "s_wakeup", "s_sethalt",
+           "s_set_gpr", "s_rfe", "s_incperf", "s_decperf")
+CARRY_OUT = ("v_add_co", "v_sub_co", "v_subrev_co", "v_addc_co", "v_subb_co", "v_subbrev_co", "v_mad_u64_u32", "v_mad_i64_i32", "v_div_scale")
+USES_SCC = ("s_cselect", "s_cmov", "s_addc", "s_subb")
+UNIFORM_SOURCE = ("s_load", "s_buffer_load", "s_getpc", "s_memtime", "s_memrealtime", "s_getreg", "s_movk")
+EXEC = ("exec", "exec_lo", "exec_hi")
+
+
+class Function:
+    """instruction list with a control-flow graph (from the branch offsets), for backward tracing of condition registers"""
+
+    def __init__(self, ins):
+        self.addr = [a for a, _ in ins]
+        self.text = [t for _, t in ins]
+        self.n = len(ins)
+        index = {a: i for i, a in enumerate(self.addr) if a is not None}
+        self.preds = [[] for _ in range(self.n)]
+        for i, t in enumerate(self.text):
+            op, ops = _split(t)
+            falls = not op.startswith(("s_branch", "s_endpgm", "s_setpc"))
+            if falls and i + 1 < self.n:
+                self.preds[i + 1].append(i)
+            if op.startswith(("s_branch", "s_cbranch_scc", "s_cbranch_vcc", "s_cbranch_exec")) and ops and self.addr[i] is not None:
+                try:
+                    off = int(ops[0], 0)
+                except ValueError:
+                    continue
+                if off >= 32768:
+                    off -= 65536
+                j = index.get(self.addr[i] + 4 + 4 * off)
+                if j is not None:
+                    self.preds[j].append(i)
+
+    def writes(self, i):
+        """(registers written by instruction i, kind): kind in valu / uniform-source / salu / other"""
+        op, ops = _split(self.text[i])
+        dst = _regs(ops[0]) if ops else set()
+        if op.startswith("v_"):
+            if len(ops) > 1 and op.startswith(CARRY_OUT):
+                dst |= _regs(ops[1])
+            if op.startswith("v_cmp") and (op.endswith("_e32") or (ops and ops[0] in ("vcc",))):
+                dst |= {("vcc", 0)}
+            return dst, "valu"
+        if op.startswith("s_"):
+            if op.startswith(("s_cmp", "s_bitcmp")):
+                return {("scc", 0)}, "salu"
+            if not op.startswith(NOT_SCC):
+                dst = dst | {("scc", 0)}
+            if op.startswith(("s_cbranch", "s_branch", "s_waitcnt", "s_nop", "s_endpgm", "s_barrier", "s_setprio", "s_sleep")):
+                return set(), "other"
+            return dst, ("uniform-source" if op.startswith(UNIFORM_SOURCE) else "salu")
+        return set(), "other"
+
+    def sources(self, i):
+        op, ops = _split(self.text[i])
+        srcs = set()
+        for o in (ops if op.startswith(("s_cmp", "s_bitcmp")) else ops[1:]):
+            if o.strip() in EXEC:
+                continue                                     # EXEC as a value: the launched lanes (tails belong to the exec-branch class)
+            srcs |= _regs(o)
+        if op.startswith(USES_SCC):
+            srcs |= {("scc", 0)}
+        return srcs
+
+    def trace(self, start, regs, depth=0, budget=None):
+        """what `regs` hold on entry to instruction `start`, over all paths: 'uniform', 'lane-data' or 'unknown'"""
+        if not regs:
+            return "uniform"
+        key = (start, frozenset(regs))
+        active = self.__dict__.setdefault("active", set())
+        if key in active:
+            return "uniform"                                 # being traced further up the recursion: a loop-carried value adds nothing new
+        if depth > 60:
+            return "unknown"
+        active.add(key)                                      # (no caching of verdicts: one reached through an open cycle is provisional)
+        try:
+            return self._trace(start, regs, depth, budget)
+        finally:
+            active.discard(key)
+
+    def _trace(self, start, regs, depth, budget):
+        budget = budget if budget is not None else [400000]
+        seen = set()
+        work = [(p, frozenset(regs)) for p in self.preds[start]]
+        verdict = "uniform"
+        while work:
+            i, pend = work.pop()
+            if (i, pend) in seen:
+                continue
+            seen.add((i, pend))
+            budget[0] -= 1
+            if budget[0] < 0:
+                return "unknown"
+            dst, kind = self.writes(i)
+            hit = dst & pend
+            if hit:
+                if kind == "valu":
+                    return "lane-data"                       # v_cmp masks, v_readlane / v_readfirstlane, carry-outs: out of the vector unit
+                if kind == "salu":
+                    r = self.trace(i, self.sources(i), depth + 1, budget)
+                    if r == "lane-data":
+                        return r
+                    if r == "unknown":
+                        verdict = "unknown"
+                elif kind != "uniform-source":
+                    verdict = "unknown"
+                pend = pend - dst
+                if not pend:
+                    continue
+            for p in self.preds[i]:
+                work.append((p, pend))
+            # (a register never written on some path is a kernel argument / launch constant: uniform)
+        return verdict
+
+
+def audit_function(ins):
+    """ins: [(address, text)] or [text] (hand-made streams: addresses are synthesised, 4 bytes per instruction)"""
+    if ins and not isinstance(ins[0], tuple):
+        ins = [(4 * i, t) for i, t in enumerate(ins)]
+    f = Function(ins)
+    out = {"scc_uniform": 0, "scc_lane_data": 0, "vcc_uniform": 0, "vcc_lane_data": 0, "exec": 0, "unknown": 0, "calls": 0, "detail": []}
+    for i, t in enumerate(f.text):
+        op, ops = _split(t)
+        if op in ("s_cbranch_scc0", "s_cbranch_scc1"):
+            c = f.trace(i, {("scc", 0)})
+            key = {"uniform": "scc_uniform", "lane-data": "scc_lane_data"}.get(c, "unknown")
+        elif op in ("s_cbranch_vccz", "s_cbranch_vccnz"):
+            c = f.trace(i, {("vcc", 0)})
+            key = {"uniform": "vcc_uniform", "lane-data": "vcc_lane_data"}.get(c, "unknown")
+        elif op in ("s_cbranch_execz", "s_cbranch_execnz"):
+            c, key = "exec", "exec"
+        elif op.startswith(("s_setpc", "s_swappc")):
+            # calls of out-of-line functions and their returns: the target is s_getpc + constant or the saved return address
+            srcs = set()
+            for o in ops[-1:]:
+                srcs |= _regs(o)
+            c = "call/return" if op.startswith("s_setpc") and f.trace(i, srcs) != "lane-data" or op.startswith("s_swappc") and f.trace(i, srcs) != "lane-data" else "lane-data"
+            key = "calls" if c == "call/return" else "unknown"
+        elif op.startswith(("s_cbranch_i_fork", "s_cbranch_g_fork", "s_cbranch_join")):
+            c, key = "fork", "unknown"
+        else:
+            continue
+        out[key] += 1
+        out["detail"].append("%5d %s -> %s" % (i, t, c))
+    return out
+
+
+def demangle(names):
+    if not names:
+        return []
+    return subprocess.run(["c++filt"] + list(names), capture_output=True, text=True).stdout.splitlines()
+
+
+def run(verbose=False):
+    bdir = os.path.join(ROOT, "modarith_amd", "build")
+    objs = sorted(os.listdir(bdir)) if os.path.isdir(bdir) else []
+    allow = json.load(open(ALLOW))["kernels"] if os.path.exists(ALLOW) else []
+    rows, problems = [], []
+    cache = {}
+    for og, pat in AUDITED:
+        for o in fnmatch.filter(objs, og):
+            if o not in cache:
+                funcs = disassemble(os.path.join(bdir, o))
+                syms = list(funcs)
+                cache[o] = (funcs, dict(zip(syms, demangle(syms))))
+            funcs, names = cache[o]
+            for sym, ins in funcs.items():
+                name = re.sub(r"^void ", "", names.get(sym, sym))
+                if pat not in name or not ins:
+                    continue
+                a = audit_function(ins)
+                short = re.sub(r"\(.*", "", name)
+                entry = next((e for e in allow if e["match"] in short), None)
+                row = {"object": o, "kernel": short, **{k: a[k] for k in a if k != "detail"}}
+                rows.append(row)
+                if verbose:
+                    print(short)
+                    for d in a["detail"]:
+                        print("    " + d)
+                if entry is None:
+                    problems.append("%s: no allow-list entry" % short)
+                    continue
+                lane = a["scc_lane_data"] + a["vcc_lane_data"]
+                if lane > entry.get("lane_data_branches", 0):
+                    problems.append("%s: %d data-dependent branch(es), %d allowed" % (short, lane, entry.get("lane_data_branches", 0)))
+                if a["exec"] > entry.get("exec_branches", 0):
+                    problems.append("%s: %d exec-mask branch(es), %d allowed" % (short, a["exec"], entry.get("exec_branches", 0)))
+                if a["unknown"] > entry.get("unknown", 0):
+                    problems.append("%s: %d unclassified branch(es)" % (short, a["unknown"]))
+    return rows, problems
+
+
+def main(argv):
+    rows, problems = run(verbose="--verbose" in argv)
+    print("%-4s %-4s %-4s %-4s %-4s %-4s %-4s  %s" % ("sccU", "sccD", "vccU", "vccD", "exec", "call", "unk", "kernel [object]"))
+    for r in rows:
+        print("%4d %4d %4d %4d %4d %4d %4d  %s [%s]" % (r["scc_uniform"], r["scc_lane_data"], r["vcc_uniform"], r["vcc_lane_data"], r["exec"], r["calls"], r["unknown"], r["kernel"][:110], r["object"]))
+    if "--json" in argv:
+        with open(argv[argv.index("--json") + 1], "w") as f:
+            json.dump({"kernels": rows, "problems": problems}, f, indent=1)
+    for p in problems:
+        print("PROBLEM:", p)
+    return 1 if problems else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
