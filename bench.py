@@ -519,6 +519,9 @@ def main():
             Cv.get(Pp)
             Cv.mul2(e[:4096].contiguous(), Cv.gen(4096), f[:4096].contiguous(), Pp)
             del Pp
+            # ... and one call at FULL size: the window-table workspace is sized to the resident grid (up to 566 MB for ED25519 at four
+            # waves per SIMD) and is allocated on the first call that needs it -- device memory management is not what the leg measures
+            Cv.mul(e, G.clone())
             Gc = G.clone()
             torch.cuda.synchronize(); t0 = time.perf_counter()
             Q = Cv.mul(e, Gc)

@@ -22,8 +22,9 @@ def pytest_configure(config):
 
 
 def load_golden(name):
-    with open(os.path.join(GOLDEN, name)) as f:
-        return json.load(f)
+    """a fixture of tests/golden/, plain JSON or gzip-compressed JSON (tests/golden/gio.py)"""
+    from tests.golden import gio
+    return gio.load(name)
 
 
 def limbs(hexlist):

@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 import refgen  # noqa: E402
+import gio  # noqa: E402
 from tests.util import BULK_BLOCK, BULK_CLASSES, BULK_N, BULK_OPS, block_digests, bulk_inputs  # noqa: E402
 
 # harness (ours): element-major loops around the reference-emitted functions
@@ -71,7 +72,7 @@ def main():
             per[cls] = d
             print(P, cls, "done", flush=True)
         out["primes"][P] = per
-    json.dump(out, open(os.path.join(HERE, "bulk_digests.json"), "w"), separators=(",", ":"))
+    gio.dump(out, "bulk_digests.json")
     print("wrote bulk_digests.json")
 
 

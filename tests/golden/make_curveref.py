@@ -15,6 +15,7 @@ import ctypes, json, os, random, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import curveref  # noqa: E402
+import gio  # noqa: E402
 
 CURVES = ("ED25519", "ED448", "NUMS256E", "ED248", "ED376", "ED500", "NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W")
 
@@ -82,7 +83,7 @@ def fixture(curve, seed, records, custom=None):
         # ecnXXXgen would take a square root (addchain); the same point from its affine coordinates (tests/golden/edwards_*.json /
         # weierstrass_*.json "gen", the reference's sign choice) through the reference's own nres and modone
         kind = "edwards" if curve.startswith(("ED", "NUMS256E")) else "weierstrass"
-        gx, gy = json.load(open(os.path.join(HERE, "%s_%s.json" % (kind, curve))))["gen"]
+        gx, gy = gio.load("%s_%s.json" % (kind, curve))["gen"]
         U = ctypes.c_uint64 * N
         def limbs(v):
             return U(*[(v >> (radix * i)) & ((1 << radix) - 1) for i in range(N)])
@@ -129,7 +130,7 @@ def fixture(curve, seed, records, custom=None):
     # weierstrass_*.json "set_xy", on and off the curve)
     if custom is None:
         kind = "edwards" if curve.startswith(("ED", "NUMS256E")) else "weierstrass"
-        aff = json.load(open(os.path.join(HERE, "%s_%s.json" % (kind, curve))))
+        aff = gio.load("%s_%s.json" % (kind, curve))
     else:
         pts = affine_multiples(custom, 6)
         hx = lambda v: v.to_bytes(nb, "big").hex()
@@ -152,14 +153,14 @@ def main():
         if only and c not in only:
             continue
         fx = fixture(c, 12000 + k, 10 if fx_small(c) else 6)
-        json.dump(fx, open(os.path.join(HERE, "curveref_%s.json" % c), "w"), indent=0, separators=(",", ":"))
+        gio.dump(fx, "curveref_%s.json" % c)
         print(c, len(fx["records"]), "records; gen x limb 0:", fx["gen"][0][0])
     # curves that are not in curve.py's table (modarith_amd.generate.EXAMPLE_CURVES), inserted the way curve.py asks its user to
     for k, (c, cu) in enumerate(custom_curves().items()):
         if only and c not in only:
             continue
         fx = fixture(c, 13000 + k, 8, custom=cu)
-        json.dump(fx, open(os.path.join(HERE, "curveref_%s.json" % c), "w"), indent=0, separators=(",", ":"))
+        gio.dump(fx, "curveref_%s.json" % c)
         print(c, len(fx["records"]), "records (custom curve); gen x limb 0:", fx["gen"][0][0])
 
 

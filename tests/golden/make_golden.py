@@ -28,6 +28,7 @@ from ctypes import c_uint64, c_int, c_uint, c_char, POINTER
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import refgen  # noqa: E402
+import gio  # noqa: E402  (tests/golden/gio.py: plain or gzip-compressed fixture files)
 
 U64P = POINTER(c_uint64)
 
@@ -940,8 +941,8 @@ def extras():
             continue
         script, arg = reference_argv(name)
         fx, _ = field_fixture(script, arg, 6000 + k, count=64, full_time=False, name=name)
-        json.dump(fx, open(os.path.join(HERE, "field_%s.json" % name), "w"), indent=0, separators=(",", ":"))
-        json.dump(sqrt_fixture(script, arg, 7000 + k, count=24, name=name), open(os.path.join(HERE, "sqrt_%s.json" % name), "w"), indent=0, separators=(",", ":"))
+        gio.dump(fx, "field_%s.json" % name)
+        gio.dump(sqrt_fixture(script, arg, 7000 + k, count=24, name=name), "sqrt_%s.json" % name)
         print(name, fx["params"]["log"][0])
 
 
@@ -955,8 +956,8 @@ def generated():
         expr = arg.split("=", 1)[-1]
         script = "pseudo.py" if fam == "pseudo" else "monty.py"
         fx, _ = field_fixture(script, expr, 9000 + k, count=64, full_time=False, name=tag)
-        json.dump(fx, open(os.path.join(HERE, "field_%s.json" % tag), "w"), indent=0, separators=(",", ":"))
-        json.dump(sqrt_fixture(script, expr, 9100 + k, count=24, name=tag), open(os.path.join(HERE, "sqrt_%s.json" % tag), "w"), indent=0, separators=(",", ":"))
+        gio.dump(fx, "field_%s.json" % tag)
+        gio.dump(sqrt_fixture(script, expr, 9100 + k, count=24, name=tag), "sqrt_%s.json" % tag)
         print(tag, fx["params"]["log"][0])
 
 
@@ -969,39 +970,38 @@ def main():
         return
     if "--weierstrass-only" in sys.argv:
         for k, wname in enumerate(("NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W")):
-            json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else (24, 20, 28, 28)[k - 1]), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
+            gio.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else (24, 20, 28, 28)[k - 1]), "weierstrass_%s.json" % wname)
         return
     if "--edwards-only" in sys.argv:
         for name, seed in (("ED25519", 5001), ("ED448", 5002), ("NUMS256E", 5003), ("ED248", 5004), ("ED376", 5005), ("ED500", 5006)):
             fx = edwards_fixture(name, seed, pairs={"ED25519": 40, "ED376": 16, "ED500": 12}.get(name, 20))
-            json.dump(fx, open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
+            gio.dump(fx, "edwards_%s.json" % name)
             if "testcurve" in fx:
                 print(name, "testcurve chain 10000:", fx["testcurve"]["mul_chain"]["10000"])
         return
     if "--sqrt-only" in sys.argv:
         for script, prime, seed in (("pseudo.py", "X25519", 4001), ("monty.py", "NIST256", 4002), ("monty.py", "X448", 4003)):
-            json.dump(sqrt_fixture(script, prime, seed), open(os.path.join(HERE, "sqrt_%s.json" % prime), "w"), indent=0, separators=(",", ":"))
+            gio.dump(sqrt_fixture(script, prime, seed), "sqrt_%s.json" % prime)
         return
     out = {}
     for script, prime, seed in (("pseudo.py", "X25519", 1001), ("monty.py", "NIST256", 1002), ("monty.py", "X448", 1003)):
         fx, ref = field_fixture(script, prime, seed)
-        path = os.path.join(HERE, "field_%s.json" % prime)
-        json.dump(fx, open(path, "w"), indent=0, separators=(",", ":"))
+        path = gio.dump(fx, "field_%s.json" % prime)
         print(prime, "time:", {k: v for k, v in fx["time"].items() if "check" in k})
         out[prime] = path
     for script, prime, seed in (("pseudo.py", "X25519", 2001), ("monty.py", "X448", 2003)):
         fx = lazy_fixture(script, prime, seed)
-        json.dump(fx, open(os.path.join(HERE, "field_%s_lazy.json" % prime), "w"), indent=0, separators=(",", ":"))
+        gio.dump(fx, "field_%s_lazy.json" % prime)
     for script, prime, seed in (("pseudo.py", "X25519", 4001), ("monty.py", "NIST256", 4002), ("monty.py", "X448", 4003)):
-        json.dump(sqrt_fixture(script, prime, seed), open(os.path.join(HERE, "sqrt_%s.json" % prime), "w"), indent=0, separators=(",", ":"))
+        gio.dump(sqrt_fixture(script, prime, seed), "sqrt_%s.json" % prime)
     extras()
     for k, wname in enumerate(("NIST256", "NIST384", "NIST521", "SECP256K1", "NUMS256W")):
-        json.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else (24, 20, 28, 28)[k - 1]), open(os.path.join(HERE, "weierstrass_%s.json" % wname), "w"), indent=0, separators=(",", ":"))
+        gio.dump(weierstrass_fixture(wname, 8001 + k, pairs=32 if k == 0 else (24, 20, 28, 28)[k - 1]), "weierstrass_%s.json" % wname)
     for name, seed in (("ED25519", 5001), ("ED448", 5002), ("NUMS256E", 5003), ("ED248", 5004), ("ED376", 5005), ("ED500", 5006)):
-        json.dump(edwards_fixture(name, seed, pairs={"ED25519": 40, "ED376": 16, "ED500": 12}.get(name, 20)), open(os.path.join(HERE, "edwards_%s.json" % name), "w"), indent=0, separators=(",", ":"))
+        gio.dump(edwards_fixture(name, seed, pairs={"ED25519": 40, "ED376": 16, "ED500": 12}.get(name, 20)), "edwards_%s.json" % name)
     for curve, seed in (("X25519", 3001), ("X448", 3003)):
         fx = ladder_fixture(curve, seed)
-        json.dump(fx, open(os.path.join(HERE, "ladder_%s.json" % curve), "w"), indent=0, separators=(",", ":"))
+        gio.dump(fx, "ladder_%s.json" % curve)
         print(curve, "ref main chain 5000:", fx["ref_main_chain"]["checkpoints"]["5000"], "dh:", fx["ref_main_chain"]["dh"]["shared"])
 
 

@@ -17,6 +17,7 @@ from ctypes import c_int
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 from make_golden import Ref, element_pool, hx  # noqa: E402
+import gio  # noqa: E402
 
 
 def limb_classes(R, rng):
@@ -76,7 +77,7 @@ def main():
         if only and name not in only:
             continue
         fx = fixture(script, arg, 9000 + k, name, count=96 if k < 3 else 32)
-        json.dump(fx, open(os.path.join(HERE, "field_%s_r2.json" % name), "w"), indent=0, separators=(",", ":"))
+        gio.dump(fx, "field_%s_r2.json" % name)
         print(name, len(fx["modnsqr"]), "modnsqr records,", len(fx["ooc"]), "out-of-contract records")
 
 

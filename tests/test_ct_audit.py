@@ -1,6 +1,6 @@
 """tools/ct_audit.py as a test (no GPU): every conditional branch in the gfx950 code of the kernels that carry the reference's
 constant-time contract (modcsw / modcmv pseudo.py:979-1048, the ladders, ecnXXXmul edwards.c:382-401, 435-482) is classified
-from the disassembly; a branch on lane data, or more exec-mask branches than the reviewed allow-list (tools/ct_allowlist.json)
+from the disassembly (with the registers it depends on traced back to loads, workitem ids or scalars); a branch on lane data, or more exec-mask / lane-index branches than the reviewed allow-list (tools/ct_allowlist.json)
 names, fails.  The classifier itself is checked on hand-made instruction streams."""
 import os
 import sys
@@ -13,20 +13,30 @@ import ct_audit  # noqa: E402
 
 
 def test_classifier_on_hand_made_streams():
+    load = "global_load_dword v1, v[4:5], off"                                           # v1 = per-lane contents of memory
     uniform_loop = ["s_mov_b32 s4, 0", "v_add_u32_e32 v1, v2, v3", "s_add_i32 s4, s4, 1", "s_cmp_lg_u32 s4, 8", "s_cbranch_scc1 65530"]
     a = ct_audit.audit_function(uniform_loop)
     assert (a["scc_uniform"], a["scc_lane_data"], a["unknown"]) == (1, 0, 0)
-    vote = ["v_cmp_gt_u32_e32 vcc, v1, v2", "s_cbranch_vccnz 12"]                       # a wave vote on lane values
+    vote = [load, "v_cmp_gt_u32_e32 vcc, v1, v2", "s_cbranch_vccnz 12"]                 # a wave vote on lane values
     a = ct_audit.audit_function(vote)
     assert a["vcc_lane_data"] == 1
-    vote2 = ["v_cmp_eq_u32_e64 s[6:7], v1, v2", "s_and_b64 vcc, exec, s[6:7]", "s_cbranch_vccz 12"]
+    vote2 = [load, "v_and_b32_e32 v7, 15, v1", "v_cmp_eq_u32_e64 s[6:7], v7, v2", "s_and_b64 vcc, exec, s[6:7]", "s_cbranch_vccz 12"]
     assert ct_audit.audit_function(vote2)["vcc_lane_data"] == 1
+    lds_digit = ["ds_read_i8 v9, v3", "v_cmp_ne_u32_e32 vcc, 0, v9", "s_cbranch_vccz 30"]     # "skip the addition when the digit is zero"
+    assert ct_audit.audit_function(lds_digit)["vcc_lane_data"] == 1
     structurizer = ["s_mov_b64 s[50:51], 0", "s_andn2_b64 vcc, exec, s[50:51]", "v_mad_u64_u32 v[2:3], s[50:51], v3, 19, v[4:5]", "s_cbranch_vccnz 61396"]
     a = ct_audit.audit_function(structurizer)                                            # vcc = exec & ~0: the compiler's uniform branch
     assert (a["vcc_uniform"], a["vcc_lane_data"]) == (1, 0)
-    firstlane = ["v_readfirstlane_b32 s5, v9", "s_cmp_eq_u32 s5, 0", "s_cbranch_scc0 40"]   # a uniform branch on what lane 0 holds
+    firstlane = [load, "v_readfirstlane_b32 s5, v1", "s_cmp_eq_u32 s5, 0", "s_cbranch_scc0 40"]   # a uniform branch on what lane 0 holds
     assert ct_audit.audit_function(firstlane)["scc_lane_data"] == 1
-    carry = ["v_subrev_co_u32_e32 v54, vcc, 1, v54", "s_and_b64 vcc, exec, vcc", "s_cbranch_vccz 100"]   # counter kept in a VGPR
+    # the `t < n` guard as a vote: lane index against a kernel argument -- not data (v0 = workitem id, never written before)
+    guard = ["s_load_dwordx2 s[2:3], s[0:1], 0x10", "v_lshl_add_u32 v5, s8, 6, v0", "v_mov_b32_e32 v6, 0", "v_cmp_gt_u64_e32 vcc, s[2:3], v[5:6]", "s_cbranch_vccz 100"]
+    a = ct_audit.audit_function(guard)
+    assert (a["lane_index"], a["vcc_lane_data"], a["unknown"]) == (1, 0, 0)
+    counter_in_vgpr = ["v_mov_b32_e32 v54, 63", "v_subrev_co_u32_e32 v54, vcc, 1, v54", "s_and_b64 vcc, exec, vcc", "s_cbranch_vccz 65533"]
+    a = ct_audit.audit_function(counter_in_vgpr)                                         # a uniform counter kept in a VGPR: constants only
+    assert a["vcc_lane_data"] == 0 and a["unknown"] == 0
+    carry = [load, "v_subrev_co_u32_e32 v54, vcc, 1, v1", "s_and_b64 vcc, exec, vcc", "s_cbranch_vccz 100"]   # a borrow out of loaded data
     assert ct_audit.audit_function(carry)["vcc_lane_data"] == 1
     div = ["v_cmp_lt_u64_e32 vcc, s[2:3], v[0:1]", "s_and_saveexec_b64 s[4:5], vcc", "s_cbranch_execz 55"]
     assert ct_audit.audit_function(div)["exec"] == 1

@@ -13,7 +13,9 @@ classifies what its condition is made of, by tracing the condition register back
                     decision on what the lanes hold -- a data-dependent branch
   vcc   s_cbranch_vccz/nz: the instruction that wrote VCC.  s_and / s_andn2 / s_or of EXEC with an SGPR pair that holds a
         constant or an s_cselect of SCC is the compiler's way of branching on a uniform condition (uniform); a v_cmp is a vote
-        on lane data (lane-data)
+        on what the lanes hold, and its VGPR operands are traced on: if everything they are computed from is the workitem id
+        (VGPRs never written before) and uniform values, the vote is a `t < n` guard (lane-index: counted with the exec class);
+        if a per-lane memory load feeds it, it is a vote on lane data (lane-data)
   exec  s_cbranch_execz/nz: divergence -- some lanes skip a region.  Constant-time only if the lane mask depends on the lane
         index and the batch size alone (the `t < n` guard and the grid-stride back-edge); cannot be told apart mechanically,
         so the NUMBER of such branches per kernel is pinned in the allow-list with the reviewed reason.
@@ -68,14 +70,14 @@ def disassemble(obj):
 
 
 def _regs(tok):
-    """registers named by an operand token: 's4' -> {('s',4)}, 's[4:5]' -> {('s',4),('s',5)}, 'vcc' -> {('vcc',0)}"""
+    """registers named by an operand token: 's4' -> {('s',4)}, 's[4:5]' -> {('s',4),('s',5)}, 'v[2:3]' -> {('v',2),('v',3)}, 'vcc' -> {('vcc',0)}"""
     tok = tok.strip().rstrip(",")
-    m = re.match(r"^s\[(\d+):(\d+)\]$", tok)
+    m = re.match(r"^([sv])\[(\d+):(\d+)\]$", tok)
     if m:
-        return {("s", i) for i in range(int(m.group(1)), int(m.group(2)) + 1)}
-    m = re.match(r"^s(\d+)$", tok)
+        return {(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    m = re.match(r"^([sv])(\d+)$", tok)
     if m:
-        return {("s", int(m.group(1)))}
+        return {(m.group(1), int(m.group(2)))}
     if tok in ("vcc", "vcc_lo", "vcc_hi"):
         return {("vcc", 0)}
     return set()
@@ -124,9 +126,14 @@ class Function:
                     self.preds[j].append(i)
 
     def writes(self, i):
-        """(registers written by instruction i, kind): kind in valu / uniform-source / salu / other"""
+        """(registers written by instruction i, kind): kind in valu / load / uniform-source / salu / other"""
         op, ops = _split(self.text[i])
         dst = _regs(ops[0]) if ops else set()
+        if op.startswith(("global_load", "buffer_load", "flat_load", "scratch_load", "ds_read", "ds_bpermute", "ds_permute", "ds_swizzle", "global_atomic", "buffer_atomic", "ds_add_rtn",
+                          "ds_consume", "ds_append", "tbuffer_load", "image_")):
+            return dst, "load"
+        if op.startswith(("global_store", "buffer_store", "flat_store", "scratch_store", "ds_write", "tbuffer_store")):
+            return set(), "other"
         if op.startswith("v_"):
             if len(ops) > 1 and op.startswith(CARRY_OUT):
                 dst |= _regs(ops[1])
@@ -146,23 +153,31 @@ class Function:
     def sources(self, i):
         op, ops = _split(self.text[i])
         srcs = set()
-        for o in (ops if op.startswith(("s_cmp", "s_bitcmp")) else ops[1:]):
+        first = 0 if op.startswith(("s_cmp", "s_bitcmp")) else 1
+        # (llvm-objdump prints the destination of every v_cmp first -- "v_cmp_ge_u64_e32 vcc, s[12:13], v[2:3]" -- so sources start at 1 there too)
+        for o in ops[first:]:
             if o.strip() in EXEC:
                 continue                                     # EXEC as a value: the launched lanes (tails belong to the exec-branch class)
             srcs |= _regs(o)
+        if op.startswith("v_") and len(ops) > 1 and op.startswith(CARRY_OUT):
+            srcs -= _regs(ops[1])                            # the carry-out operand is a destination
         if op.startswith(USES_SCC):
             srcs |= {("scc", 0)}
         return srcs
 
+    RANK = {"uniform": 0, "lane-index": 1, "unknown": 2, "lane-data": 3}
+
     def trace(self, start, regs, depth=0, budget=None):
-        """what `regs` hold on entry to instruction `start`, over all paths: 'uniform', 'lane-data' or 'unknown'"""
+        """what `regs` hold on entry to instruction `start`, over all paths:
+        'uniform' (scalar constants, arguments, counters), 'lane-index' (functions of the lane / workitem id and uniform values only),
+        'lane-data' (something loaded from memory per lane) or 'unknown'"""
         if not regs:
             return "uniform"
         key = (start, frozenset(regs))
         active = self.__dict__.setdefault("active", set())
         if key in active:
             return "uniform"                                 # being traced further up the recursion: a loop-carried value adds nothing new
-        if depth > 60:
+        if depth > 80:
             return "unknown"
         active.add(key)                                      # (no caching of verdicts: one reached through an open cycle is provisional)
         try:
@@ -171,10 +186,15 @@ class Function:
             active.discard(key)
 
     def _trace(self, start, regs, depth, budget):
-        budget = budget if budget is not None else [400000]
+        budget = budget if budget is not None else [600000]
         seen = set()
         work = [(p, frozenset(regs)) for p in self.preds[start]]
         verdict = "uniform"
+        if not self.preds[start] and any(r[0] == "v" for r in regs):
+            verdict = "lane-index"
+
+        def worse(a, b):
+            return a if self.RANK[a] >= self.RANK[b] else b
         while work:
             i, pend = work.pop()
             if (i, pend) in seen:
@@ -182,26 +202,33 @@ class Function:
             seen.add((i, pend))
             budget[0] -= 1
             if budget[0] < 0:
-                return "unknown"
+                return worse(verdict, "unknown")
             dst, kind = self.writes(i)
             hit = dst & pend
             if hit:
-                if kind == "valu":
-                    return "lane-data"                       # v_cmp masks, v_readlane / v_readfirstlane, carry-outs: out of the vector unit
-                if kind == "salu":
-                    r = self.trace(i, self.sources(i), depth + 1, budget)
+                if kind == "load":
+                    return "lane-data"                       # per-lane contents of memory
+                if kind in ("valu", "salu"):
+                    op = self.text[i].split()[0]
+                    if op.startswith("v_mbcnt"):
+                        r = "lane-index"
+                    else:
+                        r = self.trace(i, self.sources(i), depth + 1, budget)
                     if r == "lane-data":
                         return r
-                    if r == "unknown":
-                        verdict = "unknown"
+                    verdict = worse(verdict, r)
                 elif kind != "uniform-source":
-                    verdict = "unknown"
+                    verdict = worse(verdict, "unknown")
                 pend = pend - dst
                 if not pend:
                     continue
+            if not self.preds[i]:
+                # function entry reached with registers never written: SGPRs are kernel arguments / launch constants (uniform),
+                # VGPRs are the workitem ids the hardware provides (lane-index)
+                if any(r[0] == "v" for r in pend):
+                    verdict = worse(verdict, "lane-index")
             for p in self.preds[i]:
                 work.append((p, pend))
-            # (a register never written on some path is a kernel argument / launch constant: uniform)
         return verdict
 
 
@@ -210,15 +237,15 @@ def audit_function(ins):
     if ins and not isinstance(ins[0], tuple):
         ins = [(4 * i, t) for i, t in enumerate(ins)]
     f = Function(ins)
-    out = {"scc_uniform": 0, "scc_lane_data": 0, "vcc_uniform": 0, "vcc_lane_data": 0, "exec": 0, "unknown": 0, "calls": 0, "detail": []}
+    out = {"scc_uniform": 0, "scc_lane_data": 0, "vcc_uniform": 0, "vcc_lane_data": 0, "lane_index": 0, "exec": 0, "unknown": 0, "calls": 0, "detail": []}
     for i, t in enumerate(f.text):
         op, ops = _split(t)
         if op in ("s_cbranch_scc0", "s_cbranch_scc1"):
             c = f.trace(i, {("scc", 0)})
-            key = {"uniform": "scc_uniform", "lane-data": "scc_lane_data"}.get(c, "unknown")
+            key = {"uniform": "scc_uniform", "lane-data": "scc_lane_data", "lane-index": "lane_index"}.get(c, "unknown")
         elif op in ("s_cbranch_vccz", "s_cbranch_vccnz"):
             c = f.trace(i, {("vcc", 0)})
-            key = {"uniform": "vcc_uniform", "lane-data": "vcc_lane_data"}.get(c, "unknown")
+            key = {"uniform": "vcc_uniform", "lane-data": "vcc_lane_data", "lane-index": "lane_index"}.get(c, "unknown")
         elif op in ("s_cbranch_execz", "s_cbranch_execnz"):
             c, key = "exec", "exec"
         elif op.startswith(("s_setpc", "s_swappc")):
@@ -275,8 +302,8 @@ def run(verbose=False):
                 lane = a["scc_lane_data"] + a["vcc_lane_data"]
                 if lane > entry.get("lane_data_branches", 0):
                     problems.append("%s: %d data-dependent branch(es), %d allowed" % (short, lane, entry.get("lane_data_branches", 0)))
-                if a["exec"] > entry.get("exec_branches", 0):
-                    problems.append("%s: %d exec-mask branch(es), %d allowed" % (short, a["exec"], entry.get("exec_branches", 0)))
+                if a["exec"] + a["lane_index"] > entry.get("exec_branches", 0):
+                    problems.append("%s: %d exec-mask / lane-index branch(es), %d allowed" % (short, a["exec"] + a["lane_index"], entry.get("exec_branches", 0)))
                 if a["unknown"] > entry.get("unknown", 0):
                     problems.append("%s: %d unclassified branch(es)" % (short, a["unknown"]))
     return rows, problems
@@ -284,9 +311,10 @@ def run(verbose=False):
 
 def main(argv):
     rows, problems = run(verbose="--verbose" in argv)
-    print("%-4s %-4s %-4s %-4s %-4s %-4s %-4s  %s" % ("sccU", "sccD", "vccU", "vccD", "exec", "call", "unk", "kernel [object]"))
+    print("%-4s %-4s %-4s %-4s %-4s %-4s %-4s %-4s  %s" % ("sccU", "sccD", "vccU", "vccD", "idx", "exec", "call", "unk", "kernel [object]"))
     for r in rows:
-        print("%4d %4d %4d %4d %4d %4d %4d  %s [%s]" % (r["scc_uniform"], r["scc_lane_data"], r["vcc_uniform"], r["vcc_lane_data"], r["exec"], r["calls"], r["unknown"], r["kernel"][:110], r["object"]))
+        print("%4d %4d %4d %4d %4d %4d %4d %4d  %s [%s]" % (r["scc_uniform"], r["scc_lane_data"], r["vcc_uniform"], r["vcc_lane_data"], r["lane_index"], r["exec"], r["calls"], r["unknown"],
+                                                         r["kernel"][:110], r["object"]))
     if "--json" in argv:
         with open(argv[argv.index("--json") + 1], "w") as f:
             json.dump({"kernels": rows, "problems": problems}, f, indent=1)
