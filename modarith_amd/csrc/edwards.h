@@ -53,7 +53,7 @@ struct Edwards : CurveOps<Edwards<C, F_>, typename C::FieldParams, F_> {
         F::modadd(p.x, p.y, B);
         F::modadd(q.x, q.y, E);
         F::modmul(B, E, p.x);
-        F::modsub(p.x, Cc, p.x);
+        F::modsub_u(p.x, Cc, p.x);      // (feeds the next modsub only: field.h "_u")
         F::modsub(p.x, D, p.x);
         F::modmul(p.x, Ff, p.x);
         F::modmul(p.x, A, p.x);
@@ -70,11 +70,13 @@ struct Edwards : CurveOps<Edwards<C, F_>, typename C::FieldParams, F_> {
         F::modsqr(p.x, Cc);
         F::modsqr(p.y, D);
         F::modsqr(p.z, H);
-        F::modadd(H, H, H);
-        if constexpr (C::A == -1) F::modneg(Cc, E); else F::modcpy(Cc, E);
+        // the sums that only feed further sums are taken in their "_u" form (field.h: same integer, same sign decision, closing
+        // carry chain left to the consumer): 2H -> J, -C -> F and Y3's factor, B - C -> X3's factor
+        F::modadd_u(H, H, H);
+        if constexpr (C::A == -1) F::modneg_u(Cc, E); else F::modcpy(Cc, E);
         F::modadd(E, D, Ff);
         F::modsub(Ff, H, J);
-        F::modsub(B, Cc, p.x);
+        F::modsub_u(B, Cc, p.x);
         F::modsub(p.x, D, p.x);
         F::modmul(p.x, J, p.x);
         F::modsub(E, D, p.y);

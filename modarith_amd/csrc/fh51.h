@@ -59,7 +59,8 @@ struct FieldH51 {
     // the nine half boundaries; the first one is fused with the limb-wise sum (v_add3_u32), carries are arithmetic shifts as in
     // prop (pseudo.py:223-251), and the top word h[9] stays unmasked as the top limb does.  Same integer at every step, hence
     // the same digits.  Inputs: h[i] < 2^30 (any element of this form inside the contract is far below).
-    template <class First>
+    // RIPPLE = false: the "_u" forms (see Field<P>::modadd_u): the closing chain is left out, n[0] and the top word carry the +2p
+    template <bool RIPPLE = true, class First>
     static MA_DEV void chains(First first, uint32_t* n) {
         // chain 1: n[i] = first(i) + carry
         int32_t c = 0;
@@ -70,6 +71,11 @@ struct FieldH51 {
         });
         int32_t top = first(std::integral_constant<int, NL - 1>{}) + c;
         const int32_t m = top >> 31;                         // all ones if the value is negative
+        if constexpr (!RIPPLE) {
+            n[0] = (uint32_t)((int32_t)n[0] - (38 & m));     // (may go negative: the consumer's first chain takes it as a signed word)
+            n[NL - 1] = (uint32_t)(top + ((1 << 26) & m));
+            return;
+        }
         // + 2p under the mask, chain 2
         int32_t y = (int32_t)n[0] - (38 & m);
         n[0] = (uint32_t)y & M26;
@@ -97,6 +103,24 @@ struct FieldH51 {
     static MA_DEV void modneg(const uint32_t* b, uint32_t* n) {
         uint32_t r[NL];
         chains([&](auto I) -> int32_t { return -(int32_t)b[I]; }, r);
+        modcpy(r, n);
+    }
+    static MA_DEV void modadd_u(const uint32_t* a, const uint32_t* b, uint32_t* n) {
+        uint32_t r[NL];
+        chains<false>([&](auto I) -> int32_t {
+            constexpr int i = I;
+            return (int32_t)(a[i] + b[i]) + (i == 0 ? 38 : 0) - (i == NL - 1 ? (1 << 26) : 0);
+        }, r);
+        modcpy(r, n);
+    }
+    static MA_DEV void modsub_u(const uint32_t* a, const uint32_t* b, uint32_t* n) {
+        uint32_t r[NL];
+        chains<false>([&](auto I) -> int32_t { return (int32_t)(a[I] - b[I]); }, r);
+        modcpy(r, n);
+    }
+    static MA_DEV void modneg_u(const uint32_t* b, uint32_t* n) {
+        uint32_t r[NL];
+        chains<false>([&](auto I) -> int32_t { return -(int32_t)b[I]; }, r);
         modcpy(r, n);
     }
 

@@ -210,6 +210,29 @@ struct Field {
         addp<2>(n, carry);
         (void)prop(n);
     }
+    // "_u" forms: the generic=True functions above WITHOUT their closing carry propagation.  The result is the same integer as the
+    // full function's (same choice of +2p, made on the propagated sum), but limbs 0..N-2 are the digits of the sum with 2p added
+    // limb-wise on top -- not yet re-normalised.  Every add-class function starts by propagating its limb-wise sum, and what it
+    // returns depends only on the INTEGER its operands represent, so a value that is consumed by modadd / modsub / modneg alone
+    // may be produced this way: the consumer returns exactly the limbs it would return for the normalised operand.  Never feed a
+    // "_u" value to a multiplication, a comparison or memory (the products' results depend on the limb representation).  Used by
+    // the curve formulas (edwards.h, weierstrass.h) for the intermediate sums that only feed further sums: one carry chain of two saved.
+    static MA_DEV void modadd_u(const spint* a, const spint* b, spint* n) {
+        static_for<0, N>([&](auto I) { n[I] = a[I] + b[I]; });
+        subp<2>(n);
+        spint carry = prop(n);
+        addp<2>(n, carry);
+    }
+    static MA_DEV void modsub_u(const spint* a, const spint* b, spint* n) {
+        static_for<0, N>([&](auto I) { n[I] = a[I] - b[I]; });
+        spint carry = prop(n);
+        addp<2>(n, carry);
+    }
+    static MA_DEV void modneg_u(const spint* b, spint* n) {
+        static_for<0, N>([&](auto I) { n[I] = (spint)0 - b[I]; });
+        spint carry = prop(n);
+        addp<2>(n, carry);
+    }
     // generic=False forms with mp=2 (rfc7748.c:20; pseudo.py:294-325, monty.py:426-489)
     static MA_DEV void modadd_lazy(const spint* a, const spint* b, spint* n) {
         static_for<0, N>([&](auto I) { n[I] = a[I] + b[I]; });

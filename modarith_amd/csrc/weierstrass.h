@@ -39,17 +39,17 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
         F::modadd(p.x, p.y, T3);
         F::modadd(q.x, q.y, T4);
         F::modmul(T3, T4, T3);
-        F::modadd(T0, T1, T4);
+        F::modadd_u(T0, T1, T4);          // "_u" (field.h): sums that only feed further sums leave their closing carry chain to the consumer
         F::modsub(T3, T4, T3);
         F::modadd(p.y, p.z, T4);
         F::modadd(q.y, q.z, B);
         F::modmul(T4, B, T4);
-        F::modadd(T1, T2, B);
+        F::modadd_u(T1, T2, B);
         F::modsub(T4, B, T4);
         F::modadd(p.x, p.z, p.x);
         F::modadd(q.z, q.x, p.y);
         F::modmul(p.x, p.y, p.x);
-        F::modadd(T0, T2, p.y);
+        F::modadd_u(T0, T2, p.y);
         F::modsub(p.x, p.y, p.y);
         if constexpr (C::A == 0) {
             F::modadd(T0, T0, p.x);
@@ -89,21 +89,21 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
             } else {
                 const_b(B);
                 F::modmul(B, T2, p.z);
-                F::modsub(p.y, p.z, p.x);
+                F::modsub_u(p.y, p.z, p.x);     // -> 2x, 3x below
                 F::modmul(p.y, B, p.y);
             }
-            F::modadd(p.x, p.x, p.z);
-            F::modadd(p.x, p.z, p.x);
+            F::modadd_u(p.x, p.x, p.z);         // 2x -> 3x
+            F::modadd_u(p.x, p.z, p.x);         // 3x -> T1 - 3x, 3x + T1
             F::modsub(T1, p.x, p.z);
             F::modadd(p.x, T1, p.x);
-            F::modadd(T2, T2, T1);
-            F::modadd(T2, T1, T2);
-            F::modsub(p.y, T2, p.y);
-            F::modsub(p.y, T0, p.y);
-            F::modadd(p.y, p.y, T1);
+            F::modadd_u(T2, T2, T1);            // 2 T2 -> 3 T2
+            F::modadd_u(T2, T1, T2);            // 3 T2 -> two differences
+            F::modsub_u(p.y, T2, p.y);          // -> next difference
+            F::modsub_u(p.y, T0, p.y);          // -> 2y, 3y
+            F::modadd_u(p.y, p.y, T1);
             F::modadd(p.y, T1, p.y);
-            F::modadd(T0, T0, T1);
-            F::modadd(T0, T1, T0);
+            F::modadd_u(T0, T0, T1);
+            F::modadd_u(T0, T1, T0);
             F::modsub(T0, T2, T0);
             F::modmul(T4, p.y, T1);
             F::modmul(T0, p.y, T2);
@@ -166,23 +166,23 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
             } else {
                 const_b(B);
                 F::modmul(T2, B, p.y);
-                F::modsub(p.y, p.z, p.y);
+                F::modsub_u(p.y, p.z, p.y);     // "_u" (field.h): -> 2y, 3y below
                 F::modmul(p.z, B, p.z);
             }
-            F::modadd(p.y, p.y, p.x);
-            F::modadd(p.y, p.x, p.y);
+            F::modadd_u(p.y, p.y, p.x);
+            F::modadd_u(p.y, p.x, p.y);
             F::modsub(T1, p.y, p.x);
             F::modadd(p.y, T1, p.y);
             F::modmul(p.y, p.x, p.y);
             F::modmul(p.x, T3, p.x);
-            F::modadd(T2, T2, T3);
-            F::modadd(T2, T3, T2);
-            F::modsub(p.z, T2, p.z);
-            F::modsub(p.z, T0, p.z);
-            F::modadd(p.z, p.z, T3);
+            F::modadd_u(T2, T2, T3);
+            F::modadd_u(T2, T3, T2);
+            F::modsub_u(p.z, T2, p.z);
+            F::modsub_u(p.z, T0, p.z);
+            F::modadd_u(p.z, p.z, T3);
             F::modadd(p.z, T3, p.z);
-            F::modadd(T0, T0, T3);
-            F::modadd(T0, T3, T0);
+            F::modadd_u(T0, T0, T3);
+            F::modadd_u(T0, T3, T0);
             F::modsub(T0, T2, T0);
             F::modmul(T0, p.z, T0);
             F::modadd(p.y, T0, p.y);
@@ -190,7 +190,7 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
             F::modmul(p.z, T4, p.z);
             F::modsub(p.x, p.z, p.x);
             F::modmul(T4, T1, p.z);
-            F::modadd(p.z, p.z, p.z);
+            F::modadd_u(p.z, p.z, p.z);
             F::modadd(p.z, p.z, p.z);
         }
     }
