@@ -263,6 +263,14 @@ class Field:
     def modinv(self, x, h=None, out=None):
         out = self._out(x, out)
         n = self._chk(x, out) if h is None else self._chk(x, h, out)
+        if h is None and out.data_ptr() == x.data_ptr() and n >= 4096:
+            # in place on a large batch: the simultaneous inversion needs n elements of scratch for its prefix products.  Taken from
+            # torch's caching allocator here (visible to it, stream-ordered, reusable) rather than from the library's own pool:
+            # the result is computed into a temporary and copied back (the kernel is VALU-bound; the copy is noise)
+            tmp = torch.empty_like(x)
+            self._call("modinv", x.data_ptr(), None, tmp.data_ptr(), n, self._ld(x), _stream(self.device))
+            out.copy_(tmp)
+            return out
         self._call("modinv", x.data_ptr(), None if h is None else h.data_ptr(), out.data_ptr(), n, self._ld(x), _stream(self.device))
         return out
 
