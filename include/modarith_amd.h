@@ -300,8 +300,9 @@ int rfc7748_X448_base_batch(const char *bk, char *bv, size_t n, void *stream);
  * multiplications sharing their doublings here, constant-time: same point, another projective representative;
  * ecn_*_mul2_exact_batch walks the reference's joint sparse form itself and returns the reference's limbs (variable time);
  * the scalar ecn_*_mul2 (one element, nothing to keep in step) takes that form.
- * Input points must have limbs below 2^(Radix+2) -- true of every point these functions or the reference's
- * produce; the field-level functions above have no such condition. */
+ * Input points must have limbs below 2^(Radix+2) and coordinates that are field elements in the API's sense (any representative
+ * below 2p) -- true of every point these functions or the reference's produce; the field-level functions above have no such
+ * condition.  (The scalar multiplications of ed25519 hold their elements in half-limb form, csrc/fh51.h: same limbs for such inputs.) */
 #define MODARITH_AMD_DECLARE_EDWARDS(c, NL)                                                                             \
     typedef struct { ma_spint x[NL], y[NL], z[NL]; } ma_point_##c##_t;                                                  \
     int ecn_##c##_get(ma_point_##c##_t *P, char *x, char *y);                          /* edwards.c:221-239 */        \

@@ -17,7 +17,9 @@ namespace ma {
 // the window's digit, so the compiler may keep them in a VGPR and close the loop with a carry-out vote (v_subrev_co + s_cbranch_vccz):
 // harmless, yet indistinguishable in the ISA from a branch on lane data (tools/ct_audit.py).  Pinned, the loop closes on s_cmp / SCC.
 MA_DEV int scalar(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)          // (the host pass of tools/fe_host_check.hip sees this header too)
     asm volatile("" : "+s"(i));
+#endif
     return i;
 }
 template <class Crv, class P_, class F_ = Field<P_, true>>
@@ -83,7 +85,9 @@ struct CurveOps {
         // kernel and live (and spill) through the whole multiplication; recomputed they cost two instructions per access
         MA_DEV unsigned here() const {
             unsigned l = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" : "+v"(l));
+#endif
             return l;
         }
         MA_DEV void put(int k, const Point& w) const {

@@ -3,7 +3,9 @@
 // limb holds above bit 26 (25 bits for a masked digit, more where the reference leaves a limb unmasked).  It is the SAME
 // element with the SAME limbs as Field<P_X25519> holds -- from_limbs() / to_limbs() are exact both ways -- and every function
 // returns exactly the limbs the reference's function returns (pseudo.py:286-348 modadd/modsub/modneg generic forms, 616-702
-// modmul/modsqr with the second pass 557-611) for inputs inside the limb contract of the FAST path (limbs < 2^53).
+// modmul/modsqr with the second pass 557-611) for field elements as the API defines them (SURVEY 8c caveat 2): limbs inside the
+// contract of the FAST path (< 2^53), VALUE below 2p for the sums (for larger values the reference's modsub / modneg leave a
+// negative top limb -- 64 bits wide there, 32 here -- which no function of the API accepts); tools/fe_host_check.hip run_fh51.
 //
 // Why: the scalar multiplications of the curve layer (csrc/curve.h) are chains of ~2 600 field multiplications with ~2 300
 // additions between them.  Field<P>::pm_modmul_half already multiplies on half limbs, but cuts each 64-bit limb into halves

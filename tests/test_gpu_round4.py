@@ -136,3 +136,58 @@ def test_bench_strong_scaling_switch_and_new_keys():
     assert d["x448"]["value"] > 1e6 and d["x448"]["roofline"]["bound"] == "valu"
     assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"]
     assert d["launch_stats"]["launches"] >= 20
+
+
+@pytest.mark.parametrize("C,name,radix,n", [("ed25519", "ED25519", 51, 1200), ("ed448", "ED448", 56, 300)])
+def test_scalar_multiplication_on_non_canonical_representatives(oracle, C, name, radix, n):
+    """the API's element contract (SURVEY 8c caveat 2): any representative below 2p, limbs possibly over Radix bits.  Points
+    whose coordinates are such representatives -- value + p where that stays below 2p, and carries pushed DOWN so that lower
+    limbs exceed their radix by up to two bits while the integer stays the same -- through ecn mul / mul2(exact): projective
+    limbs equal to the oracle's (for ED25519 this goes through the half-limb resident field, csrc/fh51.h, with excess bits in
+    every upper half)."""
+    import ctypes
+    from modarith_amd.edwards import Edwards
+    from modarith_amd.params import derive
+    Ed = Edwards(name)
+    nb, nl = Ed.nbytes, Ed.N
+    fp = derive("X25519" if name == "ED25519" else "X448")
+    rng = np.random.default_rng(29)
+    k0 = rng.integers(0, 256, size=(n, nb), dtype=np.uint8)
+    e = rng.integers(0, 256, size=(n, nb), dtype=np.uint8)
+    f = rng.integers(0, 256, size=(n, nb), dtype=np.uint8)
+    base = Ed.mul(torch.from_numpy(k0).cuda(), Ed.gen(n)).cpu().numpy().view(np.uint64).copy()       # [3, nl, n], limbs of the reference
+    mask = (1 << radix) - 1
+    for c in range(3):
+        for j in range(n):
+            limbs = [int(v) for v in base[c, :, j]]
+            if name == "ED25519":                             # plain field: the other representative of the same residue
+                v = sum(l << (radix * i) for i, l in enumerate(limbs))
+                if j % 3 == 0 and v + fp.p < 2 * fp.p:
+                    v += fp.p
+                    limbs = [(v >> (radix * i)) & mask for i in range(nl - 1)] + [v >> (radix * (nl - 1))]
+            if j % 2 == 0:                                    # same integer, lower limbs over Radix bits (borrow 1..3 from the limb above)
+                for i in range(nl - 1):
+                    take = min(int(rng.integers(1, 4)), limbs[i + 1])
+                    limbs[i + 1] -= take
+                    limbs[i] += take << radix
+            base[c, :, j] = np.array(limbs, dtype=np.uint64)
+    assert int(base.max()) < 1 << (radix + 2)
+    P = torch.from_numpy(base.view(np.int64)).cuda()
+    want = base.reshape(3 * nl, n).copy()
+    oracle.ecn(C, "batch_mul")(e.ctypes.data_as(ctypes.c_void_p), want.ctypes.data_as(ctypes.c_void_p), n, n)
+    got = Ed.mul(torch.from_numpy(e).cuda(), P.clone()).cpu().numpy().view(np.uint64).reshape(3 * nl, n)
+    assert np.array_equal(got, want)
+    # the same points through add and dbl (element-wise kernels, limb form) and through the exact double multiplication
+    Q = Ed.dbl(P.clone())
+    R = Ed.mul2(torch.from_numpy(e).cuda(), P, torch.from_numpy(f).cuda(), Q, exact=True).cpu().numpy().view(np.uint64)
+    Pt, _ = oracle.ed[C]
+    for j in range(0, n, max(1, n // 24)):
+        p, q, r = Pt(), Pt(), Pt()
+        for c, nm in enumerate(("x", "y", "z")):
+            for i in range(nl):
+                getattr(p, nm)[i] = int(base[c, i, j])
+        oracle.ecn(C, "cpy")(ctypes.byref(p), ctypes.byref(q))
+        oracle.ecn(C, "dbl")(ctypes.byref(q))
+        oracle.ecn(C, "mul2")(e[j].ctypes.data_as(ctypes.c_char_p), ctypes.byref(p), f[j].ctypes.data_as(ctypes.c_char_p), ctypes.byref(q), ctypes.byref(r))
+        for c, nm in enumerate(("x", "y", "z")):
+            assert [int(v) for v in R[c, :, j]] == list(getattr(r, nm)), (j, nm)

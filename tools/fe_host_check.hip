@@ -17,6 +17,10 @@
 #include "../modarith_amd/csrc/wn26.h"
 #include "../modarith_amd/csrc/generated/comb_ED25519.h"
 #include "../modarith_amd/csrc/generated/comb_ED448.h"
+#include "../modarith_amd/csrc/generated/curve_ED448.h"
+#include "../modarith_amd/csrc/edwards.h"
+#include "../modarith_amd/csrc/weierstrass.h"
+#include "../modarith_amd/csrc/fh51.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -560,10 +564,143 @@ static int run_ed448_mulgen2(int n) {
     return bad;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 4: the half-limb RESIDENT form of 2^255-19 (csrc/fh51.h) and the "_u" sums (csrc/field.h modadd_u / modsub_u / modneg_u)
+// against the oracle, limb for limb; then the curve formulas built on them (csrc/edwards.h on FieldH51, csrc/weierstrass.h with
+// "_u" sums) against the oracle's ecn add / dbl on random projective points.
+extern "C" void modadd_X25519(const uint64_t*, const uint64_t*, uint64_t*);
+extern "C" void modsub_X25519(const uint64_t*, const uint64_t*, uint64_t*);
+extern "C" void modneg_X25519(const uint64_t*, uint64_t*);
+extern "C" void modadd_NIST256(const uint64_t*, const uint64_t*, uint64_t*);
+extern "C" void modsub_NIST256(const uint64_t*, const uint64_t*, uint64_t*);
+extern "C" void modneg_NIST256(const uint64_t*, uint64_t*);
+extern "C" void modadd_X448(const uint64_t*, const uint64_t*, uint64_t*);
+extern "C" void modsub_X448(const uint64_t*, const uint64_t*, uint64_t*);
+extern "C" void modneg_X448(const uint64_t*, uint64_t*);
+
+static int run_fh51(int n) {
+    using H = ma::FieldH51<ma::P_X25519>;
+    int bad = 0;
+    const uint64_t edge[] = {0, 1, (1ull << 51) - 1, 1ull << 51, (1ull << 52) - 1, (1ull << 53) - 1, (1ull << 26) - 1, 1ull << 26, (1ull << 51) - 19, 37, 38, 39, (1ull << 51) - 38};
+    for (int it = 0; it < n; it++) {
+        uint64_t a[5], b[5], c[5], got[5], want[5], t[5];
+        for (int i = 0; i < 5; i++) {
+            uint64_t r = sm();
+            a[i] = (r % 10 < 8 && it % 3) ? edge[r % 13] : (sm() & ((1ull << 53) - 1));
+            r = sm();
+            b[i] = (r % 10 < 8 && it % 3 == 1) ? edge[r % 13] : (sm() & ((1ull << 53) - 1));
+            c[i] = sm() & ((1ull << 52) - 1);
+        }
+        if (it == 0) for (int i = 0; i < 5; i++) a[i] = b[i] = (1ull << 53) - 1;
+        if (it == 1) for (int i = 0; i < 5; i++) { a[i] = 0; b[i] = 0; }
+        uint32_t ha[10], hb[10], hc[10], hr[10], hu[10];
+        H::from_limbs(a, ha); H::from_limbs(b, hb); H::from_limbs(c, hc);
+        H::to_limbs(ha, got);
+        int d = memcmp(got, a, sizeof got) != 0;                                  // the resident form is the same element
+        H::modmul(ha, hb, hr); H::to_limbs(hr, got); modmul_X25519(a, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        H::modsqr(ha, hr); H::to_limbs(hr, got); modsqr_X25519(a, want); d |= memcmp(got, want, sizeof got) != 0;
+        // the sums take field elements as the API defines them (SURVEY 8c caveat 2): any representative below 2p, limbs possibly over
+        // Radix bits -- lower limbs up to 2^53, top limb below 2^52 - 8.  (For a VALUE of 2p or more the reference's modsub / modneg
+        // leave a negative top limb, 64 bits wide there and 32 here: outside every contract of the API.)
+        a[4] &= (1ull << 52) - 9; b[4] &= (1ull << 52) - 9;
+        if (a[4] > (1ull << 52) - 9) a[4] = (1ull << 52) - 9;
+        if (b[4] > (1ull << 52) - 9) b[4] = (1ull << 52) - 9;
+        H::from_limbs(a, ha); H::from_limbs(b, hb);
+        H::modadd(ha, hb, hr); H::to_limbs(hr, got); modadd_X25519(a, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        H::modsub(ha, hb, hr); H::to_limbs(hr, got); modsub_X25519(a, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        H::modneg(ha, hr); H::to_limbs(hr, got); modneg_X25519(a, want); d |= memcmp(got, want, sizeof got) != 0;
+        // a product of sums, as the formulas chain them: (a + b)(a - b), squared
+        H::modadd(ha, hb, hr); H::modsub(ha, hb, hu); H::modmul(hr, hu, hr); H::modsqr(hr, hr); H::to_limbs(hr, got);
+        modadd_X25519(a, b, want); modsub_X25519(a, b, t); modmul_X25519(want, t, want); modsqr_X25519(want, want);
+        d |= memcmp(got, want, sizeof got) != 0;
+        // "_u" sums feeding sums: (a - b) - c, a - 2c, -a + b, -a - b, ((a + b) + c) - a
+        H::modsub_u(ha, hb, hu); H::modsub(hu, hc, hr); H::to_limbs(hr, got); modsub_X25519(a, b, t); modsub_X25519(t, c, want); d |= memcmp(got, want, sizeof got) != 0;
+        H::modadd_u(hc, hc, hu); H::modsub(ha, hu, hr); H::to_limbs(hr, got); modadd_X25519(c, c, t); modsub_X25519(a, t, want); d |= memcmp(got, want, sizeof got) != 0;
+        H::modneg_u(ha, hu); H::modadd(hu, hb, hr); H::to_limbs(hr, got); modneg_X25519(a, t); modadd_X25519(t, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        H::modsub(hu, hb, hr); H::to_limbs(hr, got); modsub_X25519(t, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        H::modadd_u(ha, hb, hu); H::modadd_u(hu, hc, hu); H::modsub(hu, ha, hr); H::to_limbs(hr, got);
+        modadd_X25519(a, b, t); modadd_X25519(t, c, t); modsub_X25519(t, a, want); d |= memcmp(got, want, sizeof got) != 0;
+        if (d) { if (bad < 4) printf("FieldH51: record %d differs\n", it); bad++; }
+    }
+    printf("FieldH51<P_X25519> resident half-limb field (mul sqr add sub neg, _u chains): %d records, %d differ from the oracle\n", n, bad);
+    return bad;
+}
+
+template <class P, int N, class ADD, class SUB, class NEG>
+static int run_u(const char* name, int n, int radix, ADD oadd, SUB osub, NEG oneg) {
+    using F = ma::Field<P, true>;
+    int bad = 0;
+    for (int it = 0; it < n; it++) {
+        uint64_t a[N], b[N], c[N], u[N], got[N], want[N], t[N];
+        for (int i = 0; i < N; i++) {
+            const uint64_t m = (1ull << (radix + (it % 4 == 0 ? 2 : 0))) - 1;       // every fourth record up to the contract's edge
+            a[i] = (it % 7 == 3) ? ((sm() & 1) ? m : 0) : (sm() & m);
+            b[i] = (it % 7 == 5) ? ((sm() & 1) ? m : 0) : (sm() & m);
+            c[i] = sm() & ((1ull << radix) - 1);
+        }
+        int d = 0;
+        F::modsub_u(a, b, u); F::modsub(u, c, got); osub(a, b, t); osub(t, c, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::modadd_u(c, c, u); F::modsub(a, u, got); oadd(c, c, t); osub(a, t, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::modneg_u(a, u); F::modadd(u, b, got); oneg(a, t); oadd(t, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::modsub(u, b, got); osub(t, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::modadd_u(a, b, u); F::modadd_u(u, c, u); F::modsub_u(u, a, u); F::modadd(u, u, got);
+        oadd(a, b, t); oadd(t, c, t); osub(t, a, t); oadd(t, t, want); d |= memcmp(got, want, sizeof got) != 0;
+        if (d) { if (bad < 4) printf("%s _u sums: record %d differs\n", name, it); bad++; }
+    }
+    printf("Field<P_%s,true> _u sums feeding sums: %d records, %d differ from the oracle\n", name, n, bad);
+    return bad;
+}
+
+extern "C" void ecn_ed25519_add(pt25519*, pt25519*);
+extern "C" void ecn_nist256_add(pt256*, pt256*);
+extern "C" void ecn_nist256_dbl(pt256*);
+extern "C" void ecn_ed448_add(pt448*, pt448*);
+extern "C" void ecn_ed448_dbl(pt448*);
+
+// E = the curve class under test (its add / dbl on its resident field form), PT = the oracle's point struct with N limbs per coordinate
+template <class E, class PT, int N, int NBYTES, class GEN, class MUL, class ADD, class DBL>
+static int run_formulas(const char* name, int n, GEN gen, MUL mul, ADD oadd, DBL odbl) {
+    using F = typename E::F;
+    int bad = 0;
+    for (int it = 0; it < n; it++) {
+        PT P, Q;
+        char e[NBYTES], f[NBYTES];
+        for (int i = 0; i < NBYTES; i++) { e[i] = (char)sm(); f[i] = (char)sm(); }
+        if (it == 1) memset(f, 0, NBYTES);                     // Q = the neutral element
+        gen(&P); mul(e, &P); gen(&Q); mul(f, &Q);
+        if (it == 2) Q = P;                                     // P + P through the addition formula
+        typename E::Point p, q;
+        F::from_limbs(P.x, p.x); F::from_limbs(P.y, p.y); F::from_limbs(P.z, p.z);
+        F::from_limbs(Q.x, q.x); F::from_limbs(Q.y, q.y); F::from_limbs(Q.z, q.z);
+        PT W = P, G;
+        odbl(&W);
+        typename E::Point d;
+        E::cpy(p, d); E::dbl(d);
+        F::to_limbs(d.x, G.x); F::to_limbs(d.y, G.y); F::to_limbs(d.z, G.z);
+        int df = memcmp(&G, &W, sizeof G) != 0;
+        W = P; oadd(&Q, &W);                                    // P += Q
+        E::cpy(p, d); E::add(q, d);
+        F::to_limbs(d.x, G.x); F::to_limbs(d.y, G.y); F::to_limbs(d.z, G.z);
+        df |= memcmp(&G, &W, sizeof G) != 0;
+        if (df) { if (bad < 4) printf("%s: record %d differs\n", name, it); bad++; }
+    }
+    printf("%s add / dbl (projective limbs): %d records, %d differ from the oracle\n", name, n, bad);
+    return bad;
+}
+
 int main(int argc, char** argv) {
     int n = argc > 1 ? atoi(argv[1]) : 2000;
     int bad = run<4>("x25519_fe26_one", n, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x25519_fe26_one(k, u, o); }, rfc7748_X25519);
     bad += run<7>("x448_fe28_one", n / 4 + 8, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x448_fe28_one(k, u, o); }, rfc7748_X448);
+    bad += run_fh51(n * 50);
+    bad += run_u<ma::P_X25519, 5>("X25519", n * 25, 51, modadd_X25519, modsub_X25519, modneg_X25519);
+    bad += run_u<ma::P_NIST256, 5>("NIST256", n * 25, 52, modadd_NIST256, modsub_NIST256, modneg_NIST256);
+    bad += run_u<ma::P_X448, 8>("X448", n * 25, 56, modadd_X448, modsub_X448, modneg_X448);
+    bad += run_formulas<ma::Edwards<ma::C_ED25519, ma::FieldH51<ma::P_X25519>>, pt25519, 5, 32>("Edwards<ED25519> on FieldH51", n / 8 + 24, ecn_ed25519_gen, ecn_ed25519_mul, ecn_ed25519_add, ecn_ed25519_dbl);
+    bad += run_formulas<ma::Edwards<ma::C_ED25519>, pt25519, 5, 32>("Edwards<ED25519> on limbs", n / 8 + 24, ecn_ed25519_gen, ecn_ed25519_mul, ecn_ed25519_add, ecn_ed25519_dbl);
+    bad += run_formulas<ma::Edwards<ma::C_ED448>, pt448, 8, 56>("Edwards<ED448>", n / 16 + 24, ecn_ed448_gen, ecn_ed448_mul, ecn_ed448_add, ecn_ed448_dbl);
+    bad += run_formulas<ma::Weierstrass<ma::C_NIST256>, pt256, 5, 32>("Weierstrass<NIST256>", n / 8 + 24, ecn_nist256_gen, ecn_nist256_mul, ecn_nist256_add, ecn_nist256_dbl);
     bad += run_half(n * 50);
     bad += run_mhalf(n * 50);
     bad += run_mhalf448(n * 25);
