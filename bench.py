@@ -481,9 +481,49 @@ def main():
                                        "layout": "tiled, tile = %d" % ad.shape[2] if ad.dim() == 3 else "flat", "note": "Field('X25519').uniform(n) / .modmul(): no layout argument given"}
         del ad, bd, cd
 
+    others = {}
+    # (Measured HERE, right after the streaming data sets and before the VALU-bound curve legs: at ~75-80 % VALU issue occupancy the
+    # four-call chain is co-limited by VALU issue, and after two minutes of multiplier-dense curve kernels the part's clock has
+    # sagged enough for it to read 0.73 of the HBM peak instead of 0.80-0.82 -- docs/fused_chains.md, profiles/r04_chain_pmc.json.)
+    # Fused chains (modarith_amd/fuse.py, DESIGN 4.7): a sequence of field.c calls per element as ONE streaming kernel on
+    # registers, against the same calls through the batched API, on the timed region's own operands.  z = ((a + b)(a - b))^2:
+    # four calls, 440 B per element call by call, 120 B fused.  The chain's plug-in is built by __graft_entry__.build() and
+    # travels with the tree (rebuilt here in seconds if it is not current); equal limbs are asserted.
+    if not args.no_others and single:
+        chain_equal = True
+        try:
+            from modarith_amd.fuse import bench_chain
+            ch = bench_chain("X25519")
+            fz = ch.build()
+            t1, t2, zc = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+            def calls():
+                F.modadd(a, b, out=t1); F.modsub(a, b, out=t2); F.modmul(t1, t2, out=t1); F.modsqr(t1, out=zc)
+            # The fused kernel is timed on the headline's own operand triple (a, b -> c): the same three streams over the same
+            # placement as the timed region, so the two rates compare like with like (a separately allocated output lands on another
+            # placement and reads 5-10 % lower, which says nothing about the kernel: profiles/r04_chain_pmc.json).  c is restored
+            # in the `finally` whatever happens, because the verifier below checks c = a * b.
+            try:
+                ms_f = rate(lambda: fz(a, b, out=[c]))
+                chain_equal = None                                   # (decided below, once zc exists)
+                ms_c = rate(calls)
+                chain_equal = bool(torch.equal(c, zc))
+            finally:
+                F.modmul(a, b, out=c)
+            others["fused_chain_X25519"] = {"chain": "modsqr(modmul(modadd(a,b), modsub(a,b)))", "elements": n, "fused_ms": ms_f, "calls_ms": ms_c,
+                                            "speedup": ms_c / ms_f, "fused_bytes_per_element": ch.traffic_bytes(), "calls_bytes_per_element": ch.unfused_traffic_bytes(),
+                                            "fused_GBps": ch.traffic_bytes() * n / (ms_f * 1e-3) / 1e9, "field_ops_per_s_per_gpu": 4 * n / (ms_f * 1e-3),
+                                            "frac_of_hbm_peak": ch.traffic_bytes() * n / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "frac_of_headline_kernel": kern_ms / ms_f,
+                                            "buffers": "the timed region's operand triple (a, b -> c)",
+                                            "limbs_equal_to_call_sequence": chain_equal}
+            del t1, t2, zc
+        except (RuntimeError, OSError, subprocess.CalledProcessError, ValueError) as ex:   # a missing compiler on the box must not cost the headline line
+            others["fused_chain_X25519"] = {"skipped": repr(ex)[:200]}
+            chain_equal = True
+        assert chain_equal, "fused chain differs from the call-by-call sequence"
+
     # the other single-GPU configs of BASELINE.json (configs[2], configs[3]) with the same protocol, short runs:
     # parity for them is in tests/; these are side figures, not the headline
-    others = {}
     if not args.no_others and single:
         for P, ops in (("NIST256", ("modmul",)), ("X448", ("modmul", "modsqr"))):
             Fp = Field(P, dev, tile=TILE or None)
@@ -617,43 +657,6 @@ def main():
             tc[leg] = {"one_wave_ns_per_op": res["one_wave"] / nops * 1e9, "ops": nops, "check_word": "0x%06x" % ref, "reference_check_word": "0x%06x" % ref,
                        "all_lanes_ops_per_s": (1 << 18) * nops / res["all_lanes"], "lanes": 1 << 18}
         others["time_c_protocol_gpu_X25519"] = tc
-
-    # Fused chains (modarith_amd/fuse.py, DESIGN 4.7): a sequence of field.c calls per element as ONE streaming kernel on
-    # registers, against the same calls through the batched API, on the timed region's own operands.  z = ((a + b)(a - b))^2:
-    # four calls, 440 B per element call by call, 120 B fused.  The chain's plug-in is built by __graft_entry__.build() and
-    # travels with the tree (rebuilt here in seconds if it is not current); equal limbs are asserted.
-    if not args.no_others and single:
-        chain_equal = True
-        try:
-            from modarith_amd.fuse import bench_chain
-            ch = bench_chain("X25519")
-            fz = ch.build()
-            t1, t2, zc = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
-            def calls():
-                F.modadd(a, b, out=t1); F.modsub(a, b, out=t2); F.modmul(t1, t2, out=t1); F.modsqr(t1, out=zc)
-            # The fused kernel is timed on the headline's own operand triple (a, b -> c): the same three streams over the same
-            # placement as the timed region, so the two rates compare like with like (a separately allocated output lands on another
-            # placement and reads 5-10 % lower, which says nothing about the kernel: profiles/r04_chain_pmc.json).  c is restored
-            # in the `finally` whatever happens, because the verifier below checks c = a * b.
-            try:
-                ms_f = rate(lambda: fz(a, b, out=[c]))
-                chain_equal = None                                   # (decided below, once zc exists)
-                ms_c = rate(calls)
-                chain_equal = bool(torch.equal(c, zc))
-            finally:
-                F.modmul(a, b, out=c)
-            others["fused_chain_X25519"] = {"chain": "modsqr(modmul(modadd(a,b), modsub(a,b)))", "elements": n, "fused_ms": ms_f, "calls_ms": ms_c,
-                                            "speedup": ms_c / ms_f, "fused_bytes_per_element": ch.traffic_bytes(), "calls_bytes_per_element": ch.unfused_traffic_bytes(),
-                                            "fused_GBps": ch.traffic_bytes() * n / (ms_f * 1e-3) / 1e9, "field_ops_per_s_per_gpu": 4 * n / (ms_f * 1e-3),
-                                            "frac_of_hbm_peak": ch.traffic_bytes() * n / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                            "frac_of_headline_kernel": kern_ms / ms_f,
-                                            "buffers": "the timed region's operand triple (a, b -> c)",
-                                            "limbs_equal_to_call_sequence": chain_equal}
-            del t1, t2, zc
-        except (RuntimeError, OSError, subprocess.CalledProcessError, ValueError) as ex:   # a missing compiler on the box must not cost the headline line
-            others["fused_chain_X25519"] = {"skipped": repr(ex)[:200]}
-            chain_equal = True
-        assert chain_equal, "fused chain differs from the call-by-call sequence"
 
     ladder = None
     my_lt = None
