@@ -664,8 +664,10 @@ def main():
     if not args.no_ladder:
         if args.scaling == "strong":
             # BASELINE.json configs[4] literally: 2^26 records in total, contiguous shards of 2^26 / N per rank
+            from modarith_amd.dist import shard_range
             total = 1 << int(os.environ.get("MA_BENCH_LOG2_LADDER_TOTAL", "26"))
-            m = total // world + (1 if rank < total % world else 0)
+            lo, hi = shard_range(total, rank, world)
+            m = hi - lo
         else:
             m = 1 << LOG2_LADDER
         k = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)

@@ -53,8 +53,10 @@ def test_bench_self_launch_two_ranks_gloo():
     """`python bench.py --gpus 2` with no launcher around it: the parent starts both ranks (they share the one GPU of
     this box; gloo carries the collectives) and relays rank 0's single line."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MA_BENCH_BACKEND="gloo", MA_BENCH_LOG2_ELEMS="22", MA_BENCH_LOG2_LADDER="18")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-cpu", "--no-others"],
+    # --scaling strong: BASELINE configs[4] literally -- 2^MA_BENCH_LOG2_LADDER_TOTAL records divided over the ranks in contiguous shards
+    # (here 2^19 over two) and gathered to rank 0
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MA_BENCH_BACKEND="gloo", MA_BENCH_LOG2_ELEMS="22", MA_BENCH_LOG2_LADDER_TOTAL="19")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-cpu", "--no-others", "--scaling", "strong"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -62,6 +64,7 @@ def test_bench_self_launch_two_ranks_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["elements_per_gpu"] == 1 << 22
     assert d["x25519"]["scalars_per_gpu"] == 1 << 18 and d["x25519"]["gather_ms"] > 0 and d["x25519"]["value"] > 0
+    assert d["x25519"]["scaling"] == "strong" and d["x25519"]["scalars_total"] == 1 << 19 and [r["x25519_records"] for r in d["ranks"]] == [1 << 18, 1 << 18]
     assert d["x25519"]["gather_GBps"] > 0
     # the N > 1 line verifies itself: every rank checked its own outputs against the oracle, AND-reduced
     v = d["verified_against_oracle"]
