@@ -8,10 +8,13 @@
 
 namespace ma {
 
-constexpr size_t ED448_ROW_SKEW = 32 + 4;   // words added to the row pitch (288 bytes)
+constexpr size_t ED448_ROW_SKEW = 32 + 4;   // (round-3 layout: words added to the row pitch; the size the workspace query still reports)
 
-// one scalar multiplication per lane; the window table of lane slot s = blockIdx.x * 64 + threadIdx.x sits in the
-// workspace at word k -> ws[k * slots + s] (every access of a wave is one coalesced 512-byte row)
+// one scalar multiplication per lane, one wave per workgroup.  The wave's window tables sit in its slab of the workspace,
+// [word][64 lanes] (every access one contiguous 512-byte row; row addresses formed at the access: ed28.h TabSlab); the recoded
+// scalar sits in LDS, one byte per window (ed28.h Win3Lds), written before the point is loaded; a lane's element index is the
+// wave-uniform base + lane, formed where it is used.  Round 3 kept the scalar words and ~84 row addresses in registers across
+// the window loop: 791 spilled VGPRs, 350-480 scratch accesses per window.
 #ifndef MA_ED448F_WAVES
 #define MA_ED448F_WAVES 2
 #endif
@@ -19,21 +22,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MA_ED448F_WA
 void k_ed448_mul_get(const unsigned char* e, const spint* Pb, unsigned char* xb, unsigned char* yb, int* sign, size_t n, size_t ld,
                      uint64_t* ws) {
     using P = P_X448;
-    const size_t slots = (size_t)gridDim.x * blockDim.x;
-    const size_t tstride = slots + ED448_ROW_SKEW;          // rows 2^k bytes apart would all fall on one memory channel
-    uint64_t* tab = ws + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += slots) {
-        spint ew[7], X[8], Y[8], Z[8], xw[7], yw[7];
-        load_be_record<P>(e, t, ew);
+    __shared__ unsigned char digs[150 * 64];
+    const TabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)ED448_TABLE_WORDS), threadIdx.x};
+    unsigned char* col = digs + threadIdx.x;
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
+        auto t = [&]() { return base + (size_t)(T.origin() - T.base); };      // base + lane, as a fresh value at each use
+        if (t() >= n) continue;
+        {
+            spint ew[7];
+            load_be_record<P>(e, t(), ew);
+            Win3Lds::fill(ew, col);
+        }
+        spint X[8], Y[8], Z[8], xw[7], yw[7];
         static_for<0, 8>([&](auto I) {
-            X[I] = Pb[(size_t)I * ld + t];
-            Y[I] = Pb[(size_t)(8 + I) * ld + t];
-            Z[I] = Pb[(size_t)(16 + I) * ld + t];
+            X[I] = Pb[(size_t)I * ld + t()];
+            Y[I] = Pb[(size_t)(8 + I) * ld + t()];
+            Z[I] = Pb[(size_t)(16 + I) * ld + t()];
         });
-        ed448_mul_get_one(ew, X, Y, Z, tab, tstride, xw, yw);
-        if (xb) store_be_record<P>(xb, t, xw);
-        if (yb) store_be_record<P>(yb, t, yw);
-        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+        Win3Lds dig{col};
+        ed448_mul_get_one(dig, X, Y, Z, T, xw, yw);
+        if (xb) store_be_record<P>(xb, t(), xw);
+        if (yb) store_be_record<P>(yb, t(), yw);
+        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
     }
 }
 

@@ -10,29 +10,39 @@ namespace ma {
 
 constexpr size_t ED448_ROW_SKEW2 = 32 + 4;   // words added to the row pitch of the table workspace (as in capi_ED448F.hip)
 
+// tables in the wave's slab, the two recoded scalars in LDS (four 2-bit windows per byte), element index formed at use: see capi_ED448F.hip
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_ed448_mul2_get(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb,
                       int* sign, size_t n, size_t ld, uint64_t* ws) {
     using P = P_X448;
-    const size_t slots = (size_t)gridDim.x * blockDim.x;
-    const size_t tstride = slots + ED448_ROW_SKEW2;
-    uint64_t* tab = ws + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += slots) {
-        spint ew[7], fw[7], PX[8], PY[8], PZ[8], QX[8], QY[8], QZ[8], xw[7], yw[7];
-        load_be_record<P>(e, t, ew);
-        load_be_record<P>(f, t, fw);
+    __shared__ unsigned char digs[2 * 57 * 64];
+    const TabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)ED448_TABLE_WORDS), threadIdx.x};
+    unsigned char* ce = digs + threadIdx.x;
+    unsigned char* cf = ce + 57 * 64;
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
+        auto t = [&]() { return base + (size_t)(T.origin() - T.base); };
+        if (t() >= n) continue;
+        {
+            spint ew[7];
+            load_be_record<P>(e, t(), ew);
+            Win2Lds::fill(ew, ce);
+            load_be_record<P>(f, t(), ew);
+            Win2Lds::fill(ew, cf);
+        }
+        spint PX[8], PY[8], PZ[8], QX[8], QY[8], QZ[8], xw[7], yw[7];
         static_for<0, 8>([&](auto I) {
-            PX[I] = Pb[(size_t)I * ld + t];
-            PY[I] = Pb[(size_t)(8 + I) * ld + t];
-            PZ[I] = Pb[(size_t)(16 + I) * ld + t];
-            QX[I] = Qb[(size_t)I * ld + t];
-            QY[I] = Qb[(size_t)(8 + I) * ld + t];
-            QZ[I] = Qb[(size_t)(16 + I) * ld + t];
+            PX[I] = Pb[(size_t)I * ld + t()];
+            PY[I] = Pb[(size_t)(8 + I) * ld + t()];
+            PZ[I] = Pb[(size_t)(16 + I) * ld + t()];
+            QX[I] = Qb[(size_t)I * ld + t()];
+            QY[I] = Qb[(size_t)(8 + I) * ld + t()];
+            QZ[I] = Qb[(size_t)(16 + I) * ld + t()];
         });
-        ed448_mul2_get_one(ew, PX, PY, PZ, fw, QX, QY, QZ, tab, tstride, xw, yw);
-        if (xb) store_be_record<P>(xb, t, xw);
-        if (yb) store_be_record<P>(yb, t, yw);
-        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+        Win2Lds de{ce}, df{cf};
+        ed448_mul2_get_one(de, PX, PY, PZ, df, QX, QY, QZ, T, xw, yw);
+        if (xb) store_be_record<P>(xb, t(), xw);
+        if (yb) store_be_record<P>(yb, t(), yw);
+        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
     }
 }
 

@@ -72,22 +72,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_ed448_mulgen2_get(const unsigned char* e, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb, int* sign,
                          size_t n, size_t ld, uint64_t* ws) {
     using P = P_X448;
-    const size_t slots = (size_t)gridDim.x * blockDim.x;
-    const size_t tstride = slots + 36;                      // row pitch skewed as in capi_ED448F.hip
-    uint64_t* tab = ws + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += slots) {
-        spint ew[7], fw[7], X[8], Y[8], Z[8], xw[7], yw[7];
-        load_be_record<P>(e, t, ew);
-        load_be_record<P>(f, t, fw);
+    __shared__ unsigned char digs[150 * 64];                 // f's windows (ed28.h Win3Lds); Q's table in the wave's slab: capi_ED448F.hip
+    const TabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)ED448_TABLE_WORDS), threadIdx.x};
+    unsigned char* col = digs + threadIdx.x;
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
+        auto t = [&]() { return base + (size_t)(T.origin() - T.base); };
+        if (t() >= n) continue;
+        {
+            spint fw[7];
+            load_be_record<P>(f, t(), fw);
+            Win3Lds::fill(fw, col);
+        }
+        spint ew[7], X[8], Y[8], Z[8], xw[7], yw[7];
         static_for<0, 8>([&](auto I) {
-            X[I] = Qb[(size_t)I * ld + t];
-            Y[I] = Qb[(size_t)(8 + I) * ld + t];
-            Z[I] = Qb[(size_t)(16 + I) * ld + t];
+            X[I] = Qb[(size_t)I * ld + t()];
+            Y[I] = Qb[(size_t)(8 + I) * ld + t()];
+            Z[I] = Qb[(size_t)(16 + I) * ld + t()];
         });
-        ed448_mulgen2_get_one<CombED448>(ew, fw, X, Y, Z, tab, tstride, xw, yw);
-        if (xb) store_be_record<P>(xb, t, xw);
-        if (yb) store_be_record<P>(yb, t, yw);
-        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+        Win3Lds dig{col};
+        Ed28::Ext R;
+        ed448_mul_acc<true>(dig, X, Y, Z, T, R);             // f*Q, leaving with its T coordinate
+        load_be_record<P>(e, t(), ew);                       // e is not needed (nor held) before this point
+        ed448_mulgen_acc<CombED448, false>(ew, R);           // += e*G through the fixed-base table
+        {
+            using F = Fe28;
+            uint32_t zi[16], ax[16], ay[16];
+            F::invert(R.Z, zi);
+            F::mul_k(R.X, zi, ax);
+            F::mul_k(R.Y, zi, ay);
+            F::to_words(ax, xw);
+            F::to_words(ay, yw);
+        }
+        if (xb) store_be_record<P>(xb, t(), xw);
+        if (yb) store_be_record<P>(yb, t(), yw);
+        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
     }
 }
 

@@ -128,10 +128,132 @@ struct Ed28 {
 
 constexpr int ED448_TABLE_WORDS = 4 * 3 * 7;       // 64-bit words per lane in the workspace
 
+// ---- where the window table of a lane lives, and where the recoded scalar comes from (round 4).  The functions below are written
+// over two small concepts so that the kernels can keep both OUT of the register file while the host check keeps plain arrays:
+//   TAB: origin() = pointer to word 0 of this lane's table (a fresh value per call in the slab form, so that row addresses are
+//        formed at the access instead of being carried -- and spilled -- across the window), stride() = words between table words;
+//   DIG: window(i) = the i-th window of the recoded scalar, in the order the loop consumes them.
+struct TabStrided {                         // word k at tab[k * tstride] (host check: tstride = 1; the round-3 kernels: lanes + skew)
+    uint64_t* tab;
+    size_t tstride;
+    MA_DEV uint64_t* origin() const { return tab; }
+    MA_DEV size_t stride() const { return tstride; }
+};
+struct TabSlab {                            // per-wave slab [word][64 lanes]: every access of a wave is one contiguous 512-byte row
+    uint64_t* base;                         // wave-uniform
+    unsigned lane;
+    MA_DEV uint64_t* origin() const {
+        unsigned l = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(l));
+#endif
+        return base + l;
+    }
+    static MA_DEV constexpr size_t stride() { return 64; }
+};
+// e' = e + sum_{i<150} 4*8^i (450 bits), 150 windows of 3 bits from the top; window(i) must be called for i = 0, 1, 2, ... in order
+struct Win3Regs {
+    uint64_t w[8];
+    MA_DEV void init(const uint64_t* ew) {
+        constexpr auto cw = [](int k) {
+            uint64_t v = 0;
+            for (int b = 0; b < 64; b++) {
+                const int pos = 64 * k + b;
+                if (pos < 450 && pos % 3 == 2) v |= (uint64_t)1 << b;
+            }
+            return v;
+        };
+        unsigned __int128 acc = 0;
+        uint64_t s[8];
+        static_for<0, 8>([&](auto K) {
+            constexpr int k = K;
+            acc += (unsigned __int128)(k < 7 ? ew[k < 7 ? k : 0] : 0) + cw(k);
+            s[k] = (uint64_t)acc;
+            acc >>= 64;
+        });
+        static_for<0, 8>([&](auto KK) {
+            constexpr int k = 7 - KK;
+            w[k] = s[k] << 62;
+            if constexpr (k > 0) w[k] |= s[k - 1] >> 2;
+        });
+    }
+    MA_DEV uint32_t window(int) {
+        const uint32_t win = (uint32_t)(w[7] >> 61);
+        static_for<0, 8>([&](auto KK) {
+            constexpr int k = 7 - KK;
+            w[k] <<= 3;
+            if constexpr (k > 0) w[k] |= w[k - 1] >> 61;
+        });
+        return win;
+    }
+};
+// the same windows, produced once into the lane's column of an LDS array (one byte per window) before the point is loaded
+struct Win3Lds {
+    const unsigned char* col;               // digs + lane, windows 64 bytes apart
+    static MA_DEV void fill(const uint64_t* ew, unsigned char* col) {
+        Win3Regs r;
+        r.init(ew);
+#pragma unroll 1
+        for (int i = 0; i < 150; i++) col[(size_t)i * 64] = (unsigned char)r.window(i);
+    }
+    MA_DEV uint32_t window(int i) const { return col[(size_t)i * 64]; }
+};
+// e' = e + sum_{i<225} 2*4^i (450 bits), 225 windows of 2 bits from the top (the double multiplication)
+struct Win2Regs {
+    uint64_t w[8];
+    MA_DEV void init(const uint64_t* in) {
+        constexpr auto cw = [](int k) {
+            uint64_t v = 0;
+            for (int b = 0; b < 64; b++) {
+                const int pos = 64 * k + b;
+                if (pos < 450 && pos % 2 == 1) v |= (uint64_t)1 << b;
+            }
+            return v;
+        };
+        unsigned __int128 acc = 0;
+        uint64_t s[8];
+        static_for<0, 8>([&](auto K) {
+            constexpr int k = K;
+            acc += (unsigned __int128)(k < 7 ? in[k < 7 ? k : 0] : 0) + cw(k);
+            s[k] = (uint64_t)acc;
+            acc >>= 64;
+        });
+        static_for<0, 8>([&](auto KK) {
+            constexpr int k = 7 - KK;
+            w[k] = s[k] << 62;
+            if constexpr (k > 0) w[k] |= s[k - 1] >> 2;
+        });
+    }
+    MA_DEV uint32_t window(int) {
+        const uint32_t win = (uint32_t)(w[7] >> 62);
+        static_for<0, 8>([&](auto KK) {
+            constexpr int k = 7 - KK;
+            w[k] <<= 2;
+            if constexpr (k > 0) w[k] |= w[k - 1] >> 62;
+        });
+        return win;
+    }
+};
+struct Win2Lds {                            // four windows per byte (57 bytes per scalar and lane)
+    const unsigned char* col;
+    static MA_DEV void fill(const uint64_t* in, unsigned char* col) {
+        Win2Regs r;
+        r.init(in);
+#pragma unroll 1
+        for (int q = 0; q < 57; q++) {
+            unsigned b = 0;
+#pragma unroll
+            for (int h = 0; h < 4; h++) b |= (4 * q + h < 225 ? r.window(0) : 0u) << (2 * h);
+            col[(size_t)q * 64] = (unsigned char)b;
+        }
+    }
+    MA_DEV uint32_t window(int i) const { return ((uint32_t)col[(size_t)(i >> 2) * 64] >> (2 * (i & 3))) & 3u; }
+};
+
 // One fused ED448 scalar multiplication + affine export.  ew: the scalar as seven little-endian words; X, Y, Z: 8 x 56-bit
 // limbs each; tab: this lane's table slots, word k at tab[k * tstride]; xw, yw: canonical affine coordinates, seven words.
-template <bool FINAL_T = false>         // FINAL_T: the sum leaves with its T coordinate (a further addition follows)
-MA_DEV void ed448_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride, Ed28::Ext& R) {
+template <bool FINAL_T = false, class TAB, class DIG>         // FINAL_T: the sum leaves with its T coordinate (a further addition follows)
+MA_DEV void ed448_mul_acc(DIG& dig, const spint* X, const spint* Y, const spint* Z, const TAB& T, Ed28::Ext& R) {
     using E = Ed28;
     using F = Fe28;
 
@@ -167,6 +289,8 @@ MA_DEV void ed448_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, co
             uint64_t w[7];
             F::mul_k(p.X, zi, x);
             F::mul_k(p.Y, zi, y);
+            uint64_t* tab = T.origin();
+            const size_t tstride = T.stride();
             F::to_words(x, w);
             static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + K) * tstride] = w[K]; });
             F::to_words(y, w);
@@ -182,32 +306,6 @@ MA_DEV void ed448_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, co
         cache(P4, i4, 3);
     }
 
-    // ---- recoding: e' = e + sum_{i<150} 4*8^i (450 bits), left-aligned so that window 149 is the top of w[7]
-    uint64_t w[8];
-    {
-        constexpr auto cw = [](int k) {
-            uint64_t v = 0;
-            for (int b = 0; b < 64; b++) {
-                const int pos = 64 * k + b;
-                if (pos < 450 && pos % 3 == 2) v |= (uint64_t)1 << b;
-            }
-            return v;
-        };
-        unsigned __int128 acc = 0;
-        uint64_t s[8];
-        static_for<0, 8>([&](auto K) {
-            constexpr int k = K;
-            acc += (unsigned __int128)(k < 7 ? ew[k < 7 ? k : 0] : 0) + cw(k);
-            s[k] = (uint64_t)acc;
-            acc >>= 64;
-        });
-        static_for<0, 8>([&](auto KK) {
-            constexpr int k = 7 - KK;
-            w[k] = s[k] << 62;
-            if constexpr (k > 0) w[k] |= s[k - 1] >> 2;
-        });
-    }
-
     F::set(0, R.X);
     F::set(1, R.Y);
     F::set(1, R.Z);
@@ -215,12 +313,7 @@ MA_DEV void ed448_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, co
 
 #pragma unroll 1
     for (int i = 0; i < 150; i++) {
-        const uint32_t win = (uint32_t)(w[7] >> 61);
-        static_for<0, 8>([&](auto KK) {
-            constexpr int k = 7 - KK;
-            w[k] <<= 3;
-            if constexpr (k > 0) w[k] |= w[k - 1] >> 61;
-        });
+        const uint32_t win = dig.window(i);                 // e' = e + sum 4*8^i: window - 4 is the signed digit
         const int dgt = (int)win - 4;                       // [-4, 3]
         const bool neg = dgt < 0;
         const uint32_t m = (uint32_t)(neg ? -dgt : dgt);    // 0..4
@@ -243,8 +336,10 @@ MA_DEV void ed448_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, co
 #pragma unroll 1
         for (int e = 0; e < 4; e += 2) {
             uint64_t ent[2][21];
+            const uint64_t* tab = T.origin() + (size_t)(e * 21) * T.stride();
+            const size_t tstride = T.stride();
             static_for<0, 2>([&](auto EI) {
-                static_for<0, 21>([&](auto K) { ent[EI][K] = tab[(size_t)((e + EI) * 21 + K) * tstride]; });
+                static_for<0, 21>([&](auto K) { ent[EI][K] = tab[(size_t)(EI * 21 + K) * tstride]; });
             });
             static_for<0, 2>([&](auto EI) {
                 const bool hit = (m == (uint32_t)(e + EI + 1));
@@ -269,11 +364,11 @@ MA_DEV void ed448_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, co
         E::add_cached(R, xs, ys, ts, FINAL_T && i == 149);
     }
 }
-MA_DEV void ed448_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
-                              uint64_t* xw, uint64_t* yw) {
+template <class TAB, class DIG>
+MA_DEV void ed448_mul_get_one(DIG& dig, const spint* X, const spint* Y, const spint* Z, const TAB& T, uint64_t* xw, uint64_t* yw) {
     using F = Fe28;
     Ed28::Ext R;
-    ed448_mul_acc<false>(ew, X, Y, Z, tab, tstride, R);
+    ed448_mul_acc<false>(dig, X, Y, Z, T, R);
     // ---- affine, canonical (ecnXXXget: edwards.c:221-239)
     uint32_t zi[16], ax[16], ay[16];
     F::invert(R.Z, zi);
@@ -282,14 +377,22 @@ MA_DEV void ed448_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y
     F::to_words(ax, xw);
     F::to_words(ay, yw);
 }
+// (scalar words, table as a strided array: the form tools/fe_host_check.hip runs on the CPU)
+MA_DEV void ed448_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
+                              uint64_t* xw, uint64_t* yw) {
+    Win3Regs dig;
+    dig.init(ew);
+    ed448_mul_get_one(dig, X, Y, Z, TabStrided{tab, tstride}, xw, yw);
+}
 
 // Fused double multiplication + affine export for ED448: the affine coordinates of e*P + f*Q (ecnXXXmul2 followed by
 // ecnXXXget, the verification pattern ed448.c:305).  Both scalars in 225 signed 2-bit digits (e' = e + sum 2*4^i,
 // digit = window - 2 in [-2, 1]); the tables {P, 2P}, {Q, 2Q} take the four entry slots of the same per-lane workspace
 // as ed448_mul_get_one; per window two doublings and two additions (one rolled copy of each in the instruction stream).
-MA_DEV void ed448_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
-                               const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
-                               uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
+template <class TAB, class DIG>
+MA_DEV void ed448_mul2_get_one(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
+                               DIG& digf, const spint* QX, const spint* QY, const spint* QZ,
+                               const TAB& T, uint64_t* xw, uint64_t* yw) {
     using E = Ed28;
     using F = Fe28;
     E::Ext R;
@@ -327,6 +430,8 @@ MA_DEV void ed448_mul2_get_one(const uint64_t* ew, const spint* PX, const spint*
             uint64_t w[7];
             F::mul_k(p.X, zi, x);
             F::mul_k(p.Y, zi, y);
+            uint64_t* tab = T.origin();
+            const size_t tstride = T.stride();
             F::to_words(x, w);
             static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + K) * tstride] = w[K]; });
             F::to_words(y, w);
@@ -341,33 +446,6 @@ MA_DEV void ed448_mul2_get_one(const uint64_t* ew, const spint* PX, const spint*
         cache(B1, i3, 2);
         cache(B2, i4, 3);
     }
-    // e' = e + sum_{i<225} 2*4^i (450 bits), left-aligned in 8 words
-    uint64_t we[8], wf[8];
-    auto recode = [&](const uint64_t* in, uint64_t* w) {
-        constexpr auto cw = [](int k) {
-            uint64_t v = 0;
-            for (int b = 0; b < 64; b++) {
-                const int pos = 64 * k + b;
-                if (pos < 450 && pos % 2 == 1) v |= (uint64_t)1 << b;
-            }
-            return v;
-        };
-        unsigned __int128 acc = 0;
-        uint64_t s[8];
-        static_for<0, 8>([&](auto K) {
-            constexpr int k = K;
-            acc += (unsigned __int128)(k < 7 ? in[k < 7 ? k : 0] : 0) + cw(k);
-            s[k] = (uint64_t)acc;
-            acc >>= 64;
-        });
-        static_for<0, 8>([&](auto KK) {
-            constexpr int k = 7 - KK;
-            w[k] = s[k] << 62;
-            if constexpr (k > 0) w[k] |= s[k - 1] >> 2;
-        });
-    };
-    recode(ew, we);
-    recode(fw, wf);
     F::set(0, R.X);
     F::set(1, R.Y);
     F::set(1, R.Z);
@@ -378,16 +456,7 @@ MA_DEV void ed448_mul2_get_one(const uint64_t* ew, const spint* PX, const spint*
 #pragma unroll 1
             for (int j = 0; j < 2; j++) E::dbl(R, j == 1);
         }
-        auto take = [&](uint64_t* w) -> int {                   // (static register indices only)
-            const int d = (int)(uint32_t)(w[7] >> 62) - 2;      // [-2, 1]
-            static_for<0, 8>([&](auto KK) {
-                constexpr int k = 7 - KK;
-                w[k] <<= 2;
-                if constexpr (k > 0) w[k] |= w[k - 1] >> 62;
-            });
-            return d;
-        };
-        const int de = take(we), df = take(wf);
+        const int de = (int)dige.window(i) - 2, df = (int)digf.window(i) - 2;       // [-2, 1]
 #pragma unroll 1
         for (int which = 0; which < 2; which++) {               // 0: digit of e, table {P, 2P};  1: digit of f, table {Q, 2Q}
             const int dgt = which ? df : de;
@@ -396,8 +465,10 @@ MA_DEV void ed448_mul2_get_one(const uint64_t* ew, const spint* PX, const spint*
             uint64_t sel[21];
             static_for<0, 21>([&](auto K) { sel[K] = (K == 7) ? 1u : 0u; });
             uint64_t ent[2][21];
+            const uint64_t* tab = T.origin() + (size_t)(2 * which * 21) * T.stride();
+            const size_t tstride = T.stride();
             static_for<0, 2>([&](auto EI) {
-                static_for<0, 21>([&](auto K) { ent[EI][K] = tab[(size_t)((2 * which + EI) * 21 + K) * tstride]; });
+                static_for<0, 21>([&](auto K) { ent[EI][K] = tab[(size_t)(EI * 21 + K) * tstride]; });
             });
             static_for<0, 2>([&](auto EI) {
                 const bool hit = (m == (uint32_t)(EI + 1));
@@ -426,6 +497,15 @@ MA_DEV void ed448_mul2_get_one(const uint64_t* ew, const spint* PX, const spint*
     F::mul_k(R.Y, zi, ay);
     F::to_words(ax, xw);
     F::to_words(ay, yw);
+}
+
+MA_DEV void ed448_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
+                               const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
+                               uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
+    Win2Regs de, df;
+    de.init(ew);
+    df.init(fw);
+    ed448_mul2_get_one(de, PX, PY, PZ, df, QX, QY, QZ, TabStrided{tab, tstride}, xw, yw);
 }
 
 // Fused GENERATOR multiplication + affine export for ED448 (see ed26.h ed25519_mulgen_get_one): ED448_KEY_PAIR and
@@ -509,19 +589,26 @@ MA_DEV void ed448_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw)
 // Fused e*G + f*Q + affine export for ED448: ED448_VERIFY's ecnXXXmul2(&G, &Q, ...) + ecnXXXget (ed448.c:290-310; the first
 // point is the generator).  f*Q as in ed448_mul_get_one (the last addition also produces T), then e*G through the fixed-base
 // table (ed448_mulgen_acc), see ed26.h ed25519_mulgen2_get_one.
-template <class TAB>
-MA_DEV void ed448_mulgen2_get_one(const uint64_t* ew, const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
-                                  uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
+template <class COMB, class TAB, class DIG>
+MA_DEV void ed448_mulgen2_get_one(const uint64_t* ew, DIG& digf, const spint* QX, const spint* QY, const spint* QZ,
+                                  const TAB& T, uint64_t* xw, uint64_t* yw) {
     using F = Fe28;
     Ed28::Ext R;
-    ed448_mul_acc<true>(fw, QX, QY, QZ, tab, tstride, R);
-    ed448_mulgen_acc<TAB, false>(ew, R);
+    ed448_mul_acc<true>(digf, QX, QY, QZ, T, R);
+    ed448_mulgen_acc<COMB, false>(ew, R);
     uint32_t zi[16], ax[16], ay[16];
     F::invert(R.Z, zi);
     F::mul_k(R.X, zi, ax);
     F::mul_k(R.Y, zi, ay);
     F::to_words(ax, xw);
     F::to_words(ay, yw);
+}
+template <class COMB>
+MA_DEV void ed448_mulgen2_get_one(const uint64_t* ew, const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
+                                  uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
+    Win3Regs df;
+    df.init(fw);
+    ed448_mulgen2_get_one<COMB>(ew, df, QX, QY, QZ, TabStrided{tab, tstride}, xw, yw);
 }
 
 // rfc7748() on the BASE POINT u = 5 of X448 (public-key generation, rfc7748.c:297-333).  ED448 (x^2 + y^2 = 1 - 39081 x^2 y^2) is
