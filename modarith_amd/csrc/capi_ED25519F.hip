@@ -8,22 +8,39 @@
 
 namespace ma {
 
-// one scalar multiplication per lane; everything (point, table, scalar) lives in registers: two waves per SIMD
+// one scalar multiplication per lane, one wave per workgroup; the point and its 4-entry table live in registers, the recoded scalar
+// in LDS (ed26.h W25519_3Lds: one byte per window, written before the point is loaded); a lane's element index is the
+// wave-uniform base + lane, formed where it is used
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_ed25519_mul_get(const unsigned char* e, const spint* Pb, unsigned char* xb, unsigned char* yb, int* sign, size_t n, size_t ld) {
     using P = P_X25519;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        spint ew[4], X[5], Y[5], Z[5], xw[4], yw[4];
-        load_be_record<P>(e, t, ew);
+    __shared__ unsigned char digs[86 * 64];
+    unsigned char* col = digs + threadIdx.x;
+    __shared__ uint64_t parked[24 * 64];                     // entries 3P, 4P of the window table (ed26.h Park24Lds)
+    Park24Lds park{parked + threadIdx.x};
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
+        auto t = [&]() {
+            unsigned l = threadIdx.x;
+            asm volatile("" : "+v"(l));
+            return base + l;
+        };
+        if (t() >= n) continue;
+        {
+            spint ew[4];
+            load_be_record<P>(e, t(), ew);
+            W25519_3Lds::fill(ew, col);
+        }
+        spint X[5], Y[5], Z[5], xw[4], yw[4];
         static_for<0, 5>([&](auto I) {
-            X[I] = Pb[(size_t)I * ld + t];
-            Y[I] = Pb[(size_t)(5 + I) * ld + t];
-            Z[I] = Pb[(size_t)(10 + I) * ld + t];
+            X[I] = Pb[(size_t)I * ld + t()];
+            Y[I] = Pb[(size_t)(5 + I) * ld + t()];
+            Z[I] = Pb[(size_t)(10 + I) * ld + t()];
         });
-        ed25519_mul_get_one<C_ED25519>(ew, X, Y, Z, xw, yw);
-        if (xb) store_be_record<P>(xb, t, xw);
-        if (yb) store_be_record<P>(yb, t, yw);
-        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+        W25519_3Lds dig{col};
+        ed25519_mul_get_dig<C_ED25519>(dig, park, X, Y, Z, xw, yw);
+        if (xb) store_be_record<P>(xb, t(), xw);
+        if (yb) store_be_record<P>(yb, t(), yw);
+        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
     }
 }
 

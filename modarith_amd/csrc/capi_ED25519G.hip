@@ -64,19 +64,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_ed25519_mulgen2_get(const unsigned char* e, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb, int* sign,
                            size_t n, size_t ld) {
     using P = P_X25519;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        spint ew[4], fw[4], X[5], Y[5], Z[5], xw[4], yw[4];
-        load_be_record<P>(e, t, ew);
-        load_be_record<P>(f, t, fw);
+    __shared__ unsigned char digs[86 * 64];                  // f's windows in LDS (ed26.h W25519_3Lds), element index formed at use: capi_ED25519F.hip
+    unsigned char* col = digs + threadIdx.x;
+    __shared__ uint64_t parked[24 * 64];                     // entries 3P, 4P of the window table (ed26.h Park24Lds)
+    Park24Lds park{parked + threadIdx.x};
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
+        auto t = [&]() {
+            unsigned l = threadIdx.x;
+            asm volatile("" : "+v"(l));
+            return base + l;
+        };
+        if (t() >= n) continue;
+        {
+            spint fw[4];
+            load_be_record<P>(f, t(), fw);
+            W25519_3Lds::fill(fw, col);
+        }
+        spint ew[4], X[5], Y[5], Z[5], xw[4], yw[4];
         static_for<0, 5>([&](auto I) {
-            X[I] = Qb[(size_t)I * ld + t];
-            Y[I] = Qb[(size_t)(5 + I) * ld + t];
-            Z[I] = Qb[(size_t)(10 + I) * ld + t];
+            X[I] = Qb[(size_t)I * ld + t()];
+            Y[I] = Qb[(size_t)(5 + I) * ld + t()];
+            Z[I] = Qb[(size_t)(10 + I) * ld + t()];
         });
-        ed25519_mulgen2_get_one<C_ED25519, CombED25519>(ew, fw, X, Y, Z, xw, yw);
-        if (xb) store_be_record<P>(xb, t, xw);
-        if (yb) store_be_record<P>(yb, t, yw);
-        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+        load_be_record<P>(e, t(), ew);
+        W25519_3Lds dig{col};
+        ed25519_mulgen2_get_dig<C_ED25519, CombED25519>(ew, dig, park, X, Y, Z, xw, yw);
+        if (xb) store_be_record<P>(xb, t(), xw);
+        if (yb) store_be_record<P>(yb, t(), yw);
+        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
     }
 }
 

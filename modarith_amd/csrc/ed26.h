@@ -162,16 +162,130 @@ struct Ed26 {
     }
 };
 
+// ---- where the recoded scalar comes from (round 4; see ed28.h): Regs = shift registers in VGPRs (host check), Lds = one byte per window
+// (3-bit windows) or four windows per byte (2-bit windows) in the lane's column of an LDS array, written before the point is loaded.
+// window(i) for i = 0, 1, 2, ... in order.
+struct W25519_3Regs {                       // e' = e + sum_{i<86} 4*8^i, window 85 (bits 255..257) first
+    uint64_t w[5];
+    MA_DEV void init(const uint64_t* ew) {
+        constexpr auto cw = [](int k) {
+            uint64_t v = 0;
+            for (int b = 0; b < 64; b++) {
+                const int pos = 64 * k + b;
+                if (pos < 258 && pos % 3 == 2) v |= (uint64_t)1 << b;
+            }
+            return v;
+        };
+        unsigned __int128 acc = 0;
+        uint64_t s[5];
+        static_for<0, 5>([&](auto K) {
+            constexpr int k = K;
+            acc += (unsigned __int128)(k < 4 ? ew[k < 4 ? k : 0] : 0) + cw(k);
+            s[k] = (uint64_t)acc;
+            acc >>= 64;
+        });
+        w[4] = (s[4] << 62) | (s[3] >> 2);
+        w[3] = (s[3] << 62) | (s[2] >> 2);
+        w[2] = (s[2] << 62) | (s[1] >> 2);
+        w[1] = (s[1] << 62) | (s[0] >> 2);
+        w[0] = s[0] << 62;
+    }
+    MA_DEV uint32_t window(int) {
+        const uint32_t win = (uint32_t)(w[4] >> 61);
+        w[4] = (w[4] << 3) | (w[3] >> 61);
+        w[3] = (w[3] << 3) | (w[2] >> 61);
+        w[2] = (w[2] << 3) | (w[1] >> 61);
+        w[1] = (w[1] << 3) | (w[0] >> 61);
+        w[0] <<= 3;
+        return win;
+    }
+};
+struct W25519_3Lds {
+    const unsigned char* col;
+    static MA_DEV void fill(const uint64_t* ew, unsigned char* col) {
+        W25519_3Regs r;
+        r.init(ew);
+#pragma unroll 1
+        for (int i = 0; i < 86; i++) col[(size_t)i * 64] = (unsigned char)r.window(i);
+    }
+    MA_DEV uint32_t window(int i) const { return col[(size_t)i * 64]; }
+};
+struct W25519_2Regs {                       // e' = e + sum_{i<129} 2*4^i (258 bits), window 128 first
+    uint64_t w[5];
+    MA_DEV void init(const uint64_t* in) {
+        constexpr auto cw = [](int k) {
+            uint64_t v = 0;
+            for (int b = 0; b < 64; b++) {
+                const int pos = 64 * k + b;
+                if (pos < 258 && pos % 2 == 1) v |= (uint64_t)1 << b;
+            }
+            return v;
+        };
+        unsigned __int128 acc = 0;
+        uint64_t s[5];
+        static_for<0, 5>([&](auto K) {
+            constexpr int k = K;
+            acc += (unsigned __int128)(k < 4 ? in[k < 4 ? k : 0] : 0) + cw(k);
+            s[k] = (uint64_t)acc;
+            acc >>= 64;
+        });
+        w[4] = (s[4] << 62) | (s[3] >> 2);
+        w[3] = (s[3] << 62) | (s[2] >> 2);
+        w[2] = (s[2] << 62) | (s[1] >> 2);
+        w[1] = (s[1] << 62) | (s[0] >> 2);
+        w[0] = s[0] << 62;
+    }
+    MA_DEV uint32_t window(int) {
+        const uint32_t win = (uint32_t)(w[4] >> 62);
+        w[4] = (w[4] << 2) | (w[3] >> 62);
+        w[3] = (w[3] << 2) | (w[2] >> 62);
+        w[2] = (w[2] << 2) | (w[1] >> 62);
+        w[1] = (w[1] << 2) | (w[0] >> 62);
+        w[0] <<= 2;
+        return win;
+    }
+};
+struct W25519_2Lds {                        // four windows per byte, 33 bytes per scalar and lane
+    const unsigned char* col;
+    static MA_DEV void fill(const uint64_t* in, unsigned char* col) {
+        W25519_2Regs r;
+        r.init(in);
+#pragma unroll 1
+        for (int q = 0; q < 33; q++) {
+            unsigned b = 0;
+#pragma unroll
+            for (int h = 0; h < 4; h++) b |= (4 * q + h < 129 ? r.window(0) : 0u) << (2 * h);
+            col[(size_t)q * 64] = (unsigned char)b;
+        }
+    }
+    MA_DEV uint32_t window(int i) const { return ((uint32_t)col[(size_t)(i >> 2) * 64] >> (2 * (i & 3))) & 3u; }
+};
+
+// ---- where the upper half of the 4-entry window table lives (round 4).  The table of canonical packed entries takes 96 VGPRs; with the
+// accumulator, the addition's temporaries and the products' columns next to it the window loop of round 3 ran at 255 VGPRs plus 87
+// scratch accesses per window.  Entries 1P, 2P stay in registers; 3P, 4P (24 words) are PARKED: the kernels keep them in LDS
+// ([word][64 lanes] of 64-bit words: 12 KB per wave, conflict-free ds_read_b64), the host check in a plain array.
+struct Park24Regs {
+    uint64_t w[24];
+    MA_DEV void put(int k, uint64_t v) { w[k] = v; }
+    MA_DEV uint64_t get(int k) const { return w[k]; }
+};
+struct Park24Lds {
+    uint64_t* col;                          // lds + lane, words 64 apart
+    MA_DEV void put(int k, uint64_t v) const { col[(size_t)k * 64] = v; }
+    MA_DEV uint64_t get(int k) const { return col[(size_t)k * 64]; }
+};
+
 // One fused ED25519 scalar multiplication + affine export.
 //   ew: the scalar as four little-endian 64-bit words (the caller has byte-swapped the big-endian record);
 //   X, Y, Z: the projective point, 5 x 51-bit limbs each (field.c form); xw, yw: canonical affine coordinates,
 //   four little-endian words each.
-template <class C, bool FINAL_T = false>       // FINAL_T: the sum leaves with its T coordinate (a further addition follows)
-MA_DEV void ed25519_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, typename Ed26<C>::Ext& R) {
+template <class C, bool FINAL_T = false, class DIG, class PARK>       // FINAL_T: the sum leaves with its T coordinate (a further addition follows)
+MA_DEV void ed25519_mul_acc(DIG& dig, PARK& park, const spint* X, const spint* Y, const spint* Z, typename Ed26<C>::Ext& R) {
     using E = Ed26<C>;
     using F = Fe26;
     typename E::Ext Q;
-    uint64_t tab[4][3][4];                  // {1,2,3,4}P as canonical packed (y+x, y-x, 2dxy)
+    uint64_t tab[2][3][4];                  // {1,2}P as canonical packed (y+x, y-x, 2dxy); {3,4}P in the park
 
     {   // ---- table: projective P -> extended; 2P, 3P, 4P; one shared inversion; cached affine form
         typename E::Ext P2, P3, P4;
@@ -217,34 +331,11 @@ MA_DEV void ed25519_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, 
         };
         cache(Q, i1, tab[0]);
         cache(P2, i2, tab[1]);
-        cache(P3, i3, tab[2]);
-        cache(P4, i4, tab[3]);
-    }
-
-    // ---- recoding: e' = e + sum_{i<86} 4*8^i, left-aligned so that window 85 (bits 255..257) is the top of w[4]
-    uint64_t w[5];
-    {
-        constexpr auto cw = [](int k) {
-            uint64_t v = 0;
-            for (int b = 0; b < 64; b++) {
-                const int pos = 64 * k + b;
-                if (pos < 258 && pos % 3 == 2) v |= (uint64_t)1 << b;
-            }
-            return v;
-        };
-        unsigned __int128 acc = 0;
-        uint64_t s[5];
-        static_for<0, 5>([&](auto K) {
-            constexpr int k = K;
-            acc += (unsigned __int128)(k < 4 ? ew[k < 4 ? k : 0] : 0) + cw(k);
-            s[k] = (uint64_t)acc;
-            acc >>= 64;
-        });
-        w[4] = (s[4] << 62) | (s[3] >> 2);
-        w[3] = (s[3] << 62) | (s[2] >> 2);
-        w[2] = (s[2] << 62) | (s[1] >> 2);
-        w[1] = (s[1] << 62) | (s[0] >> 2);
-        w[0] = s[0] << 62;
+        uint64_t tmp[3][4];
+        cache(P3, i3, tmp);
+        static_for<0, 3>([&](auto CI) { static_for<0, 4>([&](auto K) { park.put(CI * 4 + K, tmp[CI][K]); }); });
+        cache(P4, i4, tmp);
+        static_for<0, 3>([&](auto CI) { static_for<0, 4>([&](auto K) { park.put(12 + CI * 4 + K, tmp[CI][K]); }); });
     }
 
     // R = neutral element (0 : 1 : 1 : 0)
@@ -255,12 +346,7 @@ MA_DEV void ed25519_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, 
 
 #pragma unroll 1
     for (int i = 0; i < 86; i++) {
-        const uint32_t win = (uint32_t)(w[4] >> 61);
-        w[4] = (w[4] << 3) | (w[3] >> 61);
-        w[3] = (w[3] << 3) | (w[2] >> 61);
-        w[2] = (w[2] << 3) | (w[1] >> 61);
-        w[1] = (w[1] << 3) | (w[0] >> 61);
-        w[0] <<= 3;
+        const uint32_t win = dig.window(i);                 // e' = e + sum 4*8^i: window - 4 is the signed digit
         const int dgt = (int)win - 4;                       // [-4, 3]
         const bool neg = dgt < 0;
         const uint32_t m = (uint32_t)(neg ? -dgt : dgt);    // 0..4
@@ -277,7 +363,9 @@ MA_DEV void ed25519_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, 
             const bool hit = (m == (uint32_t)(e + 1));
             static_for<0, 3>([&](auto CI) {
                 static_for<0, 4>([&](auto K) {
-                    const uint64_t a = tab[e][CI][K], b = sel[CI][K];
+                    uint64_t a;
+                    if constexpr (e < 2) a = tab[e][CI][K]; else a = park.get((e - 2) * 12 + CI * 4 + K);
+                    const uint64_t b = sel[CI][K];
                     sel[CI][K] = hit ? a : b;
                 });
             });
@@ -300,11 +388,26 @@ MA_DEV void ed25519_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, 
         else E::add_cached(R, yp, ym, t2);
     }
 }
+template <class C, class DIG, class PARK>
+MA_DEV void ed25519_mul_get_dig(DIG& dig, PARK& park, const spint* X, const spint* Y, const spint* Z, uint64_t* xw, uint64_t* yw) {
+    using F = Fe26;
+    typename Ed26<C>::Ext R;
+    ed25519_mul_acc<C>(dig, park, X, Y, Z, R);
+    uint32_t zi[10], ax[10], ay[10];
+    F::invert(R.Z, zi);
+    F::mul(R.X, zi, ax);
+    F::mul(R.Y, zi, ay);
+    F::to_words(ax, xw);
+    F::to_words(ay, yw);
+}
 template <class C>
 MA_DEV void ed25519_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* xw, uint64_t* yw) {
     using F = Fe26;
     typename Ed26<C>::Ext R;
-    ed25519_mul_acc<C>(ew, X, Y, Z, R);
+    W25519_3Regs dig;
+    dig.init(ew);
+    Park24Regs park;
+    ed25519_mul_acc<C>(dig, park, X, Y, Z, R);
     // ---- affine, canonical (ecnXXXget: edwards.c:221-239)
     uint32_t zi[10], ax[10], ay[10];
     F::invert(R.Z, zi);
@@ -586,12 +689,29 @@ MA_DEV void ed25519_mulgen_get_many(LOAD load, uint64_t (*xw)[4], uint64_t (*yw)
 // point is the GENERATOR).  f*Q as in ed25519_mul_get_one (3-bit windows, table of Q in registers, the last addition also
 // produces T), then e*G through the fixed-base table with mixed additions and no doublings (ed25519_mulgen_acc): 255
 // doublings + 86 + 65 additions against the 258 + 258 of the general ed25519_mul2_get_one.
+template <class C, class TAB, class DIG, class PARK>
+MA_DEV void ed25519_mulgen2_get_dig(const uint64_t* ew, DIG& digf, PARK& park, const spint* QX, const spint* QY, const spint* QZ,
+                                    uint64_t* xw, uint64_t* yw) {
+    using F = Fe26;
+    typename Ed26<C>::Ext R;
+    ed25519_mul_acc<C, true>(digf, park, QX, QY, QZ, R);
+    ed25519_mulgen_acc<C, TAB, false>(ew, R);
+    uint32_t zi[10], ax[10], ay[10];
+    F::invert(R.Z, zi);
+    F::mul(R.X, zi, ax);
+    F::mul(R.Y, zi, ay);
+    F::to_words(ax, xw);
+    F::to_words(ay, yw);
+}
 template <class C, class TAB>
 MA_DEV void ed25519_mulgen2_get_one(const uint64_t* ew, const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
                                     uint64_t* xw, uint64_t* yw) {
     using F = Fe26;
     typename Ed26<C>::Ext R;
-    ed25519_mul_acc<C, true>(fw, QX, QY, QZ, R);
+    W25519_3Regs digf;
+    digf.init(fw);
+    Park24Regs park;
+    ed25519_mul_acc<C, true>(digf, park, QX, QY, QZ, R);
     ed25519_mulgen_acc<C, TAB, false>(ew, R);
     uint32_t zi[10], ax[10], ay[10];
     F::invert(R.Z, zi);
