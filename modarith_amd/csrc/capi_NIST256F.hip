@@ -10,27 +10,36 @@ namespace ma {
 
 constexpr size_t NIST256_ROW_SKEW = 32 + 4;   // words added to the row pitch of the table workspace (as in capi_ED448F.hip)
 
-// one scalar multiplication per lane; the window table of lane slot s = blockIdx.x * 64 + threadIdx.x sits in the
-// workspace at word k -> ws[k * pitch + s] (every access of a wave is one coalesced 512-byte row)
+// one scalar multiplication per lane, one wave per workgroup: window tables in the wave's slab of the workspace ([word][64 lanes]: every
+// access one contiguous 512-byte row, row addresses formed at the access -- wn26.h WnTabSlab), recoded scalar in LDS (one byte per
+// window, written before the point is loaded), element index = wave-uniform base + lane, formed where it is used
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_nist256_mul_get(const unsigned char* e, const spint* Pb, unsigned char* xb, unsigned char* yb, int* sign, size_t n, size_t ld,
                        uint64_t* ws) {
     using P = P_NIST256;
-    const size_t slots = (size_t)gridDim.x * blockDim.x;
-    const size_t tstride = slots + NIST256_ROW_SKEW;
-    uint64_t* tab = ws + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += slots) {
-        spint ew[4], X[5], Y[5], Z[5], xw[4], yw[4];
-        load_be_record<P>(e, t, ew);
+    using DIG = WnLds<4, 260>;
+    __shared__ unsigned char digs[DIG::COUNT * 64];
+    const WnTabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)NIST256_TABLE_WORDS), threadIdx.x};
+    unsigned char* col = digs + threadIdx.x;
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
+        auto t = [&]() { return base + (size_t)(T.origin() - T.base); };
+        if (t() >= n) continue;
+        {
+            spint ew[4];
+            load_be_record<P>(e, t(), ew);
+            DIG::fill(ew, col);
+        }
+        spint X[5], Y[5], Z[5], xw[4], yw[4];
         static_for<0, 5>([&](auto I) {
-            X[I] = Pb[(size_t)I * ld + t];
-            Y[I] = Pb[(size_t)(5 + I) * ld + t];
-            Z[I] = Pb[(size_t)(10 + I) * ld + t];
+            X[I] = Pb[(size_t)I * ld + t()];
+            Y[I] = Pb[(size_t)(5 + I) * ld + t()];
+            Z[I] = Pb[(size_t)(10 + I) * ld + t()];
         });
-        nist256_mul_get_one<C_NIST256>(ew, X, Y, Z, tab, tstride, xw, yw);
-        if (xb) store_be_record<P>(xb, t, xw);
-        if (yb) store_be_record<P>(yb, t, yw);
-        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+        DIG dig{col};
+        wn26_mul_get_dig<CvNist256>(dig, X, Y, Z, T, xw, yw);
+        if (xb) store_be_record<P>(xb, t(), xw);
+        if (yb) store_be_record<P>(yb, t(), yw);
+        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
     }
 }
 

@@ -12,29 +12,40 @@ namespace ma {
 
 constexpr size_t NIST256_ROW_SKEW2 = 32 + 4;
 
+// tables in the wave's slab, the two recoded scalars in LDS, element index formed at use: see the mul_get unit
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_nist256_mul2_get(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb,
                         int* sign, size_t n, size_t ld, uint64_t* ws) {
     using P = P_NIST256;
-    const size_t slots = (size_t)gridDim.x * blockDim.x;
-    const size_t tstride = slots + NIST256_ROW_SKEW2;
-    uint64_t* tab = ws + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += slots) {
-        spint ew[4], fw[4], PX[5], PY[5], PZ[5], QX[5], QY[5], QZ[5], xw[4], yw[4];
-        load_be_record<P>(e, t, ew);
-        load_be_record<P>(f, t, fw);
+    using DIG = WnLds<3, 258>;
+    __shared__ unsigned char digs[2 * DIG::COUNT * 64];
+    const WnTabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)WN26_TABLE_WORDS), threadIdx.x};
+    unsigned char* ce = digs + threadIdx.x;
+    unsigned char* cf = ce + DIG::COUNT * 64;
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
+        auto t = [&]() { return base + (size_t)(T.origin() - T.base); };
+        if (t() >= n) continue;
+        {
+            spint ew[4];
+            load_be_record<P>(e, t(), ew);
+            DIG::fill(ew, ce);
+            load_be_record<P>(f, t(), ew);
+            DIG::fill(ew, cf);
+        }
+        spint PX[5], PY[5], PZ[5], QX[5], QY[5], QZ[5], xw[4], yw[4];
         static_for<0, 5>([&](auto I) {
-            PX[I] = Pb[(size_t)I * ld + t];
-            PY[I] = Pb[(size_t)(5 + I) * ld + t];
-            PZ[I] = Pb[(size_t)(10 + I) * ld + t];
-            QX[I] = Qb[(size_t)I * ld + t];
-            QY[I] = Qb[(size_t)(5 + I) * ld + t];
-            QZ[I] = Qb[(size_t)(10 + I) * ld + t];
+            PX[I] = Pb[(size_t)I * ld + t()];
+            PY[I] = Pb[(size_t)(5 + I) * ld + t()];
+            PZ[I] = Pb[(size_t)(10 + I) * ld + t()];
+            QX[I] = Qb[(size_t)I * ld + t()];
+            QY[I] = Qb[(size_t)(5 + I) * ld + t()];
+            QZ[I] = Qb[(size_t)(10 + I) * ld + t()];
         });
-        nist256_mul2_get_one<C_NIST256>(ew, PX, PY, PZ, fw, QX, QY, QZ, tab, tstride, xw, yw);
-        if (xb) store_be_record<P>(xb, t, xw);
-        if (yb) store_be_record<P>(yb, t, yw);
-        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+        DIG de{ce}, df{cf};
+        wn26_mul2_get_dig<CvNist256>(de, PX, PY, PZ, df, QX, QY, QZ, T, xw, yw);
+        if (xb) store_be_record<P>(xb, t(), xw);
+        if (yb) store_be_record<P>(yb, t(), yw);
+        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
     }
 }
 

@@ -436,32 +436,83 @@ MA_DEV uint32_t wn26_take(uint64_t* w) {
     return win;
 }
 
+// ---- digit sources and table accessors (round 4; the concepts of ed28.h): Regs = the shift registers above, Lds = one byte per
+// window in the lane's column of an LDS array, written before the point is loaded; the table accessor is ed28.h's TabStrided
+// (host check, round-3 layout) or TabSlab (per-wave slab, row addresses formed at the access).  window(i) for i = 0, 1, ... in order.
+template <int W, int BITS>
+struct WnRegs {
+    uint64_t w[5];
+    MA_DEV void init(const uint64_t* ew) { wn26_recode<W, BITS>(ew, w); }
+    MA_DEV uint32_t window(int) { return wn26_take<W>(w); }
+};
+template <int W, int BITS>
+struct WnLds {
+    static constexpr int COUNT = (BITS + W - 1) / W;            // 65 windows of 4 bits (260), 86 of 3 bits (258)
+    const unsigned char* col;
+    static MA_DEV void fill(const uint64_t* ew, unsigned char* col) {
+        WnRegs<W, BITS> r;
+        r.init(ew);
+#pragma unroll 1
+        for (int i = 0; i < COUNT; i++) col[(size_t)i * 64] = (unsigned char)r.window(i);
+    }
+    MA_DEV uint32_t window(int i) const { return col[(size_t)i * 64]; }
+};
+struct WnTabStrided {
+    uint64_t* tab;
+    size_t tstride;
+    MA_DEV uint64_t* origin() const { return tab; }
+    MA_DEV size_t stride() const { return tstride; }
+};
+struct WnTabSlab {
+    uint64_t* base;                         // the wave's slab [word][64 lanes], wave-uniform
+    unsigned lane;
+    MA_DEV uint64_t* origin() const {
+        unsigned l = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(l));
+#endif
+        return base + l;
+    }
+    static MA_DEV constexpr size_t stride() { return 64; }
+};
+
 // One fused P-256 scalar multiplication + affine export.
 //   ew: the scalar as four little-endian 64-bit words (the caller has byte-swapped the big-endian record);
 //   X, Y, Z: the projective point, 5 x 52-bit limbs each (field.c form); tab: this lane's table slot (NIST256_TABLE_WORDS
 //   words, tstride apart); xw, yw: canonical affine coordinates, four little-endian words each.
-template <class CV>
-MA_DEV void wn26_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
+template <class CV, class TAB, class DIG>
+MA_DEV void wn26_mul_acc(DIG& dig, const spint* X, const spint* Y, const spint* Z, const TAB& T,
                          typename Wn26<CV>::Pt& R) {
     using E = Wn26<CV>;
     typename E::Pt Q;
     E::load_point(X, Y, Z, Q);
-    E::template build_table<8>(Q, tab, tstride, 0);
-    uint64_t w[5];
-    wn26_recode<4, 260>(ew, w);
+    E::template build_table<8>(Q, T.origin(), T.stride(), 0);
     E::inf(R);
 #pragma unroll 1
     for (int i = 0; i < 65; i++) {
-        const int dgt = (int)wn26_take<4>(w) - 8;               // [-8, 7]
+        const int dgt = (int)dig.window(i) - 8;                 // [-8, 7]
         const bool neg = dgt < 0;
         const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0..8
         if (i != 0) {
 #pragma unroll 1
             for (int j = 0; j < 4; j++) E::dbl(R);
         }
-        E::template lookup<8>(tab, tstride, 0, m, neg, Q);
+        E::template lookup<8>(T.origin(), T.stride(), 0, m, neg, Q);
         E::add(Q, R);
     }
+}
+template <class CV>
+MA_DEV void wn26_mul_acc(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
+                         typename Wn26<CV>::Pt& R) {
+    WnRegs<4, 260> dig;
+    dig.init(ew);
+    wn26_mul_acc<CV>(dig, X, Y, Z, WnTabStrided{tab, tstride}, R);
+}
+template <class CV, class TAB, class DIG>
+MA_DEV void wn26_mul_get_dig(DIG& dig, const spint* X, const spint* Y, const spint* Z, const TAB& T, uint64_t* xw, uint64_t* yw) {
+    typename Wn26<CV>::Pt R;
+    wn26_mul_acc<CV>(dig, X, Y, Z, T, R);
+    Wn26<CV>::affine_words(R, xw, yw);
 }
 template <class CV>
 MA_DEV void wn26_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
@@ -476,23 +527,20 @@ MA_DEV void wn26_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y,
 // [-4, 3]) so that the two tables {1..4}P and {1..4}Q share the eight entry slots of the same per-lane workspace; per
 // window three doublings and two additions, all lookups scan their table.  (The reference's mul2 is a joint sparse form
 // with data-dependent branches; any evaluation reaches the same affine point.)  An infinite result leaves as (0, 1).
-template <class CV>
-MA_DEV void wn26_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
-                              const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
-                              uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
+template <class CV, class TAB, class DIG>
+MA_DEV void wn26_mul2_get_dig(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
+                              DIG& digf, const spint* QX, const spint* QY, const spint* QZ,
+                              const TAB& T, uint64_t* xw, uint64_t* yw) {
     using E = Wn26<CV>;
     typename E::Pt R, Q;
     E::load_point(PX, PY, PZ, Q);
-    E::template build_table<4>(Q, tab, tstride, 0);
+    E::template build_table<4>(Q, T.origin(), T.stride(), 0);
     E::load_point(QX, QY, QZ, Q);
-    E::template build_table<4>(Q, tab, tstride, 4);
-    uint64_t we[5], wf[5];
-    wn26_recode<3, 258>(ew, we);
-    wn26_recode<3, 258>(fw, wf);
+    E::template build_table<4>(Q, T.origin(), T.stride(), 4);
     E::inf(R);
 #pragma unroll 1
     for (int i = 0; i < 86; i++) {
-        const int de = (int)wn26_take<3>(we) - 4, df = (int)wn26_take<3>(wf) - 4;   // [-4, 3]
+        const int de = (int)dige.window(i) - 4, df = (int)digf.window(i) - 4;       // [-4, 3]
         if (i != 0) {
 #pragma unroll 1
             for (int j = 0; j < 3; j++) E::dbl(R);
@@ -502,11 +550,20 @@ MA_DEV void wn26_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* 
             const int dgt = which ? df : de;
             const bool neg = dgt < 0;
             const uint32_t m = (uint32_t)(neg ? -dgt : dgt);    // 0..4
-            E::template lookup<4>(tab, tstride, 4 * which, m, neg, Q);
+            E::template lookup<4>(T.origin(), T.stride(), 4 * which, m, neg, Q);
             E::add(Q, R);
         }
     }
     E::affine_words(R, xw, yw);
+}
+template <class CV>
+MA_DEV void wn26_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
+                              const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
+                              uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
+    WnRegs<3, 258> de, df;
+    de.init(ew);
+    df.init(fw);
+    wn26_mul2_get_dig<CV>(de, PX, PY, PZ, df, QX, QY, QZ, WnTabStrided{tab, tstride}, xw, yw);
 }
 
 // Fused GENERATOR multiplication + affine export: the affine coordinates of e*G -- ecnXXXgen, ecnXXXmul, ecnXXXget, the
@@ -604,6 +661,14 @@ MA_DEV void wn26_mulgen2_get_one(const uint64_t* ew, const uint64_t* fw, const s
     typename Wn26<CV>::Pt R;
     wn26_mul_acc<CV>(fw, QX, QY, QZ, tab, tstride, R);
     wn26_mulgen_acc<CV, TAB, false>(ew, R);
+    Wn26<CV>::affine_words(R, xw, yw);
+}
+template <class CV, class COMB, class TAB, class DIG>
+MA_DEV void wn26_mulgen2_get_dig(const uint64_t* ew, DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T,
+                                 uint64_t* xw, uint64_t* yw) {
+    typename Wn26<CV>::Pt R;
+    wn26_mul_acc<CV>(digf, QX, QY, QZ, T, R);
+    wn26_mulgen_acc<CV, COMB, false>(ew, R);
     Wn26<CV>::affine_words(R, xw, yw);
 }
 
