@@ -9,26 +9,45 @@
 
 namespace ma {
 
+// P's table entries in registers, Q's parked in LDS (ed26.h Park24Lds), both recoded scalars in LDS (four 2-bit windows per byte),
+// element index formed at use: see capi_ED25519F.hip
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_ed25519_mul2_get(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb,
                         int* sign, size_t n, size_t ld) {
     using P = P_X25519;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        spint ew[4], fw[4], PX[5], PY[5], PZ[5], QX[5], QY[5], QZ[5], xw[4], yw[4];
-        load_be_record<P>(e, t, ew);
-        load_be_record<P>(f, t, fw);
+    __shared__ unsigned char digs[2 * 33 * 64];
+    __shared__ uint64_t parked[24 * 64];
+    unsigned char* ce = digs + threadIdx.x;
+    unsigned char* cf = ce + 33 * 64;
+    Park24Lds park{parked + threadIdx.x};
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
+        auto t = [&]() {
+            unsigned l = threadIdx.x;
+            asm volatile("" : "+v"(l));
+            return base + l;
+        };
+        if (t() >= n) continue;
+        {
+            spint ew[4];
+            load_be_record<P>(e, t(), ew);
+            W25519_2Lds::fill(ew, ce);
+            load_be_record<P>(f, t(), ew);
+            W25519_2Lds::fill(ew, cf);
+        }
+        spint PX[5], PY[5], PZ[5], QX[5], QY[5], QZ[5], xw[4], yw[4];
         static_for<0, 5>([&](auto I) {
-            PX[I] = Pb[(size_t)I * ld + t];
-            PY[I] = Pb[(size_t)(5 + I) * ld + t];
-            PZ[I] = Pb[(size_t)(10 + I) * ld + t];
-            QX[I] = Qb[(size_t)I * ld + t];
-            QY[I] = Qb[(size_t)(5 + I) * ld + t];
-            QZ[I] = Qb[(size_t)(10 + I) * ld + t];
+            PX[I] = Pb[(size_t)I * ld + t()];
+            PY[I] = Pb[(size_t)(5 + I) * ld + t()];
+            PZ[I] = Pb[(size_t)(10 + I) * ld + t()];
+            QX[I] = Qb[(size_t)I * ld + t()];
+            QY[I] = Qb[(size_t)(5 + I) * ld + t()];
+            QZ[I] = Qb[(size_t)(10 + I) * ld + t()];
         });
-        ed25519_mul2_get_one<C_ED25519>(ew, PX, PY, PZ, fw, QX, QY, QZ, xw, yw);
-        if (xb) store_be_record<P>(xb, t, xw);
-        if (yb) store_be_record<P>(yb, t, yw);
-        if (sign) sign[t] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+        W25519_2Lds de{ce}, df{cf};
+        ed25519_mul2_get_dig<C_ED25519>(de, PX, PY, PZ, df, QX, QY, QZ, park, xw, yw);
+        if (xb) store_be_record<P>(xb, t(), xw);
+        if (yb) store_be_record<P>(yb, t(), yw);
+        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
     }
 }
 

@@ -423,13 +423,13 @@ MA_DEV void ed25519_mul_get_one(const uint64_t* ew, const spint* X, const spint*
 // {P, 2P} and {Q, 2Q} fit the register file together (4 x 24 VGPRs); per window two doublings and two additions, all
 // lookups scan their table.  (The reference's mul2 is a joint sparse form with data-dependent branches; any
 // evaluation reaches the same affine point.)
-template <class C>
-MA_DEV void ed25519_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
-                                 const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ, uint64_t* xw, uint64_t* yw) {
+template <class C, class DIG, class PARK>
+MA_DEV void ed25519_mul2_get_dig(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
+                                 DIG& digf, const spint* QX, const spint* QY, const spint* QZ, PARK& park, uint64_t* xw, uint64_t* yw) {
     using E = Ed26<C>;
     using F = Fe26;
     typename E::Ext R;
-    uint64_t tab[4][3][4];                  // P, 2P, Q, 2Q as canonical packed (y+x, y-x, 2dxy)
+    uint64_t tab[2][3][4];                  // P, 2P as canonical packed (y+x, y-x, 2dxy); Q, 2Q in the park
     {
         typename E::Ext A1, A2, B1, B2;
         uint32_t px[10], py[10], pz[10];
@@ -475,51 +475,18 @@ MA_DEV void ed25519_mul2_get_one(const uint64_t* ew, const spint* PX, const spin
         };
         cache(A1, i1, tab[0]);
         cache(A2, i2, tab[1]);
-        cache(B1, i3, tab[2]);
-        cache(B2, i4, tab[3]);
+        uint64_t tmp[3][4];
+        cache(B1, i3, tmp);
+        static_for<0, 3>([&](auto CI) { static_for<0, 4>([&](auto K) { park.put(CI * 4 + K, tmp[CI][K]); }); });
+        cache(B2, i4, tmp);
+        static_for<0, 3>([&](auto CI) { static_for<0, 4>([&](auto K) { park.put(12 + CI * 4 + K, tmp[CI][K]); }); });
     }
-    // e' = e + sum_{i<129} 2*4^i (258 bits), left-aligned
-    uint64_t we[5], wf[5];
-    auto recode = [&](const uint64_t* in, uint64_t* w) {
-        constexpr auto cw = [](int k) {
-            uint64_t v = 0;
-            for (int b = 0; b < 64; b++) {
-                const int pos = 64 * k + b;
-                if (pos < 258 && pos % 2 == 1) v |= (uint64_t)1 << b;
-            }
-            return v;
-        };
-        unsigned __int128 acc = 0;
-        uint64_t s[5];
-        static_for<0, 5>([&](auto K) {
-            constexpr int k = K;
-            acc += (unsigned __int128)(k < 4 ? in[k < 4 ? k : 0] : 0) + cw(k);
-            s[k] = (uint64_t)acc;
-            acc >>= 64;
-        });
-        w[4] = (s[4] << 62) | (s[3] >> 2);
-        w[3] = (s[3] << 62) | (s[2] >> 2);
-        w[2] = (s[2] << 62) | (s[1] >> 2);
-        w[1] = (s[1] << 62) | (s[0] >> 2);
-        w[0] = s[0] << 62;
-    };
-    recode(ew, we);
-    recode(fw, wf);
     F::set(0, R.X);
     F::set(1, R.Y);
     F::set(1, R.Z);
     F::set(0, R.T);
-    auto take = [&](uint64_t* w) -> int {
-        const int d = (int)(uint32_t)(w[4] >> 62) - 2;
-        w[4] = (w[4] << 2) | (w[3] >> 62);
-        w[3] = (w[3] << 2) | (w[2] >> 62);
-        w[2] = (w[2] << 2) | (w[1] >> 62);
-        w[1] = (w[1] << 2) | (w[0] >> 62);
-        w[0] <<= 2;
-        return d;
-    };
     // sign * table[|d|] (|d| in 0..2), scanned, then added to R
-    auto lookup_add = [&](int dgt, int base, auto want_t) {
+    auto lookup_add = [&](int dgt, auto from_park, auto want_t) {
         const bool neg = dgt < 0;
         const uint32_t m = (uint32_t)(neg ? -dgt : dgt);
         uint64_t sel[3][4];
@@ -528,7 +495,7 @@ MA_DEV void ed25519_mul2_get_one(const uint64_t* ew, const spint* PX, const spin
             const bool hit = (m == (uint32_t)(EI + 1));
             static_for<0, 3>([&](auto CI) {
                 static_for<0, 4>([&](auto K) {
-                    const uint64_t a = tab[base + EI][CI][K], b = sel[CI][K];
+                    const uint64_t a = decltype(from_park)::value ? park.get(EI * 12 + CI * 4 + K) : tab[EI][CI][K], b = sel[CI][K];
                     sel[CI][K] = hit ? a : b;
                 });
             });
@@ -550,13 +517,13 @@ MA_DEV void ed25519_mul2_get_one(const uint64_t* ew, const spint* PX, const spin
     };
 #pragma unroll 1
     for (int i = 0; i < 129; i++) {
-        const int de = take(we), df = take(wf);
+        const int de = (int)dige.window(i) - 2, df = (int)digf.window(i) - 2;       // [-2, 1]
         if (i != 0) {
             E::template dbl<false>(R);
             E::template dbl<true>(R);
         }
-        lookup_add(de, 0, std::true_type{});
-        lookup_add(df, 2, std::false_type{});
+        lookup_add(de, std::false_type{}, std::true_type{});
+        lookup_add(df, std::true_type{}, std::false_type{});
     }
     uint32_t zi[10], ax[10], ay[10];
     F::invert(R.Z, zi);
@@ -564,6 +531,15 @@ MA_DEV void ed25519_mul2_get_one(const uint64_t* ew, const spint* PX, const spin
     F::mul(R.Y, zi, ay);
     F::to_words(ax, xw);
     F::to_words(ay, yw);
+}
+template <class C>
+MA_DEV void ed25519_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
+                                 const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ, uint64_t* xw, uint64_t* yw) {
+    W25519_2Regs de, df;
+    de.init(ew);
+    df.init(fw);
+    Park24Regs park;
+    ed25519_mul2_get_dig<C>(de, PX, PY, PZ, df, QX, QY, QZ, park, xw, yw);
 }
 
 // Fused GENERATOR multiplication + affine export: the affine coordinates of e*G -- ecnXXXgen, ecnXXXmul, ecnXXXget, the
