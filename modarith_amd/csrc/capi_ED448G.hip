@@ -17,7 +17,7 @@ struct CombED448 {
     static __device__ __forceinline__ int32_t get(int idx) { return comb_ed448[idx]; }
 };
 
-// the first of the two results of a lane waits here (48 words per lane, [word][lane]: conflict-free) while the second scalar runs
+// the first of the two results of a lane waits here (64 words per lane, [word][lane]: conflict-free; the second result's X, Y join it across the shared inversion) while the second scalar runs
 struct LdsPark {
     uint32_t* base;
     __device__ __forceinline__ void put(int k, uint32_t v) { base[k * 64] = v; }
@@ -28,7 +28,7 @@ struct LdsPark {
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_ed448_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned char* yb, int* sign, size_t n) {
     using P = P_X448;
-    __shared__ uint32_t lds[48 * 64];
+    __shared__ uint32_t lds[64 * 64];
     LdsPark park{lds + threadIdx.x};
     const size_t lanes = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += 2 * lanes) {
@@ -49,7 +49,7 @@ void k_ed448_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned char
 // rfc7748() on the base point u = 5 (x448_base_one): little-endian 56-byte records as rfc7748_X448_batch takes them
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_x448_base(const uint64_t* bk, uint64_t* bv, size_t n) {
-    __shared__ uint32_t lds[48 * 64];
+    __shared__ uint32_t lds[64 * 64];
     LdsPark park{lds + threadIdx.x};
     const size_t lanes = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += 2 * lanes) {

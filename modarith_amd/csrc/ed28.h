@@ -124,6 +124,31 @@ struct Ed28 {
         F::mul(s1, s2, M);
         add_tail(A, B, Cc, D, M, p);
     }
+    // The same with q fetched coordinate by coordinate -- fetch(c, out), c = 0..3 for X, Y, Z, T -- so that the table builder holds
+    // one point while it forms 3P (q waits in its table slot)
+    template <class FETCH>
+    static MA_DEV void add_ext_fetched(Ext& p, FETCH fetch) {
+        uint32_t A[16], B[16], Cc[16], D[16], M[16];
+        {
+            uint32_t q[16];
+            fetch(3, q);
+            F::mul_k(p.T, q, Cc);
+            F::mul_small<D_ABS>(Cc, Cc);
+            fetch(2, q);
+            F::mul_k(p.Z, q, D);
+        }
+        {
+            uint32_t qx[16], qy[16], s1[16], s2[16];
+            fetch(0, qx);
+            fetch(1, qy);
+            F::mul_k(p.X, qx, A);
+            F::mul_k(p.Y, qy, B);
+            F::add(p.X, p.Y, s1);
+            F::add(qx, qy, s2);
+            F::mul(s1, s2, M);
+        }
+        add_tail(A, B, Cc, D, M, p);
+    }
 };
 
 constexpr int ED448_TABLE_WORDS = 4 * 3 * 7;       // 64-bit words per lane in the workspace
@@ -250,6 +275,98 @@ struct Win2Lds {                            // four windows per byte (57 bytes p
     MA_DEV uint32_t window(int i) const { return ((uint32_t)col[(size_t)(i >> 2) * 64] >> (2 * (i & 3))) & 3u; }
 };
 
+// The four entry slots of one lane's table while it is being built (round 4).  Each multiple is STASHED in its slot as canonical
+// (X, Y, Z) -- 3 x 7 words, exactly the size of an entry -- as soon as it exists, so that the builder never holds more than two
+// points; to_affine_entries() then forms the products of the four Z from the slots (a = Z1 Z2, b = a Z3, c = b Z4), inverts once,
+// and overwrites every slot with its affine entry (x, y, 39081 x y).
+template <class TAB>
+struct Ed448Slots {
+    using E = Ed28;
+    using F = Fe28;
+    const TAB& T;
+    MA_DEV void put7(int word, const uint32_t* f) const {
+        uint64_t w[7];
+        F::to_words(f, w);
+        uint64_t* tab = T.origin();
+        const size_t tstride = T.stride();
+        static_for<0, 7>([&](auto K) { tab[(size_t)(word + K) * tstride] = w[K]; });
+    }
+    MA_DEV void get7(int word, uint32_t* f) const {
+        uint64_t w[7];
+        const uint64_t* tab = T.origin();
+        const size_t tstride = T.stride();
+        static_for<0, 7>([&](auto K) { w[K] = tab[(size_t)(word + K) * tstride]; });
+        F::from_words(w, f);
+    }
+    MA_DEV void stash(const E::Ext& p, int entry) const {
+        put7(entry * 21, p.X);
+        put7(entry * 21 + 7, p.Y);
+        put7(entry * 21 + 14, p.Z);
+    }
+    MA_DEV void finish(int entry, const uint32_t* zi) const {
+        uint32_t x[16], y[16], s[16];
+        get7(entry * 21, x);
+        get7(entry * 21 + 7, y);
+        F::mul_k(x, zi, x);
+        F::mul_k(y, zi, y);
+        put7(entry * 21, x);
+        put7(entry * 21 + 7, y);
+        F::mul_k(x, y, s);
+        F::mul_small<E::D_ABS>(s, s);
+        put7(entry * 21 + 14, s);
+    }
+    MA_DEV void to_affine_entries() const {
+        // Montgomery's trick on the four stashed Z: a = Z1 Z2, b = a Z3, c = b Z4, one inversion, then back down.  Nothing but the
+        // product is live across the inversion (its own working set is four elements): a and b are formed a second time afterwards
+        // -- two multiplications against the 460 of the inversion -- and the Z's are fetched again.
+        uint32_t a[16], b[16], inv[16], z[16];
+        auto products = [&]() {
+            get7(0 * 21 + 14, a);
+            get7(1 * 21 + 14, z);
+            F::mul_k(a, z, a);
+            get7(2 * 21 + 14, z);
+            F::mul_k(a, z, b);
+            get7(3 * 21 + 14, z);
+        };
+        products();
+        F::mul_k(b, z, inv);
+        F::invert(inv, inv);
+        products();
+        uint32_t i1[16], i2[16], i3[16], i4[16];
+        F::mul_k(inv, b, i4);                       // 1 / Z4
+        F::mul_k(inv, z, inv);                      // 1 / (Z1 Z2 Z3)      (z = Z4)
+        F::mul_k(inv, a, i3);
+        get7(2 * 21 + 14, z);
+        F::mul_k(inv, z, inv);                      // 1 / (Z1 Z2)
+        get7(0 * 21 + 14, z);
+        F::mul_k(inv, z, i2);
+        get7(1 * 21 + 14, z);
+        F::mul_k(inv, z, i1);
+        finish(0, i1);
+        finish(1, i2);
+        finish(2, i3);
+        finish(3, i4);
+    }
+};
+
+// Affine, canonical coordinates of R (ecnXXXget: edwards.c:221-239).  X and Y wait in the first table slot -- the table is dead
+// by now -- while Z is inverted, so that the inversion has the register file to itself.
+template <class TAB>
+MA_DEV void ed448_affine_words(Ed28::Ext& R, const TAB& T, uint64_t* xw, uint64_t* yw) {
+    using F = Fe28;
+    Ed448Slots<TAB> S{T};
+    S.put7(0, R.X);
+    S.put7(7, R.Y);
+    uint32_t zi[16], c[16];
+    F::invert(R.Z, zi);
+    S.get7(0, c);
+    F::mul_k(c, zi, c);
+    F::to_words(c, xw);
+    S.get7(7, c);
+    F::mul_k(c, zi, c);
+    F::to_words(c, yw);
+}
+
 // One fused ED448 scalar multiplication + affine export.  ew: the scalar as seven little-endian words; X, Y, Z: 8 x 56-bit
 // limbs each; tab: this lane's table slots, word k at tab[k * tstride]; xw, yw: canonical affine coordinates, seven words.
 template <bool FINAL_T = false, class TAB, class DIG>         // FINAL_T: the sum leaves with its T coordinate (a further addition follows)
@@ -257,53 +374,37 @@ MA_DEV void ed448_mul_acc(DIG& dig, const spint* X, const spint* Y, const spint*
     using E = Ed28;
     using F = Fe28;
 
-    {   // ---- table: projective P -> extended; 2P, 3P, 4P; one shared inversion; cached affine form
-        E::Ext Q, P2, P3, P4;
-        uint32_t px[16], py[16], pz[16];
-        E::from56(X, px);
-        E::from56(Y, py);
-        E::from56(Z, pz);
-        F::mul_k(px, pz, Q.X);              // (XZ : YZ : Z^2 : XY)
-        F::mul_k(py, pz, Q.Y);
-        F::sqr_k(pz, Q.Z);
-        F::mul_k(px, py, Q.T);
-        P2 = Q;
-        E::dbl<true>(P2);
-        P3 = P2;
-        E::add_ext(P3, Q);
-        P4 = P2;
-        E::dbl<false>(P4);
-        uint32_t z12[16], z123[16], inv[16], i1[16], i2[16], i3[16], i4[16];
-        F::mul_k(Q.Z, P2.Z, z12);
-        F::mul_k(z12, P3.Z, z123);
-        F::mul_k(z123, P4.Z, inv);
-        F::invert(inv, inv);
-        F::mul_k(inv, z123, i4);
-        F::mul_k(inv, P4.Z, inv);
-        F::mul_k(inv, z12, i3);
-        F::mul_k(inv, P3.Z, inv);
-        F::mul_k(inv, Q.Z, i2);
-        F::mul_k(inv, P2.Z, i1);
-        auto cache = [&](const E::Ext& p, const uint32_t* zi, int entry) {
-            uint32_t x[16], y[16], s[16];
-            uint64_t w[7];
-            F::mul_k(p.X, zi, x);
-            F::mul_k(p.Y, zi, y);
-            uint64_t* tab = T.origin();
-            const size_t tstride = T.stride();
-            F::to_words(x, w);
-            static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + K) * tstride] = w[K]; });
-            F::to_words(y, w);
-            static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + 7 + K) * tstride] = w[K]; });
-            F::mul_k(x, y, s);
-            F::mul_small<E::D_ABS>(s, s);
-            F::to_words(s, w);
-            static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + 14 + K) * tstride] = w[K]; });
-        };
-        cache(Q, i1, 0);
-        cache(P2, i2, 1);
-        cache(P3, i3, 2);
-        cache(P4, i4, 3);
+    {   // ---- table: projective P -> extended; 2P, 3P, 4P; one shared inversion; cached affine form.
+        // Round 4: ONE point is live at any time.  Each multiple is STASHED in its own table slot as canonical
+        // (X, Y, Z) -- 3 x 7 words, exactly the size of an entry -- as soon as it exists; the products of the Z's are formed from the
+        // slots afterwards (a = Z1 Z2, b = a Z3, c = b Z4), and after the one inversion every slot is fetched, scaled and overwritten with its
+        // affine entry (x, y, 39081 x y).  (Round 3 kept Q, 2P, 3P, 4P -- 256 VGPRs -- to the end: 600 spilled registers.)
+        Ed448Slots<TAB> S{T};
+        {
+            E::Ext Q;
+            {
+                uint32_t px[16], py[16], pz[16];
+                E::from56(X, px);
+                E::from56(Y, py);
+                E::from56(Z, pz);
+                F::mul_k(px, pz, Q.X);              // (XZ : YZ : Z^2 : XY)
+                F::mul_k(py, pz, Q.Y);
+                F::sqr_k(pz, Q.Z);
+                F::mul_k(px, py, Q.T);
+            }
+            S.stash(Q, 0);
+            S.put7(3 * 21, Q.T);                    // (the fourth slot is free until 4P exists)
+            E::dbl<true>(Q);                        // 2P, with T (the addition below reads it)
+            S.stash(Q, 1);
+            E::add_ext_fetched(Q, [&](int c, uint32_t* out) { S.get7(c == 3 ? 3 * 21 : c * 7, out); });     // 3P = 2P + P
+            S.stash(Q, 2);
+            S.get7(1 * 21, Q.X);                      // 2P again (the doubling reads X, Y, Z only)
+            S.get7(1 * 21 + 7, Q.Y);
+            S.get7(1 * 21 + 14, Q.Z);
+            E::dbl<false>(Q);                       // 4P
+            S.stash(Q, 3);
+        }
+        S.to_affine_entries();
     }
 
     F::set(0, R.X);
@@ -366,16 +467,10 @@ MA_DEV void ed448_mul_acc(DIG& dig, const spint* X, const spint* Y, const spint*
 }
 template <class TAB, class DIG>
 MA_DEV void ed448_mul_get_one(DIG& dig, const spint* X, const spint* Y, const spint* Z, const TAB& T, uint64_t* xw, uint64_t* yw) {
-    using F = Fe28;
     Ed28::Ext R;
     ed448_mul_acc<false>(dig, X, Y, Z, T, R);
     // ---- affine, canonical (ecnXXXget: edwards.c:221-239)
-    uint32_t zi[16], ax[16], ay[16];
-    F::invert(R.Z, zi);
-    F::mul_k(R.X, zi, ax);
-    F::mul_k(R.Y, zi, ay);
-    F::to_words(ax, xw);
-    F::to_words(ay, yw);
+    ed448_affine_words(R, T, xw, yw);
 }
 // (scalar words, table as a strided array: the form tools/fe_host_check.hip runs on the CPU)
 MA_DEV void ed448_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
@@ -397,54 +492,26 @@ MA_DEV void ed448_mul2_get_one(DIG& dige, const spint* PX, const spint* PY, cons
     using F = Fe28;
     E::Ext R;
     {
-        E::Ext A1, A2, B1, B2;
-        uint32_t px[16], py[16], pz[16];
-        auto ext = [&](const spint* X, const spint* Y, const spint* Z, E::Ext& o) {
-            E::from56(X, px);
-            E::from56(Y, py);
-            E::from56(Z, pz);
-            F::mul_k(px, pz, o.X);
-            F::mul_k(py, pz, o.Y);
-            F::sqr_k(pz, o.Z);
-            F::mul_k(px, py, o.T);
+        // (round 4: one point live at a time; see Ed448Slots)
+        Ed448Slots<TAB> S{T};
+        auto ext2 = [&](const spint* X, const spint* Y, const spint* Z, int entry) {
+            E::Ext A;
+            {
+                uint32_t px[16], py[16], pz[16];
+                E::from56(X, px);
+                E::from56(Y, py);
+                E::from56(Z, pz);
+                F::mul_k(px, pz, A.X);
+                F::mul_k(py, pz, A.Y);
+                F::sqr_k(pz, A.Z);
+            }
+            S.stash(A, entry);
+            E::dbl<false>(A);
+            S.stash(A, entry + 1);
         };
-        ext(PX, PY, PZ, A1);
-        A2 = A1;
-        E::dbl<false>(A2);
-        ext(QX, QY, QZ, B1);
-        B2 = B1;
-        E::dbl<false>(B2);
-        uint32_t z12[16], z123[16], inv[16], i1[16], i2[16], i3[16], i4[16];
-        F::mul_k(A1.Z, A2.Z, z12);
-        F::mul_k(z12, B1.Z, z123);
-        F::mul_k(z123, B2.Z, inv);
-        F::invert(inv, inv);
-        F::mul_k(inv, z123, i4);
-        F::mul_k(inv, B2.Z, inv);
-        F::mul_k(inv, z12, i3);
-        F::mul_k(inv, B1.Z, inv);
-        F::mul_k(inv, A1.Z, i2);
-        F::mul_k(inv, A2.Z, i1);
-        auto cache = [&](const E::Ext& p, const uint32_t* zi, int entry) {
-            uint32_t x[16], y[16], s[16];
-            uint64_t w[7];
-            F::mul_k(p.X, zi, x);
-            F::mul_k(p.Y, zi, y);
-            uint64_t* tab = T.origin();
-            const size_t tstride = T.stride();
-            F::to_words(x, w);
-            static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + K) * tstride] = w[K]; });
-            F::to_words(y, w);
-            static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + 7 + K) * tstride] = w[K]; });
-            F::mul_k(x, y, s);
-            F::mul_small<E::D_ABS>(s, s);
-            F::to_words(s, w);
-            static_for<0, 7>([&](auto K) { tab[(size_t)(entry * 21 + 14 + K) * tstride] = w[K]; });
-        };
-        cache(A1, i1, 0);
-        cache(A2, i2, 1);
-        cache(B1, i3, 2);
-        cache(B2, i4, 3);
+        ext2(PX, PY, PZ, 0);
+        ext2(QX, QY, QZ, 2);
+        S.to_affine_entries();
     }
     F::set(0, R.X);
     F::set(1, R.Y);
@@ -491,12 +558,7 @@ MA_DEV void ed448_mul2_get_one(DIG& dige, const spint* PX, const spint* PY, cons
             E::add_cached(R, xs, ys, ts, which == 0);
         }
     }
-    uint32_t zi[16], ax[16], ay[16];
-    F::invert(R.Z, zi);
-    F::mul_k(R.X, zi, ax);
-    F::mul_k(R.Y, zi, ay);
-    F::to_words(ax, xw);
-    F::to_words(ay, yw);
+    ed448_affine_words(R, T, xw, yw);
 }
 
 MA_DEV void ed448_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
@@ -592,16 +654,10 @@ MA_DEV void ed448_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw)
 template <class COMB, class TAB, class DIG>
 MA_DEV void ed448_mulgen2_get_one(const uint64_t* ew, DIG& digf, const spint* QX, const spint* QY, const spint* QZ,
                                   const TAB& T, uint64_t* xw, uint64_t* yw) {
-    using F = Fe28;
     Ed28::Ext R;
     ed448_mul_acc<true>(digf, QX, QY, QZ, T, R);
     ed448_mulgen_acc<COMB, false>(ew, R);
-    uint32_t zi[16], ax[16], ay[16];
-    F::invert(R.Z, zi);
-    F::mul_k(R.X, zi, ax);
-    F::mul_k(R.Y, zi, ay);
-    F::to_words(ax, xw);
-    F::to_words(ay, yw);
+    ed448_affine_words(R, T, xw, yw);
 }
 template <class COMB>
 MA_DEV void ed448_mulgen2_get_one(const uint64_t* ew, const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
@@ -633,7 +689,7 @@ MA_DEV void x448_base_one(const uint64_t* kw_in, uint64_t* ow) {
 }
 
 // TWO scalars per lane with one inversion.  The register file has no room for a second ED448 point next to the working set
-// of the window loop (216 VGPRs), so the first result waits in a PARK (the kernels: 48 words per lane of LDS, 12 KB per wave;
+// of the window loop (216 VGPRs), so the first result waits in a PARK (the kernels: 64 words per lane of LDS, 16 KB per wave;
 // the host check: a local array) while the second scalar runs; 1 / Za = Zb / (Za Zb) afterwards (Z is never 0 on this curve).
 // load(g, ew) fetches the g-th scalar; xw, yw: 2 x 7 words.
 template <class TAB, class PARK, class LOAD>
@@ -649,19 +705,25 @@ MA_DEV void ed448_mulgen_get_two(LOAD load, PARK& park, uint64_t (*xw)[7], uint6
             static_for<0, 16>([&](auto K) { park.put(K, R.X[K]); park.put(16 + K, R.Y[K]); park.put(32 + K, R.Z[K]); });
         }
     }
-    uint32_t X0[16], Y0[16], Z0[16], zz[16], inv[16], t[16], u[16];
-    static_for<0, 16>([&](auto K) { X0[K] = park.get(K); Y0[K] = park.get(16 + K); Z0[K] = park.get(32 + K); });
+    // (round 4) only Z0 and R.Z cross the inversion in registers: X0, Y0 stay parked and R.X, R.Y join them (words 32..63)
+    uint32_t Z0[16], zz[16], inv[16], t[16], u[16], c[16];
+    static_for<0, 16>([&](auto K) { Z0[K] = park.get(32 + K); });
     F::mul_k(Z0, R.Z, zz);
+    static_for<0, 16>([&](auto K) { park.put(32 + K, R.X[K]); park.put(48 + K, R.Y[K]); });
     F::invert(zz, inv);
     F::mul_k(inv, R.Z, t);              // 1 / Z0
-    F::mul_k(X0, t, u);
+    static_for<0, 16>([&](auto K) { c[K] = park.get(K); });
+    F::mul_k(c, t, u);
     F::to_words(u, xw[0]);
-    F::mul_k(Y0, t, u);
+    static_for<0, 16>([&](auto K) { c[K] = park.get(16 + K); });
+    F::mul_k(c, t, u);
     F::to_words(u, yw[0]);
     F::mul_k(inv, Z0, t);               // 1 / Z1
-    F::mul_k(R.X, t, u);
+    static_for<0, 16>([&](auto K) { c[K] = park.get(32 + K); });
+    F::mul_k(c, t, u);
     F::to_words(u, xw[1]);
-    F::mul_k(R.Y, t, u);
+    static_for<0, 16>([&](auto K) { c[K] = park.get(48 + K); });
+    F::mul_k(c, t, u);
     F::to_words(u, yw[1]);
 }
 // x448_base_one for two private keys with one inversion: u = Y^2 / X^2, the denominators X^2 share it.  X = 0 (the clamped key
@@ -684,23 +746,30 @@ MA_DEV void x448_base_two(LOAD load, PARK& park, uint64_t (*ow)[7]) {
             static_for<0, 16>([&](auto K) { park.put(K, x2[K]); park.put(16 + K, y2[K]); });
         }
     }
-    uint32_t a2[16], b2[16], one[16], da[16], db[16], zz[16], inv[16], t[16], u[16];
+    // (round 4) the numerators wait in the park (b2 where it is, y2 in words 32..47) while the product of the denominators is inverted
+    uint32_t da[16], db[16], zz[16], inv[16], t[16], u[16], c[16];
     uint64_t zw[7];
-    static_for<0, 16>([&](auto K) { a2[K] = park.get(K); b2[K] = park.get(16 + K); });
-    F::set(1, one);
-    F::to_words(a2, zw);
-    const bool a0 = (zw[0] | zw[1] | zw[2] | zw[3] | zw[4] | zw[5] | zw[6]) == 0;
-    F::to_words(x2, zw);
-    const bool c0 = (zw[0] | zw[1] | zw[2] | zw[3] | zw[4] | zw[5] | zw[6]) == 0;
-    F::select(a0, a2, one, da);
-    F::select(c0, x2, one, db);
+    bool a0, c0;
+    {
+        uint32_t a2[16], one[16];
+        static_for<0, 16>([&](auto K) { a2[K] = park.get(K); park.put(32 + K, y2[K]); });
+        F::set(1, one);
+        F::to_words(a2, zw);
+        a0 = (zw[0] | zw[1] | zw[2] | zw[3] | zw[4] | zw[5] | zw[6]) == 0;
+        F::to_words(x2, zw);
+        c0 = (zw[0] | zw[1] | zw[2] | zw[3] | zw[4] | zw[5] | zw[6]) == 0;
+        F::select(a0, a2, one, da);
+        F::select(c0, x2, one, db);
+    }
     F::mul_k(da, db, zz);
     F::invert(zz, inv);
     F::mul_k(inv, db, t);
-    F::mul_k(b2, t, u);
+    static_for<0, 16>([&](auto K) { c[K] = park.get(16 + K); });
+    F::mul_k(c, t, u);
     F::to_words(u, ow[0]);
     F::mul_k(inv, da, t);
-    F::mul_k(y2, t, u);
+    static_for<0, 16>([&](auto K) { c[K] = park.get(32 + K); });
+    F::mul_k(c, t, u);
     F::to_words(u, ow[1]);
     static_for<0, 7>([&](auto K) {
         ow[0][K] = a0 ? 0u : ow[0][K];

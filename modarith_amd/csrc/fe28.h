@@ -7,7 +7,7 @@
 //
 // Radix 2^28, value = sum f_i 2^(28 i), phi = 2^224 is limb 8, 2^448 = phi + 1 (mod p).
 // "tight" = as left by carry(): f_i < 2^28 (f_1, f_9 < 2^28 + 2^9).  add() of tight operands gives limbs < 2^29;
-// sub() adds 2p and carries back to tight.  mul()/sqr() accept limbs < 2^29 on both sides: the raw columns
+// sub() adds 4p and carries back to tight.  mul()/sqr() accept limbs < 2^29 on both sides: the raw columns
 // c_0..c_30 hold at most 16 products of 2^58, and the folded column r_m = c_m + c_{m+8} + 2 c_{m+16} (m >= 8) or
 // c_m + c_{m+16} + c_{m+24} (m < 8) at most 38 of them: < 2^63.3.
 #pragma once
@@ -214,14 +214,17 @@ struct Fe28 {
     static MA_DEV void add(const uint32_t* f, const uint32_t* g, uint32_t* r) {
         static_for<0, 16>([&](auto I) { r[I] = f[I] + g[I]; });
     }
-    // r = f - g + 2p, carried back to tight (limbs of 2p: 2^29-2, limb 8: 2^29-4)
-    // (f, g < 2^29 + small: every limb of f + 2p - g is below 2^31, so the carries run in 32-bit registers)
+    // r = f - g + 4p, carried back to tight (limbs of 4p: 2^30-4, limb 8: 2^30-8)
+    // (f, g < 2^29 + 2^10, i.e. sums of two tight values: no limb of f + 4p - g goes below 0 and every one is below 2^31, so the
+    // carries run in 32-bit registers.  Rounds 1-3 added 2p, whose limbs 2^29-2 do NOT cover a subtrahend that is itself a sum
+    // when its limb is at the top of its range and the minuend's limb is 0 or 1 -- which no random input produces, and which the
+    // doubling of the order-4 point (0, 1, p-1) does: found in round 4 when the table builder began to stash canonical values.)
     static MA_DEV void sub(const uint32_t* f, const uint32_t* g, uint32_t* r) {
         uint32_t h[16];
         static_for<0, 16>([&](auto I) {
             constexpr int i = I;
-            constexpr uint32_t twop = (i == 8) ? 0x1ffffffcu : 0x1ffffffeu;
-            h[i] = (f[i] + twop) - g[i];
+            constexpr uint32_t fourp = (i == 8) ? 0x3ffffff8u : 0x3ffffffcu;
+            h[i] = (f[i] + fourp) - g[i];
         });
         static_for<0, 15>([&](auto I) {
             constexpr int i = I;

@@ -689,10 +689,54 @@ static int run_formulas(const char* name, int n, GEN gen, MUL mul, ADD oadd, DBL
     return bad;
 }
 
+
+// Fe28::sub at the limb extremes (round 4).  Its operands may each be a sum of two tight values; the subtrahend's limb can then sit
+// at 2^29 (+ 2^10 for limbs 1 and 9) while the minuend's is 0 -- a pattern no random input has, and the doubling of the order-4
+// point (0, 1, p-1) does.  Checked without the oracle: r + g == f (mod p) on the canonical words, and r is tight.
+static int run_fe28_sub_extremes(int n) {
+    using F = ma::Fe28;
+    int bad = 0;
+    uint64_t s = 0x9e3779b97f4a7c15ull;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    auto tight = [&](uint32_t* t) {
+        for (int i = 0; i < 16; i++) {
+            const uint64_t r = rnd();
+            const uint32_t hi = (i == 1 || i == 9) ? (1u << 28) + (1u << 9) - 1 : (1u << 28) - 1;
+            switch (r & 7) {
+                case 0: t[i] = 0; break;
+                case 1: t[i] = 1; break;
+                case 2: t[i] = hi; break;
+                case 3: t[i] = hi - 1; break;
+                case 4: t[i] = (1u << 28) - 1; break;
+                default: t[i] = (uint32_t)(r >> 8) % (hi + 1);
+            }
+        }
+    };
+    for (int it = 0; it < n; it++) {
+        uint32_t a[16], b[16], c[16], d[16], f[16], g[16], r[16], back[16];
+        tight(a); tight(b); tight(c); tight(d);
+        const uint64_t m = rnd();
+        for (int i = 0; i < 16; i++) { f[i] = a[i] + ((m & 1) ? b[i] : 0); g[i] = c[i] + ((m & 2) ? d[i] : 0); }
+        if (it % 4 == 0) for (int i = 0; i < 16; i++) { f[i] = (m >> (8 + i)) & 1; g[i] = ((i == 1 || i == 9) ? (1u << 29) + (1u << 10) - 2 : (1u << 29) - 2); }
+        F::sub(f, g, r);
+        bool ok = true;
+        for (int i = 0; i < 16; i++) ok = ok && r[i] < (1u << 28) + ((i == 1 || i == 9) ? (1u << 9) : 0);
+        F::add(r, g, back);
+        uint64_t w1[7], w2[7];
+        F::to_words(back, w1);
+        F::to_words(f, w2);
+        for (int k = 0; k < 7; k++) ok = ok && w1[k] == w2[k];
+        if (!ok) { if (bad < 5) printf("Fe28::sub extremes: record %d differs\n", it); bad++; }
+    }
+    printf("Fe28::sub at the limb extremes: %d records, %d differ from f - g (mod p)\n", n, bad);
+    return bad;
+}
+
 int main(int argc, char** argv) {
     int n = argc > 1 ? atoi(argv[1]) : 2000;
     int bad = run<4>("x25519_fe26_one", n, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x25519_fe26_one(k, u, o); }, rfc7748_X25519);
     bad += run<7>("x448_fe28_one", n / 4 + 8, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x448_fe28_one(k, u, o); }, rfc7748_X448);
+    bad += run_fe28_sub_extremes(n * 50);
     bad += run_fh51(n * 50);
     bad += run_u<ma::P_X25519, 5>("X25519", n * 25, 51, modadd_X25519, modsub_X25519, modneg_X25519);
     bad += run_u<ma::P_NIST256, 5>("NIST256", n * 25, 52, modadd_NIST256, modsub_NIST256, modneg_NIST256);
@@ -730,7 +774,7 @@ int main(int argc, char** argv) {
                                       for (int k = 0; k < 4; k++) { x[k] = xw[2][k]; y[k] = yw[2][k]; }
                                   }, ecn_ed25519_gen, ecn_ed25519_mul, ecn_ed25519_get);
     bad += run_ed25519_mulgen2(n / 8 + 24);
-    struct HostPark { uint32_t w[48]; void put(int k, uint32_t v) { w[k] = v; } uint32_t get(int k) const { return w[k]; } };
+    struct HostPark { uint32_t w[64]; void put(int k, uint32_t v) { w[k] = v; } uint32_t get(int k) const { return w[k]; } };
     bad += run_edgen<56, pt448>("ed448_mulgen_get_two", n / 8 + 130, [](const uint64_t* e, uint64_t* x, uint64_t* y) {
                                     uint64_t xw[2][7], yw[2][7];        // this scalar first and second of a pair, both must agree
                                     HostPark park;
