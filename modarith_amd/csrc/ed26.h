@@ -45,14 +45,6 @@ struct Ed26 {
         f[0] = h0 & M26;
         f[1] += h0 >> 26;
     }
-    // r = f - g + 4p, for g up to scale 1.99 (limbs of 4p: 2^28-76, 2^27-4, 2^28-4, 2^27-4, ...)
-    static MA_DEV void sub4(const uint32_t* f, const uint32_t* g, uint32_t* r) {
-        static_for<0, 10>([&](auto I) {
-            constexpr int i = I;
-            constexpr uint32_t fourp = (i == 0) ? 0xfffffb4u : ((i & 1) ? 0x7fffffcu : 0xffffffcu);
-            r[i] = (f[i] + fourp) - g[i];
-        });
-    }
     // 5 x 51-bit limbs (field.c form, limbs below 2^53: the contract of the curve layer) -> tight fe26
     static MA_DEV void from51(const spint* x, uint32_t* r) {
         static_for<0, 5>([&](auto K) {

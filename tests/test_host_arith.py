@@ -235,3 +235,170 @@ def test_fused_generator_multiplication_on_host_against_oracle(oracle, tmp_path)
             oracle.ecn(C, "get")(ctypes.byref(R), x, y)
             got = (b"".join(int(xw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0)), b"".join(int(yw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0)))
             assert got == (x.raw, y.raw), (C, "mulgen2", it)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")
+def test_unsigned_limb_fields_at_the_edges_of_their_ranges(tmp_path):
+    """fe26.h / fe28.h and the Edwards formulas of ed26.h / ed28.h (tools/fe_limb_host.hip, host build) with every limb drawn from
+    {0, 1, max - 1, max, random} of the range the header documents for that operand -- tight values, sums of two tight values,
+    the scaled operands of ed26.h -- against Python integers: value of the result mod p, and the range the header promises for
+    it.  Unsigned limbs wrap silently when a subtrahend's limb exceeds minuend + k p; random field elements never come
+    near that (probability 2^-55), a stashed canonical 0 does (round 4: Fe28::sub under the doubling of the order-4 point)."""
+    import ctypes
+    import random
+    so = str(tmp_path / "libfe_limb_host.so")
+    cc = HIPCC if os.path.exists(HIPCC) else "hipcc"
+    subprocess.run([cc, "-O2", "-std=c++17", "-w", "-shared", "-fPIC", "--offload-host-only", os.path.join(ROOT, "tools", "fe_limb_host.hip"), "-o", so],
+                   check=True, timeout=900)
+    lib = ctypes.CDLL(so)
+    rng = random.Random(2026)
+    U32 = ctypes.c_uint32
+
+    class Fld:
+        def __init__(self, name, nl, p, pos, tight_hi):
+            self.name, self.nl, self.p, self.pos, self.tight_hi = name, nl, p, pos, tight_hi
+            self.op = getattr(lib, name + "_op")
+            self.formula = getattr(lib, "ed" + name[2:] + "_formula")
+
+        def value(self, limbs):
+            return sum(int(v) << self.pos[i] for i, v in enumerate(limbs)) % self.p
+
+        def scaled(self, scale2):            # exclusive upper bounds: scale2 x the tight range (ed26.h's scale s = scale2 / 2)
+            return [h * scale2 for h in self.tight_hi]
+
+        def draw(self, hi, style=None):
+            style = rng.randrange(6) if style is None else style
+            out = []
+            for h in hi:
+                k = style if style < 4 else rng.randrange(6)
+                out.append([0, 1, h - 2, h - 1][k] if k < 4 else rng.randrange(h))
+            return out
+
+        def run(self, op, f, g=None):
+            r = (U32 * self.nl)()
+            self.op(op, (U32 * self.nl)(*f), (U32 * self.nl)(*(g if g is not None else f)), r)
+            return list(r)
+
+        def inside(self, limbs, hi):
+            return all(v < h for v, h in zip(limbs, hi))
+
+    p25519, p448 = 2**255 - 19, 2**448 - 2**224 - 1
+    # tight as the headers define it: fe26 even < 2^26, odd < 2^25, limb 1 < 2^25 + 2^16;  fe28 < 2^28, limbs 1 and 9 < 2^28 + 2^9
+    f26 = Fld("fe26", 10, p25519, [(51 * i + 1) // 2 for i in range(10)], [(1 << 26) if i % 2 == 0 else (1 << 25) + ((1 << 16) if i == 1 else 0) for i in range(10)])
+    f28 = Fld("fe28", 16, p448, [28 * i for i in range(16)], [(1 << 28) + ((1 << 9) if i in (1, 9) else 0) for i in range(16)])
+    ADD, SUB, MUL, SQR, MLI, MLA, WC, MULK, SQRK = range(9)
+
+    def pairs(n):                              # every pure style against every pure style, then mixtures
+        for a in range(4):
+            for b in range(4):
+                yield a, b
+        for _ in range(n):
+            yield None, None
+
+    # ---- fe26 (scale 1 = twice tight, as ed26.h counts)
+    T26 = f26.tight_hi
+    S = lambda s: f26.scaled(int(2 * s))       # noqa: E731   scale s -> bounds
+    for sa, sb in pairs(300):
+        f, g = f26.draw(S(1.0), sa), f26.draw(T26, sb)                      # sub: minuend a sum of two tight values, subtrahend tight
+        r = f26.run(SUB, f, g)
+        assert f26.value(r) == (f26.value(f) - f26.value(g)) % p25519 and f26.inside(r, S(2.0)), ("fe26 sub", sa, sb)
+        for fs, gs in ((2.0, 1.5), (1.5, 1.5), (2.5, 1.0), (1.0, 1.5), (2.0, 0.5)):     # the operand scales ed26.h multiplies
+            f, g = f26.draw(S(fs), sa), f26.draw(S(gs), sb)
+            r = f26.run(MUL, f, g)
+            assert f26.value(r) == f26.value(f) * f26.value(g) % p25519 and f26.inside(r, T26), ("fe26 mul", fs, gs, sa, sb)
+        f = f26.draw(S(1.5), sa)
+        r = f26.run(SQR, f)
+        assert f26.value(r) == f26.value(f) ** 2 % p25519 and f26.inside(r, T26), ("fe26 sqr", sa)
+        f, g = f26.draw(S(1.5), sa), f26.draw(T26, sb)
+        r = f26.run(MLA, f, g)
+        assert f26.value(r) == (f26.value(f) * 121665 + f26.value(g)) % p25519 and f26.inside(r, [h + 64 for h in S(1.0)]), ("fe26 mul_small_add", sa, sb)
+        r = f26.run(MLI, f)
+        assert f26.value(r) == f26.value(f) * 121665 % p25519 and f26.inside(r, T26), ("fe26 mul_small", sa)
+        f = f26.draw([1 << 31] * 10, sa)
+        r = f26.run(WC, f)
+        assert f26.value(r) == f26.value(f) and f26.inside(r, T26), ("fe26 wc", sa)
+
+    # ---- fe28: sums of two tight values everywhere the Edwards formulas put them
+    T28 = f28.tight_hi
+    SUM28 = [2 * h - 1 for h in T28]
+    for sa, sb in pairs(300):
+        f, g = f28.draw(SUM28, sa), f28.draw(SUM28, sb)
+        r = f28.run(SUB, f, g)
+        assert f28.value(r) == (f28.value(f) - f28.value(g)) % p448 and f28.inside(r, T28), ("fe28 sub", sa, sb)
+        r = f28.run(MUL, f, g)
+        assert f28.value(r) == f28.value(f) * f28.value(g) % p448 and f28.inside(r, T28), ("fe28 mul", sa, sb)
+        h15 = [h + (h - 1) // 2 for h in SUM28]                              # (xs + y) of add_cached: below 1.5 x 2^29
+        f, g = f28.draw(SUM28, sa), f28.draw(h15, sb)
+        r = f28.run(MUL, f, g)
+        assert f28.value(r) == f28.value(f) * f28.value(g) % p448 and f28.inside(r, T28), ("fe28 mul 1.5", sa, sb)
+        r = f28.run(SQR, f)
+        assert f28.value(r) == f28.value(f) ** 2 % p448 and f28.inside(r, T28), ("fe28 sqr", sa)
+        f, g = f28.draw(T28, sa), f28.draw(SUM28, sb)
+        for a, b in ((f, g), (g, f)):
+            r = f28.run(MULK, a, b)
+            assert f28.value(r) == f28.value(f) * f28.value(g) % p448 and f28.inside(r, T28), ("fe28 mul_k", sa, sb)
+        r = f28.run(SQRK, f)
+        assert f28.value(r) == f28.value(f) ** 2 % p448 and f28.inside(r, T28), ("fe28 sqr_k", sa)
+        g = f28.draw(T28, sb)
+        r = f28.run(MLA, f, g)
+        assert f28.value(r) == (f28.value(f) * 39081 + f28.value(g)) % p448 and f28.inside(r, [h + 64 for h in SUM28]), ("fe28 mul_small_add", sa, sb)
+        r = f28.run(MLI, f)
+        assert f28.value(r) == f28.value(f) * 39081 % p448 and f28.inside(r, T28), ("fe28 mul_small", sa)
+        f = f28.draw([1 << 31] * 16, sa)
+        r = f28.run(WC, f)
+        assert f28.value(r) == f28.value(f) and f28.inside(r, T28), ("fe28 wc", sa)
+
+    # ---- the formulas, on field elements (not curve points: the formulas are polynomial identities checked coordinate by coordinate)
+    def coords(F, flat):
+        return [F.value(flat[k * F.nl:(k + 1) * F.nl]) for k in range(4)]
+
+    def formula(F, what, P, a, b=None, c=None):
+        buf = (U32 * (4 * F.nl))(*[v for co in P for v in co])
+        arr = lambda v, n: (U32 * n)(*v) if v is not None else (U32 * n)()        # noqa: E731
+        F.formula(what, buf, arr(a, 4 * F.nl if len(a) == 4 * F.nl else F.nl) if a is not None else arr(None, F.nl), arr(b, F.nl), arr(c, F.nl))
+        out = list(buf)
+        assert all(F.inside(out[k * F.nl:(k + 1) * F.nl], F.tight_hi) for k in range(4)), (F.name, "formula output not tight", what)
+        return coords(F, out)
+
+    d25519 = 0x52036cee2b6ffe738cc740797779e89800700a4d4141d8ab75eb4dca135978a3
+    for sa, sb in pairs(120):
+        for F, p in ((f26, p25519), (f28, p448)):
+            P = [F.draw(F.tight_hi, sa if k != 1 else sb) for k in range(4)]
+            X, Y, Z, T = [F.value(v) for v in P]
+            # doubling
+            A, B, C = X * X, Y * Y, 2 * Z * Z
+            if F is f26:                       # a = -1
+                H = A + B; E = H - (X + Y) ** 2; G = A - B; Fv = C + G              # noqa: E702
+            else:                              # a = 1
+                G = A + B; E = (X + Y) ** 2 - G; Fv = G - C; H = A - B             # noqa: E702
+            want = [E * Fv % p, G * H % p, Fv * G % p, E * H % p]
+            assert formula(F, 0, P, None) == want, (F.name, "dbl", sa, sb)
+            # addition of a cached affine operand
+            if F is f26:
+                yp, ym, t2d = F.draw(F.tight_hi, sb), F.draw(F.tight_hi, sa), F.draw(F.scaled(3), sb)      # t2d up to scale 1.5 (3 x tight)
+                a, b, c, d = (Y - X) * F.value(ym), (Y + X) * F.value(yp), T * F.value(t2d), 2 * Z
+                e, f_, g, h = b - a, d - c, d + c, b + a
+                want = [e * f_ % p, g * h % p, f_ * g % p, e * h % p]
+                assert formula(F, 1, P, yp, ym, t2d) == want, (F.name, "add_cached", sa, sb)
+                assert formula(F, 3, P, yp, ym, t2d) == want, (F.name, "add_cached_rt", sa, sb)
+            else:
+                xs, y, tds = F.draw(SUM28, sb), F.draw(F.tight_hi, sa), F.draw(SUM28, sb)
+                A, B, Cc, D, M = X * F.value(xs), Y * F.value(y), T * F.value(tds), Z, (X + Y) * (F.value(xs) + F.value(y))
+                E, Fv, G, H = M - A - B, D + Cc, D - Cc, B - A
+                want = [E * Fv % p, G * H % p, Fv * G % p, E * H % p]
+                assert formula(F, 1, P, xs, y, tds) == want, (F.name, "add_cached", sa, sb)
+            # addition of two extended points
+            Q = [F.draw(F.tight_hi, sb if k != 2 else sa) for k in range(4)]
+            X2, Y2, Z2, T2 = [F.value(v) for v in Q]
+            flatQ = [v for co in Q for v in co]
+            if F is f26:
+                a, b, c, d = (Y - X) * (Y2 - X2), (Y + X) * (Y2 + X2), T * T2 * 2 * d25519, 2 * Z * Z2
+                e, f_, g, h = b - a, d - c, d + c, b + a
+                want = [e * f_ % p, g * h % p, f_ * g % p]
+                assert formula(F, 2, P, flatQ)[:3] == want, (F.name, "add_ext", sa, sb)
+            else:
+                A, B, Cc, D, M = X * X2, Y * Y2, 39081 * T * T2, Z * Z2, (X + Y) * (X2 + Y2)
+                E, Fv, G, H = M - A - B, D + Cc, D - Cc, B - A
+                want = [E * Fv % p, G * H % p, Fv * G % p]
+                assert formula(F, 2, P, flatQ)[:3] == want, (F.name, "add_ext", sa, sb)
+                assert formula(F, 3, P, flatQ)[:3] == want, (F.name, "add_ext_fetched", sa, sb)
