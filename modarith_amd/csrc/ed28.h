@@ -771,9 +771,10 @@ MA_DEV void x448_base_two(LOAD load, PARK& park, uint64_t (*ow)[7]) {
     static_for<0, 16>([&](auto K) { c[K] = park.get(32 + K); });
     F::mul_k(c, t, u);
     F::to_words(u, ow[1]);
+    const uint64_t ka = lane_mask(!a0), kc = lane_mask(!c0);         // (field.h: masks, not selects)
     static_for<0, 7>([&](auto K) {
-        ow[0][K] = a0 ? 0u : ow[0][K];
-        ow[1][K] = c0 ? 0u : ow[1][K];
+        ow[0][K] &= ka;
+        ow[1][K] &= kc;
     });
 }
 

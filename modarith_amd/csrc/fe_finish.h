@@ -8,8 +8,8 @@
 // {r * L + j : r < rounds} (L lanes, so that every access of a wave is one coalesced row), multiplies their z up into
 // prefix products, inverts the last one, and walks back with three multiplications per element.  A z2 of zero (u = 0, the
 // low-order points of RFC 7748 section 7) would annihilate the whole product: it is replaced by 1 on the way in and its
-// output -- x2 * 0^(p-2) = 0 in the reference -- is set to zero on the way out, by lane predication (v_cndmask on the
-// words), never by a branch.  Same bytes as the one-inversion-per-lane kernels for every input.
+// output -- x2 * 0^(p-2) = 0 in the reference -- is set to zero on the way out, by a per-lane mask (v_cndmask on the way in,
+// v_and on the way out; field.h lane_mask()), never by a branch.  Same bytes as the one-inversion-per-lane kernels for every input.
 #pragma once
 #include "field.h"
 
@@ -47,7 +47,7 @@ struct FeFinish {
             const size_t e = (size_t)r * L + j;
             if (e >= n) continue;                                   // (its z counted as 1: nothing to undo)
             uint32_t zinv[NL], x[NL];
-            const bool zero = load_z(wz, n, e, true, z);
+            const uint64_t keep = lane_mask(!load_z(wz, n, e, true, z));     // (field.h: an opaque mask, not a select)
             if (r > 0) {
                 uint32_t cp[NL];
                 const size_t e1 = e - L;
@@ -62,7 +62,7 @@ struct FeFinish {
             F::from_words(xw, x);
             F::mul(x, zinv, x);
             F::to_words(x, ow);
-            static_for<0, NW>([&](auto K) { bv[e * NW + K] = zero ? 0 : ow[K]; });
+            static_for<0, NW>([&](auto K) { bv[e * NW + K] = ow[K] & keep; });
         }
     }
 };

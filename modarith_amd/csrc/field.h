@@ -39,6 +39,18 @@ using dpint = unsigned __int128;
 #define MA_PIN(x) ((void)0)
 #endif
 
+// lane_mask(c): all ones where c holds, 0 elsewhere, as a value the compiler knows NOTHING about.  `c ? 0 : w` on the words of a
+// result invites it to move the whole computation of w under an EXEC region for the lanes that keep it, headed by
+// s_cbranch_execz -- a branch on lane data (found by tools/ct_audit.py's EXEC-mask tracing in round 4: the zero-z records of
+// k_fe_finish, the infinite results of the fused Weierstrass exports).  `w & lane_mask(!c)` is computed by every lane.
+MA_DEV uint64_t lane_mask(bool c) {
+    uint64_t m = c ? ~0ull : 0ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(m));
+#endif
+    return m;
+}
+
 template <int I, int End, class Fn>
 MA_DEV void static_for(Fn&& fn) {
     if constexpr (I < End) {

@@ -356,9 +356,10 @@ struct Wn26 {
         F::mul(p.Y, zi, ay);
         F::to_words(ax, xw);
         F::to_words(ay, yw);
+        const uint64_t keep = lane_mask(!z0);             // (field.h: a mask, not a select -- no EXEC region around the export)
         static_for<0, 4>([&](auto K) {
-            xw[K] = z0 ? 0u : xw[K];
-            yw[K] = z0 ? (K == 0 ? 1u : 0u) : yw[K];
+            xw[K] &= keep;
+            yw[K] = (yw[K] & keep) | (K == 0 ? (1u & ~keep) : 0u);
         });
     }
     // affine_words for G points with ONE inversion (Montgomery's trick on the prefix products of the Z); a point at infinity
@@ -390,9 +391,10 @@ struct Wn26 {
             F::to_words(u, xw[g]);
             F::mul(pts[g].Y, t, u);
             F::to_words(u, yw[g]);
+            const uint64_t keep = lane_mask(!inf_[g]);
             static_for<0, 4>([&](auto K) {
-                xw[g][K] = inf_[g] ? 0u : xw[g][K];
-                yw[g][K] = inf_[g] ? (K == 0 ? 1u : 0u) : yw[g][K];
+                xw[g][K] &= keep;
+                yw[g][K] = (yw[g][K] & keep) | (K == 0 ? (1u & ~keep) : 0u);
             });
         });
     }

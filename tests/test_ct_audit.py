@@ -1,5 +1,6 @@
 """tools/ct_audit.py as a test (no GPU): every conditional branch in the gfx950 code of the kernels that carry the reference's
-constant-time contract (modcsw / modcmv pseudo.py:979-1048, the ladders, ecnXXXmul edwards.c:382-401, 435-482) is classified
+constant-time contract (modcsw / modcmv pseudo.py:979-1048, the ladders, ecnXXXmul edwards.c:382-401, 435-482, and the fused kernels
+that take a secret scalar: mul + get, gen + mul + get, the base-point ladders) is classified
 from the disassembly (with the registers it depends on traced back to loads, workitem ids or scalars); a branch on lane data, or more exec-mask / lane-index branches than the reviewed allow-list (tools/ct_allowlist.json)
 names, fails.  The classifier itself is checked on hand-made instruction streams."""
 import os
@@ -39,7 +40,17 @@ def test_classifier_on_hand_made_streams():
     carry = [load, "v_subrev_co_u32_e32 v54, vcc, 1, v1", "s_and_b64 vcc, exec, vcc", "s_cbranch_vccz 100"]   # a borrow out of loaded data
     assert ct_audit.audit_function(carry)["vcc_lane_data"] == 1
     div = ["v_cmp_lt_u64_e32 vcc, s[2:3], v[0:1]", "s_and_saveexec_b64 s[4:5], vcc", "s_cbranch_execz 55"]
-    assert ct_audit.audit_function(div)["exec"] == 1
+    a = ct_audit.audit_function(div)                                                     # EXEC narrowed by the lane index: the `t < n` tail
+    assert (a["exec"], a["exec_lane_data"], a["unknown"]) == (1, 0, 0)
+    # EXEC narrowed by lane DATA: "only the lanes whose z is not zero compute the export" (what `zero ? 0 : w` compiled to in round 4)
+    sunk = [load, "v_cmp_ne_u32_e32 vcc, 0, v1", "s_and_saveexec_b64 s[0:1], vcc", "s_cbranch_execz 40"]
+    a = ct_audit.audit_function(sunk)
+    assert (a["exec"], a["exec_lane_data"]) == (1, 1)
+    # ... and a structured region that ENDS before the branch does not taint it: EXEC |= saved mask restores the outer (index) mask
+    nested = ["v_cmp_lt_u64_e32 vcc, s[2:3], v[0:1]", "s_and_saveexec_b64 s[4:5], vcc", load, "v_cmp_ne_u32_e32 vcc, 0, v1", "s_and_saveexec_b64 s[6:7], vcc",
+              "v_mov_b32_e32 v9, 0", "s_or_b64 exec, exec, s[6:7]", "v_cmp_lt_u64_e32 vcc, s[2:3], v[10:11]", "s_and_saveexec_b64 s[8:9], vcc", "s_cbranch_execz 12"]
+    a = ct_audit.audit_function(nested)
+    assert (a["exec"], a["exec_lane_data"], a["unknown"]) == (1, 0, 0)
 
 
 def test_audited_kernels_have_no_data_dependent_branch():
@@ -49,7 +60,9 @@ def test_audited_kernels_have_no_data_dependent_branch():
     rows, problems = ct_audit.run()
     names = " ".join(r["kernel"] for r in rows)
     for must in ("k_cond<ma::P_X25519", "k_x25519_fe26_xz", "k_x448_fe28_xz", "k_fe_finish<ma::Fe26", "k_ed_mul<ma::Edwards<ma::C_ED25519", "k_ed_mul<ma::Edwards<ma::C_ED448",
-                 "k_ed_mul<ma::Weierstrass<ma::C_NIST256", "k_ed_mul2<ma::Edwards<ma::C_ED25519"):
+                 "k_ed_mul<ma::Weierstrass<ma::C_NIST256", "k_ed_mul2<ma::Edwards<ma::C_ED25519",
+                 "k_ed25519_mul_get", "k_ed448_mul_get", "k_nist256_mul_get", "k_secp256k1_mul_get", "k_ed25519_mulgen_get", "k_ed448_mulgen_get",
+                 "k_nist256_mulgen_get", "k_secp256k1_mulgen_get", "k_x25519_base", "k_x448_base"):
         assert must in names, "audited kernel missing from the build: " + must
     assert not problems, "\n".join(problems)
-    assert all(r["scc_lane_data"] == 0 and r["vcc_lane_data"] == 0 and r["unknown"] == 0 for r in rows)
+    assert all(r["scc_lane_data"] == 0 and r["vcc_lane_data"] == 0 and r["exec_lane_data"] == 0 and r["unknown"] == 0 for r in rows)

@@ -43,6 +43,11 @@ AUDITED = [
     ("capi_X25519.o", "k_fe_finish<"), ("capi_X448.o", "k_fe_finish<"),
     ("capi_X25519.o", "k_rfc7748<"), ("capi_X448.o", "k_rfc7748<"),
     ("capi_*_part1.o", "k_ed_mul<"), ("capi_*_part2.o", "k_ed_mul2<"),
+    # the fused kernels that take a SECRET scalar (key generation, signing, key agreement): mul + get, gen + mul + get, base-point ladders.
+    # (mul2_get / mulgen2_get are the verification patterns: public inputs, and the reference's own mul2 is variable time.)
+    ("capi_ED25519F.o", "k_ed25519_mul_get"), ("capi_ED448F.o", "k_ed448_mul_get"), ("capi_NIST256F.o", "_mul_get"), ("capi_SECP256K1F.o", "_mul_get"),
+    ("capi_ED25519G.o", "mulgen_get"), ("capi_ED448G.o", "mulgen_get"), ("capi_NIST256G.o", "mulgen_get"), ("capi_SECP256K1G.o", "mulgen_get"),
+    ("capi_ED25519G.o", "k_x25519_base"), ("capi_ED448G.o", "k_x448_base"),
 ]
 
 
@@ -80,6 +85,8 @@ def _regs(tok):
         return {(m.group(1), int(m.group(2)))}
     if tok in ("vcc", "vcc_lo", "vcc_hi"):
         return {("vcc", 0)}
+    if tok in EXEC:
+        return {("exec", 0)}
     return set()
 
 
@@ -139,26 +146,39 @@ class Function:
                 dst |= _regs(ops[1])
             if op.startswith("v_cmp") and (op.endswith("_e32") or (ops and ops[0] in ("vcc",))):
                 dst |= {("vcc", 0)}
+            if op.startswith("v_cmpx"):
+                dst |= {("exec", 0)}
             return dst, "valu"
         if op.startswith("s_"):
             if op.startswith(("s_cmp", "s_bitcmp")):
                 return {("scc", 0)}, "salu"
             if not op.startswith(NOT_SCC):
                 dst = dst | {("scc", 0)}
+            if "saveexec" in op:
+                dst = dst | {("exec", 0)}                     # s_and_saveexec_b64 sdst, ssrc: sdst = EXEC, EXEC = ssrc & EXEC
             if op.startswith(("s_cbranch", "s_branch", "s_waitcnt", "s_nop", "s_endpgm", "s_barrier", "s_setprio", "s_sleep")):
                 return set(), "other"
             return dst, ("uniform-source" if op.startswith(UNIFORM_SOURCE) else "salu")
         return set(), "other"
 
-    def sources(self, i):
+    def sources(self, i, hit=None):
+        """registers instruction i reads to produce the registers `hit` (None: any of its results)"""
         op, ops = _split(self.text[i])
         srcs = set()
+        if "saveexec" in op and hit is not None and ("exec", 0) not in hit:
+            return {("exec", 0)}                             # only the saved copy is wanted: sdst = the OLD mask, whatever ssrc holds
+        if op == "s_or_b64" and len(ops) == 3 and ops[0] in EXEC and ops[1] in EXEC:
+            return _regs(ops[2])                             # end of a structured region: EXEC |= the mask saved at its head, of which the
+                                                             # current EXEC is a subset -- the result IS the saved mask
         first = 0 if op.startswith(("s_cmp", "s_bitcmp")) else 1
         # (llvm-objdump prints the destination of every v_cmp first -- "v_cmp_ge_u64_e32 vcc, s[12:13], v[2:3]" -- so sources start at 1 there too)
+        writes_exec = "saveexec" in op or op.startswith("v_cmpx") or (ops and ops[0].strip() in EXEC)
         for o in ops[first:]:
-            if o.strip() in EXEC:
-                continue                                     # EXEC as a value: the launched lanes (tails belong to the exec-branch class)
+            if o.strip() in EXEC and not writes_exec:
+                continue                                     # EXEC read as a value (ballots, v_cndmask masks): the launched lanes
             srcs |= _regs(o)
+        if "saveexec" in op or op.startswith("v_cmpx"):
+            srcs |= {("exec", 0)}                            # the new mask narrows the old one
         if op.startswith("v_") and len(ops) > 1 and op.startswith(CARRY_OUT):
             srcs -= _regs(ops[1])                            # the carry-out operand is a destination
         if op.startswith(USES_SCC):
@@ -213,7 +233,7 @@ class Function:
                     if op.startswith("v_mbcnt"):
                         r = "lane-index"
                     else:
-                        r = self.trace(i, self.sources(i), depth + 1, budget)
+                        r = self.trace(i, self.sources(i, hit), depth + 1, budget)
                     if r == "lane-data":
                         return r
                     verdict = worse(verdict, r)
@@ -237,7 +257,7 @@ def audit_function(ins):
     if ins and not isinstance(ins[0], tuple):
         ins = [(4 * i, t) for i, t in enumerate(ins)]
     f = Function(ins)
-    out = {"scc_uniform": 0, "scc_lane_data": 0, "vcc_uniform": 0, "vcc_lane_data": 0, "lane_index": 0, "exec": 0, "unknown": 0, "calls": 0, "detail": []}
+    out = {"scc_uniform": 0, "scc_lane_data": 0, "vcc_uniform": 0, "vcc_lane_data": 0, "lane_index": 0, "exec": 0, "exec_lane_data": 0, "unknown": 0, "calls": 0, "detail": []}
     for i, t in enumerate(f.text):
         op, ops = _split(t)
         if op in ("s_cbranch_scc0", "s_cbranch_scc1"):
@@ -247,7 +267,14 @@ def audit_function(ins):
             c = f.trace(i, {("vcc", 0)})
             key = {"uniform": "vcc_uniform", "lane-data": "vcc_lane_data", "lane-index": "lane_index"}.get(c, "unknown")
         elif op in ("s_cbranch_execz", "s_cbranch_execnz"):
-            c, key = "exec", "exec"
+            # the mask tested: traced through s_and_saveexec / s_and / s_or / s_mov on EXEC to the v_cmp results that formed it
+            c = f.trace(i, {("exec", 0)})
+            key = "exec"
+            if c == "lane-data":
+                out["exec_lane_data"] += 1
+            elif c == "unknown":
+                out["unknown"] += 1
+            c = "exec mask from " + c
         elif op.startswith(("s_setpc", "s_swappc")):
             # calls of out-of-line functions and their returns: the target is s_getpc + constant or the saved return address
             srcs = set()
@@ -299,7 +326,7 @@ def run(verbose=False):
                 if entry is None:
                     problems.append("%s: no allow-list entry" % short)
                     continue
-                lane = a["scc_lane_data"] + a["vcc_lane_data"]
+                lane = a["scc_lane_data"] + a["vcc_lane_data"] + a["exec_lane_data"]
                 if lane > entry.get("lane_data_branches", 0):
                     problems.append("%s: %d data-dependent branch(es), %d allowed" % (short, lane, entry.get("lane_data_branches", 0)))
                 if a["exec"] + a["lane_index"] > entry.get("exec_branches", 0):
@@ -309,11 +336,44 @@ def run(verbose=False):
     return rows, problems
 
 
+def survey():
+    """--all: every kernel of every built object that holds a branch on lane data (report only).  Outside the audited set these are the
+    documented contract votes of the `Auto` policies (kernels.h: "is any limb of this wave beyond the contract?" -- false for every
+    output of a field function) and the zero test of the simultaneous inversion; the `_ct` entry points do not take them."""
+    bdir = os.path.join(ROOT, "modarith_amd", "build")
+    total, flagged = 0, {}
+    for o in sorted(os.listdir(bdir)):
+        if not o.endswith(".o"):
+            continue
+        funcs = disassemble(os.path.join(bdir, o))
+        syms = list(funcs)
+        names = dict(zip(syms, demangle(syms)))
+        for sym, ins in funcs.items():
+            if not ins:
+                continue
+            total += 1
+            a = audit_function(ins)
+            lane = a["scc_lane_data"] + a["vcc_lane_data"] + a["exec_lane_data"]
+            if lane or a["unknown"]:
+                short = re.sub(r"\(.*", "", re.sub(r"^void ", "", names.get(sym, sym)))
+                family = re.sub(r"P_\w+|C_\w+", "*", short)
+                f = flagged.setdefault(family, {"kernels": 0, "lane_data_branches": 0, "unknown": 0, "example": short + " [" + o + "]"})
+                f["kernels"] += 1
+                f["lane_data_branches"] = max(f["lane_data_branches"], lane)
+                f["unknown"] = max(f["unknown"], a["unknown"])
+    print("%d kernels in %s; families with a branch on lane data:" % (total, bdir))
+    for fam, f in sorted(flagged.items()):
+        print("  %4d kernels, up to %d branch(es)%s  %s   e.g. %s" % (f["kernels"], f["lane_data_branches"], (", %d unclassified" % f["unknown"]) if f["unknown"] else "", fam, f["example"]))
+    return 0
+
+
 def main(argv):
+    if "--all" in argv:
+        return survey()
     rows, problems = run(verbose="--verbose" in argv)
-    print("%-4s %-4s %-4s %-4s %-4s %-4s %-4s %-4s  %s" % ("sccU", "sccD", "vccU", "vccD", "idx", "exec", "call", "unk", "kernel [object]"))
+    print("%-4s %-4s %-4s %-4s %-4s %-4s %-4s %-4s %-4s  %s" % ("sccU", "sccD", "vccU", "vccD", "idx", "exec", "excD", "call", "unk", "kernel [object]"))
     for r in rows:
-        print("%4d %4d %4d %4d %4d %4d %4d %4d  %s [%s]" % (r["scc_uniform"], r["scc_lane_data"], r["vcc_uniform"], r["vcc_lane_data"], r["lane_index"], r["exec"], r["calls"], r["unknown"],
+        print("%4d %4d %4d %4d %4d %4d %4d %4d %4d  %s [%s]" % (r["scc_uniform"], r["scc_lane_data"], r["vcc_uniform"], r["vcc_lane_data"], r["lane_index"], r["exec"], r["exec_lane_data"], r["calls"], r["unknown"],
                                                          r["kernel"][:110], r["object"]))
     if "--json" in argv:
         with open(argv[argv.index("--json") + 1], "w") as f:
