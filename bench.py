@@ -419,10 +419,20 @@ def main():
     assert torch.equal(chk, c), "modmul is not commutative bit-for-bit: kernel bug"
     del chk
 
-    def rate(fn, reps=20, warm=3):
+    def rate(fn, reps=20, warm=3, warm_ms=60.0):
+        # >= 3 warm-up launches AND >= 60 ms of them: the side legs are separated by host work (allocations, input
+        # generation, a plug-in load), during which the part drops its clocks; the first 20-40 streaming launches after such a gap
+        # run 2-5 % slower while they ramp back (tools/chain_dvfs.py, profiles/r04_chain_dvfs.log: every kernel, not one in
+        # particular), and three launches of 0.3 ms do not cover that.  Kernels of tens of ms per launch get their three.
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         for _ in range(warm):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e1.record()
+        torch.cuda.synchronize()
+        spent = e0.elapsed_time(e1)
+        for _ in range(min(2000, int(max(0.0, warm_ms - spent) / max(spent / warm, 1e-3)))):
+            fn()
         torch.cuda.synchronize()
         e0.record()
         for _ in range(reps):
@@ -482,9 +492,9 @@ def main():
         del ad, bd, cd
 
     others = {}
-    # (Measured HERE, right after the streaming data sets and before the VALU-bound curve legs: at ~75-80 % VALU issue occupancy the
-    # four-call chain is co-limited by VALU issue, and after two minutes of multiplier-dense curve kernels the part's clock has
-    # sagged enough for it to read 0.73 of the HBM peak instead of 0.80-0.82 -- docs/fused_chains.md, profiles/r04_chain_pmc.json.)
+    # (Measured right after the streaming data sets.  With ~75-80 % VALU issue occupancy the four-call chain has little headroom over
+    # HBM and is the first kernel to show the clock ramp after a host-side pause -- rate() warms for 60 ms for that reason:
+    # docs/fused_chains.md, profiles/r04_chain_dvfs.log.)
     # Fused chains (modarith_amd/fuse.py): a sequence of field.c calls per element as ONE streaming kernel on
     # registers, against the same calls through the batched API, on the timed region's own operands.  z = ((a + b)(a - b))^2:
     # four calls, 440 B per element call by call, 120 B fused.  The chain's plug-in is built by __graft_entry__.build() and
