@@ -177,6 +177,20 @@ def test_scalar_multiplication_on_non_canonical_representatives(oracle, C, name,
     oracle.ecn(C, "batch_mul")(e.ctypes.data_as(ctypes.c_void_p), want.ctypes.data_as(ctypes.c_void_p), n, n)
     got = Ed.mul(torch.from_numpy(e).cuda(), P.clone()).cpu().numpy().view(np.uint64).reshape(3 * nl, n)
     assert np.array_equal(got, want)
+    # ... and through the fused kernels, which re-pack the limbs into 32-bit words (from51 / from56 + a weak carry): the bytes of
+    # get(mul(e, P)) -- the limbs of that product were just compared with the oracle's
+    et = torch.from_numpy(e).cuda()
+    ft = torch.from_numpy(f).cuda()
+    xw, yw, _ = Ed.get(Ed.mul(et, P.clone()))
+    xg, yg, _ = Ed.mul_get(et, P)
+    assert torch.equal(xg, xw) and torch.equal(yg, yw)
+    D = Ed.dbl(P.clone())
+    x2, y2, _ = Ed.get(Ed.mul2(et, P, ft, D))
+    xg, yg, _ = Ed.mul2_get(et, P, ft, D)
+    assert torch.equal(xg, x2) and torch.equal(yg, y2)
+    x3, y3, _ = Ed.get(Ed.mul2(et, Ed.gen(n), ft, P))
+    xg, yg, _ = Ed.mulgen2_get(et, ft, P)
+    assert torch.equal(xg, x3) and torch.equal(yg, y3)
     # the same points through add and dbl (element-wise kernels, limb form) and through the exact double multiplication
     Q = Ed.dbl(P.clone())
     R = Ed.mul2(torch.from_numpy(e).cuda(), P, torch.from_numpy(f).cuda(), Q, exact=True).cpu().numpy().view(np.uint64)
