@@ -879,7 +879,19 @@ struct Field {
                         constexpr int q = e / H, sh = e % H;                 // u << sh at half column 2(j+l) + q + (half index)
                         static_for<0, M>([&](auto JJ) {                       // JJ = index of the digit half
                             constexpr int jh = JJ;
-                            if constexpr (2 * l + q + jh == k && jh < k) { acc += (uint64_t)u[jh] << sh; pin(acc); }
+                            if constexpr (2 * l + q + jh == k && jh < k) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MA_MHALF_SHIFT_TERMS)
+                                // u * 2^sh as ONE multiply-add (5 issue cycles) instead of a 64-bit shift and a 64-bit add (two
+                                // 64-bit instructions, 9-10, and a register pair per shifted digit: the scalar multiplication over P-256
+                                // went from 242 to 150 VGPRs with this line): the power of two sits in an SGPR the compiler cannot see through
+                                uint32_t pw = 1u << sh;
+                                asm("" : "+s"(pw));
+                                acc += (uint64_t)u[jh] * pw;
+#else
+                                acc += (uint64_t)u[jh] << sh;
+#endif
+                                pin(acc);
+                            }
                         });
                     } else {
                         constexpr uint32_t dlo = (uint32_t)((unsigned long long)d & HM), dhi = (uint32_t)((unsigned long long)d >> H);

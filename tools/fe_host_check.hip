@@ -21,6 +21,7 @@
 #include "../modarith_amd/csrc/edwards.h"
 #include "../modarith_amd/csrc/weierstrass.h"
 #include "../modarith_amd/csrc/fh51.h"
+#include "../modarith_amd/csrc/fh56.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -627,6 +628,68 @@ static int run_fh51(int n) {
     return bad;
 }
 
+
+extern "C" void modmli_X448(const uint64_t*, int, uint64_t*);
+extern "C" void modone_X448(uint64_t*);
+// FieldH56<P_X448>: the resident half-limb form of the 8 x 56-bit Montgomery field against the oracle's limb functions
+static int run_fh56(int n) {
+    using Hf = ma::FieldH56<ma::P_X448>;
+    int bad = 0;
+    const uint64_t R = 56, Q = 1ull << R;
+    const uint64_t edge[] = {0, 1, Q - 1, Q, 2 * Q - 1, 4 * Q - 1, (1ull << 28) - 1, 1ull << 28, Q - 2, 2, 3, (1ull << 29) - 1, Q - 3};
+    for (int it = 0; it < n; it++) {
+        uint64_t a[8], b[8], c[8], got[8], want[8], t[8];
+        for (int i = 0; i < 8; i++) {
+            uint64_t r = sm();
+            a[i] = (r % 10 < 8 && it % 3) ? edge[r % 13] : (sm() & (4 * Q - 1));
+            r = sm();
+            b[i] = (r % 10 < 8 && it % 3 == 1) ? edge[r % 13] : (sm() & (4 * Q - 1));
+            c[i] = sm() & (Q - 1);
+        }
+        if (it == 0) for (int i = 0; i < 8; i++) a[i] = b[i] = 4 * Q - 1;
+        if (it == 1) for (int i = 0; i < 8; i++) { a[i] = 0; b[i] = 0; }
+        uint32_t ha[16], hb[16], hc[16], hr[16], hu[16];
+        Hf::from_limbs(a, ha); Hf::from_limbs(b, hb); Hf::from_limbs(c, hc);
+        Hf::to_limbs(ha, got);
+        int d = 0;                                                                // the resident form is the same element: same integer,
+        { unsigned __int128 cg = 0, ca = 0;                                      // and the same limbs when none exceeds 56 bits
+          bool same = true, tight = true;
+          for (int i = 0; i < 8; i++) {
+              cg += got[i]; ca += a[i];
+              if (i < 7) { same = same && (uint64_t)(cg & (Q - 1)) == (uint64_t)(ca & (Q - 1)); cg >>= 56; ca >>= 56; tight = tight && a[i] < Q; }
+          }
+          same = same && cg == ca;
+          d |= !same || (tight && memcmp(got, a, sizeof got) != 0); }
+        Hf::modmul(ha, hb, hr); Hf::to_limbs(hr, got); modmul_X448(a, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        Hf::modsqr(ha, hr); Hf::to_limbs(hr, got); modsqr_X448(a, want); d |= memcmp(got, want, sizeof got) != 0;
+        const int ml = 2 + (int)(sm() % 40000);
+        Hf::modmli(ha, ml, hr); Hf::to_limbs(hr, got); modmli_X448(a, ml, want); d |= memcmp(got, want, sizeof got) != 0;
+        Hf::modmli(ha, 39081, hr); Hf::to_limbs(hr, got); modmli_X448(a, 39081, want); d |= memcmp(got, want, sizeof got) != 0;
+        // the sums take field elements as the API defines them: any representative below 2p, limbs possibly over Radix bits -- lower
+        // limbs up to 2^58, top limb below 2^57 - 8
+        a[7] &= (2 * Q) - 9; b[7] &= (2 * Q) - 9;
+        Hf::from_limbs(a, ha); Hf::from_limbs(b, hb);
+        Hf::modadd(ha, hb, hr); Hf::to_limbs(hr, got); modadd_X448(a, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        Hf::modsub(ha, hb, hr); Hf::to_limbs(hr, got); modsub_X448(a, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        Hf::modneg(ha, hr); Hf::to_limbs(hr, got); modneg_X448(a, want); d |= memcmp(got, want, sizeof got) != 0;
+        // a product of sums, as the formulas chain them: (a + b)(a - b), squared, times 39081
+        Hf::modadd(ha, hb, hr); Hf::modsub(ha, hb, hu); Hf::modmul(hr, hu, hr); Hf::modsqr(hr, hr); Hf::modmli(hr, 39081, hr); Hf::to_limbs(hr, got);
+        modadd_X448(a, b, want); modsub_X448(a, b, t); modmul_X448(want, t, want); modsqr_X448(want, want); modmli_X448(want, 39081, want);
+        d |= memcmp(got, want, sizeof got) != 0;
+        // "_u" sums feeding sums: (a - b) - c, a - 2c, -a + b, -a - b, ((a + b) + c) - a
+        Hf::modsub_u(ha, hb, hu); Hf::modsub(hu, hc, hr); Hf::to_limbs(hr, got); modsub_X448(a, b, t); modsub_X448(t, c, want); d |= memcmp(got, want, sizeof got) != 0;
+        Hf::modadd_u(hc, hc, hu); Hf::modsub(ha, hu, hr); Hf::to_limbs(hr, got); modadd_X448(c, c, t); modsub_X448(a, t, want); d |= memcmp(got, want, sizeof got) != 0;
+        Hf::modneg_u(ha, hu); Hf::modadd(hu, hb, hr); Hf::to_limbs(hr, got); modneg_X448(a, t); modadd_X448(t, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        Hf::modsub(hu, hb, hr); Hf::to_limbs(hr, got); modsub_X448(t, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        Hf::modadd_u(ha, hb, hu); Hf::modadd_u(hu, hc, hu); Hf::modsub(hu, ha, hr); Hf::to_limbs(hr, got);
+        modadd_X448(a, b, t); modadd_X448(t, c, t); modsub_X448(t, a, want); d |= memcmp(got, want, sizeof got) != 0;
+        if (it == 2) { Hf::modone(hr); Hf::to_limbs(hr, got); modone_X448(want); d |= memcmp(got, want, sizeof got) != 0; }
+        if (d) { if (bad < 4) printf("FieldH56: record %d differs\n", it); bad++; }
+    }
+    printf("FieldH56<P_X448> resident half-limb field (mul sqr mli add sub neg, _u chains): %d records, %d differ from the oracle\n", n, bad);
+    return bad;
+}
+
 template <class P, int N, class ADD, class SUB, class NEG>
 static int run_u(const char* name, int n, int radix, ADD oadd, SUB osub, NEG oneg) {
     using F = ma::Field<P, true>;
@@ -738,12 +801,14 @@ int main(int argc, char** argv) {
     bad += run<7>("x448_fe28_one", n / 4 + 8, [](const uint64_t* k, const uint64_t* u, uint64_t* o) { ma::x448_fe28_one(k, u, o); }, rfc7748_X448);
     bad += run_fe28_sub_extremes(n * 50);
     bad += run_fh51(n * 50);
+    bad += run_fh56(n * 25);
     bad += run_u<ma::P_X25519, 5>("X25519", n * 25, 51, modadd_X25519, modsub_X25519, modneg_X25519);
     bad += run_u<ma::P_NIST256, 5>("NIST256", n * 25, 52, modadd_NIST256, modsub_NIST256, modneg_NIST256);
     bad += run_u<ma::P_X448, 8>("X448", n * 25, 56, modadd_X448, modsub_X448, modneg_X448);
     bad += run_formulas<ma::Edwards<ma::C_ED25519, ma::FieldH51<ma::P_X25519>>, pt25519, 5, 32>("Edwards<ED25519> on FieldH51", n / 8 + 24, ecn_ed25519_gen, ecn_ed25519_mul, ecn_ed25519_add, ecn_ed25519_dbl);
     bad += run_formulas<ma::Edwards<ma::C_ED25519>, pt25519, 5, 32>("Edwards<ED25519> on limbs", n / 8 + 24, ecn_ed25519_gen, ecn_ed25519_mul, ecn_ed25519_add, ecn_ed25519_dbl);
     bad += run_formulas<ma::Edwards<ma::C_ED448>, pt448, 8, 56>("Edwards<ED448>", n / 16 + 24, ecn_ed448_gen, ecn_ed448_mul, ecn_ed448_add, ecn_ed448_dbl);
+    bad += run_formulas<ma::Edwards<ma::C_ED448, ma::FieldH56<ma::P_X448>>, pt448, 8, 56>("Edwards<ED448> on FieldH56", n / 16 + 24, ecn_ed448_gen, ecn_ed448_mul, ecn_ed448_add, ecn_ed448_dbl);
     bad += run_formulas<ma::Weierstrass<ma::C_NIST256>, pt256, 5, 32>("Weierstrass<NIST256>", n / 8 + 24, ecn_nist256_gen, ecn_nist256_mul, ecn_nist256_add, ecn_nist256_dbl);
     bad += run_half(n * 50);
     bad += run_mhalf(n * 50);
