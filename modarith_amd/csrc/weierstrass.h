@@ -10,20 +10,21 @@
 
 namespace ma {
 
-template <class C>
-struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
-    using Base = CurveOps<Weierstrass<C>, typename C::FieldParams>;
+template <class C, class F_ = Field<typename C::FieldParams, true>>     // F_: the limb form, or a resident half-limb form (fh52.h) for the scalar multiplications
+struct Weierstrass : CurveOps<Weierstrass<C, F_>, typename C::FieldParams, F_> {
+    using Base = CurveOps<Weierstrass<C, F_>, typename C::FieldParams, F_>;
     using P = typename C::FieldParams;
-    using F = Field<P, true>;
+    using F = F_;
     using Point = typename Base::Point;
+    using limb_t = typename F::limb_t;
     using Base::cmv;
     using Base::cpy;
-    static constexpr int N = P::N;
+    static constexpr int N = P::N, NL = F::NL;
     static constexpr bool HAS_Y_ONLY_SET = false;   // weierstrass.c:417-428: x is mandatory
     static constexpr bool SELECT_FROM_NEUTRAL = (P::N < 9);    // curve.h select(): start the table scan from the neutral element
 
-    static MA_DEV void const_b(spint* b) { static_for<0, N>([&](auto I) { b[I] = C::b(I); }); }
-    static MA_DEV void const_b3(spint* b) { static_for<0, N>([&](auto I) { b[I] = C::b3(I); }); }
+    static MA_DEV void const_b(limb_t* b) { spint l[N]; static_for<0, N>([&](auto I) { l[I] = C::b(I); }); F::from_limbs(l, b); }
+    static MA_DEV void const_b3(limb_t* b) { spint l[N]; static_for<0, N>([&](auto I) { l[I] = C::b3(I); }); F::from_limbs(l, b); }
 
     static MA_DEV void neg(Point& p) { F::modneg(p.y, p.y); }                          // weierstrass.c:61-64
     static MA_DEV void inf(Point& p) { F::modzer(p.x); F::modone(p.y); F::modzer(p.z); }  // weierstrass.c:284-289
@@ -32,7 +33,7 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
 
     // P += Q, complete (weierstrass.c:68-175)
     static MA_DEV void add(const Point& q, Point& p) {
-        spint B[N], T0[N], T1[N], T2[N], T3[N], T4[N];
+        limb_t B[NL], T0[NL], T1[NL], T2[NL], T3[NL], T4[NL];
         F::modmul(p.x, q.x, T0);
         F::modmul(p.y, q.y, T1);
         F::modmul(p.z, q.z, T2);
@@ -119,7 +120,7 @@ struct Weierstrass : CurveOps<Weierstrass<C>, typename C::FieldParams> {
 
     // P = 2P, complete (weierstrass.c:187-281)
     static MA_DEV void dbl(Point& p) {
-        spint B[N], T0[N], T1[N], T2[N], T3[N], T4[N];
+        limb_t B[NL], T0[NL], T1[NL], T2[NL], T3[NL], T4[NL];
         if constexpr (C::A == 0) {
             F::modsqr(p.y, T0);
             F::modadd(T0, T0, T3);

@@ -690,6 +690,7 @@ static int run_fh56(int n) {
     return bad;
 }
 
+
 template <class P, int N, class ADD, class SUB, class NEG>
 static int run_u(const char* name, int n, int radix, ADD oadd, SUB osub, NEG oneg) {
     using F = ma::Field<P, true>;
