@@ -682,7 +682,16 @@ struct Field {
             uint64_t acc = column(KK, cy, std::false_type{}, std::false_type{});
             acc += (uint64_t)d[k] * MLO;
             pin(acc);
-            if constexpr (k > 0 && MHI) { acc += (uint64_t)d[k - 1] << 10; pin(acc); }
+            if constexpr (k > 0 && MHI) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MA_MHALF_SHIFT_TERMS)
+                uint32_t p10 = 1u << 10;                     // (one multiply-add instead of a 64-bit shift and a 64-bit add: see monty_mul_half)
+                asm("" : "+s"(p10));
+                acc += (uint64_t)d[k - 1] * p10;
+#else
+                acc += (uint64_t)d[k - 1] << 10;
+#endif
+                pin(acc);
+            }
             u[k] = (uint32_t)acc & HM;
             cy = acc >> H;
         });
