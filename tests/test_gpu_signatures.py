@@ -318,3 +318,17 @@ def test_example_program_prints_the_reference_transcript():
     out = p.stdout
     assert out.count("Signature is valid") == 2 and "NOT valid" not in out
     assert RFC8032_ED448[1][1] in out and RFC8032_ED448[1][3] in out
+
+
+def test_c_example_ecdsa_verify_batch(tmp_path):
+    """examples/ecdsa_verify_batch.c: NIST256_VERIFY (nist256.c:226-260) for n signatures through the plain C-ABI -- the FIPS 186
+    vector in every fourth lane, the reference's three rejections (other message, s = 0, r out of range) in the others"""
+    import subprocess
+    exe = str(tmp_path / "ecdsa_verify_batch")
+    subprocess.check_call(["gcc", "-O2", os.path.join(ROOT, "examples", "ecdsa_verify_batch.c"), "-I", os.path.join(ROOT, "include"),
+                           "-L", os.path.join(ROOT, "modarith_amd"), "-l:libmodarith_amd.so", "-Wl,-rpath," + os.path.join(ROOT, "modarith_amd"), "-o", exe])
+    for n in (4096, 10000, 7):
+        p = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        out = p.stdout.splitlines()
+        assert out[-2] == "%d signatures, %d valid, %d verdicts as expected" % (n, (n + 3) // 4, n) and out[-1].endswith("as the reference decides")
