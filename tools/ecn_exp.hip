@@ -16,6 +16,9 @@
 #ifdef USE_FH51
 #include "fh51.h"
 #endif
+#ifdef USE_FH56
+#include "fh56.h"
+#endif
 
 using namespace ma;
 using E = CURVE_CLASS;
