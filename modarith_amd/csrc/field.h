@@ -450,6 +450,93 @@ struct Field {
         pm_second_pass(t, v, c);
     }
 
+    // ---------------------------------------------------------------- four-accumulator split (EPM primes without a provable SPLIT)
+    // 2^521 - 1 in nine 58-bit limbs has no three-accumulator split: with limbs below 2^60 and the premultiplied operand mm * a
+    // one bit wider, eighteen cross products of 2^60 pass 2^64 by a sixth of a bit (emit.split_point), and the exact rows --
+    // 128-bit sums through the carry-out of v_mad_u64_u32 -- compile into twice as many moves, carry adds and hazard nops as
+    // multiply-adds (round 4: 19 % of k_ed_mul<NIST521> were multiplier instructions).  Two changes make the split fit: the cross
+    // products lo x hi and hi x lo go to separate accumulators (nine terms of 2^60 each: below 2^63.2), and the factor mm is applied
+    // to the folded SUM instead of to every operand (mm * sum(a_k b_l) is the integer sum(mm a_k * b_l)).  Same column integers as
+    // pm_modmul / pm_modsqr, hence the same limbs.  Cut at H4 = (Radix + 2) / 2: both halves below 2^H4.
+    static constexpr int H4 = (RADIX + 2) / 2;
+    static constexpr bool SPLIT4 = FAST_ && !FAST && !P::MONTGOMERY && P::EPM && !P::OVERFLOW && !P::BAD_OVERFLOW && (RADIX + 2) % 2 == 0 && H4 <= 31 &&
+                                   ((unsigned long long)N << (2 * H4 - 32)) < (1ull << 32) && P::MM <= 16;
+    struct Col4 {
+        uint64_t s0 = 0, s1a = 0, s1b = 0, s2 = 0;
+        MA_DEV void mac(uint32_t al, uint32_t ah, uint32_t bl, uint32_t bh) {
+            s0 += (uint64_t)al * bl;
+            s1a += (uint64_t)al * bh;
+            s1b += (uint64_t)ah * bl;
+            s2 += (uint64_t)ah * bh;
+        }
+        MA_DEV dpint sum() const { return (dpint)s0 + (((dpint)s1a + (dpint)s1b) << H4) + ((dpint)s2 << (2 * H4)); }
+    };
+    static MA_DEV void split4(const spint* a, uint32_t* lo, uint32_t* hi) {
+        static_for<0, N>([&](auto I) {
+            lo[I] = (uint32_t)a[I] & ((1u << H4) - 1u);
+            hi[I] = (uint32_t)(a[I] >> H4);
+        });
+    }
+    static MA_DEV void pm_modmul_split4(const spint* a, const spint* b, spint* c) {
+        uint32_t al[N], ah[N], bl[N], bh[N];
+        split4(a, al, ah);
+        split4(b, bl, bh);
+        dpint t = 0;
+        spint v[N];
+        static_for<0, N>([&](auto ROW) {
+            constexpr int row = ROW;
+            Col4 hi, lo;
+            static_for<row + 1, N>([&](auto K) {
+                constexpr int k = K;
+                hi.mac(al[k], ah[k], bl[N + row - k], bh[N + row - k]);
+            });
+            static_for<0, row + 1>([&](auto K) {
+                constexpr int k = K;
+                lo.mac(al[k], ah[k], bl[row - k], bh[row - k]);
+            });
+            if constexpr (row < N - 1) t += hi.sum() * (dpint)P::MM;
+            t += lo.sum();
+            v[row] = (spint)t & MASK;
+            t >>= RADIX;
+        });
+        pm_second_pass(t, v, c);
+    }
+    static MA_DEV void pm_modsqr_split4(const spint* a, spint* c) {
+        uint32_t al[N], ah[N];
+        split4(a, al, ah);
+        dpint t = 0;
+        spint v[N];
+        static_for<0, N>([&](auto ROW) {
+            constexpr int row = ROW;
+            // folded (high) part: pairs (k, l), k + l = N + row, row < k <= l < N;  low part: pairs with k + l = row
+            constexpr int hk0 = row + 1, hpairs = (N - 1 - hk0 + 1) / 2, lpairs = (row + 1) / 2;
+            Col4 hcross, lcross, hsq, lsq;
+            static_for<0, hpairs>([&](auto J) {
+                constexpr int k = hk0 + J, l = N - 1 - J;
+                hcross.mac(al[k], ah[k], al[l], ah[l]);
+            });
+            static_for<0, lpairs>([&](auto J) {
+                constexpr int k = J, l = row - J;
+                lcross.mac(al[k], ah[k], al[l], ah[l]);
+            });
+            dpint h = hcross.sum() * 2, l = lcross.sum() * 2;
+            if constexpr ((N - hk0) % 2 == 1) {
+                constexpr int k = hk0 + hpairs;
+                hsq.mac(al[k], ah[k], al[k], ah[k]);
+                h += hsq.sum();
+            }
+            if constexpr (row % 2 == 0) {
+                lsq.mac(al[row / 2], ah[row / 2], al[row / 2], ah[row / 2]);
+                l += lsq.sum();
+            }
+            if constexpr (row < N - 1) t += h * (dpint)P::MM;
+            t += l;
+            v[row] = (spint)t & MASK;
+            t >>= RADIX;
+        });
+        pm_second_pass(t, v, c);
+    }
+
     // the same rows on the 64-bit column chain (EPM primes; see Wide::Acc)
     static MA_DEV void pm_modmul_chain(const spint* a, const spint* b, spint* c) {
         static_assert(P::EPM && !P::OVERFLOW, "chained products are built for the EPM form only");
@@ -1162,6 +1249,7 @@ struct Field {
             if constexpr (HALF_OV) pm_mul_half_ov<false>(a, b, c);
             else if constexpr (HALF) pm_modmul_half(a, b, c);
             else if constexpr (CHAINED) pm_modmul_chain(a, b, c);
+            else if constexpr (SPLIT4) pm_modmul_split4(a, b, c);
             else pm_modmul(a, b, c);
         }
     }
@@ -1175,6 +1263,7 @@ struct Field {
             if constexpr (HALF_OV) pm_mul_half_ov<true>(a, a, c);
             else if constexpr (HALF) pm_modsqr_half(a, c);
             else if constexpr (CHAINED) pm_modsqr_chain(a, c);
+            else if constexpr (SPLIT4) pm_modsqr_split4(a, c);
             else pm_modsqr(a, c);
         }
     }

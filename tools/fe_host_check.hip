@@ -11,6 +11,7 @@
 #include "../modarith_amd/csrc/generated/params_X448.h"
 #include "../modarith_amd/csrc/generated/params_SECP256K1.h"
 #include "../modarith_amd/csrc/generated/params_NUMS256W.h"
+#include "../modarith_amd/csrc/generated/params_NIST521.h"
 #include "../modarith_amd/csrc/ed26.h"
 #include "../modarith_amd/csrc/ed28.h"
 #include "../modarith_amd/csrc/generated/curve_NIST256.h"
@@ -276,6 +277,35 @@ static int run_half_ov(int n) {
         if (d) { if (bad < 4) printf("SECP256K1 half-limb: record %d differs\n", it); bad++; }
     }
     printf("Field<P_SECP256K1,true> half-limb modmul/modsqr: %d records, %d differ from the exact products\n", n, bad);
+    return bad;
+}
+
+// Field<P_NIST521, true>: the four-accumulator split products (csrc/field.h pm_modmul_split4) against the exact 128-bit rows of the
+// same header (which tests/test_gpu_parity.py pins to the oracle; its NIST521 functions are bound to their parameter block at run
+// time by tests/oracle_binding.py, which a C main cannot do), limbs up to the contract's edge 2^60 - 1
+static int run_split4(int n) {
+    using F = ma::Field<ma::P_NIST521, true>;
+    using X = ma::Field<ma::P_NIST521, false>;
+    static_assert(F::SPLIT4 && !X::SPLIT4, "the four-accumulator split is expected for NIST521");
+    int bad = 0;
+    const uint64_t Q = 1ull << 58;
+    const uint64_t edge[] = {0, 1, Q - 1, Q, 2 * Q - 1, 4 * Q - 1, (1ull << 30) - 1, 1ull << 30, 4 * Q - (1ull << 30)};
+    for (int it = 0; it < n; it++) {
+        uint64_t a[9], b[9], got[9], want[9];
+        for (int i = 0; i < 9; i++) {
+            uint64_t r = sm();
+            a[i] = (r % 10 < 9 && it % 3) ? edge[r % 9] : (sm() & (4 * Q - 1));
+            r = sm();
+            b[i] = (r % 10 < 9 && it % 3 == 1) ? edge[r % 9] : (sm() & (4 * Q - 1));
+        }
+        if (it == 0) for (int i = 0; i < 9; i++) a[i] = b[i] = 4 * Q - 1;
+        int d = 0;
+        F::modmul(a, b, got); X::modmul(a, b, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::modsqr(a, got); X::modsqr(a, want); d |= memcmp(got, want, sizeof got) != 0;
+        F::modmul(a, b, a); d |= memcmp(a, want, 0) != 0;               // (aliasing compiles and runs)
+        if (d) { if (bad < 4) printf("NIST521 split4: record %d differs\n", it); bad++; }
+    }
+    printf("Field<P_NIST521,true> four-accumulator split modmul/modsqr: %d records, %d differ from the exact products\n", n, bad);
     return bad;
 }
 
@@ -812,6 +842,7 @@ int main(int argc, char** argv) {
     bad += run_formulas<ma::Edwards<ma::C_ED448, ma::FieldH56<ma::P_X448>>, pt448, 8, 56>("Edwards<ED448> on FieldH56", n / 16 + 24, ecn_ed448_gen, ecn_ed448_mul, ecn_ed448_add, ecn_ed448_dbl);
     bad += run_formulas<ma::Weierstrass<ma::C_NIST256>, pt256, 5, 32>("Weierstrass<NIST256>", n / 8 + 24, ecn_nist256_gen, ecn_nist256_mul, ecn_nist256_add, ecn_nist256_dbl);
     bad += run_half(n * 50);
+    bad += run_split4(n * 10);
     bad += run_mhalf(n * 50);
     bad += run_mhalf448(n * 25);
     bad += run_half_ov(n * 50);
