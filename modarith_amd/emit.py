@@ -261,14 +261,33 @@ def split_point(fp: FieldParams) -> int:
     else:
         wa, wb, n = W, W, 2 * fp.nlimbs
     lim = 1 << 64
-    best, best_cost = 0, None
-    for H in range(20, 33):
-        if wa - H > 32 or wb - H > 32:
-            continue
-        s0, s1, s2 = n << (2 * H), n * ((1 << wa) + (1 << wb)), n << max(wa + wb - 2 * H, 0)
-        if s0 < lim and s1 < lim and s2 < lim and (best_cost is None or max(s0, s2) < best_cost):
-            best, best_cost = H, max(s0, s2)
+
+    def cut(n):
+        best, best_cost = 0, None
+        for H in range(20, 33):
+            if wa - H > 32 or wb - H > 32:
+                continue
+            s0, s1, s2 = n << (2 * H), n * ((1 << wa) + (1 << wb)), n << max(wa + wb - 2 * H, 0)
+            if s0 < lim and s1 < lim and s2 < lim and (best_cost is None or max(s0, s2) < best_cost):
+                best, best_cost = H, max(s0, s2)
+        return best
+
+    best = cut(n)
+    if best == 0 and fp.family != "pseudo" and not sparse_terms(fp) is None:
+        # a sparse prime: a column holds the N products and ONE multiply-accumulate per non-zero prime limb above the low one
+        # (field.h monty_reduce: limbs 0, +-1 and powers of two never enter the accumulators), not N of them -- ED500 = 9 x 57 bits
+        # with a single such limb: ten terms of 2^59 x 2^59 instead of eighteen (round 4)
+        best = cut(sparse_terms(fp))
     return best
+
+
+def sparse_terms(fp: FieldParams):
+    """products + accumulator-borne reduction terms of one column for a Montgomery prime with ndash == 1 and few non-zero limbs
+    (+ 1 for the doubled cross terms of the squarings' odd term count), or None where the dense count 2N has to stand"""
+    if fp.family == "pseudo" or fp.pm or fp.ndash != 1:
+        return None
+    k = sum(1 for i, v in enumerate(fp.ppw) if i > 0 and v not in (0, 1, -1) and (v & (v - 1)) != 0)
+    return fp.nlimbs + k + 1
 
 
 def chain_ok(fp: FieldParams) -> bool:
@@ -283,6 +302,8 @@ def chain_ok(fp: FieldParams) -> bool:
     R, N, W = fp.radix, fp.nlimbs, fp.radix + 2
     if H == 0 or R - H > 32 or 2 * H < R or 2 * H >= 64:
         return False
+    if fp.family != "pseudo" and (2 * N) * ((1 << W) + (1 << W)) >= 1 << 64:
+        return False            # SPLIT came from the sparse count (split_point): the chain's bounds below assume the dense one
     if fp.family == "pseudo":
         if not fp.epm or fp.overflow:
             return False
