@@ -83,3 +83,26 @@ def test_limb_split_roundtrip():
         fp = derive(P)
         for x in (0, 1, fp.p - 1, fp.p, 2 * fp.p - 1):
             assert fp.from_limbs(fp.to_limbs(x)) == x
+
+
+def test_split_proofs_per_prime():
+    """emit.split_point / chain_ok: the three-accumulator cut positions the kernels were tuned with stay what they were, and the two
+    primes that had no provable cut under the dense count of 2N column terms (ED500, SIDH503: Montgomery primes with ndash = 1 whose
+    limbs are mostly 0 / -1 / powers of two, which never enter the accumulators -- field.h monty_reduce) get one from the per-prime
+    count (emit.sparse_terms); a bound check of that count against the worst column redone here"""
+    from modarith_amd import emit
+    from modarith_amd.params import derive
+    want = {"X25519": (28, True), "NIST256": (27, True), "X448": (29, True), "NIST384": (29, True), "SECP256K1": (27, False), "ED248": (26, True),
+            "ED376": (28, True), "NIST521": (0, False), "ED500": (29, False), "SIDH503": (29, False), "SIDH751": (0, False), "CSIDH512": (0, False)}
+    for name, (h, chain) in want.items():
+        fp = derive(name)
+        assert (emit.split_point(fp), emit.chain_ok(fp)) == (h, chain), name
+    for name in ("ED500", "SIDH503"):
+        fp = derive(name)
+        n, H, W = emit.sparse_terms(fp), emit.split_point(fp), fp.radix + 2
+        big = [v for i, v in enumerate(fp.ppw) if i > 0 and v not in (0, 1, -1) and v & (v - 1)]
+        assert n == fp.nlimbs + len(big) + 1 and 2 * fp.nlimbs > n            # sparse indeed: fewer terms than the dense count
+        lo, hi = (1 << H) - 1, (1 << (W - H)) - 1                              # halves of a limb below 2^W
+        assert n * lo * lo < 1 << 64 and n * 2 * lo * hi < 1 << 64 and n * hi * hi < 1 << 64
+        assert all(0 < v < 1 << fp.radix for v in big)                         # the prime limbs themselves are narrower than a limb
+    assert emit.sparse_terms(derive("NIST384")) is None                        # ndash != 1: the dense count stands
