@@ -2,11 +2,13 @@
 // (csrc/ed26.h ed25519_mulgen_get_one), the call sequence ecnXXXgen + ecnXXXmul + ecnXXXget that opens EdDSA key generation
 // and signing in the reference (ed448.c:167-184, 196-199).  Fixed-base table: generated/comb_ED25519.h.
 #include "../../include/modarith_amd.h"
+#include <string.h>
 #include "capi_common.h"
 #include "generated/curve_ED25519.h"
 #include "generated/comb_ED25519.h"
 #include "kernels.h"
 #include "ed26.h"
+#include "ed26l_k.h"
 
 namespace ma {
 
@@ -95,18 +97,70 @@ void k_ed25519_mulgen2_get(const unsigned char* e, const unsigned char* f, const
     }
 }
 
+// round 5, the ladder form (csrc/ed26l.h): f*Q by the Montgomery ladder with the recovered Edwards point in extended coordinates,
+// e*G added through the constant table; the inversions in front and behind are shared (ed26l_k.h)
+// 163 VGPRs, no scratch: three waves per SIMD (a 128-register build for four waves measured the same rate, 1.128e8 mul_get/s, and
+// spilled 39 registers in the recovery; two waves -- enforced from outside through an LDS claim -- lost 12 %: profiles/r05_lad_ab.log)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_ed25519_lad_gen2(const unsigned char* e, const unsigned char* f, size_t first, Ed26lWs ws) {
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= ws.m) return;
+    using L = Ed26Lad<C_ED25519>;
+    uint32_t u[10], w[10], x2[10], z2[10], x3[10], z3[10];
+    bool f_odd;
+    {
+        spint fw[4];
+        load_be_record<P_X25519>(f, first + t, fw);
+        f_odd = (fw[0] & 1) != 0;
+        ed26l_load_u(ws, t, u);
+        L::ladder(fw, u, x2, z2, x3, z3);
+    }
+    ed26l_load_u(ws, t, u);
+    const uint32_t fl = ed26l_load_w(ws, t, w);
+    Ed26<C_ED25519>::Ext R;
+    L::recover<true>(u, w, fl, f_odd, x2, z2, x3, z3, R);
+    spint ew[4];
+    load_be_record<P_X25519>(e, first + t, ew);
+    ed25519_mulgen_acc<C_ED25519, CombED25519, false>(ew, R);
+    ed26l_store_xyz(ws, t, R.X, R.Y, R.Z);
+}
+
 }  // namespace ma
 
 using namespace ma;
 
-extern "C" size_t ecn_ed25519_mulgen2_get_workspace_bytes(size_t) { return 0; }
+static bool ed25519_fused_window() {        // MA_ED25519_FUSED=window: the round-2..4 kernel for every batch (capi_ED25519F.hip)
+    static bool v = [] { const char* s = getenv("MA_ED25519_FUSED"); return s && strcmp(s, "window") == 0; }();
+    return v;
+}
+constexpr size_t ED25519_LAD_MIN = 4096;
+
+extern "C" size_t ecn_ed25519_mulgen2_get_workspace_bytes(size_t n) { return n >= ED25519_LAD_MIN ? ed26l_workspace_bytes(n) : 0; }
 
 extern "C" int ecn_ed25519_mulgen2_get_batch(const char* e, const char* f, const ma_spint* Q, char* x, char* y, int* sign, size_t n, size_t ld,
-                                             void*, size_t, void* st) {
+                                             void* workspace, size_t workspace_bytes, void* st) {
     if (n == 0) return 0;
     if ((reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 7u) {
         set_error("ecn mulgen2_get: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
+    }
+    hipStream_t s = (hipStream_t)st;
+    if (n >= ED25519_LAD_MIN && !ed25519_fused_window()) {       // the ladder form; workspace rules as for mul_get (capi_ED25519F.hip)
+        const size_t need = ed26l_workspace_bytes(n);
+        void* ws = (workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 7u) == 0) ? workspace : nullptr;
+        void* own = nullptr;
+        if (!ws) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (s == nullptr || (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)) ws = own = scratch_alloc(need, s);
+            else (void)hipGetLastError();
+        }
+        if (ws) {
+            const unsigned char *eb = reinterpret_cast<const unsigned char*>(e), *fb = reinterpret_cast<const unsigned char*>(f);
+            ed26l_pipeline<C_ED25519, 2>(Q, ld, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n, ws, s,
+                                         [&](size_t first, size_t m, const Ed26lWs& w) { k_ed25519_lad_gen2<<<(unsigned)((m + 63) / 64), 64, 0, s>>>(eb, fb, first, w); });
+            if (own) scratch_free(own, s);
+            return check_launch("ecn mulgen2_get (ladder form)");
+        }
     }
     const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
     k_ed25519_mulgen2_get<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(

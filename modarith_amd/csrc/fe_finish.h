@@ -74,4 +74,70 @@ __global__ __launch_bounds__(256) void k_fe_finish(uint64_t* bv, const uint64_t*
     if (j < L) FeFinish<F, NL, NW>::run(bv, wz, wc, n, L, rounds, j);
 }
 
+// ---- round 5: the same trick with TWO numerators per denominator, for the ladder form of the fused Edwards multiplications
+// (ed26l.h: u = nu / D and w = nw / D in front of the ladder, x = X / Z and y = Y / Z behind it).  A, B, C: canonical words,
+// word-major [NW][n] (every access of a wave is one coalesced row).  B[e] <- B[e] / A[e], C[e] <- C[e] / A[e] handed to a SINK:
+//   sink(e, bw, cw)                 bw, cw = the canonical quotients (zero where A[e] was zero)
+template <class F, int NL, int NW>
+struct FeBatchDiv {
+    using Z = FeFinish<F, NL, NW>;
+    template <class SINK>
+    static MA_DEV void run(const uint64_t* A, const uint64_t* B, const uint64_t* Cn, uint32_t* wc, size_t n, size_t L, int rounds, size_t j, SINK& sink) {
+        uint32_t c[NL], z[NL];
+        F::set(1, c);
+#pragma unroll 1
+        for (int r = 0; r < rounds; r++) {
+            const size_t e = (size_t)r * L + j;
+            const bool valid = e < n;
+            (void)Z::load_z(A, n, e, valid, z);
+            F::mul(c, z, c);
+            if (valid) static_for<0, NL>([&](auto I) { wc[(size_t)I * n + e] = c[I]; });
+        }
+        uint32_t inv[NL];
+        F::invert(c, inv);
+#pragma unroll 1
+        for (int r = rounds - 1; r >= 0; r--) {
+            const size_t e = (size_t)r * L + j;
+            if (e >= n) continue;                                   // (its denominator counted as 1: nothing to undo)
+            uint32_t zinv[NL], x[NL];
+            const uint64_t keep = lane_mask(!Z::load_z(A, n, e, true, z));
+            if (r > 0) {
+                uint32_t cp[NL];
+                const size_t e1 = e - L;
+                static_for<0, NL>([&](auto I) { cp[I] = wc[(size_t)I * n + e1]; });
+                F::mul(inv, cp, zinv);
+                F::mul(inv, z, inv);
+            } else {
+                F::copy(inv, zinv);
+            }
+            uint64_t xw[NW], bw[NW], cw[NW];
+            static_for<0, NW>([&](auto K) { xw[K] = B[(size_t)K * n + e]; });
+            F::from_words(xw, x);
+            F::mul(x, zinv, x);
+            F::to_words(x, bw);
+            static_for<0, NW>([&](auto K) { xw[K] = Cn[(size_t)K * n + e]; });
+            F::from_words(xw, x);
+            F::mul(x, zinv, x);
+            F::to_words(x, cw);
+            static_for<0, NW>([&](auto K) { bw[K] &= keep; cw[K] &= keep; });
+            sink(e, bw, cw);
+        }
+    }
+};
+// TAG keeps the instantiations of different translation units apart (one code object each)
+template <class F, int NL, int NW, class SINK, int TAG>
+__global__ __launch_bounds__(64) void k_fe_batch_div(const uint64_t* A, const uint64_t* B, const uint64_t* Cn, uint32_t* wc, size_t n, size_t L, int rounds, SINK sink) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < L) FeBatchDiv<F, NL, NW>::run(A, B, Cn, wc, n, L, rounds, j, sink);
+}
+// the quotients back into their own arrays as canonical words
+template <int NW>
+struct SinkWords {
+    uint64_t *B, *Cn;
+    size_t n;
+    MA_DEV void operator()(size_t e, uint64_t* bw, uint64_t* cw) const {
+        static_for<0, NW>([&](auto K) { B[(size_t)K * n + e] = bw[K]; Cn[(size_t)K * n + e] = cw[K]; });
+    }
+};
+
 }  // namespace ma

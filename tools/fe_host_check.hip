@@ -13,6 +13,7 @@
 #include "../modarith_amd/csrc/generated/params_NUMS256W.h"
 #include "../modarith_amd/csrc/generated/params_NIST521.h"
 #include "../modarith_amd/csrc/ed26.h"
+#include "../modarith_amd/csrc/ed26l.h"
 #include "../modarith_amd/csrc/ed28.h"
 #include "../modarith_amd/csrc/generated/curve_NIST256.h"
 #include "../modarith_amd/csrc/wn26.h"
@@ -565,6 +566,158 @@ static int run_ed25519_mulgen2(int n) {
     return bad;
 }
 
+
+// ---- round 5: the ladder form of the fused ED25519 multiplications (csrc/ed26l.h) against the oracle's ecn mul (+ mul2) + get.
+// The window form's complete formulas have no exceptional pair (P, e); the ladder + recovery has four classes of them
+// (P in {O, T2}; [e]P in {O, T2}; [e]P = -P), so the records are built to hit every class: P = [k]G + S for every S of the
+// 8-torsion subgroup (orders 1, 2, 4, 4, 8, 8, 8, 8 -- and the torsion points themselves, k = 0), e = j q - 1, j q, j q + 1
+// for j = 0 .. 8 (q the prime group order: [j q]P runs through the torsion part of P), 0, 1, 2, 2^256 - 1, random.
+extern "C" void ecn_ed25519_add(pt25519*, pt25519*);
+extern "C" int ecn_ed25519_isinf(const pt25519*);
+static const unsigned char ED25519_Q[32] = {0x10,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0x14,0xde,0xf9,0xde,0xa2,0xf7,0x9c,0xd6,0x58,0x12,0x63,0x1a,0x5c,0xf5,0xd3,0xed};
+static void ed25519_jq(int j, int delta, unsigned char* e) {      // e = j q + delta (big-endian, mod 2^256), delta in {-1, 0, 1}
+    unsigned __int128 acc = 0;
+    uint64_t w[4], qw[4];
+    for (int k = 0; k < 4; k++) { uint64_t v = 0; for (int b = 0; b < 8; b++) v |= (uint64_t)ED25519_Q[31 - (8 * k + b)] << (8 * b); qw[k] = v; }
+    for (int k = 0; k < 4; k++) { acc += (unsigned __int128)qw[k] * (unsigned)j; w[k] = (uint64_t)acc; acc >>= 64; }
+    if (delta > 0) { for (int k = 0; k < 4 && ++w[k] == 0; k++) {} }
+    if (delta < 0) { for (int k = 0; k < 4 && w[k]-- == 0; k++) {} }
+    for (int i = 0; i < 32; i++) e[31 - i] = (unsigned char)(w[i / 8] >> (8 * (i % 8)));
+}
+static bool ed25519_torsion8(pt25519* T8) {                       // a point of order 8: [q] of a decompressed point, until 4 T != O
+    for (int y0 = 2; y0 < 200; y0++) {
+        char y[32];
+        memset(y, 0, 32);
+        y[31] = (char)y0;
+        pt25519 P;
+        ecn_ed25519_set(0, nullptr, y, &P);
+        if (ecn_ed25519_isinf(&P)) continue;                      // not a y-coordinate of the curve
+        ecn_ed25519_mul((const char*)ED25519_Q, &P);
+        pt25519 D = P;
+        ecn_ed25519_dbl(&D); ecn_ed25519_dbl(&D);
+        if (!ecn_ed25519_isinf(&D)) { *T8 = P; return true; }
+    }
+    return false;
+}
+template <class FUSED>
+static int run_ed25519_lad(const char* name, int n, FUSED fused) {
+    int bad = 0, it = 0;
+    pt25519 T8;
+    if (!ed25519_torsion8(&T8)) { printf("%s: no point of order 8 found\n", name); return 1; }
+    pt25519 S[8];
+    ecn_ed25519_inf(&S[0]);
+    for (int j = 1; j < 8; j++) { S[j] = S[j - 1]; ecn_ed25519_add(&T8, &S[j]); }
+    auto one = [&](const pt25519& P0, const unsigned char* e) {
+        pt25519 P = P0, Q = P0;
+        uint64_t ew[4], xw[4], yw[4];
+        for (int w = 0; w < 4; w++) { uint64_t v = 0; for (int b = 0; b < 8; b++) v |= (uint64_t)e[31 - (8 * w + b)] << (8 * b); ew[w] = v; }
+        fused(ew, P.x, P.y, P.z, xw, yw);
+        char wx[32], wy[32];
+        ecn_ed25519_mul((const char*)e, &Q);
+        ecn_ed25519_get(&Q, wx, wy);
+        unsigned char gx[32], gy[32];
+        for (int i = 0; i < 32; i++) { gx[i] = (unsigned char)(xw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); gy[i] = (unsigned char)(yw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); }
+        if (memcmp(gx, wx, 32) != 0 || memcmp(gy, wy, 32) != 0) { if (bad < 8) printf("%s: record %d differs\n", name, it); bad++; }
+        it++;
+    };
+    for (int tors = 0; tors < 8; tors++) {
+        for (int base = 0; base < 3; base++) {                    // S alone; [k]G + S projective; the same made affine (Z = 1)
+            pt25519 P = S[tors];
+            if (base) {
+                unsigned char k[32];
+                for (int i = 0; i < 32; i++) k[i] = (unsigned char)sm();
+                pt25519 B;
+                ecn_ed25519_gen(&B);
+                ecn_ed25519_mul((const char*)k, &B);
+                ecn_ed25519_add(&B, &P);
+                if (base == 2) { char x[32], y[32]; ecn_ed25519_get(&P, x, y); ecn_ed25519_set(0, x, y, &P); }
+            }
+            unsigned char e[32];
+            for (int j = 0; j <= 8; j++) for (int dl = -1; dl <= 1; dl++) { ed25519_jq(j, dl, e); one(P, e); }
+            memset(e, 0, 32); e[31] = 2; one(P, e);
+            memset(e, 0xff, 32); one(P, e);
+            memset(e, 0, 32); e[0] = 0x80; one(P, e);
+            for (int r = 0; r < 2; r++) { for (int i = 0; i < 32; i++) e[i] = (unsigned char)sm(); one(P, e); }
+        }
+    }
+    for (int r = 0; r < n; r++) {                                 // random projective points (not normalised), random scalars
+        unsigned char e[32], k[32];
+        for (int i = 0; i < 32; i++) { e[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
+        pt25519 P;
+        ecn_ed25519_gen(&P);
+        ecn_ed25519_mul((const char*)k, &P);
+        if (r % 16 == 4) ecn_ed25519_gen(&P);
+        one(P, e);
+    }
+    printf("%s: %d records, %d differ from the oracle's ecn mul + get\n", name, it, bad);
+    return bad;
+}
+
+
+// e*G + f*Q in the ladder form (Ed26Lad::mulgen2_get_one) against the oracle's gen, mul2, get: Q and f through the exceptional classes of
+// run_ed25519_lad (f*Q by ladder + recovery), e random / 0 / -f-ish corner values (the fixed-base part adds with complete formulas)
+static int run_ed25519_mulgen2_lad(int n) {
+    int bad = 0, it = 0;
+    pt25519 T8;
+    if (!ed25519_torsion8(&T8)) { printf("Ed26Lad::mulgen2_get_one: no point of order 8 found\n"); return 1; }
+    pt25519 S[8];
+    ecn_ed25519_inf(&S[0]);
+    for (int j = 1; j < 8; j++) { S[j] = S[j - 1]; ecn_ed25519_add(&T8, &S[j]); }
+    auto one = [&](const pt25519& Q0, const unsigned char* e, const unsigned char* f) {
+        pt25519 G, Q = Q0, Qc = Q0, R;
+        ecn_ed25519_gen(&G);
+        uint64_t ew[4], fw[4], xw[4], yw[4];
+        for (int w = 0; w < 4; w++) { uint64_t v = 0, u = 0; for (int b = 0; b < 8; b++) { v |= (uint64_t)e[31 - (8 * w + b)] << (8 * b); u |= (uint64_t)f[31 - (8 * w + b)] << (8 * b); } ew[w] = v; fw[w] = u; }
+        ma::Ed26Lad<ma::C_ED25519>::mulgen2_get_one<HostComb25519>(ew, fw, Q.x, Q.y, Q.z, xw, yw);
+        char wx[32], wy[32];
+        ecn_ed25519_mul2((const char*)e, &G, (const char*)f, &Qc, &R);
+        ecn_ed25519_get(&R, wx, wy);
+        unsigned char gx[32], gy[32];
+        for (int i = 0; i < 32; i++) { gx[i] = (unsigned char)(xw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); gy[i] = (unsigned char)(yw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); }
+        if (memcmp(gx, wx, 32) != 0 || memcmp(gy, wy, 32) != 0) { if (bad < 8) printf("Ed26Lad::mulgen2_get_one: record %d differs\n", it); bad++; }
+        it++;
+    };
+    for (int tors = 0; tors < 8; tors++) {
+        for (int base = 0; base < 2; base++) {
+            pt25519 Q = S[tors];
+            if (base) {
+                unsigned char k[32];
+                for (int i = 0; i < 32; i++) k[i] = (unsigned char)sm();
+                pt25519 B;
+                ecn_ed25519_gen(&B);
+                ecn_ed25519_mul((const char*)k, &B);
+                ecn_ed25519_add(&B, &Q);
+            }
+            unsigned char e[32], f[32];
+            for (int j = 0; j <= 8; j += (tors & 1) ? 1 : 2) for (int dl = -1; dl <= 1; dl++) {
+                ed25519_jq(j, dl, f);
+                for (int i = 0; i < 32; i++) e[i] = (unsigned char)sm();
+                if (dl == 0) memset(e, 0, 32);
+                one(Q, e, f);
+            }
+            memset(f, 0xff, 32); memset(e, 0xff, 32); one(Q, e, f);
+        }
+    }
+    for (int r = 0; r < n; r++) {
+        unsigned char e[32], f[32], k[32];
+        for (int i = 0; i < 32; i++) { e[i] = (unsigned char)sm(); f[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
+        pt25519 Q;
+        ecn_ed25519_gen(&Q);
+        if (r % 8 != 3) ecn_ed25519_mul((const char*)k, &Q);      // (r % 8 == 3: Q = G; then f = q - e makes the sum neutral)
+        if (r % 8 == 3 && r % 16 == 3) {
+            uint64_t ew[4], qw[4], fw[4];
+            for (int w = 0; w < 4; w++) { uint64_t v = 0, u = 0; for (int b = 0; b < 8; b++) { v |= (uint64_t)e[31 - (8 * w + b)] << (8 * b); u |= (uint64_t)ED25519_Q[31 - (8 * w + b)] << (8 * b); } ew[w] = v; qw[w] = u; }
+            ew[3] &= 0x0fffffffffffffffull;                        // e < q
+            unsigned __int128 br = 0;
+            for (int w = 0; w < 4; w++) { unsigned __int128 d = (unsigned __int128)qw[w] - ew[w] - (uint64_t)br; fw[w] = (uint64_t)d; br = (d >> 64) & 1; }
+            for (int i = 0; i < 32; i++) { e[31 - i] = (unsigned char)(ew[i / 8] >> (8 * (i % 8))); f[31 - i] = (unsigned char)(fw[i / 8] >> (8 * (i % 8))); }
+        }
+        one(Q, e, f);
+    }
+    printf("Ed26Lad::mulgen2_get_one: %d records, %d differ from the oracle's ecn gen + mul2 + get\n", it, bad);
+    return bad;
+}
+
 extern "C" void ecn_ed448_mul2(const char* e, pt448* P, const char* f, pt448* Q, pt448* R);
 static int run_ed448_mulgen2(int n) {
     int bad = 0;
@@ -849,6 +1002,7 @@ int main(int argc, char** argv) {
     bad += run_fold52(n * 50);
     bad += run_ed25519(n / 4 + 16);
     bad += run_ed25519_mul2(n / 8 + 16);
+    bad += run_ed25519_lad("Ed26Lad::mul_get_one", n / 4 + 16, [](const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, uint64_t* xw, uint64_t* yw) { ma::Ed26Lad<ma::C_ED25519>::mul_get_one(ew, X, Y, Z, xw, yw); });
     bad += run_ed448(n / 16 + 16);
     bad += run_ed448_mul2(n / 32 + 16);
     bad += run_ed448_mulgen2(n / 32 + 16);
@@ -871,6 +1025,7 @@ int main(int argc, char** argv) {
                                       for (int k = 0; k < 4; k++) { x[k] = xw[2][k]; y[k] = yw[2][k]; }
                                   }, ecn_ed25519_gen, ecn_ed25519_mul, ecn_ed25519_get);
     bad += run_ed25519_mulgen2(n / 8 + 24);
+    bad += run_ed25519_mulgen2_lad(n / 8 + 24);
     struct HostPark { uint32_t w[64]; void put(int k, uint32_t v) { w[k] = v; } uint32_t get(int k) const { return w[k]; } };
     bad += run_edgen<56, pt448>("ed448_mulgen_get_two", n / 8 + 130, [](const uint64_t* e, uint64_t* x, uint64_t* y) {
                                     uint64_t xw[2][7], yw[2][7];        // this scalar first and second of a pair, both must agree
