@@ -42,9 +42,12 @@
  * element, 20-30 x the rate.
  * Errors: the reference signals none.  Batched calls return 0 or a hipError_t value (launch/device
  * errors only); modarith_amd_last_error() describes the last failure on the calling thread.  Scalar
- * _ct calls abort() on a device error (their reference signatures have no way to report one).
+ * _ct calls keep the reference's void / predicate signatures and therefore cannot return a device error: they RECORD it
+ * (modarith_amd_last_error() on the calling thread, and the process-wide sticky modarith_amd_status()), launch nothing and
+ * hand back zero-filled outputs.  Nothing in the library calls abort() or exit().
  * Streams: `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on it.
- * Threading: entry points are re-entrant; scalar _ct calls serialise on an internal staging buffer.
+ * Threading: entry points are re-entrant; scalar _ct calls serialise on the staging buffer of THEIR device (one buffer and
+ * one mutex per device: scalar calls on different devices run side by side).
  */
 #ifndef MODARITH_AMD_H
 #define MODARITH_AMD_H
@@ -61,6 +64,10 @@ typedef uint64_t ma_spint; /* spint of the 64-bit field.c (pseudo.py:1395) */
 /* ---- library / device utilities (no counterpart in the reference: it has no runtime) ---- */
 int modarith_amd_abi_version(void);            /* = MODARITH_AMD_ABI */
 const char *modarith_amd_last_error(void);
+/* the first error code (a hipError_t value) any scalar _ct entry point of this process has recorded since the last clear; 0 = none.
+ * A caller of the reference's void signatures polls this where field.c's caller would have had nothing to check. */
+int modarith_amd_status(void);
+void modarith_amd_clear_status(void);
 int modarith_amd_device_count(void);
 int modarith_amd_set_device(int dev);
 int modarith_amd_malloc(void **dptr, size_t bytes);
@@ -87,6 +94,13 @@ size_t modarith_amd_batch_words(size_t n, int nlimbs, size_t ld);
 /* the library's stream-ordered scratch (the split form of rfc7748_<C>_batch, in-place modinv_<P>_batch) caches up to 1.25 GiB per
  * device between calls; scratch_trim gives what is cached beyond keep_bytes on the current device back to the driver */
 int modarith_amd_scratch_trim(size_t keep_bytes);
+/* diagnostic: the shader clock a kernel sees WHILE other work runs.  Enqueue on a second stream in front of the work to be observed:
+ * one wave waits delay_us of wall clock, then reads the shader-clock counter (s_memtime) and the constant-rate wall clock
+ * (s_memrealtime) at both ends of a window of window_us and stores the two differences in out[0] (shader cycles) and out[1]
+ * (wall-clock ticks), device memory.  clock = out[0] / out[1] x modarith_amd_wall_clock_khz() kHz.  bench.py brackets every
+ * VALU-bound leg with it, so that a rate can be told from the clock the part held while it was measured. */
+int modarith_amd_sclk_probe(uint64_t *out, unsigned delay_us, unsigned window_us, void *stream);
+int modarith_amd_wall_clock_khz(void);
 /* diagnostic: the name of the kernel family this thread's last batched call launched ("rfc7748(split)", "rfc7748(field form)", ...) */
 const char *modarith_amd_last_launch(void);
 /* per-prime macro block of field.c (pseudo.py:1403-1407): returns 0 if `prime` is unknown */
@@ -375,9 +389,14 @@ MODARITH_AMD_DECLARE_EDWARDS(nums256w, 5)
  * (or field.c-style code) produced does; the fused kernels re-pack the 64-bit limbs into 32-bit ones and silently drop what
  * lies above (checkable beforehand with modlimbs_<P>_batch on the three coordinates; the plain ecn_<c>_mul_batch instead
  * reproduces the reference's 64-bit wrap-around for such fabricated limbs).  This precondition holds for every fused entry
- * point below (mul_get, mul2_get, mulgen2_get).  Constant-time fixed window like ecnXXXmul.  workspace: a device buffer of
- * ecn_<c>_mul_get_workspace_bytes(n) bytes for the per-lane window tables (0 for ed25519, whose table lives in
- * registers: workspace may then be NULL; ed448: 672 bytes per resident lane, at most 88 MB). */
+ * point below (mul_get, mul2_get, mulgen2_get).  Constant time like ecnXXXmul: ed448, nist256, secp256k1 by fixed windows with
+ * scanned tables; ed25519 (round 5, csrc/ed26l.h) by a Montgomery ladder on the birationally equivalent curve with the second
+ * coordinate recovered at the end and both inversions shared by up to 32 records -- no table at all.  workspace: a device buffer of
+ * ecn_<c>_mul_get_workspace_bytes(n) bytes (ed448: the per-lane window tables, 672 bytes per resident lane, at most 88 MB;
+ * ed25519: 140 bytes per record for at most 2^20 records at a time, i.e. at most 147 MB whatever n).  ed25519 only: with
+ * workspace NULL (or too small) the call takes stream-ordered scratch from the library's own pool instead -- callers written
+ * against rounds 2-4, where this function returned 0, keep working -- and fails with hipErrorInvalidValue only when that is
+ * impossible (a stream under graph capture). */
 size_t ecn_ed25519_mul_get_workspace_bytes(size_t n);
 int ecn_ed25519_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
                               void *workspace, size_t workspace_bytes, void *stream);
@@ -426,7 +445,7 @@ int ecn_ed448_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_
 
 /* e*G + f*Q and its affine export: ecnXXXgen, ecnXXXmul2(e, &G, f, &Q, &R), ecnXXXget -- signature verification, where the
  * first point of the reference's double multiplication is always the generator (nist256.c:251-256, ed448.c:305).  f*Q as in
- * mul_get (workspace of ecn_<c>_mulgen2_get_workspace_bytes(n) bytes for nist256 / secp256k1 / ed448, 0 and NULL for ed25519), e*G through
+ * mul_get (workspace of ecn_<c>_mulgen2_get_workspace_bytes(n) bytes, rules as for mul_get), e*G through
  * the fixed-base table without doublings of its own; Q is not modified; same bytes as the three calls. */
 size_t ecn_nist256_mulgen2_get_workspace_bytes(size_t n);
 int ecn_nist256_mulgen2_get_batch(const char *e, const char *f, const ma_spint *Q, char *x, char *y, int *sign, size_t n, size_t ld,

@@ -85,7 +85,7 @@ UTIL_FUNCS = ("modarith_amd_abi_version", "modarith_amd_last_error", "modarith_a
               "modarith_amd_memcpy_d2h", "modarith_amd_sync", "modarith_amd_aos_to_soa", "modarith_amd_soa_to_aos",
               "modarith_amd_stream_create", "modarith_amd_stream_destroy", "modarith_amd_stream_wait", "modarith_amd_host_alloc", "modarith_amd_host_free",
               "modarith_amd_field_info", "modarith_amd_recommended_ld", "modarith_amd_batch_words", "modarith_amd_scratch_trim",
-              "modarith_amd_last_launch")
+              "modarith_amd_last_launch", "modarith_amd_status", "modarith_amd_clear_status", "modarith_amd_sclk_probe", "modarith_amd_wall_clock_khz")
 
 
 def _declare_curve(lib, C: str) -> None:
@@ -197,6 +197,11 @@ def load() -> ctypes.CDLL:
     lib.modarith_amd_scratch_trim.argtypes = [c_size_t]
     lib.modarith_amd_scratch_trim.restype = c_int
     lib.modarith_amd_last_launch.restype = c_char_p
+    lib.modarith_amd_status.restype = c_int
+    lib.modarith_amd_clear_status.restype = None
+    lib.modarith_amd_sclk_probe.argtypes = [_P, ctypes.c_uint, ctypes.c_uint, _P]
+    lib.modarith_amd_sclk_probe.restype = c_int
+    lib.modarith_amd_wall_clock_khz.restype = c_int
     _lib = lib
     return lib
 

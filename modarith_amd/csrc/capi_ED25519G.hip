@@ -2,7 +2,6 @@
 // (csrc/ed26.h ed25519_mulgen_get_one), the call sequence ecnXXXgen + ecnXXXmul + ecnXXXget that opens EdDSA key generation
 // and signing in the reference (ed448.c:167-184, 196-199).  Fixed-base table: generated/comb_ED25519.h.
 #include "../../include/modarith_amd.h"
-#include <string.h>
 #include "capi_common.h"
 #include "generated/curve_ED25519.h"
 #include "generated/comb_ED25519.h"
@@ -60,43 +59,6 @@ void k_x25519_base(const uint64_t* bk, uint64_t* bv, size_t n) {
     }
 }
 
-// e*G + f*Q and its affine export (verification, ed448.c:305): the table of Q in registers as for mul_get, the generator part
-// through the constant table above
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_ed25519_mulgen2_get(const unsigned char* e, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb, int* sign,
-                           size_t n, size_t ld) {
-    using P = P_X25519;
-    __shared__ unsigned char digs[86 * 64];                  // f's windows in LDS (ed26.h W25519_3Lds), element index formed at use: capi_ED25519F.hip
-    unsigned char* col = digs + threadIdx.x;
-    __shared__ uint64_t parked[24 * 64];                     // entries 3P, 4P of the window table (ed26.h Park24Lds)
-    Park24Lds park{parked + threadIdx.x};
-    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
-        auto t = [&]() {
-            unsigned l = threadIdx.x;
-            asm volatile("" : "+v"(l));
-            return base + l;
-        };
-        if (t() >= n) continue;
-        {
-            spint fw[4];
-            load_be_record<P>(f, t(), fw);
-            W25519_3Lds::fill(fw, col);
-        }
-        spint ew[4], X[5], Y[5], Z[5], xw[4], yw[4];
-        static_for<0, 5>([&](auto I) {
-            X[I] = Qb[(size_t)I * ld + t()];
-            Y[I] = Qb[(size_t)(5 + I) * ld + t()];
-            Z[I] = Qb[(size_t)(10 + I) * ld + t()];
-        });
-        load_be_record<P>(e, t(), ew);
-        W25519_3Lds dig{col};
-        ed25519_mulgen2_get_dig<C_ED25519, CombED25519>(ew, dig, park, X, Y, Z, xw, yw);
-        if (xb) store_be_record<P>(xb, t(), xw);
-        if (yb) store_be_record<P>(yb, t(), yw);
-        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
-    }
-}
-
 // round 5, the ladder form (csrc/ed26l.h): f*Q by the Montgomery ladder with the recovered Edwards point in extended coordinates,
 // e*G added through the constant table; the inversions in front and behind are shared (ed26l_k.h)
 // 163 VGPRs, no scratch: three waves per SIMD (a 128-register build for four waves measured the same rate, 1.128e8 mul_get/s, and
@@ -129,13 +91,7 @@ void k_ed25519_lad_gen2(const unsigned char* e, const unsigned char* f, size_t f
 
 using namespace ma;
 
-static bool ed25519_fused_window() {        // MA_ED25519_FUSED=window: the round-2..4 kernel for every batch (capi_ED25519F.hip)
-    static bool v = [] { const char* s = getenv("MA_ED25519_FUSED"); return s && strcmp(s, "window") == 0; }();
-    return v;
-}
-constexpr size_t ED25519_LAD_MIN = 4096;
-
-extern "C" size_t ecn_ed25519_mulgen2_get_workspace_bytes(size_t n) { return n >= ED25519_LAD_MIN ? ed26l_workspace_bytes(n) : 0; }
+extern "C" size_t ecn_ed25519_mulgen2_get_workspace_bytes(size_t n) { return ed26l_workspace_bytes(n); }
 
 extern "C" int ecn_ed25519_mulgen2_get_batch(const char* e, const char* f, const ma_spint* Q, char* x, char* y, int* sign, size_t n, size_t ld,
                                              void* workspace, size_t workspace_bytes, void* st) {
@@ -145,28 +101,15 @@ extern "C" int ecn_ed25519_mulgen2_get_batch(const char* e, const char* f, const
         return (int)hipErrorInvalidValue;
     }
     hipStream_t s = (hipStream_t)st;
-    if (n >= ED25519_LAD_MIN && !ed25519_fused_window()) {       // the ladder form; workspace rules as for mul_get (capi_ED25519F.hip)
-        const size_t need = ed26l_workspace_bytes(n);
-        void* ws = (workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 7u) == 0) ? workspace : nullptr;
-        void* own = nullptr;
-        if (!ws) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (s == nullptr || (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)) ws = own = scratch_alloc(need, s);
-            else (void)hipGetLastError();
-        }
-        if (ws) {
-            const unsigned char *eb = reinterpret_cast<const unsigned char*>(e), *fb = reinterpret_cast<const unsigned char*>(f);
-            ed26l_pipeline<C_ED25519, 2>(Q, ld, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n, ws, s,
-                                         [&](size_t first, size_t m, const Ed26lWs& w) { k_ed25519_lad_gen2<<<(unsigned)((m + 63) / 64), 64, 0, s>>>(eb, fb, first, w); });
-            if (own) scratch_free(own, s);
-            return check_launch("ecn mulgen2_get (ladder form)");
-        }
+    Ed26lScratch ws(workspace, workspace_bytes, n, s);
+    if (!ws.p) {
+        set_error("ecn mulgen2_get: no workspace (pass ecn_ed25519_mulgen2_get_workspace_bytes(n) bytes; the library's own scratch pool is not available while the stream is being captured)");
+        return (int)hipErrorInvalidValue;
     }
-    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
-    k_ed25519_mulgen2_get<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(
-        reinterpret_cast<const unsigned char*>(e), reinterpret_cast<const unsigned char*>(f), Q, reinterpret_cast<unsigned char*>(x),
-        reinterpret_cast<unsigned char*>(y), sign, n, ld);
-    return check_launch("ecn mulgen2_get");
+    const unsigned char *eb = reinterpret_cast<const unsigned char*>(e), *fb = reinterpret_cast<const unsigned char*>(f);
+    ed26l_pipeline<C_ED25519, 2>(Q, ld, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n, ws.p, s,
+                                 [&](size_t first, size_t m, const Ed26lWs& w) { k_ed25519_lad_gen2<<<(unsigned)((m + 63) / 64), 64, 0, s>>>(eb, fb, first, w); });
+    return check_launch("ecn mulgen2_get (ladder form)");
 }
 
 extern "C" int ecn_ed25519_mulgen_get_batch(const char* e, char* x, char* y, int* sign, size_t n, void* st) {

@@ -36,17 +36,38 @@ inline unsigned grid_for(size_t nthreads, int block = 256, bool tiled = false) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// staging area for the scalar (_ct) entry points: a small device buffer guarded by a mutex
+// Failures of the host side that the reference's void / predicate signatures cannot return (the scalar _ct entry points: no staging
+// buffer, a failed copy, a failed launch): recorded, never fatal.  fail() sets the calling thread's modarith_amd_last_error() text and
+// the process-wide sticky status modarith_amd_status() (first error code since the last modarith_amd_clear_status()); the entry point
+// then returns without launching, its outputs zero-filled.  (Up to round 4 these paths called abort() inside the shared library.)
+void fail(const char* what, hipError_t e);
+int sticky_status();
+void clear_sticky_status();
+
+// staging area for the scalar (_ct) entry points: one small device buffer PER DEVICE, each guarded by its own mutex (scalar calls on
+// different devices do not serialise each other)
 struct Staging {
-    std::mutex mu;
     static constexpr int MAX_DEVICES = 64;
+    std::mutex mu[MAX_DEVICES];
     unsigned char* dev[MAX_DEVICES] = {};         // one buffer per device of this process, made on first use
     static constexpr size_t BYTES = 512 * 1024;   // holds the scalar ecn mul2 window tables (64 lanes x up to 486 words)
-    unsigned char* get();
+    unsigned char* get(int d);                    // nullptr (and fail()) when the buffer cannot be made; call with mu[d] held
 };
 Staging& staging();
+// One scalar call's use of the staging buffer: locks the current device's buffer for its lifetime.  bad = no buffer (no device, failed
+// allocation, overflow) or a failed step: every later step is skipped, d2h() zero-fills what the caller expects back.
+struct StageBase {
+    std::unique_lock<std::mutex> lock;
+    unsigned char* base = nullptr;
+    size_t used = 0;
+    bool bad = false;
+    StageBase();
+    void* take(size_t bytes);
+    void h2d(void* d, const void* h, size_t b);
+    void d2h(void* h, const void* d, size_t b);
+    void check(int rc, const char* what);
+};
 void* scratch_alloc(size_t bytes, hipStream_t s);   // stream-ordered scratch from the library's own pool; nullptr if unavailable
 void scratch_free(void* p, hipStream_t s);
-[[noreturn]] void die(const char* what, hipError_t e);
 
 }  // namespace ma

@@ -3,6 +3,7 @@
 #include "../../include/modarith_amd.h"
 #include "capi_common.h"
 #include "kernels.h"
+#include <atomic>
 #include <string.h>
 
 namespace ma {
@@ -65,16 +66,61 @@ bool ladder_use_field() {
     return v;
 }
 
-unsigned char* Staging::get() {
-    int d = 0;
-    hipError_t e = hipGetDevice(&d);
-    if (e != hipSuccess) die("hipGetDevice(staging)", e);
-    if (d < 0 || d >= MAX_DEVICES) die("staging: device index out of range", hipErrorInvalidDevice);
+static std::atomic<int> g_sticky{0};
+void fail(const char* what, hipError_t e) {
+    set_error(std::string(what) + " failed: " + hipGetErrorString(e));
+    int zero = 0;
+    g_sticky.compare_exchange_strong(zero, e == hipSuccess ? (int)hipErrorUnknown : (int)e);
+    (void)hipGetLastError();
+}
+int sticky_status() { return g_sticky.load(); }
+void clear_sticky_status() { g_sticky.store(0); }
+
+unsigned char* Staging::get(int d) {
     if (!dev[d]) {
-        e = hipMalloc((void**)&dev[d], BYTES);
-        if (e != hipSuccess) die("hipMalloc(staging)", e);
+        // MA_TEST_STAGING_FAIL=1 (tests only): behave as if the device had no memory left for the staging buffer
+        static const bool test_fail = [] { const char* s = getenv("MA_TEST_STAGING_FAIL"); return s && *s == '1'; }();
+        hipError_t e = test_fail ? hipErrorOutOfMemory : hipMalloc((void**)&dev[d], BYTES);
+        if (e != hipSuccess) {
+            dev[d] = nullptr;
+            fail("hipMalloc(staging)", e);
+            return nullptr;
+        }
     }
     return dev[d];
+}
+StageBase::StageBase() {
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) { fail("hipGetDevice(staging)", e); bad = true; return; }
+    if (d < 0 || d >= Staging::MAX_DEVICES) { fail("staging: device index out of range", hipErrorInvalidDevice); bad = true; return; }
+    lock = std::unique_lock<std::mutex>(staging().mu[d]);
+    base = staging().get(d);
+    bad = base == nullptr;
+}
+void* StageBase::take(size_t bytes) {
+    if (bad) return nullptr;
+    void* d = base + used;
+    used += (bytes + 15) / 16 * 16;
+    if (used > Staging::BYTES) { fail("staging overflow", hipErrorOutOfMemory); bad = true; return nullptr; }
+    return d;
+}
+void StageBase::h2d(void* d, const void* h, size_t b) {
+    if (bad) return;
+    hipError_t e = hipMemcpy(d, h, b, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { fail("hipMemcpy(h2d)", e); bad = true; }
+}
+void StageBase::d2h(void* h, const void* d, size_t b) {
+    if (!bad) {
+        hipError_t e = hipMemcpy(h, d, b, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) return;
+        fail("hipMemcpy(d2h)", e);
+        bad = true;
+    }
+    memset(h, 0, b);
+}
+void StageBase::check(int rc, const char* what) {
+    if (rc != 0) { fail(what, (hipError_t)rc); bad = true; }
 }
 // stream-ordered scratch of the library's own (the batched ladders' split form): one memory pool per device, created on
 // first use, that keeps what it has handed out once (release threshold = max), so that a resident caller pays for the
@@ -141,11 +187,6 @@ Staging& staging() {
     static Staging s;
     return s;
 }
-void die(const char* what, hipError_t e) {
-    fprintf(stderr, "modarith_amd: %s failed: %s\n", what, hipGetErrorString(e));
-    abort();
-}
-
 // element-major (AoS, spint x[n][N] as CPU callers hold elements) <-> limb-interleaved SoA (flat or tiled: kernels.h Ld); any limb count
 static __device__ __forceinline__ size_t soa_off(Ld L, int nlimbs, size_t j) {
     return (((j >> L.s) * (size_t)nlimbs) << L.s) + (j & ((((size_t)1) << L.s) - 1));
@@ -267,11 +308,34 @@ static int wrap(hipError_t e, const char* what) {
 
 using namespace ma;
 
+// one wave: wait `delay` wall-clock ticks, then the shader-clock counter against the wall clock over `window` ticks
+static __global__ __launch_bounds__(64) void k_sclk_probe(uint64_t* out, uint64_t delay, uint64_t window) {
+    const uint64_t w0 = wall_clock64();
+    while (wall_clock64() - w0 < delay) __builtin_amdgcn_s_sleep(32);
+    const uint64_t wa = wall_clock64(), ca = clock64();
+    while (wall_clock64() - wa < window) __builtin_amdgcn_s_sleep(32);
+    const uint64_t wb = wall_clock64(), cb = clock64();
+    if (threadIdx.x == 0) { out[0] = cb - ca; out[1] = wb - wa; }
+}
+
 extern "C" {
 
 int modarith_amd_abi_version(void) { return MODARITH_AMD_ABI; }
 const char* modarith_amd_last_error(void) { return g_err.c_str(); }
 const char* modarith_amd_last_launch(void) { return g_last_launch; }
+int modarith_amd_status(void) { return sticky_status(); }
+void modarith_amd_clear_status(void) { clear_sticky_status(); }
+int modarith_amd_wall_clock_khz(void) {
+    int d = 0, khz = 0;
+    if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return khz;
+}
+int modarith_amd_sclk_probe(uint64_t* out, unsigned delay_us, unsigned window_us, void* st) {
+    const int khz = modarith_amd_wall_clock_khz();
+    if (khz <= 0) { set_error("sclk_probe: no wall-clock rate for this device"); return (int)hipErrorNotSupported; }
+    k_sclk_probe<<<1, 64, 0, (hipStream_t)st>>>(out, (uint64_t)delay_us * (uint64_t)khz / 1000, (uint64_t)window_us * (uint64_t)khz / 1000);
+    return check_launch("sclk_probe");
+}
 int modarith_amd_scratch_trim(size_t keep_bytes) { return scratch_trim(keep_bytes); }
 // the limb stride a caller without a layout of its own should use (include/modarith_amd.h, TILED): tiles of 4096 elements once
 // the batch holds two of them, flat rows below

@@ -154,54 +154,9 @@ struct Ed26 {
     }
 };
 
-// ---- where the recoded scalar comes from (round 4; see ed28.h): Regs = shift registers in VGPRs (host check), Lds = one byte per window
-// (3-bit windows) or four windows per byte (2-bit windows) in the lane's column of an LDS array, written before the point is loaded.
-// window(i) for i = 0, 1, 2, ... in order.
-struct W25519_3Regs {                       // e' = e + sum_{i<86} 4*8^i, window 85 (bits 255..257) first
-    uint64_t w[5];
-    MA_DEV void init(const uint64_t* ew) {
-        constexpr auto cw = [](int k) {
-            uint64_t v = 0;
-            for (int b = 0; b < 64; b++) {
-                const int pos = 64 * k + b;
-                if (pos < 258 && pos % 3 == 2) v |= (uint64_t)1 << b;
-            }
-            return v;
-        };
-        unsigned __int128 acc = 0;
-        uint64_t s[5];
-        static_for<0, 5>([&](auto K) {
-            constexpr int k = K;
-            acc += (unsigned __int128)(k < 4 ? ew[k < 4 ? k : 0] : 0) + cw(k);
-            s[k] = (uint64_t)acc;
-            acc >>= 64;
-        });
-        w[4] = (s[4] << 62) | (s[3] >> 2);
-        w[3] = (s[3] << 62) | (s[2] >> 2);
-        w[2] = (s[2] << 62) | (s[1] >> 2);
-        w[1] = (s[1] << 62) | (s[0] >> 2);
-        w[0] = s[0] << 62;
-    }
-    MA_DEV uint32_t window(int) {
-        const uint32_t win = (uint32_t)(w[4] >> 61);
-        w[4] = (w[4] << 3) | (w[3] >> 61);
-        w[3] = (w[3] << 3) | (w[2] >> 61);
-        w[2] = (w[2] << 3) | (w[1] >> 61);
-        w[1] = (w[1] << 3) | (w[0] >> 61);
-        w[0] <<= 3;
-        return win;
-    }
-};
-struct W25519_3Lds {
-    const unsigned char* col;
-    static MA_DEV void fill(const uint64_t* ew, unsigned char* col) {
-        W25519_3Regs r;
-        r.init(ew);
-#pragma unroll 1
-        for (int i = 0; i < 86; i++) col[(size_t)i * 64] = (unsigned char)r.window(i);
-    }
-    MA_DEV uint32_t window(int i) const { return col[(size_t)i * 64]; }
-};
+// ---- where the recoded scalar of the double multiplication comes from (round 4; see ed28.h): Regs = shift registers in VGPRs (host
+// check), Lds = four 2-bit windows per byte in the lane's column of an LDS array, written before the point is loaded.  window(i) for
+// i = 0, 1, 2, ... in order.  (The 3-bit windows of the single multiplication went with it in round 5: ed26l.h.)
 struct W25519_2Regs {                       // e' = e + sum_{i<129} 2*4^i (258 bits), window 128 first
     uint64_t w[5];
     MA_DEV void init(const uint64_t* in) {
@@ -268,149 +223,12 @@ struct Park24Lds {
     MA_DEV uint64_t get(int k) const { return col[(size_t)k * 64]; }
 };
 
-// One fused ED25519 scalar multiplication + affine export.
-//   ew: the scalar as four little-endian 64-bit words (the caller has byte-swapped the big-endian record);
-//   X, Y, Z: the projective point, 5 x 51-bit limbs each (field.c form); xw, yw: canonical affine coordinates,
-//   four little-endian words each.
-template <class C, bool FINAL_T = false, class DIG, class PARK>       // FINAL_T: the sum leaves with its T coordinate (a further addition follows)
-MA_DEV void ed25519_mul_acc(DIG& dig, PARK& park, const spint* X, const spint* Y, const spint* Z, typename Ed26<C>::Ext& R) {
-    using E = Ed26<C>;
-    using F = Fe26;
-    typename E::Ext Q;
-    uint64_t tab[2][3][4];                  // {1,2}P as canonical packed (y+x, y-x, 2dxy); {3,4}P in the park
-
-    {   // ---- table: projective P -> extended; 2P, 3P, 4P; one shared inversion; cached affine form
-        typename E::Ext P2, P3, P4;
-        uint32_t px[10], py[10], pz[10];
-        E::from51(X, px);
-        E::from51(Y, py);
-        E::from51(Z, pz);
-        F::mul(px, pz, Q.X);                // (XZ : YZ : Z^2 : XY)
-        F::mul(py, pz, Q.Y);
-        F::sqr(pz, Q.Z);
-        F::mul(px, py, Q.T);
-        P2 = Q;
-        E::template dbl<true>(P2);
-        P3 = P2;
-        E::add_ext(P3, Q);
-        P4 = P2;
-        E::template dbl<false>(P4);
-        // Montgomery's trick: the four Z inverted with one inversion
-        uint32_t z12[10], z123[10], inv[10], i1[10], i2[10], i3[10], i4[10];
-        F::mul(Q.Z, P2.Z, z12);
-        F::mul(z12, P3.Z, z123);
-        F::mul(z123, P4.Z, inv);
-        F::invert(inv, inv);
-        F::mul(inv, z123, i4);
-        F::mul(inv, P4.Z, inv);             // 1 / (Z1 Z2 Z3)
-        F::mul(inv, z12, i3);
-        F::mul(inv, P3.Z, inv);             // 1 / (Z1 Z2)
-        F::mul(inv, Q.Z, i2);
-        F::mul(inv, P2.Z, i1);
-        uint32_t dd[10];
-        E::d2(dd);
-        auto cache = [&](const typename E::Ext& p, const uint32_t* zi, uint64_t (*out)[4]) {
-            uint32_t x[10], y[10], s[10];
-            F::mul(p.X, zi, x);
-            F::mul(p.Y, zi, y);
-            F::add(y, x, s);
-            F::to_words(s, out[0]);
-            F::sub(y, x, s);
-            F::to_words(s, out[1]);
-            F::mul(x, y, s);
-            F::mul(s, dd, s);
-            F::to_words(s, out[2]);
-        };
-        cache(Q, i1, tab[0]);
-        cache(P2, i2, tab[1]);
-        uint64_t tmp[3][4];
-        cache(P3, i3, tmp);
-        static_for<0, 3>([&](auto CI) { static_for<0, 4>([&](auto K) { park.put(CI * 4 + K, tmp[CI][K]); }); });
-        cache(P4, i4, tmp);
-        static_for<0, 3>([&](auto CI) { static_for<0, 4>([&](auto K) { park.put(12 + CI * 4 + K, tmp[CI][K]); }); });
-    }
-
-    // R = neutral element (0 : 1 : 1 : 0)
-    F::set(0, R.X);
-    F::set(1, R.Y);
-    F::set(1, R.Z);
-    F::set(0, R.T);
-
-#pragma unroll 1
-    for (int i = 0; i < 86; i++) {
-        const uint32_t win = dig.window(i);                 // e' = e + sum 4*8^i: window - 4 is the signed digit
-        const int dgt = (int)win - 4;                       // [-4, 3]
-        const bool neg = dgt < 0;
-        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);    // 0..4
-        if (i != 0) {
-            E::template dbl<false>(R);
-            E::template dbl<false>(R);
-            E::template dbl<true>(R);
-        }
-        // constant-time lookup: scan all entries, start from the neutral element (y+x, y-x, 2dxy) = (1, 1, 0)
-        uint64_t sel[3][4];
-        static_for<0, 3>([&](auto CI) { static_for<0, 4>([&](auto K) { sel[CI][K] = (CI < 2 && K == 0) ? 1u : 0u; }); });
-        static_for<0, 4>([&](auto EI) {
-            constexpr int e = EI;
-            const bool hit = (m == (uint32_t)(e + 1));
-            static_for<0, 3>([&](auto CI) {
-                static_for<0, 4>([&](auto K) {
-                    uint64_t a;
-                    if constexpr (e < 2) a = tab[e][CI][K]; else a = park.get((e - 2) * 12 + CI * 4 + K);
-                    const uint64_t b = sel[CI][K];
-                    sel[CI][K] = hit ? a : b;
-                });
-            });
-        });
-        // -Q = (y-x, y+x, -2dxy)
-        uint32_t yp[10], ym[10], t2[10], nt[10];
-        uint64_t sp[4], sm[4];
-        static_for<0, 4>([&](auto K) {
-            const uint64_t a = sel[0][K], b = sel[1][K];
-            sp[K] = neg ? b : a;
-            sm[K] = neg ? a : b;
-        });
-        F::from_words(sp, yp);
-        F::from_words(sm, ym);
-        F::from_words(sel[2], t2);
-        F::set(0, nt);
-        F::sub(nt, t2, nt);                                 // 2p - t: 1.0 .. 1.5
-        F::select(neg, t2, nt, t2);
-        if constexpr (FINAL_T) E::add_cached_rt(R, yp, ym, t2, i == 85);
-        else E::add_cached(R, yp, ym, t2);
-    }
-}
-template <class C, class DIG, class PARK>
-MA_DEV void ed25519_mul_get_dig(DIG& dig, PARK& park, const spint* X, const spint* Y, const spint* Z, uint64_t* xw, uint64_t* yw) {
-    using F = Fe26;
-    typename Ed26<C>::Ext R;
-    ed25519_mul_acc<C>(dig, park, X, Y, Z, R);
-    uint32_t zi[10], ax[10], ay[10];
-    F::invert(R.Z, zi);
-    F::mul(R.X, zi, ax);
-    F::mul(R.Y, zi, ay);
-    F::to_words(ax, xw);
-    F::to_words(ay, yw);
-}
-template <class C>
-MA_DEV void ed25519_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* xw, uint64_t* yw) {
-    using F = Fe26;
-    typename Ed26<C>::Ext R;
-    W25519_3Regs dig;
-    dig.init(ew);
-    Park24Regs park;
-    ed25519_mul_acc<C>(dig, park, X, Y, Z, R);
-    // ---- affine, canonical (ecnXXXget: edwards.c:221-239)
-    uint32_t zi[10], ax[10], ay[10];
-    F::invert(R.Z, zi);
-    F::mul(R.X, zi, ax);
-    F::mul(R.Y, zi, ay);
-    F::to_words(ax, xw);
-    F::to_words(ay, yw);
-}
+// (The window form of the single multiplication -- 3-bit signed windows, the table {1,2,3,4}P in registers / LDS, 255 doublings + 86
+// mixed additions + two inversions per lane: rounds 2-4, 9.1e7/s, 170 spilled registers in its table builder -- was replaced in
+// round 5 by the ladder form of csrc/ed26l.h: 1.13e8/s, no spills; same-box A/B in profiles/r05_lad_ab.log.)
 
 // Fused double multiplication + affine export: the affine coordinates of e*P + f*Q (ecnXXXmul2 followed by ecnXXXget,
-// the verification pattern ed448.c:305 / nist256.c:251-254).  Same arithmetic as ed25519_mul_get_one; both scalars are
+// the verification pattern ed448.c:305 / nist256.c:251-254).  Both scalars are
 // recoded into 129 signed 2-bit digits (e' = e + sum 2*4^i, digit = window - 2 in [-2, 1]) so that the two tables
 // {P, 2P} and {Q, 2Q} fit the register file together (4 x 24 VGPRs); per window two doublings and two additions, all
 // lookups scan their table.  (The reference's mul2 is a joint sparse form with data-dependent branches; any
@@ -651,42 +469,6 @@ MA_DEV void ed25519_mulgen_get_many(LOAD load, uint64_t (*xw)[4], uint64_t (*yw)
         F::mul(Y[g], t, u);
         F::to_words(u, yw[g]);
     });
-}
-
-// Fused e*G + f*Q + affine export: the verification pattern ecnXXXmul2(u, &G, v, &Q, &R); ecnXXXget (ed448.c:305, the first
-// point is the GENERATOR).  f*Q as in ed25519_mul_get_one (3-bit windows, table of Q in registers, the last addition also
-// produces T), then e*G through the fixed-base table with mixed additions and no doublings (ed25519_mulgen_acc): 255
-// doublings + 86 + 65 additions against the 258 + 258 of the general ed25519_mul2_get_one.
-template <class C, class TAB, class DIG, class PARK>
-MA_DEV void ed25519_mulgen2_get_dig(const uint64_t* ew, DIG& digf, PARK& park, const spint* QX, const spint* QY, const spint* QZ,
-                                    uint64_t* xw, uint64_t* yw) {
-    using F = Fe26;
-    typename Ed26<C>::Ext R;
-    ed25519_mul_acc<C, true>(digf, park, QX, QY, QZ, R);
-    ed25519_mulgen_acc<C, TAB, false>(ew, R);
-    uint32_t zi[10], ax[10], ay[10];
-    F::invert(R.Z, zi);
-    F::mul(R.X, zi, ax);
-    F::mul(R.Y, zi, ay);
-    F::to_words(ax, xw);
-    F::to_words(ay, yw);
-}
-template <class C, class TAB>
-MA_DEV void ed25519_mulgen2_get_one(const uint64_t* ew, const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
-                                    uint64_t* xw, uint64_t* yw) {
-    using F = Fe26;
-    typename Ed26<C>::Ext R;
-    W25519_3Regs digf;
-    digf.init(fw);
-    Park24Regs park;
-    ed25519_mul_acc<C, true>(digf, park, QX, QY, QZ, R);
-    ed25519_mulgen_acc<C, TAB, false>(ew, R);
-    uint32_t zi[10], ax[10], ay[10];
-    F::invert(R.Z, zi);
-    F::mul(R.X, zi, ax);
-    F::mul(R.Y, zi, ay);
-    F::to_words(ax, xw);
-    F::to_words(ay, yw);
 }
 
 // rfc7748() on the BASE POINT u = 9 (public-key generation: every Diffie-Hellman exchange opens with it, rfc7748.c:297-333

@@ -30,6 +30,20 @@ struct Ed26lWs {
     }
 };
 
+// the caller's workspace when it is large enough, else stream-ordered scratch of the library's own pool (released in stream order when
+// this object goes); p = nullptr when neither is to be had (a stream under capture and no caller workspace)
+struct Ed26lScratch {
+    void* p = nullptr;
+    void* own = nullptr;
+    hipStream_t s;
+    Ed26lScratch(void* workspace, size_t workspace_bytes, size_t n, hipStream_t s_) : s(s_) {
+        const size_t need = ed26l_workspace_bytes(n);
+        if (workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 7u) == 0) { p = workspace; return; }
+        p = own = scratch_alloc(need, s);
+    }
+    ~Ed26lScratch() { if (own) scratch_free(own, s); }
+};
+
 // P = (X : Y : Z), rows of the caller's batch (limb stride ld), records first .. first + m
 template <class C, int TAG>
 __global__ __launch_bounds__(256) void k_ed26l_prep(const spint* Pb, size_t first, size_t ld, Ed26lWs ws) {

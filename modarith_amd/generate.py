@@ -325,13 +325,12 @@ def generate_ladder(name: str, field: str, a24: int, cof: int, twist_secure: boo
         "}",
         "// the reference's own signature (rfc7748.c:156), host pointers: one record through the staging buffer",
         'extern "C" void %s(const char* bk, const char* bu, char* bv) {' % sym,
-        "    std::lock_guard<std::mutex> lock(staging().mu);",
-        "    char* d = reinterpret_cast<char*>(staging().get());",
-        "    char *dk = d, *du = d + 64 * ((NB + 63) / 64), *dv = du + 64 * ((NB + 63) / 64);",
-        '    hipError_t e = hipMemcpy(dk, bk, NB, hipMemcpyHostToDevice); if (e != hipSuccess) die("hipMemcpy", e);',
-        '    e = hipMemcpy(du, bu, NB, hipMemcpyHostToDevice); if (e != hipSuccess) die("hipMemcpy", e);',
-        '    if (%s_batch(dk, du, dv, 1, nullptr) != 0) die("%s", hipErrorLaunchFailure);' % (sym, sym),
-        '    e = hipMemcpy(bv, dv, NB, hipMemcpyDeviceToHost); if (e != hipSuccess) die("hipMemcpy", e);',
+        "    StageBase s;                   // failures are recorded (modarith_amd_status()), never fatal; bv is zero-filled then",
+        "    char *dk = (char*)s.take(NB), *du = (char*)s.take(NB), *dv = (char*)s.take(NB);",
+        "    s.h2d(dk, bk, NB);",
+        "    s.h2d(du, bu, NB);",
+        '    if (!s.bad) s.check(%s_batch(dk, du, dv, 1, nullptr), "%s");' % (sym, sym),
+        "    s.d2h(bv, dv, NB);",
         "}", ""])
     os.makedirs(d, exist_ok=True)
     unit, obj = os.path.join(d, "capi_ladder_%s.hip" % name), os.path.join(d, "capi_ladder_%s.o" % name)

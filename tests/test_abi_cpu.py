@@ -145,3 +145,39 @@ def test_recommended_layout_helpers(lib):
 
 def test_last_launch_and_scratch_trim_are_callable_without_a_gpu(lib):
     assert lib.modarith_amd_last_launch() in (b"",) or isinstance(lib.modarith_amd_last_launch(), bytes)
+
+
+def test_scalar_entry_points_record_device_errors_instead_of_aborting():
+    """Up to round 4 a scalar _ct call whose staging buffer could not be made (no device, no memory) called abort() inside the shared
+    library.  Now it records the failure -- modarith_amd_last_error() for the thread, the sticky modarith_amd_status() for the
+    process --, launches nothing and hands back zero-filled outputs.  Here: no GPU at all (a child process, so that a regression
+    that aborts fails this test instead of ending the test run)."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, sys
+sys.path.insert(0, %r)
+from modarith_amd import _lib
+L = _lib.load()
+L.modarith_amd_status.restype = ctypes.c_int
+L.modarith_amd_last_error.restype = ctypes.c_char_p
+assert L.modarith_amd_status() == 0
+U = ctypes.c_uint64 * 5
+a, b, c = U(1, 2, 3, 4, 5), U(5, 4, 3, 2, 1), U(9, 9, 9, 9, 9)
+L.modmul_X25519_ct(a, b, c)                      # void modmul(const spint*, const spint*, spint*): nothing to return an error through
+st = L.modarith_amd_status()
+msg = L.modarith_amd_last_error().decode()
+L.modis0_X25519_ct.restype = ctypes.c_int
+r = L.modis0_X25519_ct(a)
+bk = (ctypes.c_char * 32)(); bv = (ctypes.c_char * 32)(*([b"x"] * 32))
+L.rfc7748_X25519(bk, bk, bv)
+print("status", st, "c", list(c), "pred", r, "bv", bytes(bv) == bytes(32), "msg", msg)
+L.modarith_amd_clear_status()
+assert L.modarith_amd_status() == 0
+''' % ROOT
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, (p.returncode, p.stdout[-500:], p.stderr[-2000:])
+    out = p.stdout.strip().splitlines()[-1]
+    assert out.startswith("status ") and int(out.split()[1]) != 0, out
+    assert "c [0, 0, 0, 0, 0]" in out and "pred 0" in out and "bv True" in out and "staging" in out, out

@@ -47,46 +47,6 @@ extern "C" void ecn_ed25519_dbl(pt25519*);
 extern "C" int ecn_ed25519_get(pt25519*, char* x, char* y);
 extern "C" void ecn_ed25519_set(int s, const char* x, const char* y, pt25519*);
 
-// fused ED25519 mul+get (csrc/ed26.h) against the oracle's ecn mul followed by ecn get, on random projective points
-// (random multiples of the generator, NOT normalised) and on the special points: neutral element, the point of order 2,
-// points of order 4 and 8 (decompressed from y = 0 and from a small-order y), scalars 0 / 1 / group order / all ones
-static int run_ed25519(int n) {
-    int bad = 0;
-    pt25519 base;
-    for (int it = 0; it < n; it++) {
-        pt25519 P;
-        unsigned char e[32], k[32];
-        for (int i = 0; i < 32; i++) { e[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
-        ecn_ed25519_gen(&P);
-        ecn_ed25519_mul((const char*)k, &P);             // random projective point
-        if (it % 16 == 1) ecn_ed25519_inf(&P);            // neutral element
-        if (it % 16 == 2) { char y[32]; memset(y, 0, 32); ecn_ed25519_set(0, nullptr, y, &P); }            // y = 0: order 4
-        if (it % 16 == 3) { char y[32]; memset(y, 0xff, 32); y[0] = 0x7f; y[31] = 0xec; ecn_ed25519_set(0, nullptr, y, &P); }  // y = -1: order 2
-        if (it % 16 == 4) ecn_ed25519_gen(&P);            // affine generator
-        if (it == 5) memset(e, 0, 32);
-        if (it == 6) { memset(e, 0, 32); e[31] = 1; }
-        if (it == 7) memset(e, 0xff, 32);
-        if (it == 8) { const unsigned char q[32] = {0x10,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0x14,0xde,0xf9,0xde,0xa2,0xf7,0x9c,0xd6,0x58,0x12,0x63,0x1a,0x5c,0xf5,0xd3,0xed}; memcpy(e, q, 32); }
-        if (it == 9) { memset(e, 0, 32); e[31] = 8; }
-        pt25519 Q = P;
-        uint64_t ew[4], xw[4], yw[4];
-        for (int w = 0; w < 4; w++) { uint64_t v = 0; for (int b = 0; b < 8; b++) v |= (uint64_t)e[31 - (8 * w + b)] << (8 * b); ew[w] = v; }
-        ma::ed25519_mul_get_one<ma::C_ED25519>(ew, P.x, P.y, P.z, xw, yw);
-        char wx[32], wy[32];
-        ecn_ed25519_mul((const char*)e, &Q);
-        ecn_ed25519_get(&Q, wx, wy);
-        unsigned char gx[32], gy[32];
-        for (int i = 0; i < 32; i++) { gx[i] = (unsigned char)(xw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); gy[i] = (unsigned char)(yw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); }
-        if (memcmp(gx, wx, 32) != 0 || memcmp(gy, wy, 32) != 0) {
-            if (bad < 6) printf("ed25519_mul_get_one: record %d differs\n", it);
-            bad++;
-        }
-    }
-    printf("ed25519_mul_get_one: %d records, %d differ from the oracle's ecn mul + get\n", n, bad);
-    (void)base;
-    return bad;
-}
-
 extern "C" void ecn_ed25519_mul2(const char* e, pt25519* P, const char* f, pt25519* Q, pt25519* R);
 
 // fused double multiplication + get against the oracle's ecn mul2 + ecn get
@@ -536,37 +496,6 @@ static int run_edgen(const char* name, int n, FN fused, GEN gen, MUL mul, GET ge
     return bad;
 }
 
-// e*G + f*Q on ED25519 (verification pattern) against the oracle's gen, mul2, get: Q random / neutral / small order / +-G
-static int run_ed25519_mulgen2(int n) {
-    int bad = 0;
-    for (int it = 0; it < n; it++) {
-        pt25519 G, Q, R;
-        unsigned char e[32], f[32], k[32];
-        for (int i = 0; i < 32; i++) { e[i] = (unsigned char)sm(); f[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
-        ecn_ed25519_gen(&G);
-        ecn_ed25519_gen(&Q); ecn_ed25519_mul((const char*)k, &Q);
-        if (it % 8 == 1) ecn_ed25519_inf(&Q);
-        if (it % 8 == 2) { char y[32]; memset(y, 0, 32); ecn_ed25519_set(0, nullptr, y, &Q); }            // order 4
-        if (it % 8 == 3) ecn_ed25519_gen(&Q);
-        if (it % 8 == 4) memset(e, 0, 32);
-        if (it % 8 == 5) memset(f, 0, 32);
-        if (it == 6) { memset(e, 0xff, 32); memset(f, 0xff, 32); }
-        pt25519 Q0 = Q;
-        uint64_t ew[4], fw[4], xw[4], yw[4];
-        for (int w = 0; w < 4; w++) { uint64_t v = 0, u = 0; for (int b = 0; b < 8; b++) { v |= (uint64_t)e[31 - (8 * w + b)] << (8 * b); u |= (uint64_t)f[31 - (8 * w + b)] << (8 * b); } ew[w] = v; fw[w] = u; }
-        ma::ed25519_mulgen2_get_one<ma::C_ED25519, HostComb25519>(ew, fw, Q.x, Q.y, Q.z, xw, yw);
-        char wx[32], wy[32];
-        ecn_ed25519_mul2((const char*)e, &G, (const char*)f, &Q0, &R);
-        ecn_ed25519_get(&R, wx, wy);
-        unsigned char gx[32], gy[32];
-        for (int i = 0; i < 32; i++) { gx[i] = (unsigned char)(xw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); gy[i] = (unsigned char)(yw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); }
-        if (memcmp(gx, wx, 32) != 0 || memcmp(gy, wy, 32) != 0) { if (bad < 6) printf("ed25519_mulgen2_get_one: record %d differs\n", it); bad++; }
-    }
-    printf("ed25519_mulgen2_get_one: %d records, %d differ from the oracle's ecn gen + mul2 + get\n", n, bad);
-    return bad;
-}
-
-
 // ---- round 5: the ladder form of the fused ED25519 multiplications (csrc/ed26l.h) against the oracle's ecn mul (+ mul2) + get.
 // The window form's complete formulas have no exceptional pair (P, e); the ladder + recovery has four classes of them
 // (P in {O, T2}; [e]P in {O, T2}; [e]P = -P), so the records are built to hit every class: P = [k]G + S for every S of the
@@ -1000,7 +929,6 @@ int main(int argc, char** argv) {
     bad += run_mhalf448(n * 25);
     bad += run_half_ov(n * 50);
     bad += run_fold52(n * 50);
-    bad += run_ed25519(n / 4 + 16);
     bad += run_ed25519_mul2(n / 8 + 16);
     bad += run_ed25519_lad("Ed26Lad::mul_get_one", n / 4 + 16, [](const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, uint64_t* xw, uint64_t* yw) { ma::Ed26Lad<ma::C_ED25519>::mul_get_one(ew, X, Y, Z, xw, yw); });
     bad += run_ed448(n / 16 + 16);
@@ -1024,7 +952,6 @@ int main(int argc, char** argv) {
                                       }, xw, yw);
                                       for (int k = 0; k < 4; k++) { x[k] = xw[2][k]; y[k] = yw[2][k]; }
                                   }, ecn_ed25519_gen, ecn_ed25519_mul, ecn_ed25519_get);
-    bad += run_ed25519_mulgen2(n / 8 + 24);
     bad += run_ed25519_mulgen2_lad(n / 8 + 24);
     struct HostPark { uint32_t w[64]; void put(int k, uint32_t v) { w[k] = v; } uint32_t get(int k) const { return w[k]; } };
     bad += run_edgen<56, pt448>("ed448_mulgen_get_two", n / 8 + 130, [](const uint64_t* e, uint64_t* x, uint64_t* y) {
