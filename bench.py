@@ -103,6 +103,42 @@ def time_c_protocol(lib, P):
     return out
 
 
+def cpu_quota_cores():
+    """the CPU time this process may use per second of wall clock, in cores: cgroup v2 cpu.max (or v1 cfs quota / period) of the
+    process's own cgroup and its ancestors, capped by the affinity mask; None when no quota is set.  The visible core count
+    (sched_getaffinity) overstates a container whose quota is smaller -- round 4's cpu_baseline.cores said 256 on a box whose
+    quota was about ten."""
+    quota = None
+    try:
+        rel = ""
+        for line in open("/proc/self/cgroup"):
+            parts = line.strip().split(":", 2)
+            if len(parts) == 3 and parts[0] == "0":
+                rel = parts[2]
+        path = os.path.normpath("/sys/fs/cgroup/" + rel.lstrip("/"))
+        while path.startswith("/sys/fs/cgroup"):
+            f = os.path.join(path, "cpu.max")
+            if os.path.exists(f):
+                q, per = open(f).read().split()[:2]
+                if q != "max":
+                    v = float(q) / float(per)
+                    quota = v if quota is None else min(quota, v)
+            if path == "/sys/fs/cgroup":
+                break
+            path = os.path.dirname(path)
+    except Exception:
+        pass
+    if quota is None:
+        try:                                                     # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return quota
+
+
 def cpu_baseline(a_host, b_host, min_seconds=6.0):
     """oracle (kind "port": CPU restatement of the reference's generated field.c, limb-exact against the
     reference's golden vectors) timed on the host cores: all-core modmul throughput over the same
@@ -111,7 +147,8 @@ def cpu_baseline(a_host, b_host, min_seconds=6.0):
     import numpy as np
     from tests.util import vp
     lib, cc, flags, built = _native_baseline_lib()
-    cores = len(os.sched_getaffinity(0))
+    cores = len(os.sched_getaffinity(0))          # threads started (what the affinity mask shows)
+    quota = cpu_quota_cores()                     # what the container may actually burn: `cores_usable` is the number to divide by
     n = a_host.shape[1]
     a, b = a_host, b_host
     c = np.empty_like(a)
@@ -149,7 +186,7 @@ def cpu_baseline(a_host, b_host, min_seconds=6.0):
     lib.oracle_parallel(3, vp(k), vp(u), vp(o), 256, 0, 1)       # one thread, for the effective parallelism
     l1 = 256 / (time.perf_counter() - t0)
     return {
-        "value": thr, "unit": "modmul/s", "cores": cores, "kind": "port",
+        "value": thr, "unit": "modmul/s", "cores": cores, "cpu_quota_cores": quota, "cores_usable": min(cores, quota) if quota else cores, "kind": "port",
         "sample": "oracle modmul_X25519 over the 2^%d-element workload (the GPU's own input arrays) x %d passes, %d threads, %.1f s wall" % (n.bit_length() - 1, passes, cores, dt),
         "compiler": cc, "flags": flags, "built": built,
         "time_c_protocol": dict(time_c, ns_per_modmul=lat * 1e9, modmul_per_s=1.0 / lat, cores=1, dependent_modmuls=10**8,
@@ -158,55 +195,50 @@ def cpu_baseline(a_host, b_host, min_seconds=6.0):
         "x25519_scalar_mults_per_s": m / ldt, "x25519_sample": "%d ladders, %d threads, %.1f s wall" % (m, cores, ldt),
         "x25519_one_thread_per_s": l1,
         "effective_parallelism": {"x25519": (m / ldt) / l1, "modmul": thr * lat,
-                                  "note": "all-thread rate / one-thread rate; well below `cores` when the host is shared or the CPU quota is smaller than the visible core count (modmul over 2 GB of SoA arrays is also DRAM-bound)"},
+                                  "note": "all-thread rate / one-thread rate; tracks cpu_quota_cores, not `cores`, when the container's CPU quota is smaller than the visible core count (modmul over 2 GB of SoA arrays is also DRAM-bound)"},
     }
 
 
-def valu_roofline(scalars_per_s_per_gpu, curve="X25519"):
-    """VALU-issue roofline of the ladder kernels.  The instruction counts per scalar multiplication come from the
-    committed PMC summary (profiles/, SQ_INSTS_VALU of one pass / scalars; round 3: the ladder kernel k_x25519_fe26_xz /
-    k_x448_fe28_xz plus the batched finish k_fe_finish<Fe26 / Fe28>); the rate is the one measured in THIS run.
-      achieved = scalars/s x wave-instructions per scalar (= per-lane instructions / 64 lanes)      [wave-instr/s]
-      peak     = 1024 SIMDs x 2.4 GHz / cost,  cost = (5.0 x mad + 2.5 x (instr - mad)) / instr     [wave-instr/s]
-    5.0 / 2.5 cycles per wave-instruction per SIMD: measured issue costs of v_mad_u64_u32 and of simple 32-bit ALU
-    instructions (profiles/r01_valubench.log); 2.4 GHz is the nominal peak clock, so frac is a lower bound when the
-    part clocks lower under this load (the PMC file records the clock seen during its pass)."""
-    for tag in ("r04", "r03", "r02", "r01g"):
-        path = os.path.join(ROOT, "profiles", "%s_valu_pmc.json" % tag)
-        if os.path.exists(path):
-            break
-    else:
+_VALU_DOC = {}
+
+
+def valu_roofline(leg, per_s_per_gpu, sclk_GHz=None):
+    """VALU-issue roofline of a VALU-bound leg (both ladders, ecn mul / mul2, the fused curve kernels).  Instruction counts per record
+    come from the committed counter summary of THIS tree's kernels (profiles/r05_valu_pmc.json, made by tools/gpu_r05_pmc.sh +
+    tools/collect_r05_pmc.py: SQ_INSTS_VALU of one pass of every kernel of the leg / records; the v_mad_u64_u32 share of each kernel
+    from its disassembly, tools/isa_mix.py); the rate is the one measured in THIS run, and so is the shader clock (modarith_amd/clock.py:
+    a one-wave probe beside the leg reads the shader-clock counter against the wall clock).
+      achieved = records/s x wave-instructions per record (= per-lane instructions / 64 lanes)          [wave-instr/s]
+      peak     = 1024 SIMDs x clock / cost,  cost = (5.0 x mad + 2.5 x (instr - mad)) / instr            [wave-instr/s]
+    5.0 / 2.5 cycles per wave-instruction per SIMD: measured issue costs of v_mad_u64_u32 and of simple 32-bit ALU instructions
+    (profiles/r01_valubench.log).  frac_at_2.4GHz prices the leg against the nominal peak clock (a lower bound when the part clocks
+    lower under this load), frac_at_measured_clock against the clock it actually held; `frac` is the former (rounds 2-4 reported it)."""
+    if "doc" not in _VALU_DOC:
+        path = os.path.join(ROOT, "profiles", "r05_valu_pmc.json")
+        _VALU_DOC["doc"] = json.load(open(path)) if os.path.exists(path) else None
+    doc = _VALU_DOC["doc"]
+    if not doc or leg not in doc.get("legs", {}):
         return None
-    doc = json.load(open(path))
-    if curve == "X448":
-        k, f = doc.get("k_x448_fe28_xz"), doc.get("k_fe_finish_fe28")
-        if not (k and f):
-            return None
-        instr = k["SQ_INSTS_VALU"] * 64.0 / k["scalars"] + f["SQ_INSTS_VALU"] * 64.0 / f["scalars"]
-        # multiply-adds per scalar from the ISA (tools/ct_audit.py's disassembly of capi_X448.o): 448 steps x 1354 v_mad_u64_u32 (2874 VALU
-        # instructions per step = the counter's 1 288 178 per scalar); finish: 3 multiplications (256 each) + 1/32 of an inversion (447 S x 136 + 13 M x 256)
-        mad = k.get("mad_per_scalar", 448 * 1354) + f.get("mad_per_scalar", 3 * 256 + (447 * 136 + 13 * 256) / 32.0)
-        kernels = "k_x448_fe28_xz + k_fe_finish<Fe28,16,7>"
-    elif "k_x25519_fe26_xz" in doc and "k_fe_finish_fe26" in doc:
-        k, f = doc["k_x25519_fe26_xz"], doc["k_fe_finish_fe26"]
-        instr = k["SQ_INSTS_VALU"] * 64.0 / k["scalars"] + f["SQ_INSTS_VALU"] * 64.0 / f["scalars"]
-        # multiply-adds per scalar from the ISA: 255 steps x 739; finish: 4 multiplications (101 each) + 1/32 of an inversion
-        mad = k.get("mad_per_scalar", 739 * 255) + f.get("mad_per_scalar", 4 * 101 + (254 * 56 + 11 * 101) / 32.0)
-        kernels = "k_x25519_fe26_xz + k_fe_finish<Fe26,10,4>"
-    else:
-        k = doc.get("k_x25519_fe26")
-        if not k:
-            return None
-        instr = k["SQ_INSTS_VALU"] * 64.0 / k["scalars"]          # per-lane VALU instructions per scalar multiplication
-        mad = k.get("mad_per_scalar", 739 * 255 + 11 * 100 + 254 * 55 + 100)
-        kernels = "k_x25519_fe26 (one inversion per lane: counters of the round-2 kernel)"
+    L = doc["legs"][leg]
+    instr, mad = L["instr_per_scalar"], L["mad_per_scalar"]
+    if not instr or not mad:
+        return None
     cost = (5.0 * mad + 2.5 * (instr - mad)) / instr
-    achieved = scalars_per_s_per_gpu * instr / 64.0
+    achieved = per_s_per_gpu * instr / 64.0
     peak = 1024 * 2.4e9 / cost
-    return {"bound": "valu", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s", "frac": achieved / peak,
-            "instr_per_scalar": instr, "mad_per_scalar": mad, "issue_cost_of_mix_cycles": cost, "kernels": kernels,
-            "cycles_per_instr": 1024 * 2.4e9 / achieved, "clock_GHz_assumed": 2.4, "source": "profiles/%s_valu_pmc.json" % tag,
-            "mad_only_ceiling_scalars_per_s": 1024 * 2.4e9 * 64 / (5.0 * mad)}
+    # the same mix priced at the ARCHITECTURAL issue rates -- 16 lanes per clock for the 64-bit multiply-add (4 cycles per wave, as fp64),
+    # 32 lanes per clock for 32-bit ALU instructions (2 cycles) -- at the measured clock: a ceiling no kernel can pass, whereas the
+    # micro-benchmarked 5.0 / 2.5 (isolated streams of one instruction, profiles/r01_valubench.log, r05_valubench.log: 4.6 / 2.5) are
+    # not additive in a mix and the ladder passes them by a few per cent when the clock sits low
+    cost_arch = (4.0 * mad + 2.0 * (instr - mad)) / instr
+    out = {"bound": "valu", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s", "frac": achieved / peak,
+           "frac_at_2.4GHz": achieved / peak, "frac_at_measured_clock": (achieved / (peak * sclk_GHz / 2.4)) if sclk_GHz else None,
+           "frac_of_architectural_issue_rate_at_measured_clock": (achieved / (1024 * sclk_GHz * 1e9 / cost_arch)) if sclk_GHz else None,
+           "sclk_GHz": sclk_GHz, "instr_per_scalar": instr, "mad_per_scalar": mad, "non_mad_per_mad": (instr - mad) / mad,
+           "issue_cost_of_mix_cycles": cost, "kernels": sorted(L["kernels"]), "cycles_per_instr_at_2.4GHz": 1024 * 2.4e9 / achieved,
+           "clock_GHz_nominal": 2.4, "source": "profiles/r05_valu_pmc.json", "static_over_measured_instr": L.get("static_over_measured"),
+           "mad_only_ceiling_per_s": 1024 * 2.4e9 * 64 / (5.0 * mad)}
+    return out
 
 
 def measure_traffic(timeout_s=240):
@@ -558,6 +590,11 @@ def main():
             del xa, xb, xc
         # the curve layer built on the path, one pass each: side figures (VALU-bound kernels)
         from modarith_amd.edwards import Curve
+        from modarith_amd.clock import timed_with_clock
+        last_clock = [None]
+
+        def vleg(key, rate):                                     # the VALU roofline of a curve leg, at the clock just measured
+            return valu_roofline(key, rate, last_clock[0]) or {"bound": "valu", "note": "no counter summary for this leg in profiles/r05_valu_pmc.json"}
         for cname, m in (("ED25519", 1 << 20), ("ED448", 1 << 19), ("SECP256K1", 1 << 19), ("NIST256", 1 << 19)):
             Cv = Curve(cname, dev)
             e = torch.randint(0, 256, (m, Cv.nbytes), dtype=torch.uint8, device=dev, generator=gen)
@@ -576,30 +613,25 @@ def main():
             def timed_leg(fn, reps=3, warm=2):
                 # median of `reps` calls, each between HIP events, after `warm` full-size calls: the first launches after a host-side
                 # pause run 3-13 % slower while the part brings its clocks back (tools/ecn_sustained.py: 2.67, 2.93, 3.08, 3.17 ...
-                # e7/s for P-256), and a single wall-clock call -- what this block timed until the end of round 4 -- reads exactly that
-                out = None
-                for _ in range(warm):
-                    out = fn()
-                ts = []
-                for _ in range(reps):
-                    a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a0.record()
-                    out = fn()
-                    a1.record()
-                    torch.cuda.synchronize()
-                    ts.append(a0.elapsed_time(a1) * 1e-3)
-                return sorted(ts)[len(ts) // 2], out
+                # e7/s for P-256), and a single wall-clock call -- what this block timed until the end of round 4 -- reads exactly that.
+                # One further call runs with the shader-clock probe beside it (modarith_amd/clock.py): last_clock[0] = GHz during the leg.
+                t, ghz, out = timed_with_clock(fn, reps=reps, warm=warm)
+                last_clock[0] = ghz
+                return t, out
 
             t_mul, Q = timed_leg(lambda: Cv.mul(e, G.clone()))                  # (the clone -- 3 x N x 8 bytes per point -- rides in the leg: < 0.1 %)
+            others["%s_ecn_mul" % cname] = {"scalar_mults_per_s_per_gpu": m / t_mul, "points": m, "bound": "VALU", "sclk_GHz": last_clock[0],
+                                            "roofline": vleg("%s_ecn_mul" % cname, m / t_mul)}
             t_mul2, R = timed_leg(lambda: Cv.mul2(e, G, f, Q))
-            others["%s_ecn_mul" % cname] = {"scalar_mults_per_s_per_gpu": m / t_mul, "points": m, "bound": "VALU"}
-            others["%s_ecn_mul2" % cname] = {"double_mults_per_s_per_gpu": m / t_mul2, "pairs": m, "bound": "VALU"}
+            others["%s_ecn_mul2" % cname] = {"double_mults_per_s_per_gpu": m / t_mul2, "pairs": m, "bound": "VALU", "sclk_GHz": last_clock[0],
+                                             "roofline": vleg("%s_ecn_mul2" % cname, m / t_mul2)}
             if cname in Cv.FUSED:
                 # the reference's call pattern ecnXXXmul + ecnXXXget (ed448.c:182-184): two-call form against the fused kernel
                 tf, (fx_, fy_, _) = timed_leg(lambda: Cv.mul_get(e, Q))
+                rl = vleg("%s_ecn_mul_get_fused" % cname, m / tf)
                 tw, (wx_, wy_, _) = timed_leg(lambda: Cv.get(Cv.mul(e, Q.clone())))
                 assert torch.equal(fx_, wx_) and torch.equal(fy_, wy_), "fused mul_get differs from mul + get"
-                others["%s_ecn_mul_get_fused" % cname] = {"scalar_mults_per_s_per_gpu": m / tf, "points": m, "bound": "VALU",
+                others["%s_ecn_mul_get_fused" % cname] = {"scalar_mults_per_s_per_gpu": m / tf, "points": m, "bound": "VALU", "sclk_GHz": rl.get("sclk_GHz"), "roofline": rl,
                                                           "two_call_form_per_s": m / tw, "speedup": tw / tf,
                                                           "bytes_equal_to_two_call_form": True}
                 del fx_, fy_, wx_, wy_
@@ -608,18 +640,20 @@ def main():
                 mq = m // 2
                 e2, f2, G2, Q2 = e[:mq].contiguous(), f[:mq].contiguous(), G[:, :, :mq].contiguous(), Q[:, :, :mq].contiguous()
                 tf, (fx_, fy_, _) = timed_leg(lambda: Cv.mul2_get(e2, G2, f2, Q2))
+                rl = vleg("%s_ecn_mul2_get_fused" % cname, mq / tf)
                 tw, (wx_, wy_, _) = timed_leg(lambda: Cv.get(Cv.mul2(e2, G2, f2, Q2)))
                 assert torch.equal(fx_, wx_) and torch.equal(fy_, wy_), "fused mul2_get differs from mul2 + get"
-                others["%s_ecn_mul2_get_fused" % cname] = {"double_mults_per_s_per_gpu": mq / tf, "pairs": mq, "bound": "VALU",
+                others["%s_ecn_mul2_get_fused" % cname] = {"double_mults_per_s_per_gpu": mq / tf, "pairs": mq, "bound": "VALU", "sclk_GHz": rl.get("sclk_GHz"), "roofline": rl,
                                                            "two_call_form_per_s": mq / tw, "speedup": tw / tf,
                                                            "bytes_equal_to_two_call_form": True}
                 del fx_, fy_, wx_, wy_, e2, f2, G2, Q2
             if cname in getattr(Cv, "FUSEDG", ()):
                 # key generation / signing opening ecnXXXgen + ecnXXXmul + ecnXXXget (nist256.c:150-161, ed448.c:167-184): fixed-base kernel
                 tf, (gx_, gy_, _) = timed_leg(lambda: Cv.mulgen_get(e))
+                rl = vleg("%s_ecn_mulgen_get_fused" % cname, m / tf)
                 tw, (wx_, wy_, _) = timed_leg(lambda: Cv.get(Cv.mul(e, Cv.gen(m))))
                 assert torch.equal(gx_, wx_) and torch.equal(gy_, wy_), "fused mulgen_get differs from gen + mul + get"
-                others["%s_ecn_mulgen_get_fused" % cname] = {"scalar_mults_per_s_per_gpu": m / tf, "scalars": m, "bound": "VALU",
+                others["%s_ecn_mulgen_get_fused" % cname] = {"scalar_mults_per_s_per_gpu": m / tf, "scalars": m, "bound": "VALU", "sclk_GHz": rl.get("sclk_GHz"), "roofline": rl,
                                                              "three_call_form_per_s": m / tw, "speedup": tw / tf,
                                                              "bytes_equal_to_three_call_form": True}
                 del gx_, gy_, wx_, wy_
@@ -628,9 +662,10 @@ def main():
                 mq = m // 2
                 e2, f2, Q2 = e[:mq].contiguous(), f[:mq].contiguous(), Q[:, :, :mq].contiguous()
                 tf, (vx_, vy_, _) = timed_leg(lambda: Cv.mulgen2_get(e2, f2, Q2))
+                rl = vleg("%s_ecn_mulgen2_get_fused" % cname, mq / tf)
                 tw, (wx_, wy_, _) = timed_leg(lambda: Cv.get(Cv.mul2(e2, Cv.gen(mq), f2, Q2)))
                 assert torch.equal(vx_, wx_) and torch.equal(vy_, wy_), "fused mulgen2_get differs from gen + mul2 + get"
-                others["%s_ecn_mulgen2_get_fused" % cname] = {"double_mults_per_s_per_gpu": mq / tf, "pairs": mq, "bound": "VALU",
+                others["%s_ecn_mulgen2_get_fused" % cname] = {"double_mults_per_s_per_gpu": mq / tf, "pairs": mq, "bound": "VALU", "sclk_GHz": rl.get("sclk_GHz"), "roofline": rl,
                                                               "three_call_form_per_s": mq / tw, "speedup": tw / tf,
                                                               "bytes_equal_to_three_call_form": True}
                 del vx_, vy_, wx_, wy_, e2, f2, Q2
@@ -678,14 +713,27 @@ def main():
         k = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)
         u = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)
         o = torch.empty_like(u)
-        rfc7748("X25519", k, u, out=o)                       # warm-up at full size (code objects, the split form's workspace)
+        # Timed like the curve legs since round 5 (two full-size warm passes, then the MEDIAN of five passes, each between HIP events
+        # on the launch stream): up to round 4 this leg was one warm pass and the wall clock over three, right behind the one-wave
+        # time.c legs that leave the part nearly idle for 0.3 s -- it read the clock ramp (driver run of round 4: 1.06e8/s where the
+        # same binary gives 1.17e8/s once warm).  The contract's barrier brackets the whole block; the shader clock during one further
+        # pass is measured by the probe of modarith_amd/clock.py and reported beside the rate.
+        from modarith_amd.clock import clock_during
+        rfc7748("X25519", k, u, out=o)                       # (code objects, the split form's workspace)
+        rfc7748("X25519", k, u, out=o)
         barrier()
-        reps = 3
-        t0 = time.perf_counter()
+        reps, lts = 5, []
         for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             rfc7748("X25519", k, u, out=o)
+            e1.record()
+            torch.cuda.synchronize()
+            lts.append(e0.elapsed_time(e1) * 1e-3)
+        lt = sorted(lts)[reps // 2]
+        lt_all = sorted(lts)
+        ladder_clock, _ = clock_during(lambda: rfc7748("X25519", k, u, out=o), lt, dev)
         barrier()
-        lt = (time.perf_counter() - t0) / reps
         my_lt = lt
         gather_ms = None
         m_all = m
@@ -710,7 +758,8 @@ def main():
                   "gather_GBps": (m_all * 32 / (gather_ms * 1e-3) / 1e9) if gather_ms else None,
                   "gather_payload_bytes": m_all * 32 if gather_ms else None,
                   "bound": "VALU 32-bit integer multiply-add issue (not HBM)",
-                  "roofline": valu_roofline(m / my_lt)}
+                  "timing": "median of %d event-timed passes after 2 full-size warm passes" % reps, "ms_per_pass_min": lt_all[0] * 1e3, "ms_per_pass_max": lt_all[-1] * 1e3,
+                  "sclk_GHz": ladder_clock, "roofline": valu_roofline("x25519", m / my_lt, ladder_clock)}
         if single:
             # public-key generation: the same function on the base point u = 9 (rfc7748.c:297-333), fixed-base kernel
             from modarith_amd.field import rfc7748_base
@@ -759,9 +808,11 @@ def main():
             k4 = torch.randint(0, 256, (m4, 56), dtype=torch.uint8, device=dev, generator=gen)
             u4 = torch.randint(0, 256, (m4, 56), dtype=torch.uint8, device=dev, generator=gen)
             o4 = torch.empty_like(u4)
-            t4 = leg(lambda: rfc7748("X448", k4, u4, out=o4), reps=2)
+            from modarith_amd.clock import timed_with_clock
+            t4, clk4, _ = timed_with_clock(lambda: rfc7748("X448", k4, u4, out=o4), reps=3, warm=2)
             x448 = {"value": m4 / t4, "unit": "X448 scalar-mults/s", "scalars_per_gpu": m4, "ms_per_pass": t4 * 1e3, "io_bytes_per_scalar": 168,
-                    "bound": "VALU 32-bit integer multiply-add issue (not HBM)", "roofline": valu_roofline(m4 / t4, "X448")}
+                    "timing": "median of 3 event-timed passes after 2 full-size warm passes", "sclk_GHz": clk4,
+                    "bound": "VALU 32-bit integer multiply-add issue (not HBM)", "roofline": valu_roofline("x448", m4 / t4, clk4)}
     # EVERY rank spot-checks its own timed outputs against the CPU oracle (checker only, outside every timed
     # region): first / last 4096 and a strided sample of the modmul batch and of the ladder records.  The verdicts are
     # AND-reduced over the ranks, so that one N-GPU line says whether all N devices computed the reference's results.

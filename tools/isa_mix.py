@@ -15,7 +15,7 @@ So the number of times each instruction executes per pass of the kernel body is 
   * an `if (i != 0)`-style region inside a loop (forward branch over part of the body) counts as executed every iteration
     (error 1 / trips on that region).
 
-Each instruction is put into a class (multiplier = v_mad_u64_u32 / v_mad_i64_i32 / v_mul_hi / v_mul_lo, 64-bit add / shift,
+Each instruction is put into a class (multiplier = v_mad_u64_u32 / v_mad_i64_i32; mul32 = v_mul_lo / v_mul_hi / 24-bit forms, true 64-bit adds, carry adds, 64-bit shifts,
 32-bit add, logic, select, move, compare, LDS, vector memory, scratch, scalar, wait / nop) and weighted by the product of the trip
 counts around it.  Issue cycles per class per wave and SIMD: 5.0 for the multiplier class, 2.5 for other VALU (profiles/r01_valubench.log:
 measured), listed per class so that a table like docs/kernels_field.md's "what is left in a ladder step" can be made for any kernel.
@@ -34,16 +34,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import ct_audit  # noqa: E402  (disassemble())
 
-MUL = ("v_mad_u64_u32", "v_mad_i64_i32", "v_mul_hi_u32", "v_mul_lo_u32", "v_mul_hi_i32", "v_mul_u32_u24", "v_mad_u32_u24", "v_mul_hi_u32_u24", "v_mad_u32_u16")
-CYCLES = {"multiplier": 5.0}          # every other VALU class: 2.5
+MUL = ("v_mad_u64_u32", "v_mad_i64_i32")        # the 32 x 32 + 64 multiply-add: the instruction the field products are made of
+MUL32 = ("v_mul_hi_u32", "v_mul_lo_u32", "v_mul_hi_i32", "v_mul_u32_u24", "v_mad_u32_u24", "v_mul_hi_u32_u24", "v_mad_u32_u16", "v_mul_i32_i24", "v_mad_i32_i24")
+CYCLES = {"multiplier": 5.0}          # every other VALU class: 2.5 (the two-cost model of bench.py valu_roofline, rounds 2-5)
 
 
 def classify(op):
     base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
     if base in MUL:
         return "multiplier"
-    if base.startswith(("v_add_co", "v_addc_co", "v_sub_co", "v_subb_co", "v_subrev_co", "v_subbrev_co", "v_lshl_add_u64", "v_add_u64")):
-        return "add64"
+    if base in MUL32:
+        return "mul32"
+    if base.startswith(("v_lshl_add_u64", "v_add_u64", "v_sub_u64")):
+        return "add_u64"
+    if base.startswith(("v_add_co", "v_addc_co", "v_sub_co", "v_subb_co", "v_subrev_co", "v_subbrev_co")):
+        return "add_carry"
     if base.startswith(("v_lshrrev_b64", "v_lshlrev_b64", "v_ashrrev_i64")):
         return "shift64"
     if base.startswith(("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_add3_u32", "v_lshl_add_u32", "v_add_lshl_u32", "v_add_nc", "v_sub_nc", "v_mad_u32")):
@@ -73,7 +78,7 @@ def classify(op):
     return "other"
 
 
-VALU_CLASSES = ("multiplier", "add64", "shift64", "add32", "shift32", "logic", "select", "move", "compare", "valu_other")
+VALU_CLASSES = ("multiplier", "mul32", "add_u64", "add_carry", "shift64", "add32", "shift32", "logic", "select", "move", "compare", "valu_other")
 
 
 def _imm(tok):
@@ -105,55 +110,96 @@ def loops_of(code):
     return sorted(heads.items(), key=lambda kv: (kv[0], -kv[1]))
 
 
+def _s32(v):
+    v &= 0xFFFFFFFF
+    return v - (1 << 32) if v >= (1 << 31) else v
+
+
 def trip_count(code, head, tail, inner):
-    """trip count of the loop [head, tail] from its scalar counter, or None.  inner: intervals of nested loops (skipped)"""
+    """trip count of the loop [head, tail] by running its scalar counter, or None.  inner: intervals of nested loops (skipped).
+    Counter = a register compared with an immediate (s_cmp / s_cmpk) whose compare decides a branch that LEAVES the loop (taken to
+    an address outside it, or the loop's last instruction falling out of it), stepped inside the loop by `s_add sX, sX, imm` or
+    through a temporary (`s_add sT, sX, imm` ... `s_mov sX, sT`); initial value from the last s_mov / s_movk in front of the head."""
     idx = {a: i for i, (a, _) in enumerate(code) if a is not None}
     body = [(a, t) for a, t in code if a is not None and head <= a <= tail and not any(h <= a <= e for h, e in inner)]
-    steps = {}
-    for a, t in body:
-        m = re.match(r"s_add_i32 (s\d+), \1, (-?\w+)$", t) or re.match(r"s_add_u32 (s\d+), \1, (-?\w+)$", t)
-        if m and _imm(m.group(2)) is not None:
-            v = _imm(m.group(2))
-            steps[m.group(1)] = v - (1 << 32) if v >= (1 << 31) else v
+    adds, movs = {}, {}
+    for k, (a, t) in enumerate(body):
+        m = re.match(r"s_(add|sub)_[iu]32 (s\d+), (s\d+), (-?\w+)$", t)
+        if m and _imm(m.group(4)) is not None:
+            st = _s32(_imm(m.group(4)))
+            adds[m.group(2)] = (m.group(3), -st if m.group(1) == "sub" else st, k)
             continue
         m = re.match(r"s_addk_i32 (s\d+), (-?\w+)$", t)
         if m and _imm(m.group(2)) is not None:
-            v = _imm(m.group(2))
-            steps[m.group(1)] = v - 65536 if v >= 32768 else v
+            v = _imm(m.group(2)) & 0xFFFF
+            adds[m.group(1)] = (m.group(1), v - 65536 if v >= 32768 else v, k)
             continue
-        m = re.match(r"s_sub_i32 (s\d+), \1, (-?\w+)$", t) or re.match(r"s_sub_u32 (s\d+), \1, (-?\w+)$", t)
-        if m and _imm(m.group(2)) is not None:
-            steps[m.group(1)] = -_imm(m.group(2))
+        m = re.match(r"s_mov_b32 (s\d+), (s\d+)$", t)
+        if m:
+            movs[m.group(1)] = (m.group(2), k)
+    steps = {}                                  # counter register -> (step, position of its update in the body)
+    for dst, (src, st, k) in adds.items():
+        if dst == src:
+            steps[dst] = (st, k)
+    for dst, (tmp, k) in movs.items():
+        if tmp in adds and adds[tmp][0] == dst and tmp != dst:
+            steps[dst] = (adds[tmp][1], k)
     best = None
-    for a, t in body:
-        m = re.match(r"s_cmpk?_(lg|eq|lt|gt|le|ge)_[iu]32 (s\d+), (-?\w+)$", t)
-        if not m or m.group(2) not in steps or _imm(m.group(3)) is None:
+    for k, (a, t) in enumerate(body):
+        m = re.match(r"s_cmpk?_(lg|eq|lt|gt|le|ge)_([iu])32 (s\d+), (-?\w+)$", t)
+        if not m or m.group(3) not in steps or _imm(m.group(4)) is None:
             continue
-        reg, bound, step = m.group(2), _imm(m.group(3)), steps[m.group(2)]
-        if bound >= (1 << 31):
-            bound -= 1 << 32
-        # init: the last s_mov / s_movk of the register in front of the loop head
+        op, sign, reg, bound = m.group(1), m.group(2), m.group(3), _imm(m.group(4))
+        if "cmpk" in t:
+            bound = (bound & 0xFFFF) - (65536 if (bound & 0x8000) and sign == "i" else 0)
+        bound = _s32(bound) if sign == "i" else bound & 0xFFFFFFFF
+        # the branch this compare decides: the next scc branch in the body
+        br = next(((a2, t2) for a2, t2 in body[k + 1:] if t2.startswith("s_cbranch_scc")), None)
+        if br is None:
+            continue
+        tg, on = _target(br[0], br[1]), br[1].startswith("s_cbranch_scc1")
+        if not (head <= tg <= tail):
+            exit_when = on                      # taken = leaves the loop
+        elif tg == head and br[0] == tail:
+            exit_when = not on                  # the back edge itself: falling through leaves the loop
+        else:
+            continue                            # an if () inside the body
         init = None
-        for j in range(idx[head] - 1, max(idx[head] - 4000, -1), -1):
+        for j in range(idx[head] - 1, -1, -1):
             mm = re.match(r"s_movk?_[ib]32 %s, (-?\w+)$" % reg, code[j][1])
             if mm and _imm(mm.group(1)) is not None:
-                init = _imm(mm.group(1))
-                if init >= (1 << 31):
-                    init -= 1 << 32
+                init = _s32(_imm(mm.group(1)))
+                break
+            mm = re.match(r"s_mov_b64 s\[(\d+):(\d+)\], (-?\w+)$", code[j][1])
+            if mm and _imm(mm.group(3)) is not None and int(mm.group(1)) <= int(reg[1:]) <= int(mm.group(2)):
+                init = _s32(_imm(mm.group(3))) if int(reg[1:]) == int(mm.group(1)) else (0 if _imm(mm.group(3)) >= 0 else -1)
                 break
             if re.match(r"s_\w+ %s[, ]" % reg, code[j][1]) and not code[j][1].startswith(("s_cmp", "s_cmpk")):
-                break                                           # some other definition: give up on this counter
-        if init is None or step == 0:
+                break
+        if init is None:
             continue
-        n = (bound - init) / step
-        if m.group(1) in ("lt", "gt", "le", "ge") and n != int(n):
-            n = int(n) + 1
-        if n == int(n) and n > 0 and (best is None or n > best):
-            best = int(n)
+        step, upd = steps[reg]
+        test = {"lg": lambda v: v != bound, "eq": lambda v: v == bound, "lt": lambda v: v < bound, "gt": lambda v: v > bound,
+                "le": lambda v: v <= bound, "ge": lambda v: v >= bound}[op]
+        v, n = init, 0
+        while n < 1000000:
+            n += 1
+            if upd < k:
+                v = _s32(v + step) if sign == "i" else (v + step) & 0xFFFFFFFF
+            scc = test(v if sign == "i" else v & 0xFFFFFFFF)
+            if upd > k:
+                v = _s32(v + step) if sign == "i" else (v + step) & 0xFFFFFFFF
+            if scc == exit_when:
+                break
+        else:
+            continue
+        if best is None or n > best:
+            best = n
     return best
 
 
-def analyse(code, trips_override=None):
+def analyse(code, trips_override=None, unknown_trips=1):
+    """unknown_trips: what a loop without a compile-time counter counts for (the `rounds` loops of the shared inversions: pass rounds)"""
     loops = loops_of(code)
     info = []
     for h, e in loops:
@@ -165,7 +211,11 @@ def analyse(code, trips_override=None):
             n = trip_count(code, h, e, inner)
             src = "counter"
         if n is None:
-            n, src = 1, "unknown (counted once)"
+            # (a `continue` inside a loop is a second backward branch, to the latch: it shows up as an interval inside the loop's own;
+            # only the outermost of nested counter-less intervals is given the caller's trip count)
+            nested = any(h2 <= h and e <= e2 and (h2, e2) != (h, e) and li2["source"] != "counter" for (h2, e2), li2 in zip(loops, info))
+            n = 1 if nested else unknown_trips
+            src = "unknown (counted %d x)" % n
         info.append({"head": key, "tail": "%05x" % e, "trips": n, "source": src, "instructions": sum(1 for a, _ in code if a is not None and h <= a <= e)})
     counts, static = {}, {}
     for a, t in code:

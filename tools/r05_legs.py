@@ -1,0 +1,39 @@
+"""The VALU-bound legs of bench.py and the kernels each one launches (round 5): shared by tools/run_r05_legs.py (one pass of every leg, the
+target of the counter passes), tools/collect_r05_pmc.py (counters -> profiles/r05_valu_pmc.json) and, through that file only, bench.py.
+A kernel entry: (substring of the demangled kernel name, object file glob under modarith_amd/build, records per pass of the kernel
+body: 1 unless a lane handles several records per outer iteration, loops without a compile-time trip count: "rounds" = the shared
+inversions' per-lane element count, else 1)."""
+
+LOG2 = {"x25519": 21, "x448": 19, "ED25519": 19, "ED448": 18, "NIST256": 19, "SECP256K1": 19}
+
+
+def legs():
+    out = {
+        "x25519": [("k_x25519_fe26_xz", "capi_X25519.o", 1, 1), ("k_fe_finish<ma::Fe26", "capi_X25519.o", 1, "rounds")],
+        "x448": [("k_x448_fe28_xz", "capi_X448.o", 1, 1), ("k_fe_finish<ma::Fe28", "capi_X448.o", 1, "rounds")],
+    }
+    for C, obj, low, g, fam in (("ED25519", "capi_ED25519", "ed25519", 4, "Edwards"), ("ED448", "capi_ED448", "ed448", 2, "Edwards"),
+                                ("NIST256", "capi_NIST256W", "nist256", 4, "Weierstrass"), ("SECP256K1", "capi_SECP256K1W", "secp256k1", 4, "Weierstrass")):
+        base = "capi_" + C
+        out[C + "_ecn_mul"] = [("k_ed_mul<ma::%s<ma::C_%s," % (fam, C), obj + "_part1.o", 1, 1)]
+        out[C + "_ecn_mul2"] = [("k_ed_mul2<ma::%s<ma::C_%s," % (fam, C), obj + "_part2.o", 1, 1)]
+        if C == "ED25519":
+            out[C + "_ecn_mul_get_fused"] = [("k_ed26l_prep<ma::C_ED25519, 1>", base + "F.o", 1, 1), ("SinkWords<4>, 1>", base + "F.o", 1, "rounds"),
+                                             ("SinkExport25519, 1>", base + "F.o", 1, "rounds"), ("k_ed25519_lad(", base + "F.o", 1, 1)]
+            out[C + "_ecn_mulgen2_get_fused"] = [("k_ed26l_prep<ma::C_ED25519, 2>", base + "G.o", 1, 1), ("SinkWords<4>, 2>", base + "G.o", 1, "rounds"),
+                                                 ("SinkExport25519, 2>", base + "G.o", 1, "rounds"), ("k_ed25519_lad_gen2", base + "G.o", 1, 1)]
+        else:
+            out[C + "_ecn_mul_get_fused"] = [("k_%s_mul_get" % low, base + "F.o", 1, 1)]
+            out[C + "_ecn_mulgen2_get_fused"] = [("k_%s_mulgen2_get" % low, base + "G.o", 1, 1)]
+        out[C + "_ecn_mul2_get_fused"] = [("k_%s_mul2_get" % low, base + "F2.o", 1, 1)]
+        out[C + "_ecn_mulgen_get_fused"] = [("k_%s_mulgen_get" % low, base + "G.o", g, 1)]
+    return out
+
+
+def records(leg):
+    """records one pass of tools/run_r05_legs.py hands to the leg"""
+    if leg in ("x25519", "x448"):
+        return 1 << LOG2[leg]
+    C = leg.split("_")[0]
+    n = 1 << LOG2[C]
+    return n // 2 if ("mul2_get" in leg or "mulgen2_get" in leg) else n

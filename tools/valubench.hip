@@ -14,8 +14,11 @@ constexpr int UNR = 16;      // instructions per trip (8 independent chains x 2)
 #define BODY8(stmt) stmt(0) stmt(1) stmt(2) stmt(3) stmt(4) stmt(5) stmt(6) stmt(7)
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k(uint64_t* out, uint32_t seed) {
+__global__ __launch_bounds__(256) void k(uint64_t* out, uint32_t seed, uint64_t* clk = nullptr) {
     uint32_t a = seed + threadIdx.x, b = seed * 3 + threadIdx.x * 7;
+    // round 5: the shader-clock counter (s_memtime) and the constant-rate wall clock (s_memrealtime) around the loop, so that the
+    // cost of an instruction comes out in CYCLES OF THE CLOCK THE PART HELD, not in nanoseconds x a nominal 2.4 GHz
+    const uint64_t c0 = clock64(), w0 = wall_clock64();
     uint64_t acc[8];
     uint32_t r[8];
     double d[8];
@@ -109,26 +112,38 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, uint32_t seed) {
     }
     uint64_t s = 0;
     for (int i = 0; i < 8; i++) s += acc[i] + r[i] + (uint64_t)d[i];
+    const uint64_t c1 = clock64(), w1 = wall_clock64();
+    if (clk && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
 template <int KIND> void run(const char* name, uint64_t* out) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     int configs[2][2] = {{256 * 8, 256}, {256, 256}};   // 8 waves/SIMD; 1 wave/SIMD
-    double cyc[2];
+    double cyc[2], real[2], ghz[2];
+    static uint64_t* clk = nullptr;
+    static int khz = 0;
+    if (!clk) { CK(hipMalloc(&clk, 16)); CK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0)); }
     for (int c = 0; c < 2; c++) {
         int blocks = configs[c][0];
         k<KIND><<<blocks, 256>>>(out, 1); CK(hipDeviceSynchronize());
+        for (int rep = 0; rep < 40; rep++) k<KIND><<<blocks, 256>>>(out, rep);      // (warm: let the clock settle under this instruction)
         CK(hipEventRecord(e0));
-        for (int rep = 0; rep < 5; rep++) k<KIND><<<blocks, 256>>>(out, rep);
+        for (int rep = 0; rep < 5; rep++) k<KIND><<<blocks, 256>>>(out, rep, clk);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
         // waves per SIMD executed in sequence = blocks*4 waves / (256 CUs * 4 SIMDs)
         double waves_per_simd = blocks * 4.0 / 1024.0;
         double instr = (double)ITER * UNR * waves_per_simd;
         cyc[c] = ms * 1e-3 * 2.4e9 / instr;    // cycles (at nominal 2.4 GHz) per wave-instruction per SIMD
+        uint64_t h[2];
+        CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+        // one wave of the middle block: its lifetime in shader cycles / the instructions its SIMD issued meanwhile (all waves resident at once)
+        real[c] = (double)h[0] / ((double)ITER * UNR * waves_per_simd);
+        ghz[c] = h[1] ? (double)h[0] / (double)h[1] * khz * 1e3 / 1e9 : 0.0;
     }
-    printf("%-22s  %6.2f cyc/instr @8 waves/SIMD   %6.2f cyc/instr @1 wave/SIMD\n", name, cyc[0], cyc[1]);
+    printf("%-22s  %6.2f cyc/instr @8 waves/SIMD   %6.2f cyc/instr @1 wave/SIMD   | at the measured clock: %5.2f (%.3f GHz)  %5.2f (%.3f GHz)\n",
+           name, cyc[0], cyc[1], real[0], ghz[0], real[1], ghz[1]);
     fflush(stdout);
 }
 
