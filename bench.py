@@ -710,8 +710,25 @@ def main():
             m = hi - lo
         else:
             m = 1 << LOG2_LADDER
-        k = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)
-        u = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)
+        if args.scaling == "strong":
+            # the records of the whole job are a function of their GLOBAL index (splitmix64 of (stream, index, word)), so that N ranks
+            # working on [lo, hi) and one rank working on [0, total) multiply the same records: the gathered bytes of an N-rank run
+            # must equal those of a one-rank run (x25519.records_sha256; tests/test_gpu_bench.py runs 8 ranks against 1)
+            def records(stream, lo_, hi_):
+                M = (1 << 64) - 1
+                def s64(v):                                    # two's-complement int64 of a 64-bit constant
+                    v &= M
+                    return v - (1 << 64) if v >= (1 << 63) else v
+                idx = torch.arange(lo_, hi_, dtype=torch.int64, device=dev).repeat_interleave(4) * 4 + torch.arange(4, dtype=torch.int64, device=dev).repeat(hi_ - lo_)
+                z = (idx + 1 + (stream << 40)) * s64(0x9E3779B97F4A7C15)
+                z = (z ^ ((z >> 30) & ((1 << 34) - 1))) * s64(0xBF58476D1CE4E5B9)
+                z = (z ^ ((z >> 27) & ((1 << 37) - 1))) * s64(0x94D049BB133111EB)
+                z = z ^ ((z >> 31) & ((1 << 33) - 1))
+                return z.view(torch.uint8).reshape(hi_ - lo_, 32).contiguous()
+            k, u = records(1, lo, hi), records(2, lo, hi)
+        else:
+            k = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)
+            u = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=gen)
         o = torch.empty_like(u)
         # Timed like the curve legs since round 5 (two full-size warm passes, then the MEDIAN of five passes, each between HIP events
         # on the launch stream): up to round 4 this leg was one warm pass and the wall clock over three, right behind the one-wave
@@ -737,6 +754,10 @@ def main():
         my_lt = lt
         gather_ms = None
         m_all = m
+        records_sha = None
+        if not use_dist and args.scaling == "strong":
+            import hashlib
+            records_sha = hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest()
         if use_dist:
             from modarith_amd.dist import gather_records
             payload = o if backend == "nccl" else o.cpu()
@@ -750,10 +771,13 @@ def main():
             gather_ms = (time.perf_counter() - t0) * 1e3
             if rank == 0:
                 assert allv.shape[0] == m_all and torch.equal(allv[:m].to(o.device), o)
+                import hashlib
+                records_sha = hashlib.sha256(allv.cpu().numpy().tobytes()).hexdigest()
             del allv
             lt, gather_ms = max_over_ranks([lt, gather_ms])
         ladder = {"value": m_all / lt, "unit": "X25519 scalar-mults/s", "scalars_per_gpu": m, "scalars_total": m_all, "ms_per_pass": lt * 1e3,
-                  "scaling": args.scaling,
+                  "scaling": args.scaling, "shard": [lo, hi] if args.scaling == "strong" else None,
+                  "records_sha256": records_sha,      # strong scaling: all results in global index order (gathered to rank 0): the same for every N
                   "gather_ms": gather_ms, "io_bytes_per_scalar": 96,
                   "gather_GBps": (m_all * 32 / (gather_ms * 1e-3) / 1e9) if gather_ms else None,
                   "gather_payload_bytes": m_all * 32 if gather_ms else None,
@@ -862,7 +886,8 @@ def main():
             "pci_bus_id": ("%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), bus, getattr(props, "pci_device_id", 0))) if bus is not None else None,
             "uuid": str(getattr(props, "uuid", "")) or None,
             "modmul_per_s": n * args.steps / my_dt, "kernel_ms": my_kern_ms, "hbm_GBps": BYTES_PER_MODMUL * n / (my_kern_ms * 1e-3) / 1e9,
-            "x25519_per_s": (k.shape[0] / my_lt) if my_lt else None, "x25519_records": k.shape[0] if my_lt else None, "verified_against_oracle": my_ok}
+            "x25519_per_s": (k.shape[0] / my_lt) if my_lt else None, "x25519_records": k.shape[0] if my_lt else None,
+            "x25519_shard": ([lo, hi] if (my_lt and args.scaling == "strong") else None), "verified_against_oracle": my_ok}
     ranks = [mine]
     dist_info = None
     if use_dist:

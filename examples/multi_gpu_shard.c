@@ -10,7 +10,10 @@
  * (rfc7748.c:271-283) on EVERY device.
  *
  *   gcc -O2 -pthread examples/multi_gpu_shard.c -Iinclude -Lmodarith_amd -l:libmodarith_amd.so \
- *       -Wl,-rpath,$PWD/modarith_amd -o examples/multi_gpu_shard && examples/multi_gpu_shard [log2 records] [devices] [out.bin]
+ *       -Wl,-rpath,$PWD/modarith_amd -o examples/multi_gpu_shard && examples/multi_gpu_shard [log2 records] [devices] [out.bin] [--oversubscribe]
+ * --oversubscribe: `devices` host threads whatever the number of GPUs, thread i on device i mod count -- eight shards on a
+ * one-GPU box drive the library's per-device staging buffer, scratch pool and streams from eight threads at once (round 5: the
+ * eight-way run before there are eight GPUs).
  */
 #include <pthread.h>
 #include <stdint.h>
@@ -23,7 +26,7 @@
 #define Nbytes 32
 
 typedef struct {
-    int dev, rc;
+    int dev, rc, shard;
     size_t off, cnt;            /* the shard [off, off + cnt) */
     const char *bk, *bu;        /* page-locked host records (whole job) */
     char *bv;
@@ -86,9 +89,13 @@ out:
 
 int main(int argc, char **argv) {
     const int lg = argc > 1 ? atoi(argv[1]) : 16;
-    int ndev = modarith_amd_device_count();
-    if (argc > 2 && atoi(argv[2]) > 0 && atoi(argv[2]) < ndev) ndev = atoi(argv[2]);
-    if (ndev < 1) { puts("no GPU"); return 2; }
+    const int gpus = modarith_amd_device_count();
+    int oversubscribe = 0;
+    for (int i = 1; i < argc; i++)
+        if (!strcmp(argv[i], "--oversubscribe")) { oversubscribe = 1; for (int j = i; j + 1 < argc; j++) argv[j] = argv[j + 1]; argc--; i--; }
+    int ndev = gpus;                                                             /* = number of shards = number of host threads */
+    if (argc > 2 && atoi(argv[2]) > 0 && (atoi(argv[2]) < ndev || oversubscribe)) ndev = atoi(argv[2]);
+    if (gpus < 1) { puts("no GPU"); return 2; }
     if (ndev > 64) ndev = 64;
     const size_t n = (size_t)1 << lg;
     void *hk, *hu, *hv;
@@ -113,7 +120,8 @@ int main(int argc, char **argv) {
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int d = 0; d < ndev; d++) {
-        sh[d].dev = d;
+        sh[d].dev = d % gpus;
+        sh[d].shard = d;
         sh[d].off = n * (size_t)d / (size_t)ndev;                              /* contiguous index blocks */
         sh[d].cnt = n * (size_t)(d + 1) / (size_t)ndev - sh[d].off;
         sh[d].bk = bk; sh[d].bu = bu; sh[d].bv = bv;
@@ -127,14 +135,16 @@ int main(int argc, char **argv) {
     char want[Nbytes];
     from_hex("8520f0098930a754748b7ddcb43ef75a0dbf3a0d26381af4eba4a98eaa9b4e6a", want);
     for (int d = 0; d < ndev; d++) {
-        if (sh[d].rc) { printf("device %d: %s\n", d, sh[d].err); bad = 1; }
-        else if (memcmp(sh[d].vec, want, Nbytes)) { printf("device %d: RFC 7748 test vector differs\n", d); bad = 1; }
-        else printf("device %d: records [%zu, %zu) ok, RFC 7748 vector ok\n", d, sh[d].off, sh[d].off + sh[d].cnt);
+        if (sh[d].rc) { printf("shard %d on device %d: %s\n", d, sh[d].dev, sh[d].err); bad = 1; }
+        else if (memcmp(sh[d].vec, want, Nbytes)) { printf("shard %d on device %d: RFC 7748 test vector differs\n", d, sh[d].dev); bad = 1; }
+        else printf("shard %d on device %d: records [%zu, %zu) ok, RFC 7748 vector ok\n", d, sh[d].dev, sh[d].off, sh[d].off + sh[d].cnt);
     }
     uint64_t h = 0xcbf29ce484222325ull;
     for (size_t i = 0; i < n * Nbytes; i++) { h ^= (unsigned char)bv[i]; h *= 0x100000001b3ull; }
-    printf("devices %d records %zu seconds %.3f rate %.3e per s (first call on each device included) digest %016llx\n", ndev, n, dt, (double)n / dt,
+    if (modarith_amd_status() != 0) { printf("a scalar entry point recorded error %d: %s\n", modarith_amd_status(), modarith_amd_last_error()); bad = 1; }
+    printf("devices %d records %zu seconds %.3f rate %.3e per s (first call on each device included) digest %016llx\n", ndev < gpus ? ndev : gpus, n, dt, (double)n / dt,
            (unsigned long long)h);
+    if (oversubscribe) printf("oversubscribed: %d shards on %d device(s)\n", ndev, gpus);
     if (argc > 3) {                                                              /* the bytes, for a checker */
         FILE *f = fopen(argv[3], "wb");
         if (!f || fwrite(bk, 1, n * Nbytes, f) != n * Nbytes || fwrite(bu, 1, n * Nbytes, f) != n * Nbytes || fwrite(bv, 1, n * Nbytes, f) != n * Nbytes) bad = 1;

@@ -1,53 +1,60 @@
 // modarith_amd/csrc/capi_ED25519F2.hip -- ecn_ed25519_mul2_get_batch: double multiplication e*P + f*Q fused with the
-// affine export (csrc/ed26.h), the verification pattern ecnXXXmul2 + ecnXXXget of the reference's signature code
+// affine export (csrc/ed26s.h: the Straus form), the verification pattern ecnXXXmul2 + ecnXXXget of the reference's signature code
 // (ed448.c:305, nist256.c:251-254).
 #include "../../include/modarith_amd.h"
 #include "capi_common.h"
 #include "generated/curve_ED25519.h"
 #include "kernels.h"
 #include "ed26.h"
+#include "ed26s.h"
+#include "ed26l_k.h"
 
 namespace ma {
 
-// P's table entries in registers, Q's parked in LDS (ed26.h Park24Lds), both recoded scalars in LDS (four 2-bit windows per byte),
-// element index formed at use: see capi_ED25519F.hip
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_ed25519_mul2_get(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb,
-                        int* sign, size_t n, size_t ld) {
+// round 5, the Straus form (csrc/ed26s.h): signed 4-bit windows of both scalars, the two 9-entry tables in the wave's slab of the
+// workspace (one 128-byte line per entry and lane, read by index), the recoded scalars in LDS, the Edwards (X : Y : Z) of the sum to
+// the shared inversion of ed26l_k.h.  Records first .. first + ws.m of the caller's arrays.
+#ifndef MA_STRAUS_WAVES
+#define MA_STRAUS_WAVES 2
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MA_STRAUS_WAVES, MA_STRAUS_WAVES)))
+void k_ed25519_mul2_straus(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, size_t first, size_t ld,
+                           uint64_t* slab, Ed26lWs ws) {
     using P = P_X25519;
-    __shared__ unsigned char digs[2 * 33 * 64];
-    __shared__ uint64_t parked[24 * 64];
+    using S = Ed26Straus<C_ED25519>;
+    __shared__ unsigned char digs[2 * 65 * 64];
     unsigned char* ce = digs + threadIdx.x;
-    unsigned char* cf = ce + 33 * 64;
-    Park24Lds park{parked + threadIdx.x};
-    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
+    unsigned char* cf = ce + 65 * 64;
+    StrausTabSlab tab{slab + ((size_t)blockIdx.x * 64 + threadIdx.x) * (18 * 16)};
+    for (size_t base = (size_t)blockIdx.x * 64; base < ws.m; base += (size_t)gridDim.x * 64) {
         auto t = [&]() {
             unsigned l = threadIdx.x;
             asm volatile("" : "+v"(l));
             return base + l;
         };
-        if (t() >= n) continue;
+        if (t() >= ws.m) continue;
         {
-            spint ew[4];
-            load_be_record<P>(e, t(), ew);
-            W25519_2Lds::fill(ew, ce);
-            load_be_record<P>(f, t(), ew);
-            W25519_2Lds::fill(ew, cf);
+            spint w[4];
+            load_be_record<P>(e, first + t(), w);
+            W25519_4Lds::fill(w, ce);
+            load_be_record<P>(f, first + t(), w);
+            W25519_4Lds::fill(w, cf);
         }
-        spint PX[5], PY[5], PZ[5], QX[5], QY[5], QZ[5], xw[4], yw[4];
-        static_for<0, 5>([&](auto I) {
-            PX[I] = Pb[(size_t)I * ld + t()];
-            PY[I] = Pb[(size_t)(5 + I) * ld + t()];
-            PZ[I] = Pb[(size_t)(10 + I) * ld + t()];
-            QX[I] = Qb[(size_t)I * ld + t()];
-            QY[I] = Qb[(size_t)(5 + I) * ld + t()];
-            QZ[I] = Qb[(size_t)(10 + I) * ld + t()];
-        });
-        W25519_2Lds de{ce}, df{cf};
-        ed25519_mul2_get_dig<C_ED25519>(de, PX, PY, PZ, df, QX, QY, QZ, park, xw, yw);
-        if (xb) store_be_record<P>(xb, t(), xw);
-        if (yb) store_be_record<P>(yb, t(), yw);
-        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+#pragma unroll 1
+        for (int which = 0; which < 2; which++) {
+            const spint* B = which ? Qb : Pb;
+            spint X[5], Y[5], Z[5];
+            static_for<0, 5>([&](auto I) {
+                X[I] = B[(size_t)I * ld + first + t()];
+                Y[I] = B[(size_t)(5 + I) * ld + first + t()];
+                Z[I] = B[(size_t)(10 + I) * ld + first + t()];
+            });
+            S::build(tab, which, X, Y, Z);
+        }
+        W25519_4Lds de{ce}, df{cf};
+        S::Ext R;
+        S::walk(de, df, tab, R);
+        ed26l_store_xyz(ws, t(), R.X, R.Y, R.Z);
     }
 }
 
@@ -55,19 +62,46 @@ void k_ed25519_mul2_get(const unsigned char* e, const spint* Pb, const unsigned 
 
 using namespace ma;
 
-extern "C" size_t ecn_ed25519_mul2_get_workspace_bytes(size_t) { return 0; }      // both tables live in registers
+static size_t straus_waves(size_t n) {
+    const size_t w = (n + 63) / 64, cap = (size_t)MA_STRAUS_WAVES * 1024;
+    return w < cap ? w : cap;
+}
+
+extern "C" size_t ecn_ed25519_mul2_get_workspace_bytes(size_t n) {
+    const size_t m = n < ED26L_CHUNK ? n : ED26L_CHUNK;
+    return straus_waves(m) * STRAUS_SLAB_BYTES_PER_WAVE + ed26l_workspace_bytes(n);
+}
 
 extern "C" int ecn_ed25519_mul2_get_batch(const char* e, const ma_spint* P, const char* f, const ma_spint* Q, char* x, char* y, int* sign,
-                                          size_t n, size_t ld, void* /*workspace*/, size_t /*workspace_bytes*/, void* st) {
+                                          size_t n, size_t ld, void* workspace, size_t workspace_bytes, void* st) {
     if (n == 0) return 0;
     if ((reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 7u) {
         set_error("ecn mul2_get: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
     }
-    const size_t lanes = (n + 63) / 64 * 64;
-    const size_t cap = (size_t)2 * 1024 * 64;
-    k_ed25519_mul2_get<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(
-        reinterpret_cast<const unsigned char*>(e), P, reinterpret_cast<const unsigned char*>(f), Q, reinterpret_cast<unsigned char*>(x),
-        reinterpret_cast<unsigned char*>(y), sign, n, ld);
-    return check_launch("ecn mul2_get");
+    {
+        hipStream_t s = (hipStream_t)st;
+        const size_t need = ecn_ed25519_mul2_get_workspace_bytes(n);
+        void* own = nullptr;
+        void* wsp = (workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 127u) == 0) ? workspace : (own = scratch_alloc(need, s));
+        if (!wsp) {
+            set_error("ecn mul2_get: no workspace (pass ecn_ed25519_mul2_get_workspace_bytes(n) bytes, 128-byte aligned; the library's own scratch pool is not available while the stream is being captured)");
+            return (int)hipErrorInvalidValue;
+        }
+        const unsigned char *eb = reinterpret_cast<const unsigned char*>(e), *fb = reinterpret_cast<const unsigned char*>(f);
+        for (size_t first = 0; first < n; first += ED26L_CHUNK) {
+            const size_t m = n - first < ED26L_CHUNK ? n - first : ED26L_CHUNK;
+            const size_t waves = straus_waves(m);
+            uint64_t* slab = reinterpret_cast<uint64_t*>(wsp);
+            Ed26lWs ws(reinterpret_cast<unsigned char*>(wsp) + straus_waves(n < ED26L_CHUNK ? n : ED26L_CHUNK) * STRAUS_SLAB_BYTES_PER_WAVE, m);
+            size_t L;
+            int rounds;
+            ed26l_rounds(m, &L, &rounds);
+            k_ed25519_mul2_straus<<<(unsigned)waves, 64, 0, s>>>(eb, P, fb, Q, first, ld, slab, ws);
+            k_fe_batch_div<Fe26, 10, 4, SinkExport25519, 3><<<(unsigned)((L + 63) / 64), 64, 0, s>>>(
+                ws.A, ws.B, ws.Cn, ws.wc, m, L, rounds, SinkExport25519{reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, first});
+        }
+        if (own) scratch_free(own, s);
+        return check_launch("ecn mul2_get (Straus form)");
+    }
 }

@@ -154,203 +154,13 @@ struct Ed26 {
     }
 };
 
-// ---- where the recoded scalar of the double multiplication comes from (round 4; see ed28.h): Regs = shift registers in VGPRs (host
-// check), Lds = four 2-bit windows per byte in the lane's column of an LDS array, written before the point is loaded.  window(i) for
-// i = 0, 1, 2, ... in order.  (The 3-bit windows of the single multiplication went with it in round 5: ed26l.h.)
-struct W25519_2Regs {                       // e' = e + sum_{i<129} 2*4^i (258 bits), window 128 first
-    uint64_t w[5];
-    MA_DEV void init(const uint64_t* in) {
-        constexpr auto cw = [](int k) {
-            uint64_t v = 0;
-            for (int b = 0; b < 64; b++) {
-                const int pos = 64 * k + b;
-                if (pos < 258 && pos % 2 == 1) v |= (uint64_t)1 << b;
-            }
-            return v;
-        };
-        unsigned __int128 acc = 0;
-        uint64_t s[5];
-        static_for<0, 5>([&](auto K) {
-            constexpr int k = K;
-            acc += (unsigned __int128)(k < 4 ? in[k < 4 ? k : 0] : 0) + cw(k);
-            s[k] = (uint64_t)acc;
-            acc >>= 64;
-        });
-        w[4] = (s[4] << 62) | (s[3] >> 2);
-        w[3] = (s[3] << 62) | (s[2] >> 2);
-        w[2] = (s[2] << 62) | (s[1] >> 2);
-        w[1] = (s[1] << 62) | (s[0] >> 2);
-        w[0] = s[0] << 62;
-    }
-    MA_DEV uint32_t window(int) {
-        const uint32_t win = (uint32_t)(w[4] >> 62);
-        w[4] = (w[4] << 2) | (w[3] >> 62);
-        w[3] = (w[3] << 2) | (w[2] >> 62);
-        w[2] = (w[2] << 2) | (w[1] >> 62);
-        w[1] = (w[1] << 2) | (w[0] >> 62);
-        w[0] <<= 2;
-        return win;
-    }
-};
-struct W25519_2Lds {                        // four windows per byte, 33 bytes per scalar and lane
-    const unsigned char* col;
-    static MA_DEV void fill(const uint64_t* in, unsigned char* col) {
-        W25519_2Regs r;
-        r.init(in);
-#pragma unroll 1
-        for (int q = 0; q < 33; q++) {
-            unsigned b = 0;
-#pragma unroll
-            for (int h = 0; h < 4; h++) b |= (4 * q + h < 129 ? r.window(0) : 0u) << (2 * h);
-            col[(size_t)q * 64] = (unsigned char)b;
-        }
-    }
-    MA_DEV uint32_t window(int i) const { return ((uint32_t)col[(size_t)(i >> 2) * 64] >> (2 * (i & 3))) & 3u; }
-};
-
-// ---- where the upper half of the 4-entry window table lives (round 4).  The table of canonical packed entries takes 96 VGPRs; with the
-// accumulator, the addition's temporaries and the products' columns next to it the window loop of round 3 ran at 255 VGPRs plus 87
-// scratch accesses per window.  Entries 1P, 2P stay in registers; 3P, 4P (24 words) are PARKED: the kernels keep them in LDS
-// ([word][64 lanes] of 64-bit words: 12 KB per wave, conflict-free ds_read_b64), the host check in a plain array.
-struct Park24Regs {
-    uint64_t w[24];
-    MA_DEV void put(int k, uint64_t v) { w[k] = v; }
-    MA_DEV uint64_t get(int k) const { return w[k]; }
-};
-struct Park24Lds {
-    uint64_t* col;                          // lds + lane, words 64 apart
-    MA_DEV void put(int k, uint64_t v) const { col[(size_t)k * 64] = v; }
-    MA_DEV uint64_t get(int k) const { return col[(size_t)k * 64]; }
-};
-
 // (The window form of the single multiplication -- 3-bit signed windows, the table {1,2,3,4}P in registers / LDS, 255 doublings + 86
 // mixed additions + two inversions per lane: rounds 2-4, 9.1e7/s, 170 spilled registers in its table builder -- was replaced in
 // round 5 by the ladder form of csrc/ed26l.h: 1.13e8/s, no spills; same-box A/B in profiles/r05_lad_ab.log.)
 
-// Fused double multiplication + affine export: the affine coordinates of e*P + f*Q (ecnXXXmul2 followed by ecnXXXget,
-// the verification pattern ed448.c:305 / nist256.c:251-254).  Both scalars are
-// recoded into 129 signed 2-bit digits (e' = e + sum 2*4^i, digit = window - 2 in [-2, 1]) so that the two tables
-// {P, 2P} and {Q, 2Q} fit the register file together (4 x 24 VGPRs); per window two doublings and two additions, all
-// lookups scan their table.  (The reference's mul2 is a joint sparse form with data-dependent branches; any
-// evaluation reaches the same affine point.)
-template <class C, class DIG, class PARK>
-MA_DEV void ed25519_mul2_get_dig(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
-                                 DIG& digf, const spint* QX, const spint* QY, const spint* QZ, PARK& park, uint64_t* xw, uint64_t* yw) {
-    using E = Ed26<C>;
-    using F = Fe26;
-    typename E::Ext R;
-    uint64_t tab[2][3][4];                  // P, 2P as canonical packed (y+x, y-x, 2dxy); Q, 2Q in the park
-    {
-        typename E::Ext A1, A2, B1, B2;
-        uint32_t px[10], py[10], pz[10];
-        auto ext = [&](const spint* X, const spint* Y, const spint* Z, typename E::Ext& o) {
-            E::from51(X, px);
-            E::from51(Y, py);
-            E::from51(Z, pz);
-            F::mul(px, pz, o.X);
-            F::mul(py, pz, o.Y);
-            F::sqr(pz, o.Z);
-            F::mul(px, py, o.T);
-        };
-        ext(PX, PY, PZ, A1);
-        A2 = A1;
-        E::template dbl<false>(A2);
-        ext(QX, QY, QZ, B1);
-        B2 = B1;
-        E::template dbl<false>(B2);
-        uint32_t z12[10], z123[10], inv[10], i1[10], i2[10], i3[10], i4[10];
-        F::mul(A1.Z, A2.Z, z12);
-        F::mul(z12, B1.Z, z123);
-        F::mul(z123, B2.Z, inv);
-        F::invert(inv, inv);
-        F::mul(inv, z123, i4);
-        F::mul(inv, B2.Z, inv);
-        F::mul(inv, z12, i3);
-        F::mul(inv, B1.Z, inv);
-        F::mul(inv, A1.Z, i2);
-        F::mul(inv, A2.Z, i1);
-        uint32_t dd[10];
-        E::d2(dd);
-        auto cache = [&](const typename E::Ext& p, const uint32_t* zi, uint64_t (*out)[4]) {
-            uint32_t x[10], y[10], s[10];
-            F::mul(p.X, zi, x);
-            F::mul(p.Y, zi, y);
-            F::add(y, x, s);
-            F::to_words(s, out[0]);
-            F::sub(y, x, s);
-            F::to_words(s, out[1]);
-            F::mul(x, y, s);
-            F::mul(s, dd, s);
-            F::to_words(s, out[2]);
-        };
-        cache(A1, i1, tab[0]);
-        cache(A2, i2, tab[1]);
-        uint64_t tmp[3][4];
-        cache(B1, i3, tmp);
-        static_for<0, 3>([&](auto CI) { static_for<0, 4>([&](auto K) { park.put(CI * 4 + K, tmp[CI][K]); }); });
-        cache(B2, i4, tmp);
-        static_for<0, 3>([&](auto CI) { static_for<0, 4>([&](auto K) { park.put(12 + CI * 4 + K, tmp[CI][K]); }); });
-    }
-    F::set(0, R.X);
-    F::set(1, R.Y);
-    F::set(1, R.Z);
-    F::set(0, R.T);
-    // sign * table[|d|] (|d| in 0..2), scanned, then added to R
-    auto lookup_add = [&](int dgt, auto from_park, auto want_t) {
-        const bool neg = dgt < 0;
-        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);
-        uint64_t sel[3][4];
-        static_for<0, 3>([&](auto CI) { static_for<0, 4>([&](auto K) { sel[CI][K] = (CI < 2 && K == 0) ? 1u : 0u; }); });
-        static_for<0, 2>([&](auto EI) {
-            const bool hit = (m == (uint32_t)(EI + 1));
-            static_for<0, 3>([&](auto CI) {
-                static_for<0, 4>([&](auto K) {
-                    const uint64_t a = decltype(from_park)::value ? park.get(EI * 12 + CI * 4 + K) : tab[EI][CI][K], b = sel[CI][K];
-                    sel[CI][K] = hit ? a : b;
-                });
-            });
-        });
-        uint32_t yp[10], ym[10], t2[10], nt[10];
-        uint64_t sp[4], sm[4];
-        static_for<0, 4>([&](auto K) {
-            const uint64_t a = sel[0][K], b = sel[1][K];
-            sp[K] = neg ? b : a;
-            sm[K] = neg ? a : b;
-        });
-        F::from_words(sp, yp);
-        F::from_words(sm, ym);
-        F::from_words(sel[2], t2);
-        F::set(0, nt);
-        F::sub(nt, t2, nt);
-        F::select(neg, t2, nt, t2);
-        E::template add_cached<decltype(want_t)::value>(R, yp, ym, t2);
-    };
-#pragma unroll 1
-    for (int i = 0; i < 129; i++) {
-        const int de = (int)dige.window(i) - 2, df = (int)digf.window(i) - 2;       // [-2, 1]
-        if (i != 0) {
-            E::template dbl<false>(R);
-            E::template dbl<true>(R);
-        }
-        lookup_add(de, std::false_type{}, std::true_type{});
-        lookup_add(df, std::true_type{}, std::false_type{});
-    }
-    uint32_t zi[10], ax[10], ay[10];
-    F::invert(R.Z, zi);
-    F::mul(R.X, zi, ax);
-    F::mul(R.Y, zi, ay);
-    F::to_words(ax, xw);
-    F::to_words(ay, yw);
-}
-template <class C>
-MA_DEV void ed25519_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
-                                 const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ, uint64_t* xw, uint64_t* yw) {
-    W25519_2Regs de, df;
-    de.init(ew);
-    df.init(fw);
-    Park24Regs park;
-    ed25519_mul2_get_dig<C>(de, PX, PY, PZ, df, QX, QY, QZ, park, xw, yw);
-}
+// (The window form of the double multiplication -- 129 signed 2-bit windows, {P, 2P} in registers and {Q, 2Q} in LDS: rounds 2-4,
+// 5.7e7/s, 178 spilled registers in its table builder -- was replaced in round 5 by the Straus form of csrc/ed26s.h: 7.9e7/s, no
+// spills; same-box A/B in profiles/r05_mul2_ab.log.)
 
 // Fused GENERATOR multiplication + affine export: the affine coordinates of e*G -- ecnXXXgen, ecnXXXmul, ecnXXXget, the
 // opening of EdDSA key generation and signing (ed448.c:167-184 ED448_KEY_PAIR, 196-199 ED448_SIGN; curve.py builds the same

@@ -1346,17 +1346,28 @@ struct Field {
     }
 #endif
 
+    // The products AROUND the progenitor in modinv / modqr / modsqrt go through the out-of-line primitives of the chain too (round 5):
+    // inlined, two modinv of a 13-limb field in one kernel (k_time's third leg) came to 512 registers and 34 432 spilled ones, modqr to
+    // 244, the Tonelli-Shanks tail of modsqrt over 2^255-19 to 26 spilled at its three-wave budget and 324 registers inside ecn set --
+    // for a handful of products next to the ~250-750 of the chain, which has been out of line since round 3.
+    static constexpr bool TAIL_OOL = true;
+    static MA_DEV void tail_mul(const spint* a, const spint* b, spint* c) { if constexpr (TAIL_OOL) chain_mul(a, b, c); else modmul(a, b, c); }
+    static MA_DEV void tail_sqr(const spint* a, spint* c) {
+        if constexpr (TAIL_OOL) { if (a != c) modcpy(a, c); chain_nsqr(c, 1); } else modsqr(a, c);
+    }
+    static MA_DEV void tail_nsqr(spint* a, int n) { if constexpr (TAIL_OOL) chain_nsqr(a, n); else modnsqr(a, n); }
+
     // pseudo.py:788-812
     static MA_DEV void modinv(const spint* x, const spint* h, spint* z) {
         spint s[N], t[N];
         if (h == nullptr) modpro(x, t); else modcpy(h, t);
         modcpy(x, s);
         for (int i = 0; i < P::PM1D2 - 1; i++) {
-            modsqr(s, s);
-            modmul(s, x, s);
+            tail_sqr(s, s);
+            tail_mul(s, x, s);
         }
-        modnsqr(t, P::PM1D2 + 1);
-        modmul(s, t, z);
+        tail_nsqr(t, P::PM1D2 + 1);
+        tail_mul(s, t, z);
     }
 
     // quadratic-residue test (pseudo.py:815-831)
@@ -1364,12 +1375,12 @@ struct Field {
         spint r[N];
         if (h == nullptr) {
             modpro(x, r);
-            modsqr(r, r);
+            tail_sqr(r, r);
         } else {
-            modsqr(h, r);
+            tail_sqr(h, r);
         }
-        modmul(r, x, r);
-        if constexpr (P::PM1D2 > 1) modnsqr(r, P::PM1D2 - 1);
+        tail_mul(r, x, r);
+        if constexpr (P::PM1D2 > 1) tail_nsqr(r, P::PM1D2 - 1);
         return modis1(r) | modis0(x);
     }
     // square root: Tonelli-Shanks on the progenitor (pseudo.py:834-874); the data-dependent choice is
@@ -1377,20 +1388,20 @@ struct Field {
     static MA_DEV void modsqrt(const spint* x, const spint* h, spint* r) {
         spint s[N], y[N];
         if (h == nullptr) modpro(x, y); else modcpy(h, y);
-        modmul(y, x, s);
+        tail_mul(y, x, s);
         if constexpr (P::PM1D2 > 1) {
             spint t[N], b[N], v[N], z[N];
             static_for<0, N>([&](auto I) { z[I] = P::roi(I); });
-            modmul(s, y, t);
+            tail_mul(s, y, t);
             nres(z, z);
             for (int k = P::PM1D2; k > 1; k--) {
                 modcpy(t, b);
-                modnsqr(b, k - 2);
+                tail_nsqr(b, k - 2);
                 int d = 1 - modis1(b);
-                modmul(s, z, v);
+                tail_mul(s, z, v);
                 modcmv(d, v, s);
-                modsqr(z, z);
-                modmul(t, z, v);
+                tail_sqr(z, z);
+                tail_mul(t, z, v);
                 modcmv(d, v, t);
             }
         }

@@ -593,22 +593,33 @@ __global__ __launch_bounds__(BLOCK) void k_uniform(spint s0, size_t first, int p
 // KIND 0: `outer` x 200 x 5 modmul;  1: `outer` x 500 x 2 modsqr;  2: `outer` x 2 modinv.
 template <class F, class P, int KIND>
 MA_DEV void time_chain(spint* x, spint* y, spint* z, long outer) {
+    // long fields: one out-of-line copy of the product / squaring (field.h chain_mul, chain_nsqr) instead of five / two inlined ones per
+    // policy -- k_time<SIDH610, 0, 2> stood at 329 registers with both policies' chains inlined
+    constexpr bool OOL = P::N >= 9;
+    auto mul = [](const spint* a, const spint* b, spint* c) { if constexpr (OOL) F::chain_mul(a, b, c); else F::modmul(a, b, c); };
     F::nres(x, x);
     if constexpr (KIND == 0) {
         F::nres(y, y);
 #pragma unroll 1
         for (long i = 0; i < outer * 200; i++) {
-            F::modmul(x, y, z);
-            F::modmul(z, x, y);
-            F::modmul(y, z, x);
-            F::modmul(x, y, z);
-            F::modmul(z, x, y);
+            mul(x, y, z);
+            mul(z, x, y);
+            mul(y, z, x);
+            mul(x, y, z);
+            mul(z, x, y);
         }
     } else if constexpr (KIND == 1) {
 #pragma unroll 1
         for (long i = 0; i < outer * 500; i++) {
-            F::modsqr(x, z);
-            F::modsqr(z, x);
+            if constexpr (OOL) {
+                F::modcpy(x, z);
+                F::chain_nsqr(z, 1);
+                F::modcpy(z, x);
+                F::chain_nsqr(x, 1);
+            } else {
+                F::modsqr(x, z);
+                F::modsqr(z, x);
+            }
         }
     } else {
 #pragma unroll 1

@@ -80,3 +80,29 @@ def test_bench_self_launch_two_ranks_gloo():
     assert d["value"] <= 2 * sp["max"] * 1.001
     # the N = 1 side figures are not run at N > 1
     assert d["other_configs"] == {} and list(d["data_sets"]) == ["uniform_mod_p"]
+
+
+def test_bench_eight_ranks_on_one_gpu_equal_one_rank():
+    """Eight ranks before there are eight GPUs (round 5): `python bench.py --gpus 8 --scaling strong` on this one-GPU box -- the ranks
+    share the device, gloo carries the collectives.  2^16 X25519 records, a function of their global index, are cut into eight
+    contiguous shards (simd/README.md:4-16: independent units, no exchange step), every rank verifies its own shard against the oracle,
+    rank 0 gathers all results; their digest must equal the digest of a ONE-rank run over the same 2^16 records."""
+    def run(n):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MA_BENCH_BACKEND="gloo", MA_BENCH_LOG2_ELEMS="18", MA_BENCH_LOG2_LADDER_TOTAL="16", MA_BENCH_PLACEMENTS="1")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2", "--no-cpu", "--no-others", "--no-traffic",
+                            "--scaling", "strong"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and p.stdout.strip().splitlines()[-1] == lines[0], p.stdout[-2000:]      # the JSON line is the last line
+        return json.loads(lines[0])
+    d8, d1 = run(8), run(1)
+    assert d8["n_gpus"] == 8 and len(d8["ranks"]) == 8 and [r["rank"] for r in d8["ranks"]] == list(range(8))
+    shards = [r["x25519_shard"] for r in d8["ranks"]]
+    assert shards[0][0] == 0 and shards[-1][1] == 1 << 16 and all(shards[i][1] == shards[i + 1][0] for i in range(7))       # a partition of 2^16
+    assert all(b - a == 1 << 13 for a, b in shards)
+    v = d8["verified_against_oracle"]
+    assert v["all_ranks_equal_oracle"] is True and v["ranks_checked"] == 8 and all(r["verified_against_oracle"] is True for r in d8["ranks"])
+    assert d8["dist"] == {"backend": "gloo", "world_size": 8, "distinct_devices": 1}
+    assert d8["x25519"]["scalars_total"] == 1 << 16 and d1["x25519"]["scalars_total"] == 1 << 16 and d1["n_gpus"] == 1
+    assert d8["x25519"]["records_sha256"] and d8["x25519"]["records_sha256"] == d1["x25519"]["records_sha256"]

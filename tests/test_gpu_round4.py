@@ -42,6 +42,33 @@ def test_multi_gpu_shard_example_bytes_equal_oracle(tmp_path):
     assert np.array_equal(bv, want)
 
 
+def test_multi_gpu_shard_example_eight_threads_on_one_device(tmp_path):
+    """round 5: the same program with eight shards / eight host threads whatever the number of GPUs (--oversubscribe: thread i on
+    device i mod count).  On this one-GPU box all eight drive the library's per-device staging buffer (eight scalar rfc7748() calls
+    at once), its scratch pool and their own streams concurrently; the bytes must be those of the one-thread run and of the oracle."""
+    from tests.oracle_binding import load_oracle
+    from tests.util import vp
+    exe = str(tmp_path / "multi_gpu_shard")
+    libdir = os.path.join(ROOT, "modarith_amd")
+    subprocess.check_call(["gcc", "-O2", "-pthread", os.path.join(ROOT, "examples", "multi_gpu_shard.c"), "-I", os.path.join(ROOT, "include"),
+                           "-L", libdir, "-l:libmodarith_amd.so", "-Wl,-rpath," + libdir, "-o", exe])
+    lg, n = 15, 1 << 15
+    out8, out1 = str(tmp_path / "r8.bin"), str(tmp_path / "r1.bin")
+    p8 = subprocess.run([exe, str(lg), "8", out8, "--oversubscribe"], capture_output=True, text=True, timeout=300)
+    assert p8.returncode == 0, p8.stdout + p8.stderr
+    assert p8.stdout.count("RFC 7748 vector ok") == 8 and "oversubscribed: 8 shards" in p8.stdout, p8.stdout
+    bounds = sorted((int(a), int(b)) for a, b in __import__("re").findall(r"records \[(\d+), (\d+)\) ok", p8.stdout))
+    assert bounds[0][0] == 0 and bounds[-1][1] == n and all(bounds[i][1] == bounds[i + 1][0] for i in range(7))      # the shards partition the batch
+    p1 = subprocess.run([exe, str(lg), "1", out1], capture_output=True, text=True, timeout=300)
+    assert p1.returncode == 0, p1.stdout + p1.stderr
+    r8, r1 = np.fromfile(out8, dtype=np.uint8), np.fromfile(out1, dtype=np.uint8)
+    assert r8.size == 3 * n * 32 and np.array_equal(r8, r1)
+    bk, bu, bv = (np.ascontiguousarray(r8[i * n * 32:(i + 1) * n * 32].reshape(n, 32)) for i in range(3))
+    want = np.empty_like(bv)
+    load_oracle().lib.oracle_parallel(3, vp(bk), vp(bu), vp(want), n, 0, max(1, len(os.sched_getaffinity(0))))
+    assert np.array_equal(bv, want)
+
+
 def test_host_resident_pipelined_ladder_equals_device_resident():
     from modarith_amd.field import rfc7748
     from modarith_amd.hostio import PinnedBytes, ladder_host

@@ -14,7 +14,9 @@
 #include "../modarith_amd/csrc/generated/params_NIST521.h"
 #include "../modarith_amd/csrc/ed26.h"
 #include "../modarith_amd/csrc/ed26l.h"
+#include "../modarith_amd/csrc/ed26s.h"
 #include "../modarith_amd/csrc/ed28.h"
+#include "../modarith_amd/csrc/ed28l.h"
 #include "../modarith_amd/csrc/generated/curve_NIST256.h"
 #include "../modarith_amd/csrc/wn26.h"
 #include "../modarith_amd/csrc/generated/comb_ED25519.h"
@@ -50,7 +52,8 @@ extern "C" void ecn_ed25519_set(int s, const char* x, const char* y, pt25519*);
 extern "C" void ecn_ed25519_mul2(const char* e, pt25519* P, const char* f, pt25519* Q, pt25519* R);
 
 // fused double multiplication + get against the oracle's ecn mul2 + ecn get
-static int run_ed25519_mul2(int n) {
+template <class FUSED>
+static int run_ed25519_mul2(const char* name, int n, FUSED fused) {
     int bad = 0;
     for (int it = 0; it < n; it++) {
         pt25519 P, Q, R;
@@ -67,17 +70,21 @@ static int run_ed25519_mul2(int n) {
         if (it == 6) memset(f, 0, 32);
         if (it == 7) { memset(e, 0xff, 32); memset(f, 0xff, 32); }
         if (it == 13) { memset(e, 0, 32); memset(f, 0, 32); }
+        if (it == 14) { memset(e, 0x88, 32); memset(f, 0x77, 32); }                    // every digit -8 (its top window carries) / -1
+        if (it == 15) { memset(e, 0x80, 32); memset(f, 0x08, 32); }
+        if (it == 20) { memset(e, 0, 32); e[31] = 8; memset(f, 0, 32); f[31] = 9; }
+        if (it % 8 == 5 && it > 8) { char y[32]; memset(y, 0xff, 32); y[0] = 0x7f; y[31] = 0xec; ecn_ed25519_set(0, nullptr, y, &P); }   // order 2
         uint64_t ew[4], fw[4], xw[4], yw[4];
         for (int w = 0; w < 4; w++) { uint64_t v = 0, u = 0; for (int b = 0; b < 8; b++) { v |= (uint64_t)e[31 - (8 * w + b)] << (8 * b); u |= (uint64_t)f[31 - (8 * w + b)] << (8 * b); } ew[w] = v; fw[w] = u; }
-        ma::ed25519_mul2_get_one<ma::C_ED25519>(ew, P.x, P.y, P.z, fw, Q.x, Q.y, Q.z, xw, yw);
+        fused(ew, P.x, P.y, P.z, fw, Q.x, Q.y, Q.z, xw, yw);
         char wx[32], wy[32];
         ecn_ed25519_mul2((const char*)e, &P, (const char*)f, &Q, &R);
         ecn_ed25519_get(&R, wx, wy);
         unsigned char gx[32], gy[32];
         for (int i = 0; i < 32; i++) { gx[i] = (unsigned char)(xw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); gy[i] = (unsigned char)(yw[(31 - i) / 8] >> (8 * ((31 - i) % 8))); }
-        if (memcmp(gx, wx, 32) != 0 || memcmp(gy, wy, 32) != 0) { if (bad < 6) printf("ed25519_mul2_get_one: record %d differs\n", it); bad++; }
+        if (memcmp(gx, wx, 32) != 0 || memcmp(gy, wy, 32) != 0) { if (bad < 6) printf("%s: record %d differs\n", name, it); bad++; }
     }
-    printf("ed25519_mul2_get_one: %d records, %d differ from the oracle's ecn mul2 + get\n", n, bad);
+    printf("%s: %d records, %d differ from the oracle's ecn mul2 + get\n", name, n, bad);
     return bad;
 }
 
@@ -647,6 +654,74 @@ static int run_ed25519_mulgen2_lad(int n) {
     return bad;
 }
 
+
+// ---- round 5: the ladder form of the fused ED448 multiplication (csrc/ed28l.h), records built like run_ed25519_lad's: P = [k]G + S for
+// every S of the 4-torsion subgroup (orders 1, 4, 2, 4) and the torsion points themselves, e = j q - 1, j q, j q + 1 for j = 0 .. 4,
+// 0 / 2 / all ones / top bit, random
+extern "C" void ecn_ed448_add(pt448*, pt448*);
+static const unsigned char ED448_Q[56] = {0x3f,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,
+                                          0x7c,0xca,0x23,0xe9,0xc4,0x4e,0xdb,0x49,0xae,0xd6,0x36,0x90,0x21,0x6c,0xc2,0x72,0x8d,0xc5,0x8f,0x55,0x23,0x78,0xc2,0x92,0xab,0x58,0x44,0xf3};
+static void ed448_jq(int j, int delta, unsigned char* e) {
+    unsigned __int128 acc = 0;
+    uint64_t w[7], qw[7];
+    for (int k = 0; k < 7; k++) { uint64_t v = 0; for (int b = 0; b < 8; b++) v |= (uint64_t)ED448_Q[55 - (8 * k + b)] << (8 * b); qw[k] = v; }
+    for (int k = 0; k < 7; k++) { acc += (unsigned __int128)qw[k] * (unsigned)j; w[k] = (uint64_t)acc; acc >>= 64; }
+    if (delta > 0) { for (int k = 0; k < 7 && ++w[k] == 0; k++) {} }
+    if (delta < 0) { for (int k = 0; k < 7 && w[k]-- == 0; k++) {} }
+    for (int i = 0; i < 56; i++) e[55 - i] = (unsigned char)(w[i / 8] >> (8 * (i % 8)));
+}
+static int run_ed448_lad(int n) {
+    int bad = 0, it = 0;
+    pt448 T4, S[4];
+    { char y[56]; memset(y, 0, 56); ecn_ed448_set(0, nullptr, y, &T4); }                  // y = 0: a point of order 4
+    ecn_ed448_inf(&S[0]);
+    for (int j = 1; j < 4; j++) { S[j] = S[j - 1]; ecn_ed448_add(&T4, &S[j]); }
+    auto one = [&](const pt448& P0, const unsigned char* e) {
+        pt448 P = P0, Q = P0;
+        uint64_t ew[7], xw[7], yw[7];
+        for (int w = 0; w < 7; w++) { uint64_t v = 0; for (int b = 0; b < 8; b++) v |= (uint64_t)e[55 - (8 * w + b)] << (8 * b); ew[w] = v; }
+        ma::Ed28Lad::mul_get_one(ew, P.x, P.y, P.z, xw, yw);
+        char wx[56], wy[56];
+        ecn_ed448_mul((const char*)e, &Q);
+        ecn_ed448_get(&Q, wx, wy);
+        unsigned char gx[56], gy[56];
+        for (int i = 0; i < 56; i++) { gx[i] = (unsigned char)(xw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); gy[i] = (unsigned char)(yw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); }
+        if (memcmp(gx, wx, 56) != 0 || memcmp(gy, wy, 56) != 0) { if (bad < 8) printf("Ed28Lad::mul_get_one: record %d differs\n", it); bad++; }
+        it++;
+    };
+    for (int tors = 0; tors < 4; tors++) {
+        for (int base = 0; base < 3; base++) {
+            pt448 P = S[tors];
+            if (base) {
+                unsigned char k[56];
+                for (int i = 0; i < 56; i++) k[i] = (unsigned char)sm();
+                pt448 B;
+                ecn_ed448_gen(&B);
+                ecn_ed448_mul((const char*)k, &B);
+                ecn_ed448_add(&B, &P);
+                if (base == 2) { char x[56], y[56]; ecn_ed448_get(&P, x, y); ecn_ed448_set(0, x, y, &P); }
+            }
+            unsigned char e[56];
+            for (int j = 0; j <= 4; j++) for (int dl = -1; dl <= 1; dl++) { ed448_jq(j, dl, e); one(P, e); }
+            memset(e, 0, 56); e[55] = 2; one(P, e);
+            memset(e, 0xff, 56); one(P, e);
+            memset(e, 0, 56); e[0] = 0x80; one(P, e);
+            for (int i = 0; i < 56; i++) e[i] = (unsigned char)sm();
+            one(P, e);
+        }
+    }
+    for (int r = 0; r < n; r++) {
+        unsigned char e[56], k[56];
+        for (int i = 0; i < 56; i++) { e[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
+        pt448 P;
+        ecn_ed448_gen(&P);
+        if (r % 8 != 4) ecn_ed448_mul((const char*)k, &P);
+        one(P, e);
+    }
+    printf("Ed28Lad::mul_get_one: %d records, %d differ from the oracle's ecn mul + get\n", it, bad);
+    return bad;
+}
+
 extern "C" void ecn_ed448_mul2(const char* e, pt448* P, const char* f, pt448* Q, pt448* R);
 static int run_ed448_mulgen2(int n) {
     int bad = 0;
@@ -929,9 +1004,10 @@ int main(int argc, char** argv) {
     bad += run_mhalf448(n * 25);
     bad += run_half_ov(n * 50);
     bad += run_fold52(n * 50);
-    bad += run_ed25519_mul2(n / 8 + 16);
+    bad += run_ed25519_mul2("ed25519_mul2_get_straus_one", n / 4 + 32, [](const uint64_t* ew, const uint64_t* PX, const uint64_t* PY, const uint64_t* PZ, const uint64_t* fw, const uint64_t* QX, const uint64_t* QY, const uint64_t* QZ, uint64_t* xw, uint64_t* yw) { ma::ed25519_mul2_get_straus_one<ma::C_ED25519>(ew, PX, PY, PZ, fw, QX, QY, QZ, xw, yw); });
     bad += run_ed25519_lad("Ed26Lad::mul_get_one", n / 4 + 16, [](const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, uint64_t* xw, uint64_t* yw) { ma::Ed26Lad<ma::C_ED25519>::mul_get_one(ew, X, Y, Z, xw, yw); });
     bad += run_ed448(n / 16 + 16);
+    bad += run_ed448_lad(n / 16 + 16);
     bad += run_ed448_mul2(n / 32 + 16);
     bad += run_ed448_mulgen2(n / 32 + 16);
     bad += run_nist256(n / 8 + 16);
