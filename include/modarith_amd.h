@@ -303,7 +303,10 @@ int rfc7748_X448_base_batch(const char *bk, char *bv, size_t n, void *stream);
  * that layout with ld = 1.  Scalars e and coordinates x,y are big-endian Nbytes records, as in the
  * reference.  ecn_*_mul is the constant-time 4-bit fixed-window multiplication (edwards.c:435-482); its
  * 9-entry table (two of them for mul2) lives in a caller-provided device workspace of
- * ecn_*_mul_workspace_bytes(n) bytes.
+ * ecn_*_mul_workspace_bytes(n) bytes: per-wave slabs for the RESIDENT grid (64 lanes x waves per SIMD x 1024 SIMDs), not for
+ * n, so the size stops growing at the grid -- 283 MB for 5-limb fields at two waves per SIMD, up to 566 MB for ed25519, whose
+ * kernels run at four waves per SIMD since round 4 (mul alone touches half of it, mul2 all of it; more than the 256 MiB
+ * Infinity Cache: the scans are whole 512-byte rows from HBM / L2).  Ask the function, do not hard-code a size.
  * add, dbl and mul run the reference's formulas (edwards.c:73-145, weierstrass.c:68-281) from the bit-exact field calls
  * in the reference's order, and their PROJECTIVE LIMBS equal the reference's: the reference's own edwards.c / weierstrass.c,
  * built in the build container from its files without the functions that need the external addchain tool, produced the
@@ -388,7 +391,11 @@ MODARITH_AMD_DECLARE_EDWARDS(nums256w, 5)
  * on the curve whose coordinate limbs keep the limb budget -- every limb below 2^(Radix+2), which every point the library
  * (or field.c-style code) produced does; the fused kernels re-pack the 64-bit limbs into 32-bit ones and silently drop what
  * lies above (checkable beforehand with modlimbs_<P>_batch on the three coordinates; the plain ecn_<c>_mul_batch instead
- * reproduces the reference's 64-bit wrap-around for such fabricated limbs).  This precondition holds for every fused entry
+ * reproduces the reference's 64-bit wrap-around for such fabricated limbs -- except for ed25519 and ed448, whose mul / mul2 /
+ * mul2_exact keep the field elements in resident half-limb form since round 4 (csrc/fh51.h, fh56.h): their results are the
+ * reference's limbs for every input inside the limb budget, i.e. every limb below 2^(Radix+2), and in fact for limbs up to
+ * 2^58 (ed25519: the half-limb cut is exact up to there; beyond it the upper half is truncated to 32 bits) / for the same
+ * INTEGER with the excess above 56 bits moved up (ed448: fh56.h from_limbs), not the reference's wrap-around).  This precondition holds for every fused entry
  * point below (mul_get, mul2_get, mulgen2_get).  Constant time like ecnXXXmul: ed448, nist256, secp256k1 by fixed windows with
  * scanned tables; ed25519 (round 5, csrc/ed26l.h) by a Montgomery ladder on the birationally equivalent curve with the second
  * coordinate recovered at the end and both inversions shared by up to 32 records -- no table at all.  workspace: a device buffer of

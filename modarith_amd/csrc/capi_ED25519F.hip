@@ -24,14 +24,14 @@ void k_ed25519_lad(const unsigned char* e, size_t first, Ed26lWs ws) {
         spint ew[4];
         load_be_record<P_X25519>(e, first + t, ew);
         e_odd = (ew[0] & 1) != 0;
-        ed26l_load_u(ws, t, u);
+        ws.load_u(t, u);
         L::ladder(ew, u, x2, z2, x3, z3);
     }
-    ed26l_load_u(ws, t, u);                     // (again: cheaper than ten registers across the ladder)
-    const uint32_t fl = ed26l_load_w(ws, t, w);
+    ws.load_u(t, u);                            // (again: cheaper than ten registers across the ladder)
+    const uint32_t fl = ws.load_w(t, w);
     Ed26<C_ED25519>::Ext R;
     L::recover<false>(u, w, fl, e_odd, x2, z2, x3, z3, R);
-    ed26l_store_xyz(ws, t, R.X, R.Y, R.Z);
+    ws.store_xyz(t, R.X, R.Y, R.Z);
 }
 
 }  // namespace ma
@@ -48,13 +48,13 @@ extern "C" int ecn_ed25519_mul_get_batch(const char* e, const ma_spint* P, char*
         return (int)hipErrorInvalidValue;
     }
     hipStream_t s = (hipStream_t)st;
-    Ed26lScratch ws(workspace, workspace_bytes, n, s);
+    EdLadScratch ws(workspace, workspace_bytes, ed26l_workspace_bytes(n), 8, s);
     if (!ws.p) {
         set_error("ecn mul_get: no workspace (pass ecn_ed25519_mul_get_workspace_bytes(n) bytes; the library's own scratch pool is not available while the stream is being captured)");
         return (int)hipErrorInvalidValue;
     }
     const unsigned char* eb = reinterpret_cast<const unsigned char*>(e);
-    ed26l_pipeline<C_ED25519, 1>(P, ld, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n, ws.p, s,
+    edlad_pipeline<LadT25519, 1>(P, ld, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n, ws.p, s,
                                  [&](size_t first, size_t m, const Ed26lWs& w) { k_ed25519_lad<<<(unsigned)((m + 63) / 64), 64, 0, s>>>(eb, first, w); });
     return check_launch("ecn mul_get (ladder form)");
 }

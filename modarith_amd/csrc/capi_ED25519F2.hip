@@ -54,7 +54,7 @@ void k_ed25519_mul2_straus(const unsigned char* e, const spint* Pb, const unsign
         W25519_4Lds de{ce}, df{cf};
         S::Ext R;
         S::walk(de, df, tab, R);
-        ed26l_store_xyz(ws, t(), R.X, R.Y, R.Z);
+        ws.store_xyz(t(), R.X, R.Y, R.Z);
     }
 }
 
@@ -68,7 +68,7 @@ static size_t straus_waves(size_t n) {
 }
 
 extern "C" size_t ecn_ed25519_mul2_get_workspace_bytes(size_t n) {
-    const size_t m = n < ED26L_CHUNK ? n : ED26L_CHUNK;
+    const size_t m = n < EDLAD_CHUNK ? n : EDLAD_CHUNK;
     return straus_waves(m) * STRAUS_SLAB_BYTES_PER_WAVE + ed26l_workspace_bytes(n);
 }
 
@@ -79,29 +79,20 @@ extern "C" int ecn_ed25519_mul2_get_batch(const char* e, const ma_spint* P, cons
         set_error("ecn mul2_get: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
     }
-    {
-        hipStream_t s = (hipStream_t)st;
-        const size_t need = ecn_ed25519_mul2_get_workspace_bytes(n);
-        void* own = nullptr;
-        void* wsp = (workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 127u) == 0) ? workspace : (own = scratch_alloc(need, s));
-        if (!wsp) {
-            set_error("ecn mul2_get: no workspace (pass ecn_ed25519_mul2_get_workspace_bytes(n) bytes, 128-byte aligned; the library's own scratch pool is not available while the stream is being captured)");
-            return (int)hipErrorInvalidValue;
-        }
-        const unsigned char *eb = reinterpret_cast<const unsigned char*>(e), *fb = reinterpret_cast<const unsigned char*>(f);
-        for (size_t first = 0; first < n; first += ED26L_CHUNK) {
-            const size_t m = n - first < ED26L_CHUNK ? n - first : ED26L_CHUNK;
-            const size_t waves = straus_waves(m);
-            uint64_t* slab = reinterpret_cast<uint64_t*>(wsp);
-            Ed26lWs ws(reinterpret_cast<unsigned char*>(wsp) + straus_waves(n < ED26L_CHUNK ? n : ED26L_CHUNK) * STRAUS_SLAB_BYTES_PER_WAVE, m);
-            size_t L;
-            int rounds;
-            ed26l_rounds(m, &L, &rounds);
-            k_ed25519_mul2_straus<<<(unsigned)waves, 64, 0, s>>>(eb, P, fb, Q, first, ld, slab, ws);
-            k_fe_batch_div<Fe26, 10, 4, SinkExport25519, 3><<<(unsigned)((L + 63) / 64), 64, 0, s>>>(
-                ws.A, ws.B, ws.Cn, ws.wc, m, L, rounds, SinkExport25519{reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, first});
-        }
-        if (own) scratch_free(own, s);
-        return check_launch("ecn mul2_get (Straus form)");
+    hipStream_t s = (hipStream_t)st;
+    EdLadScratch wsp(workspace, workspace_bytes, ecn_ed25519_mul2_get_workspace_bytes(n), 128, s);
+    if (!wsp.p) {
+        set_error("ecn mul2_get: no workspace (pass ecn_ed25519_mul2_get_workspace_bytes(n) bytes, 128-byte aligned; the library's own scratch pool is not available while the stream is being captured)");
+        return (int)hipErrorInvalidValue;
     }
+    const unsigned char *eb = reinterpret_cast<const unsigned char*>(e), *fb = reinterpret_cast<const unsigned char*>(f);
+    const size_t slab_bytes = straus_waves(n < EDLAD_CHUNK ? n : EDLAD_CHUNK) * STRAUS_SLAB_BYTES_PER_WAVE;
+    for (size_t first = 0; first < n; first += EDLAD_CHUNK) {
+        const size_t m = n - first < EDLAD_CHUNK ? n - first : EDLAD_CHUNK;
+        Ed26lWs ws(reinterpret_cast<unsigned char*>(wsp.p) + slab_bytes, m);
+        k_ed25519_mul2_straus<<<(unsigned)straus_waves(m), 64, 0, s>>>(eb, P, fb, Q, first, ld, reinterpret_cast<uint64_t*>(wsp.p), ws);
+        edlad_export<LadT25519, 3>(ws, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, first, s);
+    }
+    return check_launch("ecn mul2_get (Straus form)");
 }
+

@@ -74,17 +74,17 @@ void k_ed25519_lad_gen2(const unsigned char* e, const unsigned char* f, size_t f
         spint fw[4];
         load_be_record<P_X25519>(f, first + t, fw);
         f_odd = (fw[0] & 1) != 0;
-        ed26l_load_u(ws, t, u);
+        ws.load_u(t, u);
         L::ladder(fw, u, x2, z2, x3, z3);
     }
-    ed26l_load_u(ws, t, u);
-    const uint32_t fl = ed26l_load_w(ws, t, w);
+    ws.load_u(t, u);
+    const uint32_t fl = ws.load_w(t, w);
     Ed26<C_ED25519>::Ext R;
     L::recover<true>(u, w, fl, f_odd, x2, z2, x3, z3, R);
     spint ew[4];
     load_be_record<P_X25519>(e, first + t, ew);
     ed25519_mulgen_acc<C_ED25519, CombED25519, false>(ew, R);
-    ed26l_store_xyz(ws, t, R.X, R.Y, R.Z);
+    ws.store_xyz(t, R.X, R.Y, R.Z);
 }
 
 }  // namespace ma
@@ -101,13 +101,13 @@ extern "C" int ecn_ed25519_mulgen2_get_batch(const char* e, const char* f, const
         return (int)hipErrorInvalidValue;
     }
     hipStream_t s = (hipStream_t)st;
-    Ed26lScratch ws(workspace, workspace_bytes, n, s);
+    EdLadScratch ws(workspace, workspace_bytes, ed26l_workspace_bytes(n), 8, s);
     if (!ws.p) {
         set_error("ecn mulgen2_get: no workspace (pass ecn_ed25519_mulgen2_get_workspace_bytes(n) bytes; the library's own scratch pool is not available while the stream is being captured)");
         return (int)hipErrorInvalidValue;
     }
     const unsigned char *eb = reinterpret_cast<const unsigned char*>(e), *fb = reinterpret_cast<const unsigned char*>(f);
-    ed26l_pipeline<C_ED25519, 2>(Q, ld, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n, ws.p, s,
+    edlad_pipeline<LadT25519, 2>(Q, ld, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n, ws.p, s,
                                  [&](size_t first, size_t m, const Ed26lWs& w) { k_ed25519_lad_gen2<<<(unsigned)((m + 63) / 64), 64, 0, s>>>(eb, fb, first, w); });
     return check_launch("ecn mulgen2_get (ladder form)");
 }

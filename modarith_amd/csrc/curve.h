@@ -323,6 +323,9 @@ struct CurveOps {
 template <class Crv>
 __global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul(const unsigned char* e, spint* Pb, size_t n, size_t ld, spint* ws) {
     using E = Crv;
+    // the LDS of a CU (160 KB on gfx950) must hold the digit arrays of all its resident workgroups (4 SIMDs x MA_MUL_WPS waves), for the
+    // double multiplications too (two / JSF arrays per workgroup): ADVICE of round 4
+    static_assert((size_t)4 * MA_MUL_WPS * 2 * E::NDIG * 64 <= (size_t)160 * 1024, "LDS budget of the resident scalar-multiplication grid");
     __shared__ signed char digs[E::NDIG * 64];
     const typename E::Table W{ws + (size_t)blockIdx.x * E::SLAB_WORDS, threadIdx.x};
     signed char* dg = digs + threadIdx.x;

@@ -688,94 +688,8 @@ MA_DEV void x448_base_one(const uint64_t* kw_in, uint64_t* ow) {
     F::to_words(u, ow);
 }
 
-// TWO scalars per lane with one inversion.  The register file has no room for a second ED448 point next to the working set
-// of the window loop (216 VGPRs), so the first result waits in a PARK (the kernels: 64 words per lane of LDS, 16 KB per wave;
-// the host check: a local array) while the second scalar runs; 1 / Za = Zb / (Za Zb) afterwards (Z is never 0 on this curve).
-// load(g, ew) fetches the g-th scalar; xw, yw: 2 x 7 words.
-template <class TAB, class PARK, class LOAD>
-MA_DEV void ed448_mulgen_get_two(LOAD load, PARK& park, uint64_t (*xw)[7], uint64_t (*yw)[7]) {
-    using F = Fe28;
-    Ed28::Ext R;
-#pragma unroll 1
-    for (int g = 0; g < 2; g++) {
-        uint64_t ew[7];
-        load(g, ew);
-        ed448_mulgen_acc<TAB>(ew, R);
-        if (g == 0) {
-            static_for<0, 16>([&](auto K) { park.put(K, R.X[K]); park.put(16 + K, R.Y[K]); park.put(32 + K, R.Z[K]); });
-        }
-    }
-    // (round 4) only Z0 and R.Z cross the inversion in registers: X0, Y0 stay parked and R.X, R.Y join them (words 32..63)
-    uint32_t Z0[16], zz[16], inv[16], t[16], u[16], c[16];
-    static_for<0, 16>([&](auto K) { Z0[K] = park.get(32 + K); });
-    F::mul_k(Z0, R.Z, zz);
-    static_for<0, 16>([&](auto K) { park.put(32 + K, R.X[K]); park.put(48 + K, R.Y[K]); });
-    F::invert(zz, inv);
-    F::mul_k(inv, R.Z, t);              // 1 / Z0
-    static_for<0, 16>([&](auto K) { c[K] = park.get(K); });
-    F::mul_k(c, t, u);
-    F::to_words(u, xw[0]);
-    static_for<0, 16>([&](auto K) { c[K] = park.get(16 + K); });
-    F::mul_k(c, t, u);
-    F::to_words(u, yw[0]);
-    F::mul_k(inv, Z0, t);               // 1 / Z1
-    static_for<0, 16>([&](auto K) { c[K] = park.get(32 + K); });
-    F::mul_k(c, t, u);
-    F::to_words(u, xw[1]);
-    static_for<0, 16>([&](auto K) { c[K] = park.get(48 + K); });
-    F::mul_k(c, t, u);
-    F::to_words(u, yw[1]);
-}
-// x448_base_one for two private keys with one inversion: u = Y^2 / X^2, the denominators X^2 share it.  X = 0 (the clamped key
-// 4q) must not zero the shared product: such a denominator enters as 1 and its result is forced to 0, the ladder's answer.
-template <class TAB, class PARK, class LOAD>
-MA_DEV void x448_base_two(LOAD load, PARK& park, uint64_t (*ow)[7]) {
-    using F = Fe28;
-    Ed28::Ext R;
-    uint32_t x2[16], y2[16];
-#pragma unroll 1
-    for (int g = 0; g < 2; g++) {
-        uint64_t kw[7];
-        load(g, kw);
-        kw[0] &= ~3ull;
-        kw[6] |= 0x8000000000000000ull;
-        ed448_mulgen_acc<TAB>(kw, R);
-        F::sqr_k(R.X, x2);
-        F::sqr_k(R.Y, y2);
-        if (g == 0) {
-            static_for<0, 16>([&](auto K) { park.put(K, x2[K]); park.put(16 + K, y2[K]); });
-        }
-    }
-    // (round 4) the numerators wait in the park (b2 where it is, y2 in words 32..47) while the product of the denominators is inverted
-    uint32_t da[16], db[16], zz[16], inv[16], t[16], u[16], c[16];
-    uint64_t zw[7];
-    bool a0, c0;
-    {
-        uint32_t a2[16], one[16];
-        static_for<0, 16>([&](auto K) { a2[K] = park.get(K); park.put(32 + K, y2[K]); });
-        F::set(1, one);
-        F::to_words(a2, zw);
-        a0 = (zw[0] | zw[1] | zw[2] | zw[3] | zw[4] | zw[5] | zw[6]) == 0;
-        F::to_words(x2, zw);
-        c0 = (zw[0] | zw[1] | zw[2] | zw[3] | zw[4] | zw[5] | zw[6]) == 0;
-        F::select(a0, a2, one, da);
-        F::select(c0, x2, one, db);
-    }
-    F::mul_k(da, db, zz);
-    F::invert(zz, inv);
-    F::mul_k(inv, db, t);
-    static_for<0, 16>([&](auto K) { c[K] = park.get(16 + K); });
-    F::mul_k(c, t, u);
-    F::to_words(u, ow[0]);
-    F::mul_k(inv, da, t);
-    static_for<0, 16>([&](auto K) { c[K] = park.get(32 + K); });
-    F::mul_k(c, t, u);
-    F::to_words(u, ow[1]);
-    const uint64_t ka = lane_mask(!a0), kc = lane_mask(!c0);         // (field.h: masks, not selects)
-    static_for<0, 7>([&](auto K) {
-        ow[0][K] &= ka;
-        ow[1][K] &= kc;
-    });
-}
+// (Rounds 2-4 ran TWO scalars per lane with one inversion -- ed448_mulgen_get_two / x448_base_two, the first result parked in LDS -- and
+// spilled 14 / 2 registers in that epilogue; round 5 shares the inversion between up to 32 records instead: csrc/edlad_k.h,
+// capi_ED448G.hip k_ed448_mulgen / k_x448_base.)
 
 }  // namespace ma

@@ -105,58 +105,86 @@ struct Ed28Lad {
         F::cswap(m, z2, z3);
     }
 
-    // the way back; R = [e]P in extended Edwards coordinates, T only when want_t (a compile-time or wave-uniform flag)
-    static MA_DEV void recover(const uint32_t* u, const uint32_t* w, uint32_t flags, bool e_odd,
+    // the way back; R = [e]P in extended Edwards coordinates, T only when want_t (a compile-time or wave-uniform flag).  u and w are
+    // FETCHED where they are used (load_u(out), load_w(out): the kernels re-read them from the workspace rows) and the ladder's
+    // outputs are consumed in an order that lets each die early -- held across the whole recovery, the six 16-limb inputs plus a
+    // product's own columns do not fit the 256 registers of the ladder kernel (34 spilled).
+    template <class LU, class LW>
+    static MA_DEV void recover(LU load_u, LW load_w, uint32_t flags, bool e_odd,
                                const uint32_t* x2, const uint32_t* z2, const uint32_t* x3, const uint32_t* z3, Ext& R, bool want_t) {
-        uint32_t t1[16], t2[16], a1[16], a2[16], zA[16], m1[16], m2[16], d[16], V[16], K[16], a[16], s[16], m[16];
-        F::mul_k(u, z2, t1);                    // u Zq
-        F::mul_k(u, x2, t2);                    // u Xq
-        F::add(t2, z2, a1);                     // < 2^29      u Xq + Zq
-        F::add(t1, x2, a2);                     // < 2^29
-        F::template mul_small<AD>(a2, a2);      // tight       Ad (u Zq + Xq)
-        F::template mul_small<AN2>(z2, zA);     // tight       |2 An| Zq
-        F::sub(a2, zA, a2);                     // tight       Ad (u Zq + Xq) + 2 An Zq
-        F::mul_k(a2, a1, m1);
-        F::mul_k(zA, z2, m2);                   // |2 An| Zq^2
-        F::add(m1, m2, m1);                     // < 2^29      ... - 2 An Zq^2
-        F::mul_k(z3, m1, m1);
-        F::sub(t1, x2, d);                      // tight       u Zq - Xq
-        F::sqr_k(d, d);
-        F::template mul_small<AD>(d, d);
-        F::mul_k(d, x3, d);
-        F::sub(m1, d, V);                       // tight       numerator of v_q over 4 v Zq^2 Zs
-        F::mul_k(w, z2, K);
-        F::mul_k(K, z3, K);                     // 4 v Zq Zs
+        uint32_t K[16], V[16], a[16], s[16], m[16];
+        const bool zq0 = is_zero(z2), xq0 = is_zero(x2), zs0 = is_zero(z3);
+        {
+            uint32_t w[16];
+            load_w(w);
+            F::mul_k(w, z2, K);
+            F::mul_k(K, z3, K);                 // 4 v Zq Zs
+        }
+        {
+            uint32_t u[16], t1[16], d[16], m1[16];
+            load_u(u);
+            F::mul_k(u, z2, t1);                // u Zq
+            F::sub(t1, x2, d);                  // tight       u Zq - Xq
+            F::sqr_k(d, d);
+            F::template mul_small<AD>(d, d);
+            F::mul_k(d, x3, d);                 // Ad (u Zq - Xq)^2 Xs                                   (x3 dies)
+            {
+                uint32_t t2[16], a1[16], a2[16], zA[16], m2[16];
+                F::mul_k(u, x2, t2);            // u Xq                                                  (u dies)
+                F::add(t2, z2, a1);             // < 2^29      u Xq + Zq
+                F::add(t1, x2, a2);             // < 2^29
+                F::template mul_small<AD>(a2, a2);      // tight       Ad (u Zq + Xq)
+                F::template mul_small<AN2>(z2, zA);     // tight       |2 An| Zq
+                F::sub(a2, zA, a2);             // tight       Ad (u Zq + Xq) + 2 An Zq
+                F::mul_k(a2, a1, m1);
+                F::mul_k(zA, z2, m2);           // |2 An| Zq^2
+                F::add(m1, m2, m1);             // < 2^29      ... - 2 An Zq^2
+            }
+            F::mul_k(z3, m1, m1);               //                                                       (z3 dies)
+            F::sub(m1, d, V);                   // tight       numerator of v_q over 4 v Zq^2 Zs
+        }
         F::mul_k(K, x2, a);                     // x = a / V
         F::add(x2, z2, s);                      // < 2^29
         F::sub(x2, z2, m);                      // tight       y = m / s
-        const bool zq0 = is_zero(z2), xq0 = is_zero(x2), zs0 = is_zero(z3);
         const bool px0 = (flags & FLAG_X0) != 0, pn = (flags & FLAG_NEUTRAL) != 0;
         const bool r_neutral = px0 ? (pn || !e_odd) : zq0;
         const bool r_two = px0 ? (!pn && e_odd) : (xq0 && !zq0);
         const bool r_negp = !px0 && zs0 && !zq0 && !xq0;
-        uint32_t one[16], zero[16], mone[16], na[16], ns[16], nm[16];
+        const uint32_t mk_n = (uint32_t)lane_mask(r_negp), mk_01 = (uint32_t)lane_mask(r_neutral || r_two), mk_2 = (uint32_t)lane_mask(r_two);
+        uint32_t one[16], zero[16];
         F::set(1, one);
         F::set(0, zero);
-        F::sub(zero, one, mone);                // p - 1, tight
-        F::template mul_small<4>(u, na);
-        F::sub(zero, na, na);                   // -P = (u, -v):  x = u / (-v) = -4 u / w,  y = (u - 1) / (u + 1)
-        F::add(u, one, ns);
-        F::sub(u, one, nm);
-        const uint32_t mk_n = (uint32_t)lane_mask(r_negp), mk_01 = (uint32_t)lane_mask(r_neutral || r_two), mk_2 = (uint32_t)lane_mask(r_two);
-        fe28_blend(mk_n, a, na, a);
-        fe28_blend(mk_n, s, ns, s);
-        fe28_blend(mk_n, m, nm, m);
-        fe28_blend(mk_n, V, w, V);
-        fe28_blend(mk_01, a, zero, a);
+        {   // -P = (u, -v):  x = u / (-v) = -4 u / w,  y = (u - 1) / (u + 1)
+            uint32_t u[16], t[16];
+            load_u(u);
+            F::template mul_small<4>(u, t);
+            F::sub(zero, t, t);
+            fe28_blend(mk_n, a, t, a);
+            F::add(u, one, t);
+            fe28_blend(mk_n, s, t, s);
+            F::sub(u, one, t);
+            fe28_blend(mk_n, m, t, m);
+            load_w(t);
+            fe28_blend(mk_n, V, t, V);
+        }
+        fe28_blend(mk_01, a, zero, a);          // (0, +-1): a = 0, V = s = 1, m = +-1
         fe28_blend(mk_01, s, one, s);
         fe28_blend(mk_01, m, one, m);
         fe28_blend(mk_01, V, one, V);
-        fe28_blend(mk_2, m, mone, m);
-        F::mul_k(a, s, R.X);                    // a, V, m tight; s below 2^29
-        F::mul_k(V, m, R.Y);
-        F::mul_k(V, s, R.Z);
+        {
+            uint32_t mone[16];
+            F::sub(zero, one, mone);            // p - 1, tight
+            fe28_blend(mk_2, m, mone, m);
+        }
+        // a, V, m tight; s below 2^29.  Each product overwrites an operand that dies with it (mul_k writes its result last): four
+        // results next to four operands and a product's own columns would not fit
         if (want_t) F::mul_k(a, m, R.T);
+        F::mul_k(a, s, a);
+        F::mul_k(V, m, m);
+        F::mul_k(V, s, V);
+        F::copy(a, R.X);
+        F::copy(m, R.Y);
+        F::copy(V, R.Z);
     }
 
     // one fused multiplication + export with its own two inversions: the per-lane reference of the kernel pipeline (host check)
@@ -168,7 +196,7 @@ struct Ed28Lad {
         F::mul_k(nw, D, w);
         ladder(ew, u, x2, z2, x3, z3);
         Ext R;
-        recover(u, w, flags, (ew[0] & 1) != 0, x2, z2, x3, z3, R, false);
+        recover([&](uint32_t* o) { F::copy(u, o); }, [&](uint32_t* o) { F::copy(w, o); }, flags, (ew[0] & 1) != 0, x2, z2, x3, z3, R, false);
         uint32_t zi[16], ax[16], ay[16];
         F::invert(R.Z, zi);
         F::mul_k(R.X, zi, ax);

@@ -31,6 +31,10 @@ struct FieldH51 {
     static constexpr int hbits(int i) { return (i & 1) ? 25 : 26; }
     static constexpr uint32_t hmask(int i) { return (i & 1) ? M25 : M26; }
 
+    // Exact for limbs below 2^58 (h[2k+1] = a_k >> 26 fits 32 bits), i.e. far beyond the limb budget 2^(Radix+2) = 2^53 of the curve
+    // layer; a limb of 2^58 or more loses its top bits here.  It is NOT normalised (as fh56.h does for the Montgomery form): the
+    // reference's pseudo-Mersenne product folds columns, so its output limbs depend on the limbs it is given, not only on the integer
+    // -- a representative with bits 51, 52 set inside the budget must go in as it is.  include/modarith_amd.h states the contract.
     static MA_DEV void from_limbs(const spint* a, uint32_t* h) {
         static_for<0, N>([&](auto K) {
             h[2 * K] = (uint32_t)a[K] & M26;

@@ -137,6 +137,12 @@ struct Wide<true, H> {
     };
 };
 
+// P::SPLIT_SPARSE (emit.split_is_sparse): the cut position SPLIT of this prime is proven from the number of prime limbs that actually enter
+// the 64-bit accumulators of monty_mul / monty_reduce (powers of two, 0 and +-1 never do) -- NOT for product forms whose columns hold
+// the dense 2N terms.  Parameter structs written before round 5 have no such member: false.
+template <class P, class = void> struct split_sparse_of : std::false_type {};
+template <class P> struct split_sparse_of<P, std::void_t<decltype(P::SPLIT_SPARSE)>> : std::bool_constant<P::SPLIT_SPARSE> {};
+
 // PIN_: keep the multiply-add chains of the half-limb products pinned (MA_PIN).  On by default; the progenitor chain
 // x^PE -- a separate, non-inlined function, for which no launch bound caps the register allocation -- is built from
 // the unpinned variant: with pins that one function takes 248 VGPRs (the whole kernel then runs at one wave per
@@ -164,6 +170,7 @@ struct Field {
     using Opd = typename W::Opd;
     using Col = typename W::Col;
     static constexpr bool CHAINED = FAST && P::CHAIN;    // product loops on the 64-bit column chain (Wide::Acc)
+    static constexpr bool SPLIT_SPARSE = split_sparse_of<P>::value;
 
     // ---------------------------------------------------------------- carries / normalisation
     // pseudo.py:223-251, monty.py:352-380 (arithmetic-shift form)
@@ -1038,6 +1045,9 @@ struct Field {
     static constexpr bool MHALF_TRI = FAST && P::MONTGOMERY && P::NDASH == 1 && P::E && RADIX == 56 && N == 8 && P::NEG_LIMB == 4 &&
                                       P::ppw(0) == -1 && P::ppw(4) == -1 && P::ppw(8) == 1 && P::ppw(1) == 0 && P::ppw(2) == 0 &&
                                       P::ppw(3) == 0 && P::ppw(5) == 0 && P::ppw(6) == 0 && P::ppw(7) == 0;
+    // a SPLIT that was proven from the sparse term count covers monty_mul / monty_reduce alone (emit.split_is_sparse, ADVICE of round 4:
+    // the pairing used to rest on an early return in emit.chain_ok and on MHALF not being selected)
+    static_assert(!(SPLIT_SPARSE && (CHAINED || MHALF || MHALF_TRI)), "SPLIT of this prime holds for the sparse columns of monty_mul only");
     template <bool SQR>
     static MA_DEV void monty_mul_half_tri(const spint* a, const spint* b, spint* c) {
         constexpr int H = RADIX / 2, M = 2 * N, NEG = P::NEG_LIMB;

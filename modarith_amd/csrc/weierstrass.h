@@ -10,7 +10,7 @@
 
 namespace ma {
 
-template <class C, class F_ = Field<typename C::FieldParams, true>>     // F_: the limb form, or a resident half-limb form (fh52.h) for the scalar multiplications
+template <class C, class F_ = Field<typename C::FieldParams, true>>     // F_: the limb form, or a resident half-limb form for the scalar multiplications (tried for P-256 in round 4 and dropped: docs/curve_layer.md)
 struct Weierstrass : CurveOps<Weierstrass<C, F_>, typename C::FieldParams, F_> {
     using Base = CurveOps<Weierstrass<C, F_>, typename C::FieldParams, F_>;
     using P = typename C::FieldParams;

@@ -281,6 +281,20 @@ def split_point(fp: FieldParams) -> int:
     return best
 
 
+def split_is_sparse(fp: FieldParams) -> bool:
+    """True when split_point(fp) is provable only with the sparse term count: the dense count 2N has no cut.  field.h refuses to
+    combine such a SPLIT with the product forms whose columns hold the dense number of accumulator terms (chain / half-limb forms)."""
+    if split_point(fp) == 0 or fp.family == "pseudo" or sparse_terms(fp) is None:
+        return False
+    W, n, lim = fp.radix + 2, 2 * fp.nlimbs, 1 << 64
+    for H in range(20, 33):
+        if W - H > 32:
+            continue
+        if (n << (2 * H)) < lim and n * ((1 << W) + (1 << W)) < lim and (n << max(2 * W - 2 * H, 0)) < lim:
+            return False            # the dense count has a cut too
+    return True
+
+
 def sparse_terms(fp: FieldParams):
     """products + accumulator-borne reduction terms of one column for a Montgomery prime with ndash == 1 and few non-zero limbs
     (+ 1 for the doubled cross terms of the squarings' odd term count), or None where the dense count 2N has to stand"""
@@ -340,6 +354,7 @@ def header_text(fp: FieldParams) -> str:
              % (N, fp.radix, fp.n, fp.nbytes, fp.xcess, fp.pm1d2))
     L.append("    static constexpr bool MONTGOMERY = %s;" % ("true" if fp.montgomery else "false"))
     L.append("    static constexpr int SPLIT = %d;   // FAST product path: operand cut position, 0 = not provable (emit.split_point)" % split_point(fp))
+    L.append("    static constexpr bool SPLIT_SPARSE = %s;   // SPLIT proven from the SPARSE term count (emit.sparse_terms): holds for Field::monty_mul / monty_reduce only" % ("true" if split_is_sparse(fp) else "false"))
     L.append("    static constexpr bool CHAIN = %s;   // FAST product loops on the 64-bit column chain (emit.chain_ok)" % ("true" if chain_ok(fp) else "false"))
     # pseudo-Mersenne block (dummies for Montgomery primes)
     L.append("    static constexpr unsigned long long M = %s, MM = %s;" % (_hexu(fp.m if not fp.montgomery else 0), _hexu(fp.mm)))

@@ -61,7 +61,14 @@ def flatten_batch(t: torch.Tensor) -> torch.Tensor:
 
 
 class Field:
-    """Batched field arithmetic for one of the built primes (X25519, NIST256, X448)."""
+    """Batched field arithmetic for one of the built primes (X25519, NIST256, X448, ...) or a generated one.
+
+    Shape of the batches this object CREATES -- it depends on n (round 4; ADVICE of round 4: say so here):
+      * `Field(prime)` / `Field(prime, tile=4096)`: a batch of n elements is TILED, a 3-D tensor [n / tile, N, tile], when it holds at
+        least two whole tiles and n is a multiple of the tile (n >= 2 * tile and n % tile == 0); every other n gives the FLAT 2-D
+        tensor [N, n].  So `uniform(8192)` is [2, N, 4096] and `uniform(8191)` is [N, 8191].
+      * `Field(prime, tile=None)`: always flat [N, n] -- what a script that indexes `[limb, j]` or labels its numbers "flat" must ask for.
+    Every method ACCEPTS both forms; `to_flat` / `to_tiled` convert; `creates_tiled(n)` tells which one n gets."""
 
     DEFAULT_TILE = 4096            # = modarith_amd_recommended_ld(n) for n >= 2 * 4096 (include/modarith_amd.h "TILED")
 

@@ -22,7 +22,7 @@ def pytest_configure(config):
 
 
 def load_golden(name):
-    """a fixture of tests/golden/, plain JSON or gzip-compressed JSON (tests/golden/gio.py)"""
+    """a fixture of tests/golden/, plain JSON or xz-compressed JSON (tests/golden/gio.py)"""
     from tests.golden import gio
     return gio.load(name)
 

@@ -1029,25 +1029,6 @@ int main(int argc, char** argv) {
                                       for (int k = 0; k < 4; k++) { x[k] = xw[2][k]; y[k] = yw[2][k]; }
                                   }, ecn_ed25519_gen, ecn_ed25519_mul, ecn_ed25519_get);
     bad += run_ed25519_mulgen2_lad(n / 8 + 24);
-    struct HostPark { uint32_t w[64]; void put(int k, uint32_t v) { w[k] = v; } uint32_t get(int k) const { return w[k]; } };
-    bad += run_edgen<56, pt448>("ed448_mulgen_get_two", n / 8 + 130, [](const uint64_t* e, uint64_t* x, uint64_t* y) {
-                                    uint64_t xw[2][7], yw[2][7];        // this scalar first and second of a pair, both must agree
-                                    HostPark park;
-                                    ma::ed448_mulgen_get_two<HostComb448>([&](int g, uint64_t* ew) { for (int k = 0; k < 7; k++) ew[k] = e[k]; }, park, xw, yw);
-                                    for (int k = 0; k < 7; k++) { x[k] = xw[0][k]; y[k] = yw[1][k]; }
-                                    for (int k = 0; k < 7; k++) if (xw[0][k] != xw[1][k] || yw[0][k] != yw[1][k]) x[0] ^= 1;
-                                }, ecn_ed448_gen, ecn_ed448_mul, ecn_ed448_get);
-    bad += run<7>("x448_base_two (u = 5)", n / 4 + 8, [](const uint64_t* k, const uint64_t*, uint64_t* o) {
-                      uint64_t ow[2][7];
-                      HostPark park;                              // partner key: the clamped 4q (X = 0) for every third record
-                      const uint64_t q4[7] = {0x8de30a4aad6113ccull, 0x85b309ca37163d54ull, 0x113b6d26bb58da40ull, 0xfffffffdf3288fa7ull, ~0ull, ~0ull, ~0ull};
-                      const bool first = (k[1] & 1) != 0, withq = (k[2] % 3) == 0;
-                      ma::x448_base_two<HostComb448>([&](int g, uint64_t* kw) {
-                          const bool mine = (g == 0) == first;
-                          for (int i = 0; i < 7; i++) kw[i] = mine ? k[i] : (withq ? q4[i] : k[(i + 3) % 7] ^ 0x5555555555555555ull);
-                      }, park, ow);
-                      for (int i = 0; i < 7; i++) o[i] = ow[first ? 0 : 1][i];
-                  }, rfc7748_X448, 5);
     bad += run_edgen<56, pt448>("ed448_mulgen_get_one", n / 8 + 130, [](const uint64_t* e, uint64_t* x, uint64_t* y) { ma::ed448_mulgen_get_one<HostComb448>(e, x, y); },
                                 ecn_ed448_gen, ecn_ed448_mul, ecn_ed448_get);
     return bad ? 1 : 0;

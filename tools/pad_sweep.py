@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from modarith_amd.field import Field
-F = Field("X25519")
+F = Field("X25519", tile=None)     # flat rows: what this script measures and labels (Field() alone is tiled since round 4)
 for lg in (int(x) for x in (sys.argv[1:] or ["25", "26"])):
     n = 1 << lg
     for pad in (0, 32, 544, 2112, 8224, 65568, 1 << 20):

@@ -17,19 +17,23 @@ def legs():
         base = "capi_" + C
         out[C + "_ecn_mul"] = [("k_ed_mul<ma::%s<ma::C_%s," % (fam, C), obj + "_part1.o", 1, 1)]
         out[C + "_ecn_mul2"] = [("k_ed_mul2<ma::%s<ma::C_%s," % (fam, C), obj + "_part2.o", 1, 1)]
-        if C == "ED25519":
-            out[C + "_ecn_mul_get_fused"] = [("k_ed26l_prep<ma::C_ED25519, 1>", base + "F.o", 1, 1), ("SinkWords<4>, 1>", base + "F.o", 1, "rounds"),
-                                             ("SinkExport25519, 1>", base + "F.o", 1, "rounds"), ("k_ed25519_lad(", base + "F.o", 1, 1)]
-            out[C + "_ecn_mulgen2_get_fused"] = [("k_ed26l_prep<ma::C_ED25519, 2>", base + "G.o", 1, 1), ("SinkWords<4>, 2>", base + "G.o", 1, "rounds"),
-                                                 ("SinkExport25519, 2>", base + "G.o", 1, "rounds"), ("k_ed25519_lad_gen2", base + "G.o", 1, 1)]
+        if C in ("ED25519", "ED448"):
+            # the ladder form (csrc/ed26l.h, ed28l.h): prep, the shared inversion in front, the ladder, the shared inversion + export
+            T, NW, PF = ("LadT25519", 4, "P_X25519") if C == "ED25519" else ("LadT448", 7, "P_X448")
+            for leg, tag, unit, lad in (("_ecn_mul_get_fused", 1, "F.o", "k_%s_lad(" % low), ("_ecn_mulgen2_get_fused", 2, "G.o", "k_%s_lad_gen2" % low)):
+                out[C + leg] = [("k_edlad_prep<ma::%s, %d>" % (T, tag), base + unit, 1, 1), ("SinkWords<%d>, %d>" % (NW, tag), base + unit, 1, "rounds"),
+                                ("SinkExportBE<ma::%s>, %d>" % (PF, tag), base + unit, 1, "rounds"), (lad, base + unit, 1, 1)]
         else:
             out[C + "_ecn_mul_get_fused"] = [("k_%s_mul_get" % low, base + "F.o", 1, 1)]
             out[C + "_ecn_mulgen2_get_fused"] = [("k_%s_mulgen2_get" % low, base + "G.o", 1, 1)]
         if C == "ED25519":
-            out[C + "_ecn_mul2_get_fused"] = [("k_ed25519_mul2_straus", base + "F2.o", 1, 1), ("SinkExport25519, 3>", base + "F2.o", 1, "rounds")]
+            out[C + "_ecn_mul2_get_fused"] = [("k_ed25519_mul2_straus", base + "F2.o", 1, 1), ("SinkExportBE<ma::P_X25519>, 3>", base + "F2.o", 1, "rounds")]
         else:
             out[C + "_ecn_mul2_get_fused"] = [("k_%s_mul2_get" % low, base + "F2.o", 1, 1)]
-        out[C + "_ecn_mulgen_get_fused"] = [("k_%s_mulgen_get" % low, base + "G.o", g, 1)]
+        if C == "ED448":
+            out[C + "_ecn_mulgen_get_fused"] = [("k_ed448_mulgen<false>", base + "G.o", 1, 1), ("SinkExportBE<ma::P_X448>, 3>", base + "G.o", 1, "rounds")]
+        else:
+            out[C + "_ecn_mulgen_get_fused"] = [("k_%s_mulgen_get" % low, base + "G.o", g, 1)]
     return out
 
 

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from modarith_amd.field import Field
-F = Field("X25519")
+F = Field("X25519", tile=None)     # flat rows: what this script measures and labels (Field() alone is tiled since round 4)
 for lg in (20, 22, 24, 25, 26, 27):
     n = 1 << lg
     a = torch.randint(0, 1 << 51, (5, n), dtype=torch.int64, device="cuda")

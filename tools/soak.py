@@ -27,7 +27,7 @@ def field_child(out):
         fp = derive(name)
         if emit.split_point(fp) == 0:
             continue
-        F = Field(name)
+        F = Field(name, tile=None)          # flat rows, as the [N, n] indexing below assumes
         R = fp.radix
         g = torch.Generator(device="cuda").manual_seed(1234)
         edges = torch.tensor([0, 1, (1 << R) - 1, 1 << R, (1 << (R + 1)) - 1, (1 << (R + 2)) - 1, 0x5555555555555 & ((1 << R) - 1)], dtype=torch.int64, device="cuda")

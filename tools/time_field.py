@@ -10,7 +10,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     n = 1 << 22
     for name in sys.argv[2:] or ["X25519", "NIST256", "X448"]:
         fp = derive(name)
-        F = Field(name)
+        F = Field(name, tile=None)          # flat rows, as the [N, n] indexing below assumes
         a = F.nres(F.uniform(n))
         for op in ("modinv", "modsqrt", "modpro"):
             fn = getattr(F, op)
