@@ -26,7 +26,8 @@ SRC = os.path.join(ROOT, "gpurun_out", "prof_r05")
 def dispatches(tag):
     """{(kernel name, dispatch id): {counter: value, duration_ns, grid}} of one pass"""
     per = collections.defaultdict(dict)
-    for f in glob.glob(os.path.join(SRC, tag, "*", "*_counter_collection.csv")):
+    files = sorted(glob.glob(os.path.join(SRC, tag, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:                 # the newest pass only: gpurun merges every call's files into gpurun_out/, older passes stay there
         for r in csv.DictReader(open(f)):
             k = (r["Kernel_Name"], r["Dispatch_Id"])
             per[k][r["Counter_Name"]] = per[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
