@@ -408,7 +408,10 @@ size_t ecn_ed25519_mul_get_workspace_bytes(size_t n);
 int ecn_ed25519_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
                               void *workspace, size_t workspace_bytes, void *stream);
 /* R = e*P + f*Q and its affine export in one kernel: ecnXXXmul2 followed by ecnXXXget, the verification pattern
- * (ed448.c:305, nist256.c:251-254); same conventions as mul_get, P and Q are not modified */
+ * (ed448.c:305, nist256.c:251-254); same conventions as mul_get, P and Q are not modified.  ed25519 / ed448 (round 5): a Straus
+ * walk over signed 4-bit windows whose table entries are read BY INDEX (variable time like the reference's own mul2: public
+ * inputs); the workspace -- 128-byte aligned -- holds the table slabs of the resident grid (302 / 604 MB) and 140 / 236 bytes per
+ * record for at most 2^20 records; NULL takes the library's scratch pool. */
 size_t ecn_ed25519_mul2_get_workspace_bytes(size_t n);
 int ecn_ed25519_mul2_get_batch(const char *e, const ma_spint *P, const char *f, const ma_spint *Q, char *x, char *y, int *sign,
                                size_t n, size_t ld, void *workspace, size_t workspace_bytes, void *stream);

@@ -1,48 +1,57 @@
 // modarith_amd/csrc/capi_ED448F2.hip -- ecn_ed448_mul2_get_batch: double multiplication e*P + f*Q fused with the affine
-// export (csrc/ed28.h), the verification pattern ecnXXXmul2 + ecnXXXget of the reference's signature code (ed448.c:305).
+// export (csrc/ed28s.h: the Straus form), the verification pattern ecnXXXmul2 + ecnXXXget of the reference's signature code
+// (ed448.c:290-310).
 #include "../../include/modarith_amd.h"
 #include "capi_common.h"
 #include "generated/params_X448.h"
 #include "kernels.h"
 #include "ed28.h"
+#include "ed28s.h"
+#include "ed28l_k.h"
 
 namespace ma {
 
-constexpr size_t ED448_ROW_SKEW2 = 32 + 4;   // words added to the row pitch of the table workspace (as in capi_ED448F.hip)
-
-// tables in the wave's slab, the two recoded scalars in LDS (four 2-bit windows per byte), element index formed at use: see capi_ED448F.hip
+// one pair per lane, one wave per workgroup: signed 4-bit windows of both scalars in LDS (one byte per window), the two 9-entry tables
+// in the wave's slab of the workspace (two 128-byte lines per entry and lane, read by index), the Edwards (X : Y : Z) of the sum to the
+// shared inversion of csrc/edlad_k.h.  Records first .. first + ws.m of the caller's arrays.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_ed448_mul2_get(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb,
-                      int* sign, size_t n, size_t ld, uint64_t* ws) {
+void k_ed448_mul2_straus(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, size_t first, size_t ld,
+                         uint64_t* slab, Ed28lWs ws) {
     using P = P_X448;
-    __shared__ unsigned char digs[2 * 57 * 64];
-    const TabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)ED448_TABLE_WORDS), threadIdx.x};
+    using S = Ed28Straus;
+    __shared__ unsigned char digs[2 * 113 * 64];
     unsigned char* ce = digs + threadIdx.x;
-    unsigned char* cf = ce + 57 * 64;
-    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
-        auto t = [&]() { return base + (size_t)(T.origin() - T.base); };
-        if (t() >= n) continue;
+    unsigned char* cf = ce + 113 * 64;
+    Straus448TabSlab tab{slab + ((size_t)blockIdx.x * 64 + threadIdx.x) * (18 * 32)};
+    for (size_t base = (size_t)blockIdx.x * 64; base < ws.m; base += (size_t)gridDim.x * 64) {
+        auto t = [&]() {
+            unsigned l = threadIdx.x;
+            asm volatile("" : "+v"(l));
+            return base + l;
+        };
+        if (t() >= ws.m) continue;
         {
-            spint ew[7];
-            load_be_record<P>(e, t(), ew);
-            Win2Lds::fill(ew, ce);
-            load_be_record<P>(f, t(), ew);
-            Win2Lds::fill(ew, cf);
+            spint w[7];
+            load_be_record<P>(e, first + t(), w);
+            W448_4Lds::fill(w, ce);
+            load_be_record<P>(f, first + t(), w);
+            W448_4Lds::fill(w, cf);
         }
-        spint PX[8], PY[8], PZ[8], QX[8], QY[8], QZ[8], xw[7], yw[7];
-        static_for<0, 8>([&](auto I) {
-            PX[I] = Pb[(size_t)I * ld + t()];
-            PY[I] = Pb[(size_t)(8 + I) * ld + t()];
-            PZ[I] = Pb[(size_t)(16 + I) * ld + t()];
-            QX[I] = Qb[(size_t)I * ld + t()];
-            QY[I] = Qb[(size_t)(8 + I) * ld + t()];
-            QZ[I] = Qb[(size_t)(16 + I) * ld + t()];
-        });
-        Win2Lds de{ce}, df{cf};
-        ed448_mul2_get_one(de, PX, PY, PZ, df, QX, QY, QZ, T, xw, yw);
-        if (xb) store_be_record<P>(xb, t(), xw);
-        if (yb) store_be_record<P>(yb, t(), yw);
-        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+#pragma unroll 1
+        for (int which = 0; which < 2; which++) {
+            const spint* B = which ? Qb : Pb;
+            spint X[8], Y[8], Z[8];
+            static_for<0, 8>([&](auto I) {
+                X[I] = B[(size_t)I * ld + first + t()];
+                Y[I] = B[(size_t)(8 + I) * ld + first + t()];
+                Z[I] = B[(size_t)(16 + I) * ld + first + t()];
+            });
+            S::build(tab, which, X, Y, Z);
+        }
+        W448_4Lds de{ce}, df{cf};
+        S::Ext R;
+        S::walk(de, df, tab, R);
+        ws.store_xyz(t(), R.X, R.Y, R.Z);
     }
 }
 
@@ -50,14 +59,15 @@ void k_ed448_mul2_get(const unsigned char* e, const spint* Pb, const unsigned ch
 
 using namespace ma;
 
-namespace {
-size_t fused_lanes(size_t n) {
-    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
-    return lanes < cap ? lanes : cap;
+static size_t straus_waves(size_t n) {
+    const size_t w = (n + 63) / 64, cap = (size_t)2 * 1024;          // two waves on each of the 1024 SIMDs
+    return w < cap ? w : cap;
 }
-}  // namespace
 
-extern "C" size_t ecn_ed448_mul2_get_workspace_bytes(size_t n) { return (fused_lanes(n) + ED448_ROW_SKEW2) * ED448_TABLE_WORDS * sizeof(uint64_t); }
+extern "C" size_t ecn_ed448_mul2_get_workspace_bytes(size_t n) {
+    const size_t m = n < EDLAD_CHUNK ? n : EDLAD_CHUNK;
+    return straus_waves(m) * STRAUS448_SLAB_BYTES_PER_WAVE + ed28l_workspace_bytes(n);
+}
 
 extern "C" int ecn_ed448_mul2_get_batch(const char* e, const ma_spint* P, const char* f, const ma_spint* Q, char* x, char* y, int* sign,
                                         size_t n, size_t ld, void* workspace, size_t workspace_bytes, void* st) {
@@ -66,13 +76,19 @@ extern "C" int ecn_ed448_mul2_get_batch(const char* e, const ma_spint* P, const 
         set_error("ecn mul2_get: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
     }
-    const size_t lanes = fused_lanes(n);
-    if (workspace == nullptr || workspace_bytes < (lanes + ED448_ROW_SKEW2) * ED448_TABLE_WORDS * sizeof(uint64_t)) {
-        set_error("ecn mul2_get: workspace too small (see ecn_ed448_mul2_get_workspace_bytes)");
+    hipStream_t s = (hipStream_t)st;
+    EdLadScratch wsp(workspace, workspace_bytes, ecn_ed448_mul2_get_workspace_bytes(n), 128, s);
+    if (!wsp.p) {
+        set_error("ecn mul2_get: no workspace (pass ecn_ed448_mul2_get_workspace_bytes(n) bytes, 128-byte aligned; the library's own scratch pool is not available while the stream is being captured)");
         return (int)hipErrorInvalidValue;
     }
-    k_ed448_mul2_get<<<(unsigned)(lanes / 64), 64, 0, (hipStream_t)st>>>(
-        reinterpret_cast<const unsigned char*>(e), P, reinterpret_cast<const unsigned char*>(f), Q, reinterpret_cast<unsigned char*>(x),
-        reinterpret_cast<unsigned char*>(y), sign, n, ld, reinterpret_cast<uint64_t*>(workspace));
-    return check_launch("ecn mul2_get");
+    const unsigned char *eb = reinterpret_cast<const unsigned char*>(e), *fb = reinterpret_cast<const unsigned char*>(f);
+    const size_t slab_bytes = straus_waves(n < EDLAD_CHUNK ? n : EDLAD_CHUNK) * STRAUS448_SLAB_BYTES_PER_WAVE;
+    for (size_t first = 0; first < n; first += EDLAD_CHUNK) {
+        const size_t m = n - first < EDLAD_CHUNK ? n - first : EDLAD_CHUNK;
+        Ed28lWs ws(reinterpret_cast<unsigned char*>(wsp.p) + slab_bytes, m);
+        k_ed448_mul2_straus<<<(unsigned)straus_waves(m), 64, 0, s>>>(eb, P, fb, Q, first, ld, reinterpret_cast<uint64_t*>(wsp.p), ws);
+        edlad_export<LadT448, 3>(ws, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, first, s);
+    }
+    return check_launch("ecn mul2_get (Straus form)");
 }

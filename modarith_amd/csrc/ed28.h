@@ -111,464 +111,12 @@ struct Ed28 {
         F::mul(s1, s2, M);
         add_tail(A, B, Cc, p.Z, M, p, want_t);
     }
-    // P += Q, both extended; used once, to build 3P
-    static MA_DEV void add_ext(Ext& p, const Ext& q) {
-        uint32_t A[16], B[16], Cc[16], D[16], M[16], s1[16], s2[16];
-        F::mul_k(p.X, q.X, A);
-        F::mul_k(p.Y, q.Y, B);
-        F::mul_k(p.T, q.T, Cc);
-        F::mul_small<D_ABS>(Cc, Cc);
-        F::mul_k(p.Z, q.Z, D);
-        F::add(p.X, p.Y, s1);
-        F::add(q.X, q.Y, s2);
-        F::mul(s1, s2, M);
-        add_tail(A, B, Cc, D, M, p);
-    }
-    // The same with q fetched coordinate by coordinate -- fetch(c, out), c = 0..3 for X, Y, Z, T -- so that the table builder holds
-    // one point while it forms 3P (q waits in its table slot)
-    template <class FETCH>
-    static MA_DEV void add_ext_fetched(Ext& p, FETCH fetch) {
-        uint32_t A[16], B[16], Cc[16], D[16], M[16];
-        {
-            uint32_t q[16];
-            fetch(3, q);
-            F::mul_k(p.T, q, Cc);
-            F::mul_small<D_ABS>(Cc, Cc);
-            fetch(2, q);
-            F::mul_k(p.Z, q, D);
-        }
-        {
-            uint32_t qx[16], qy[16], s1[16], s2[16];
-            fetch(0, qx);
-            fetch(1, qy);
-            F::mul_k(p.X, qx, A);
-            F::mul_k(p.Y, qy, B);
-            F::add(p.X, p.Y, s1);
-            F::add(qx, qy, s2);
-            F::mul(s1, s2, M);
-        }
-        add_tail(A, B, Cc, D, M, p);
-    }
 };
 
-constexpr int ED448_TABLE_WORDS = 4 * 3 * 7;       // 64-bit words per lane in the workspace
-
-// ---- where the window table of a lane lives, and where the recoded scalar comes from (round 4).  The functions below are written
-// over two small concepts so that the kernels can keep both OUT of the register file while the host check keeps plain arrays:
-//   TAB: origin() = pointer to word 0 of this lane's table (a fresh value per call in the slab form, so that row addresses are
-//        formed at the access instead of being carried -- and spilled -- across the window), stride() = words between table words;
-//   DIG: window(i) = the i-th window of the recoded scalar, in the order the loop consumes them.
-struct TabStrided {                         // word k at tab[k * tstride] (host check: tstride = 1; the round-3 kernels: lanes + skew)
-    uint64_t* tab;
-    size_t tstride;
-    MA_DEV uint64_t* origin() const { return tab; }
-    MA_DEV size_t stride() const { return tstride; }
-};
-struct TabSlab {                            // per-wave slab [word][64 lanes]: every access of a wave is one contiguous 512-byte row
-    uint64_t* base;                         // wave-uniform
-    unsigned lane;
-    MA_DEV uint64_t* origin() const {
-        unsigned l = lane;
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+v"(l));
-#endif
-        return base + l;
-    }
-    static MA_DEV constexpr size_t stride() { return 64; }
-};
-// e' = e + sum_{i<150} 4*8^i (450 bits), 150 windows of 3 bits from the top; window(i) must be called for i = 0, 1, 2, ... in order
-struct Win3Regs {
-    uint64_t w[8];
-    MA_DEV void init(const uint64_t* ew) {
-        constexpr auto cw = [](int k) {
-            uint64_t v = 0;
-            for (int b = 0; b < 64; b++) {
-                const int pos = 64 * k + b;
-                if (pos < 450 && pos % 3 == 2) v |= (uint64_t)1 << b;
-            }
-            return v;
-        };
-        unsigned __int128 acc = 0;
-        uint64_t s[8];
-        static_for<0, 8>([&](auto K) {
-            constexpr int k = K;
-            acc += (unsigned __int128)(k < 7 ? ew[k < 7 ? k : 0] : 0) + cw(k);
-            s[k] = (uint64_t)acc;
-            acc >>= 64;
-        });
-        static_for<0, 8>([&](auto KK) {
-            constexpr int k = 7 - KK;
-            w[k] = s[k] << 62;
-            if constexpr (k > 0) w[k] |= s[k - 1] >> 2;
-        });
-    }
-    MA_DEV uint32_t window(int) {
-        const uint32_t win = (uint32_t)(w[7] >> 61);
-        static_for<0, 8>([&](auto KK) {
-            constexpr int k = 7 - KK;
-            w[k] <<= 3;
-            if constexpr (k > 0) w[k] |= w[k - 1] >> 61;
-        });
-        return win;
-    }
-};
-// the same windows, produced once into the lane's column of an LDS array (one byte per window) before the point is loaded
-struct Win3Lds {
-    const unsigned char* col;               // digs + lane, windows 64 bytes apart
-    static MA_DEV void fill(const uint64_t* ew, unsigned char* col) {
-        Win3Regs r;
-        r.init(ew);
-#pragma unroll 1
-        for (int i = 0; i < 150; i++) col[(size_t)i * 64] = (unsigned char)r.window(i);
-    }
-    MA_DEV uint32_t window(int i) const { return col[(size_t)i * 64]; }
-};
-// e' = e + sum_{i<225} 2*4^i (450 bits), 225 windows of 2 bits from the top (the double multiplication)
-struct Win2Regs {
-    uint64_t w[8];
-    MA_DEV void init(const uint64_t* in) {
-        constexpr auto cw = [](int k) {
-            uint64_t v = 0;
-            for (int b = 0; b < 64; b++) {
-                const int pos = 64 * k + b;
-                if (pos < 450 && pos % 2 == 1) v |= (uint64_t)1 << b;
-            }
-            return v;
-        };
-        unsigned __int128 acc = 0;
-        uint64_t s[8];
-        static_for<0, 8>([&](auto K) {
-            constexpr int k = K;
-            acc += (unsigned __int128)(k < 7 ? in[k < 7 ? k : 0] : 0) + cw(k);
-            s[k] = (uint64_t)acc;
-            acc >>= 64;
-        });
-        static_for<0, 8>([&](auto KK) {
-            constexpr int k = 7 - KK;
-            w[k] = s[k] << 62;
-            if constexpr (k > 0) w[k] |= s[k - 1] >> 2;
-        });
-    }
-    MA_DEV uint32_t window(int) {
-        const uint32_t win = (uint32_t)(w[7] >> 62);
-        static_for<0, 8>([&](auto KK) {
-            constexpr int k = 7 - KK;
-            w[k] <<= 2;
-            if constexpr (k > 0) w[k] |= w[k - 1] >> 62;
-        });
-        return win;
-    }
-};
-struct Win2Lds {                            // four windows per byte (57 bytes per scalar and lane)
-    const unsigned char* col;
-    static MA_DEV void fill(const uint64_t* in, unsigned char* col) {
-        Win2Regs r;
-        r.init(in);
-#pragma unroll 1
-        for (int q = 0; q < 57; q++) {
-            unsigned b = 0;
-#pragma unroll
-            for (int h = 0; h < 4; h++) b |= (4 * q + h < 225 ? r.window(0) : 0u) << (2 * h);
-            col[(size_t)q * 64] = (unsigned char)b;
-        }
-    }
-    MA_DEV uint32_t window(int i) const { return ((uint32_t)col[(size_t)(i >> 2) * 64] >> (2 * (i & 3))) & 3u; }
-};
-
-// The four entry slots of one lane's table while it is being built (round 4).  Each multiple is STASHED in its slot as canonical
-// (X, Y, Z) -- 3 x 7 words, exactly the size of an entry -- as soon as it exists, so that the builder never holds more than two
-// points; to_affine_entries() then forms the products of the four Z from the slots (a = Z1 Z2, b = a Z3, c = b Z4), inverts once,
-// and overwrites every slot with its affine entry (x, y, 39081 x y).
-template <class TAB>
-struct Ed448Slots {
-    using E = Ed28;
-    using F = Fe28;
-    const TAB& T;
-    MA_DEV void put7(int word, const uint32_t* f) const {
-        uint64_t w[7];
-        F::to_words(f, w);
-        uint64_t* tab = T.origin();
-        const size_t tstride = T.stride();
-        static_for<0, 7>([&](auto K) { tab[(size_t)(word + K) * tstride] = w[K]; });
-    }
-    MA_DEV void get7(int word, uint32_t* f) const {
-        uint64_t w[7];
-        const uint64_t* tab = T.origin();
-        const size_t tstride = T.stride();
-        static_for<0, 7>([&](auto K) { w[K] = tab[(size_t)(word + K) * tstride]; });
-        F::from_words(w, f);
-    }
-    MA_DEV void stash(const E::Ext& p, int entry) const {
-        put7(entry * 21, p.X);
-        put7(entry * 21 + 7, p.Y);
-        put7(entry * 21 + 14, p.Z);
-    }
-    MA_DEV void finish(int entry, const uint32_t* zi) const {
-        uint32_t x[16], y[16], s[16];
-        get7(entry * 21, x);
-        get7(entry * 21 + 7, y);
-        F::mul_k(x, zi, x);
-        F::mul_k(y, zi, y);
-        put7(entry * 21, x);
-        put7(entry * 21 + 7, y);
-        F::mul_k(x, y, s);
-        F::mul_small<E::D_ABS>(s, s);
-        put7(entry * 21 + 14, s);
-    }
-    MA_DEV void to_affine_entries() const {
-        // Montgomery's trick on the four stashed Z: a = Z1 Z2, b = a Z3, c = b Z4, one inversion, then back down.  Nothing but the
-        // product is live across the inversion (its own working set is four elements): a and b are formed a second time afterwards
-        // -- two multiplications against the 460 of the inversion -- and the Z's are fetched again.
-        uint32_t a[16], b[16], inv[16], z[16];
-        auto products = [&]() {
-            get7(0 * 21 + 14, a);
-            get7(1 * 21 + 14, z);
-            F::mul_k(a, z, a);
-            get7(2 * 21 + 14, z);
-            F::mul_k(a, z, b);
-            get7(3 * 21 + 14, z);
-        };
-        products();
-        F::mul_k(b, z, inv);
-        F::invert(inv, inv);
-        products();
-        uint32_t i1[16], i2[16], i3[16], i4[16];
-        F::mul_k(inv, b, i4);                       // 1 / Z4
-        F::mul_k(inv, z, inv);                      // 1 / (Z1 Z2 Z3)      (z = Z4)
-        F::mul_k(inv, a, i3);
-        get7(2 * 21 + 14, z);
-        F::mul_k(inv, z, inv);                      // 1 / (Z1 Z2)
-        get7(0 * 21 + 14, z);
-        F::mul_k(inv, z, i2);
-        get7(1 * 21 + 14, z);
-        F::mul_k(inv, z, i1);
-        finish(0, i1);
-        finish(1, i2);
-        finish(2, i3);
-        finish(3, i4);
-    }
-};
-
-// Affine, canonical coordinates of R (ecnXXXget: edwards.c:221-239).  X and Y wait in the first table slot -- the table is dead
-// by now -- while Z is inverted, so that the inversion has the register file to itself.
-template <class TAB>
-MA_DEV void ed448_affine_words(Ed28::Ext& R, const TAB& T, uint64_t* xw, uint64_t* yw) {
-    using F = Fe28;
-    Ed448Slots<TAB> S{T};
-    S.put7(0, R.X);
-    S.put7(7, R.Y);
-    uint32_t zi[16], c[16];
-    F::invert(R.Z, zi);
-    S.get7(0, c);
-    F::mul_k(c, zi, c);
-    F::to_words(c, xw);
-    S.get7(7, c);
-    F::mul_k(c, zi, c);
-    F::to_words(c, yw);
-}
-
-// One fused ED448 scalar multiplication + affine export.  ew: the scalar as seven little-endian words; X, Y, Z: 8 x 56-bit
-// limbs each; tab: this lane's table slots, word k at tab[k * tstride]; xw, yw: canonical affine coordinates, seven words.
-template <bool FINAL_T = false, class TAB, class DIG>         // FINAL_T: the sum leaves with its T coordinate (a further addition follows)
-MA_DEV void ed448_mul_acc(DIG& dig, const spint* X, const spint* Y, const spint* Z, const TAB& T, Ed28::Ext& R) {
-    using E = Ed28;
-    using F = Fe28;
-
-    {   // ---- table: projective P -> extended; 2P, 3P, 4P; one shared inversion; cached affine form.
-        // Round 4: ONE point is live at any time.  Each multiple is STASHED in its own table slot as canonical
-        // (X, Y, Z) -- 3 x 7 words, exactly the size of an entry -- as soon as it exists; the products of the Z's are formed from the
-        // slots afterwards (a = Z1 Z2, b = a Z3, c = b Z4), and after the one inversion every slot is fetched, scaled and overwritten with its
-        // affine entry (x, y, 39081 x y).  (Round 3 kept Q, 2P, 3P, 4P -- 256 VGPRs -- to the end: 600 spilled registers.)
-        Ed448Slots<TAB> S{T};
-        {
-            E::Ext Q;
-            {
-                uint32_t px[16], py[16], pz[16];
-                E::from56(X, px);
-                E::from56(Y, py);
-                E::from56(Z, pz);
-                F::mul_k(px, pz, Q.X);              // (XZ : YZ : Z^2 : XY)
-                F::mul_k(py, pz, Q.Y);
-                F::sqr_k(pz, Q.Z);
-                F::mul_k(px, py, Q.T);
-            }
-            S.stash(Q, 0);
-            S.put7(3 * 21, Q.T);                    // (the fourth slot is free until 4P exists)
-            E::dbl<true>(Q);                        // 2P, with T (the addition below reads it)
-            S.stash(Q, 1);
-            E::add_ext_fetched(Q, [&](int c, uint32_t* out) { S.get7(c == 3 ? 3 * 21 : c * 7, out); });     // 3P = 2P + P
-            S.stash(Q, 2);
-            S.get7(1 * 21, Q.X);                      // 2P again (the doubling reads X, Y, Z only)
-            S.get7(1 * 21 + 7, Q.Y);
-            S.get7(1 * 21 + 14, Q.Z);
-            E::dbl<false>(Q);                       // 4P
-            S.stash(Q, 3);
-        }
-        S.to_affine_entries();
-    }
-
-    F::set(0, R.X);
-    F::set(1, R.Y);
-    F::set(1, R.Z);
-    F::set(0, R.T);
-
-#pragma unroll 1
-    for (int i = 0; i < 150; i++) {
-        const uint32_t win = dig.window(i);                 // e' = e + sum 4*8^i: window - 4 is the signed digit
-        const int dgt = (int)win - 4;                       // [-4, 3]
-        const bool neg = dgt < 0;
-        const uint32_t m = (uint32_t)(neg ? -dgt : dgt);    // 0..4
-        if (i != 0) {
-#pragma unroll 1
-            for (int j = 0; j < 3; j++) E::dbl(R, j == 2);
-        }
-        // constant-time lookup: every entry is read; start from the neutral element (x, y, td) = (0, 1, 0)
-        uint64_t sel[21];
-        static_for<0, 21>([&](auto K) { sel[K] = (K == 7) ? 1u : 0u; });
-        // (all 84 loads are issued before the first select: one memory latency per window, and the doublings' temporaries
-        // are dead here, so the 168 landing registers are free)
-        // The memory clobber keeps the (loop-invariant) loads inside the iteration: hoisted out of the loop they would
-        // occupy 168 registers across the doublings, i.e. be spilled and reloaded from scratch one by one, each with
-        // its own s_waitcnt vmcnt(0) -- measured as 40 % of the kernel's time in SQ_WAIT_ANY.
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" ::: "memory");
-#endif
-        // two entries (84 landing registers) per round: four at once do not fit next to the point
-#pragma unroll 1
-        for (int e = 0; e < 4; e += 2) {
-            uint64_t ent[2][21];
-            const uint64_t* tab = T.origin() + (size_t)(e * 21) * T.stride();
-            const size_t tstride = T.stride();
-            static_for<0, 2>([&](auto EI) {
-                static_for<0, 21>([&](auto K) { ent[EI][K] = tab[(size_t)(EI * 21 + K) * tstride]; });
-            });
-            static_for<0, 2>([&](auto EI) {
-                const bool hit = (m == (uint32_t)(e + EI + 1));
-                static_for<0, 21>([&](auto K) {
-                    const uint64_t a = ent[EI][K], b = sel[K];
-                    sel[K] = hit ? a : b;
-                });
-            });
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" ::: "memory");
-#endif
-        }
-        // -Q = (-x, y, -td)
-        uint32_t xs[16], ys[16], ts[16], nx[16], nt[16];
-        F::from_words(sel, xs);
-        F::from_words(sel + 7, ys);
-        F::from_words(sel + 14, ts);
-        E::neg2p(xs, nx);
-        E::neg2p(ts, nt);
-        F::select(neg, xs, nx, xs);
-        F::select(neg, ts, nt, ts);
-        E::add_cached(R, xs, ys, ts, FINAL_T && i == 149);
-    }
-}
-template <class TAB, class DIG>
-MA_DEV void ed448_mul_get_one(DIG& dig, const spint* X, const spint* Y, const spint* Z, const TAB& T, uint64_t* xw, uint64_t* yw) {
-    Ed28::Ext R;
-    ed448_mul_acc<false>(dig, X, Y, Z, T, R);
-    // ---- affine, canonical (ecnXXXget: edwards.c:221-239)
-    ed448_affine_words(R, T, xw, yw);
-}
-// (scalar words, table as a strided array: the form tools/fe_host_check.hip runs on the CPU)
-MA_DEV void ed448_mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* tab, size_t tstride,
-                              uint64_t* xw, uint64_t* yw) {
-    Win3Regs dig;
-    dig.init(ew);
-    ed448_mul_get_one(dig, X, Y, Z, TabStrided{tab, tstride}, xw, yw);
-}
-
-// Fused double multiplication + affine export for ED448: the affine coordinates of e*P + f*Q (ecnXXXmul2 followed by
-// ecnXXXget, the verification pattern ed448.c:305).  Both scalars in 225 signed 2-bit digits (e' = e + sum 2*4^i,
-// digit = window - 2 in [-2, 1]); the tables {P, 2P}, {Q, 2Q} take the four entry slots of the same per-lane workspace
-// as ed448_mul_get_one; per window two doublings and two additions (one rolled copy of each in the instruction stream).
-template <class TAB, class DIG>
-MA_DEV void ed448_mul2_get_one(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
-                               DIG& digf, const spint* QX, const spint* QY, const spint* QZ,
-                               const TAB& T, uint64_t* xw, uint64_t* yw) {
-    using E = Ed28;
-    using F = Fe28;
-    E::Ext R;
-    {
-        // (round 4: one point live at a time; see Ed448Slots)
-        Ed448Slots<TAB> S{T};
-        auto ext2 = [&](const spint* X, const spint* Y, const spint* Z, int entry) {
-            E::Ext A;
-            {
-                uint32_t px[16], py[16], pz[16];
-                E::from56(X, px);
-                E::from56(Y, py);
-                E::from56(Z, pz);
-                F::mul_k(px, pz, A.X);
-                F::mul_k(py, pz, A.Y);
-                F::sqr_k(pz, A.Z);
-            }
-            S.stash(A, entry);
-            E::dbl<false>(A);
-            S.stash(A, entry + 1);
-        };
-        ext2(PX, PY, PZ, 0);
-        ext2(QX, QY, QZ, 2);
-        S.to_affine_entries();
-    }
-    F::set(0, R.X);
-    F::set(1, R.Y);
-    F::set(1, R.Z);
-    F::set(0, R.T);
-#pragma unroll 1
-    for (int i = 0; i < 225; i++) {
-        if (i != 0) {
-#pragma unroll 1
-            for (int j = 0; j < 2; j++) E::dbl(R, j == 1);
-        }
-        const int de = (int)dige.window(i) - 2, df = (int)digf.window(i) - 2;       // [-2, 1]
-#pragma unroll 1
-        for (int which = 0; which < 2; which++) {               // 0: digit of e, table {P, 2P};  1: digit of f, table {Q, 2Q}
-            const int dgt = which ? df : de;
-            const bool neg = dgt < 0;
-            const uint32_t m = (uint32_t)(neg ? -dgt : dgt);
-            uint64_t sel[21];
-            static_for<0, 21>([&](auto K) { sel[K] = (K == 7) ? 1u : 0u; });
-            uint64_t ent[2][21];
-            const uint64_t* tab = T.origin() + (size_t)(2 * which * 21) * T.stride();
-            const size_t tstride = T.stride();
-            static_for<0, 2>([&](auto EI) {
-                static_for<0, 21>([&](auto K) { ent[EI][K] = tab[(size_t)(EI * 21 + K) * tstride]; });
-            });
-            static_for<0, 2>([&](auto EI) {
-                const bool hit = (m == (uint32_t)(EI + 1));
-                static_for<0, 21>([&](auto K) {
-                    const uint64_t a = ent[EI][K], b = sel[K];
-                    sel[K] = hit ? a : b;
-                });
-            });
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" ::: "memory");
-#endif
-            uint32_t xs[16], ys[16], ts[16], nx[16], nt[16];
-            F::from_words(sel, xs);
-            F::from_words(sel + 7, ys);
-            F::from_words(sel + 14, ts);
-            E::neg2p(xs, nx);
-            E::neg2p(ts, nt);
-            F::select(neg, xs, nx, xs);
-            F::select(neg, ts, nt, ts);
-            E::add_cached(R, xs, ys, ts, which == 0);
-        }
-    }
-    ed448_affine_words(R, T, xw, yw);
-}
-
-MA_DEV void ed448_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* PY, const spint* PZ,
-                               const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
-                               uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
-    Win2Regs de, df;
-    de.init(ew);
-    df.init(fw);
-    ed448_mul2_get_one(de, PX, PY, PZ, df, QX, QY, QZ, TabStrided{tab, tstride}, xw, yw);
-}
+// (Rounds 2-4 kept here the window forms of the fused multiplications -- 3-bit / 2-bit signed windows over affine tables {1..4}P in a
+// workspace slab, scanned; the one-point-at-a-time table builder Ed448Slots; the digit sources Win3 / Win2 -- 2.0e7 mul_get/s,
+// 1.4e7 mul2_get/s.  Round 5 replaced them by the ladder form (ed28l.h) and the Straus form (ed28s.h); what is left below is the
+// fixed-base part, which both still use.)
 
 // Fused GENERATOR multiplication + affine export for ED448 (see ed26.h ed25519_mulgen_get_one): ED448_KEY_PAIR and
 // ED448_SIGN open with ecnXXXgen, ecnXXXmul, ecnXXXget (ed448.c:167-184, 196-199).  W = 4: e' = e + sum_{i<113} 8*16^i, 113
@@ -648,25 +196,6 @@ MA_DEV void ed448_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw)
     F::to_words(ax, xw);
     F::to_words(ay, yw);
 }
-// Fused e*G + f*Q + affine export for ED448: ED448_VERIFY's ecnXXXmul2(&G, &Q, ...) + ecnXXXget (ed448.c:290-310; the first
-// point is the generator).  f*Q as in ed448_mul_get_one (the last addition also produces T), then e*G through the fixed-base
-// table (ed448_mulgen_acc), see ed26.h ed25519_mulgen2_get_one.
-template <class COMB, class TAB, class DIG>
-MA_DEV void ed448_mulgen2_get_one(const uint64_t* ew, DIG& digf, const spint* QX, const spint* QY, const spint* QZ,
-                                  const TAB& T, uint64_t* xw, uint64_t* yw) {
-    Ed28::Ext R;
-    ed448_mul_acc<true>(digf, QX, QY, QZ, T, R);
-    ed448_mulgen_acc<COMB, false>(ew, R);
-    ed448_affine_words(R, T, xw, yw);
-}
-template <class COMB>
-MA_DEV void ed448_mulgen2_get_one(const uint64_t* ew, const uint64_t* fw, const spint* QX, const spint* QY, const spint* QZ,
-                                  uint64_t* tab, size_t tstride, uint64_t* xw, uint64_t* yw) {
-    Win3Regs df;
-    df.init(fw);
-    ed448_mulgen2_get_one<COMB>(ew, df, QX, QY, QZ, TabStrided{tab, tstride}, xw, yw);
-}
-
 // rfc7748() on the BASE POINT u = 5 of X448 (public-key generation, rfc7748.c:297-333).  ED448 (x^2 + y^2 = 1 - 39081 x^2 y^2) is
 // 4-isogenous to curve448 with (u, v) = (y^2 / x^2, ...) (RFC 7748 section 4.2), and its generator maps to u = 5: the isogeny is
 // a group homomorphism, so [k](5) = Y^2 / X^2 of k*G, k*G from the fixed-base table (ed448_mulgen_acc).  k clamped as

@@ -187,6 +187,25 @@ struct Ed28Lad {
         F::copy(V, R.Z);
     }
 
+    // e*G + f*Q with its own two inversions (host check): f*Q by the ladder, e*G added through the fixed-base table (ed28.h ed448_mulgen_acc)
+    template <class TAB>
+    static MA_DEV void mulgen2_get_one(const uint64_t* ew, const uint64_t* fw, const spint* X, const spint* Y, const spint* Z, uint64_t* xw, uint64_t* yw) {
+        uint32_t D[16], nu[16], nw[16], u[16], w[16], x2[16], z2[16], x3[16], z3[16];
+        const uint32_t flags = prep(X, Y, Z, D, nu, nw);
+        F::invert(D, D);
+        F::mul_k(nu, D, u);
+        F::mul_k(nw, D, w);
+        ladder(fw, u, x2, z2, x3, z3);
+        Ext R;
+        recover([&](uint32_t* o) { F::copy(u, o); }, [&](uint32_t* o) { F::copy(w, o); }, flags, (fw[0] & 1) != 0, x2, z2, x3, z3, R, true);
+        ed448_mulgen_acc<TAB, false>(ew, R);
+        uint32_t zi[16], ax[16], ay[16];
+        F::invert(R.Z, zi);
+        F::mul_k(R.X, zi, ax);
+        F::mul_k(R.Y, zi, ay);
+        F::to_words(ax, xw);
+        F::to_words(ay, yw);
+    }
     // one fused multiplication + export with its own two inversions: the per-lane reference of the kernel pipeline (host check)
     static MA_DEV void mul_get_one(const uint64_t* ew, const spint* X, const spint* Y, const spint* Z, uint64_t* xw, uint64_t* yw) {
         uint32_t D[16], nu[16], nw[16], u[16], w[16], x2[16], z2[16], x3[16], z3[16];

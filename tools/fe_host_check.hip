@@ -17,6 +17,7 @@
 #include "../modarith_amd/csrc/ed26s.h"
 #include "../modarith_amd/csrc/ed28.h"
 #include "../modarith_amd/csrc/ed28l.h"
+#include "../modarith_amd/csrc/ed28s.h"
 #include "../modarith_amd/csrc/generated/curve_NIST256.h"
 #include "../modarith_amd/csrc/wn26.h"
 #include "../modarith_amd/csrc/generated/comb_ED25519.h"
@@ -94,40 +95,6 @@ extern "C" void ecn_ed448_inf(pt448*);
 extern "C" void ecn_ed448_mul(const char* e, pt448*);
 extern "C" int ecn_ed448_get(pt448*, char* x, char* y);
 extern "C" void ecn_ed448_set(int s, const char* x, const char* y, pt448*);
-
-static int run_ed448(int n) {
-    int bad = 0;
-    for (int it = 0; it < n; it++) {
-        pt448 P;
-        unsigned char e[56], k[56];
-        for (int i = 0; i < 56; i++) { e[i] = (unsigned char)sm(); k[i] = (unsigned char)sm(); }
-        ecn_ed448_gen(&P);
-        ecn_ed448_mul((const char*)k, &P);
-        if (it % 16 == 1) ecn_ed448_inf(&P);
-        if (it % 16 == 2) { char y[56]; memset(y, 0, 56); ecn_ed448_set(0, nullptr, y, &P); }            // y = 0: order 4
-        if (it % 16 == 3) { char y[56]; memset(y, 0xff, 56); y[27] = (char)0xfe; y[55] = (char)0xfe; ecn_ed448_set(0, nullptr, y, &P); }  // y = p - 1: order 2
-        if (it % 16 == 4) ecn_ed448_gen(&P);
-        if (it == 5) memset(e, 0, 56);
-        if (it == 6) { memset(e, 0, 56); e[55] = 1; }
-        if (it == 7) memset(e, 0xff, 56);
-        if (it == 9) { memset(e, 0, 56); e[55] = 4; }
-        pt448 Q = P;
-        uint64_t ew[7], xw[7], yw[7], tab[ma::ED448_TABLE_WORDS];
-        for (int w = 0; w < 7; w++) { uint64_t v = 0; for (int b = 0; b < 8; b++) v |= (uint64_t)e[55 - (8 * w + b)] << (8 * b); ew[w] = v; }
-        ma::ed448_mul_get_one(ew, P.x, P.y, P.z, tab, 1, xw, yw);
-        char wx[56], wy[56];
-        ecn_ed448_mul((const char*)e, &Q);
-        ecn_ed448_get(&Q, wx, wy);
-        unsigned char gx[56], gy[56];
-        for (int i = 0; i < 56; i++) { gx[i] = (unsigned char)(xw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); gy[i] = (unsigned char)(yw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); }
-        if (memcmp(gx, wx, 56) != 0 || memcmp(gy, wy, 56) != 0) {
-            if (bad < 6) printf("ed448_mul_get_one: record %d differs\n", it);
-            bad++;
-        }
-    }
-    printf("ed448_mul_get_one: %d records, %d differ from the oracle's ecn mul + get\n", n, bad);
-    return bad;
-}
 
 extern "C" void modmul_X25519(const uint64_t*, const uint64_t*, uint64_t*);
 extern "C" void modsqr_X25519(const uint64_t*, uint64_t*);
@@ -322,17 +289,21 @@ static int run_ed448_mul2(int n) {
         if (it == 5) memset(e, 0, 56);
         if (it == 6) memset(f, 0, 56);
         if (it == 7) { memset(e, 0xff, 56); memset(f, 0xff, 56); }
-        uint64_t ew[7], fw[7], xw[7], yw[7], tab[ma::ED448_TABLE_WORDS];
+        if (it == 14) { memset(e, 0x88, 56); memset(f, 0x77, 56); }                    // every digit -8 (the top window carries) / -1
+        if (it == 15) { memset(e, 0x80, 56); memset(f, 0x08, 56); }
+        if (it == 13) { memset(e, 0, 56); memset(f, 0, 56); }
+        if (it % 8 == 5 && it > 8) { char y[56]; memset(y, 0xff, 56); y[27] = (char)0xfe; y[55] = (char)0xfe; ecn_ed448_set(0, nullptr, y, &P); }   // order 2
+        uint64_t ew[7], fw[7], xw[7], yw[7];
         for (int w = 0; w < 7; w++) { uint64_t v = 0, u = 0; for (int b = 0; b < 8; b++) { v |= (uint64_t)e[55 - (8 * w + b)] << (8 * b); u |= (uint64_t)f[55 - (8 * w + b)] << (8 * b); } ew[w] = v; fw[w] = u; }
-        ma::ed448_mul2_get_one(ew, P.x, P.y, P.z, fw, Q.x, Q.y, Q.z, tab, 1, xw, yw);
+        ma::ed448_mul2_get_straus_one(ew, P.x, P.y, P.z, fw, Q.x, Q.y, Q.z, xw, yw);
         char wx[56], wy[56];
         ecn_ed448_mul2((const char*)e, &P, (const char*)f, &Q, &R);
         ecn_ed448_get(&R, wx, wy);
         unsigned char gx[56], gy[56];
         for (int i = 0; i < 56; i++) { gx[i] = (unsigned char)(xw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); gy[i] = (unsigned char)(yw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); }
-        if (memcmp(gx, wx, 56) != 0 || memcmp(gy, wy, 56) != 0) { if (bad < 6) printf("ed448_mul2_get_one: record %d differs\n", it); bad++; }
+        if (memcmp(gx, wx, 56) != 0 || memcmp(gy, wy, 56) != 0) { if (bad < 6) printf("ed448_mul2_get_straus_one: record %d differs\n", it); bad++; }
     }
-    printf("ed448_mul2_get_one: %d records, %d differ from the oracle's ecn mul2 + get\n", n, bad);
+    printf("ed448_mul2_get_straus_one: %d records, %d differ from the oracle's ecn mul2 + get\n", n, bad);
     return bad;
 }
 
@@ -738,17 +709,18 @@ static int run_ed448_mulgen2(int n) {
         if (it % 8 == 5) memset(f, 0, 56);
         if (it == 6) { memset(e, 0xff, 56); memset(f, 0xff, 56); }
         pt448 Q0 = Q;
-        uint64_t ew[7], fw[7], xw[7], yw[7], tab[ma::ED448_TABLE_WORDS];
+        if (it >= 9 && it < 21) ed448_jq((it - 9) / 3, (it - 9) % 3 - 1, f);          // f = j q - 1, j q, j q + 1: f*Q runs through -Q, the neutral element, Q (+ torsion)
+        uint64_t ew[7], fw[7], xw[7], yw[7];
         for (int w = 0; w < 7; w++) { uint64_t v = 0, u = 0; for (int b = 0; b < 8; b++) { v |= (uint64_t)e[55 - (8 * w + b)] << (8 * b); u |= (uint64_t)f[55 - (8 * w + b)] << (8 * b); } ew[w] = v; fw[w] = u; }
-        ma::ed448_mulgen2_get_one<HostComb448>(ew, fw, Q.x, Q.y, Q.z, tab, 1, xw, yw);
+        ma::Ed28Lad::mulgen2_get_one<HostComb448>(ew, fw, Q.x, Q.y, Q.z, xw, yw);
         char wx[56], wy[56];
         ecn_ed448_mul2((const char*)e, &G, (const char*)f, &Q0, &R);
         ecn_ed448_get(&R, wx, wy);
         unsigned char gx[56], gy[56];
         for (int i = 0; i < 56; i++) { gx[i] = (unsigned char)(xw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); gy[i] = (unsigned char)(yw[(55 - i) / 8] >> (8 * ((55 - i) % 8))); }
-        if (memcmp(gx, wx, 56) != 0 || memcmp(gy, wy, 56) != 0) { if (bad < 6) printf("ed448_mulgen2_get_one: record %d differs\n", it); bad++; }
+        if (memcmp(gx, wx, 56) != 0 || memcmp(gy, wy, 56) != 0) { if (bad < 6) printf("Ed28Lad::mulgen2_get_one: record %d differs\n", it); bad++; }
     }
-    printf("ed448_mulgen2_get_one: %d records, %d differ from the oracle's ecn gen + mul2 + get\n", n, bad);
+    printf("Ed28Lad::mulgen2_get_one: %d records, %d differ from the oracle's ecn gen + mul2 + get\n", n, bad);
     return bad;
 }
 
@@ -1006,10 +978,9 @@ int main(int argc, char** argv) {
     bad += run_fold52(n * 50);
     bad += run_ed25519_mul2("ed25519_mul2_get_straus_one", n / 4 + 32, [](const uint64_t* ew, const uint64_t* PX, const uint64_t* PY, const uint64_t* PZ, const uint64_t* fw, const uint64_t* QX, const uint64_t* QY, const uint64_t* QZ, uint64_t* xw, uint64_t* yw) { ma::ed25519_mul2_get_straus_one<ma::C_ED25519>(ew, PX, PY, PZ, fw, QX, QY, QZ, xw, yw); });
     bad += run_ed25519_lad("Ed26Lad::mul_get_one", n / 4 + 16, [](const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, uint64_t* xw, uint64_t* yw) { ma::Ed26Lad<ma::C_ED25519>::mul_get_one(ew, X, Y, Z, xw, yw); });
-    bad += run_ed448(n / 16 + 16);
     bad += run_ed448_lad(n / 16 + 16);
-    bad += run_ed448_mul2(n / 32 + 16);
-    bad += run_ed448_mulgen2(n / 32 + 16);
+    bad += run_ed448_mul2(n / 16 + 24);
+    bad += run_ed448_mulgen2(n / 16 + 24);
     bad += run_nist256(n / 8 + 16);
     bad += run_nist256_mul2(n / 16 + 16);
     bad += run<4>("x25519_base_many<4> (u = 9)", n, [](const uint64_t* k, const uint64_t*, uint64_t* o) {

@@ -26,8 +26,8 @@ def legs():
         else:
             out[C + "_ecn_mul_get_fused"] = [("k_%s_mul_get" % low, base + "F.o", 1, 1)]
             out[C + "_ecn_mulgen2_get_fused"] = [("k_%s_mulgen2_get" % low, base + "G.o", 1, 1)]
-        if C == "ED25519":
-            out[C + "_ecn_mul2_get_fused"] = [("k_ed25519_mul2_straus", base + "F2.o", 1, 1), ("SinkExportBE<ma::P_X25519>, 3>", base + "F2.o", 1, "rounds")]
+        if C in ("ED25519", "ED448"):
+            out[C + "_ecn_mul2_get_fused"] = [("k_%s_mul2_straus" % low, base + "F2.o", 1, 1), ("SinkExportBE<ma::%s>, 3>" % ("P_X25519" if C == "ED25519" else "P_X448"), base + "F2.o", 1, "rounds")]
         else:
             out[C + "_ecn_mul2_get_fused"] = [("k_%s_mul2_get" % low, base + "F2.o", 1, 1)]
         if C == "ED448":
