@@ -115,43 +115,6 @@ struct Ed26 {
         F::add(p.Z, p.Z, d);        // 1.0
         add_tail<WANT_T>(a, b, c, d, p);
     }
-    // add_cached with a wave-uniform run-time flag for T (a loop counter, never data): one copy of the addition in the
-    // instruction stream serves the windows that do not need T and the last one, which hands its sum to the fixed-base part
-    static MA_DEV void add_cached_rt(Ext& p, const uint32_t* yp, const uint32_t* ym, const uint32_t* t2d, bool want_t) {
-        uint32_t a[10], b[10], c[10], d[10], e[10], f[10], g[10], h[10], g19[10], e19[10];
-        F::sub(p.Y, p.X, a);        // 1.5
-        F::mul(a, ym, a);
-        F::add(p.Y, p.X, b);        // 1.0
-        F::mul(b, yp, b);
-        F::mul(p.T, t2d, c);
-        F::add(p.Z, p.Z, d);        // 1.0
-        F::sub(b, a, e);            // 1.5
-        F::sub(d, c, f);            // 2.0
-        F::add(d, c, g);            // 1.5
-        F::add(b, a, h);            // 1.0
-        F::pre19(g, g19);
-        F::pre19(e, e19);
-        F::mul(f, e, e19, p.X);
-        F::mul(f, g, g19, p.Z);
-        F::mul(h, g, g19, p.Y);
-        if (want_t) F::mul(h, e, e19, p.T);
-    }
-    // P += Q, both extended (add-2008-hwcd-3, a = -1); used once, to build 3P
-    static MA_DEV void add_ext(Ext& p, const Ext& q) {
-        uint32_t a[10], b[10], c[10], d[10], t[10], dd[10];
-        F::sub(p.Y, p.X, a);        // 1.5
-        F::sub(q.Y, q.X, t);        // 1.5
-        F::mul(a, t, a);
-        F::add(p.Y, p.X, b);        // 1.0
-        F::add(q.Y, q.X, t);        // 1.0
-        F::mul(b, t, b);
-        F::mul(p.T, q.T, c);
-        d2(dd);
-        F::mul(c, dd, c);
-        F::mul(p.Z, q.Z, d);
-        F::add(d, d, d);            // 1.0
-        add_tail(a, b, c, d, p);
-    }
 };
 
 // (The window form of the single multiplication -- 3-bit signed windows, the table {1,2,3,4}P in registers / LDS, 255 doublings + 86

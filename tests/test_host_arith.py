@@ -380,25 +380,25 @@ def test_unsigned_limb_fields_at_the_edges_of_their_ranges(tmp_path):
                 e, f_, g, h = b - a, d - c, d + c, b + a
                 want = [e * f_ % p, g * h % p, f_ * g % p, e * h % p]
                 assert formula(F, 1, P, yp, ym, t2d) == want, (F.name, "add_cached", sa, sb)
-                assert formula(F, 3, P, yp, ym, t2d) == want, (F.name, "add_cached_rt", sa, sb)
             else:
                 xs, y, tds = F.draw(SUM28, sb), F.draw(F.tight_hi, sa), F.draw(SUM28, sb)
                 A, B, Cc, D, M = X * F.value(xs), Y * F.value(y), T * F.value(tds), Z, (X + Y) * (F.value(xs) + F.value(y))
                 E, Fv, G, H = M - A - B, D + Cc, D - Cc, B - A
                 want = [E * Fv % p, G * H % p, Fv * G % p, E * H % p]
                 assert formula(F, 1, P, xs, y, tds) == want, (F.name, "add_cached", sa, sb)
-            # addition of two extended points
+            # the Straus forms' addition of a projective cached table entry (ed26s.h / ed28s.h), both signs; entries are tight
+            # (they come out of from_words)
             Q = [F.draw(F.tight_hi, sb if k != 2 else sa) for k in range(4)]
-            X2, Y2, Z2, T2 = [F.value(v) for v in Q]
+            q0, q1, q2, q3 = [F.value(v) for v in Q]
             flatQ = [v for co in Q for v in co]
-            if F is f26:
-                a, b, c, d = (Y - X) * (Y2 - X2), (Y + X) * (Y2 + X2), T * T2 * 2 * d25519, 2 * Z * Z2
-                e, f_, g, h = b - a, d - c, d + c, b + a
-                want = [e * f_ % p, g * h % p, f_ * g % p]
-                assert formula(F, 2, P, flatQ)[:3] == want, (F.name, "add_ext", sa, sb)
-            else:
-                A, B, Cc, D, M = X * X2, Y * Y2, 39081 * T * T2, Z * Z2, (X + Y) * (X2 + Y2)
-                E, Fv, G, H = M - A - B, D + Cc, D - Cc, B - A
-                want = [E * Fv % p, G * H % p, Fv * G % p]
-                assert formula(F, 2, P, flatQ)[:3] == want, (F.name, "add_ext", sa, sb)
-                assert formula(F, 3, P, flatQ)[:3] == want, (F.name, "add_ext_fetched", sa, sb)
+            for what, sg in ((2, 1), (3, -1)):
+                if F is f26:                   # (Y+X, Y-X, 2dT, 2Z); the negated entry swaps the sums and negates 2dT
+                    yp_, ym_, t2_ = (q0, q1, q2) if sg == 1 else (q1, q0, -q2)
+                    a, b, c, d = (Y - X) * ym_, (Y + X) * yp_, T * t2_, Z * q3
+                    e, f_, g, h = b - a, d - c, d + c, b + a
+                    want = [e * f_ % p, g * h % p, f_ * g % p, e * h % p]
+                else:                          # (X, Y, 39081 T, Z); the negated entry negates X and 39081 T
+                    A, B, Cc, D, M = X * sg * q0, Y * q1, T * sg * q2, Z * q3, (X + Y) * (sg * q0 + q1)
+                    E, Fv, G, H = M - A - B, D + Cc, D - Cc, B - A
+                    want = [E * Fv % p, G * H % p, Fv * G % p, E * H % p]
+                assert formula(F, what, P, flatQ) == want, (F.name, "Straus add_pc", what, sa, sb)

@@ -11,6 +11,8 @@
 #include "../modarith_amd/csrc/generated/params_X448.h"
 #include "../modarith_amd/csrc/ed26.h"
 #include "../modarith_amd/csrc/ed28.h"
+#include "../modarith_amd/csrc/ed26s.h"
+#include "../modarith_amd/csrc/ed28s.h"
 
 using E26 = ma::Ed26<ma::C_ED25519>;
 using F26 = ma::Fe26;
@@ -51,31 +53,33 @@ extern "C" void fe28_words(const uint32_t* f, uint64_t* w) { F28::to_words(f, w)
 extern "C" void fe26_from_words(const uint64_t* w, uint32_t* f) { F26::from_words(w, f); }
 extern "C" void fe28_from_words(const uint64_t* w, uint32_t* f) { F28::from_words(w, f); }
 
-// Edwards formulas.  p: X, Y, Z, T (4 x NL limbs, in place).  what = 0: dbl with T, 1: add_cached(a, b, c) with T,
-// 2: add_ext(q = a[0..4NL)), 3: add_cached_rt with T (ed26) / add_ext_fetched (ed28)
+// Edwards formulas.  p: X, Y, Z, T (4 x NL limbs, in place).  what = 0: dbl with T, 1: add_cached(a, b, c) with T (the mixed addition of the
+// fixed-base parts), 2 / 3: the Straus forms' addition of a PROJECTIVE cached entry a[0..4NL) with T, sign + / - (ed26s.h: (Y+X, Y-X, 2dT, 2Z);
+// ed28s.h: (X, Y, 39081 T, Z), fetched coordinate by coordinate)
 extern "C" void ed26_formula(int what, uint32_t* p, const uint32_t* a, const uint32_t* b, const uint32_t* c) {
-    E26::Ext P, Q;
+    E26::Ext P;
     for (int i = 0; i < 10; i++) { P.X[i] = p[i]; P.Y[i] = p[10 + i]; P.Z[i] = p[20 + i]; P.T[i] = p[30 + i]; }
     if (what == 0) E26::dbl<true>(P);
     else if (what == 1) E26::add_cached<true>(P, a, b, c);
-    else if (what == 3) E26::add_cached_rt(P, a, b, c, true);
     else {
-        for (int i = 0; i < 10; i++) { Q.X[i] = a[i]; Q.Y[i] = a[10 + i]; Q.Z[i] = a[20 + i]; Q.T[i] = a[30 + i]; }
-        E26::add_ext(P, Q);
-        for (int i = 0; i < 10; i++) P.T[i] = 0;
+        using S = ma::Ed26Straus<ma::C_ED25519>;
+        S::Cached q;
+        for (int i = 0; i < 10; i++) { q.yp[i] = a[i]; q.ym[i] = a[10 + i]; q.t2d[i] = a[20 + i]; q.z2[i] = a[30 + i]; }
+        if (what == 3) {        // the negated entry, as ed26s.h unpack() forms it: sums swapped, 2dT -> 2p - 2dT
+            uint32_t zero[10], nt[10];
+            F26::set(0, zero);
+            F26::sub(zero, q.t2d, nt);
+            for (int i = 0; i < 10; i++) { const uint32_t t = q.yp[i]; q.yp[i] = q.ym[i]; q.ym[i] = t; q.t2d[i] = nt[i]; }
+        }
+        S::add_pc(P, q, true);
     }
     for (int i = 0; i < 10; i++) { p[i] = P.X[i]; p[10 + i] = P.Y[i]; p[20 + i] = P.Z[i]; p[30 + i] = P.T[i]; }
 }
 extern "C" void ed28_formula(int what, uint32_t* p, const uint32_t* a, const uint32_t* b, const uint32_t* c) {
-    E28::Ext P, Q;
+    E28::Ext P;
     for (int i = 0; i < 16; i++) { P.X[i] = p[i]; P.Y[i] = p[16 + i]; P.Z[i] = p[32 + i]; P.T[i] = p[48 + i]; }
     if (what == 0) E28::dbl<true>(P);
     else if (what == 1) E28::add_cached(P, a, b, c, true);
-    else {
-        for (int i = 0; i < 16; i++) { Q.X[i] = a[i]; Q.Y[i] = a[16 + i]; Q.Z[i] = a[32 + i]; Q.T[i] = a[48 + i]; }
-        if (what == 2) E28::add_ext(P, Q);
-        else E28::add_ext_fetched(P, [&](int coord, uint32_t* out) { for (int i = 0; i < 16; i++) out[i] = a[16 * coord + i]; });
-        for (int i = 0; i < 16; i++) P.T[i] = 0;
-    }
+    else ma::Ed28Straus::add_pc(P, [&](int coord, uint32_t* out) { for (int i = 0; i < 16; i++) out[i] = a[16 * coord + i]; }, what == 3, true);
     for (int i = 0; i < 16; i++) { p[i] = P.X[i]; p[16 + i] = P.Y[i]; p[32 + i] = P.Z[i]; p[48 + i] = P.T[i]; }
 }
