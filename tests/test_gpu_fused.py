@@ -174,6 +174,58 @@ def test_fused_more_points_than_resident_lanes(fx):
     assert torch.equal(x, wx) and torch.equal(y, wy)
 
 
+def test_fused_ladder_and_straus_forms_cross_their_chunk_boundary():
+    """round 5: the ladder / Straus forms of the Edwards curves work through a batch in chunks of 2^20 records (csrc/edlad_k.h EDLAD_CHUNK:
+    the workspace stops growing there) -- one full chunk and a ragged second one, with the exceptional inputs of the ladder form placed
+    on both sides of the boundary (the neutral element, the point of order two, scalar 0, the group order), against the call-by-call
+    forms; and the same call with NO workspace argument (the library's scratch pool), as callers of rounds 2-4 made it for ed25519"""
+    import torch
+    from modarith_amd.edwards import Curve
+    from modarith_amd import _lib
+    Ed = Curve("ED25519")
+    n = (1 << 20) + 4099
+    gen = torch.Generator(device="cuda").manual_seed(95)
+    rnd = lambda m: torch.randint(0, 256, (m, 32), dtype=torch.uint8, device="cuda", generator=gen)
+    e, f = rnd(n), rnd(n)
+    P = Ed.mul(rnd(n), Ed.gen(n))
+    q = bytes.fromhex("1000000000000000000000000000000014def9dea2f79cd65812631a5cf5d3ed")
+    for j in (5, (1 << 20) - 1, 1 << 20, n - 3):
+        P[:, :, j] = Ed.inf(1)[:, :, 0]                                  # neutral element on both sides of the chunk boundary
+        e[j + 1] = 0                                                       # scalar 0
+        e[j + 2] = torch.tensor(list(q), dtype=torch.uint8)                # [q]P = neutral
+    two = Ed.set(torch.zeros(1, dtype=torch.int32, device="cuda"), None, torch.tensor([list(bytes.fromhex("7f" + "ff" * 30 + "ec"))], dtype=torch.uint8, device="cuda"))
+    P[:, :, 9] = two[:, :, 0]                                            # (0, -1)
+    P[:, :, (1 << 20) + 9] = two[:, :, 0]
+    x, y, _ = Ed.mul_get(e, P)
+    wx, wy, _ = Ed.get(Ed.mul(e, P.clone()))
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+    x, y, _ = Ed.mulgen2_get(e, f, P)
+    wx, wy, _ = Ed.get(Ed.mul2(e, Ed.gen(n), f, P))
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+    Q = Ed.mul(f, Ed.gen(n))
+    x, y, _ = Ed.mul2_get(e, P, f, Q)
+    wx, wy, _ = Ed.get(Ed.mul2(e, P, f, Q))
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+    # no workspace argument at all: the rounds-2..4 calling convention of ed25519 (workspace_bytes = 0, NULL)
+    L = _lib.load()
+    x2 = torch.empty_like(x); y2 = torch.empty_like(y)
+    m = 8192 + 3
+    _lib.check(L.ecn_ed25519_mul_get_batch(e.data_ptr(), P.data_ptr(), x2.data_ptr(), y2.data_ptr(), None, m, n, None, 0, None), "mul_get without a workspace")
+    torch.cuda.synchronize()
+    wx, wy, _ = Ed.get(Ed.mul(e[:m].contiguous(), P[:, :, :m].contiguous()))
+    assert torch.equal(x2[:m], wx) and torch.equal(y2[:m], wy)
+    del Ed, P, Q
+    Ed = Curve("ED448")
+    n = (1 << 20) + 130
+    rnd = lambda m: torch.randint(0, 256, (m, 56), dtype=torch.uint8, device="cuda", generator=gen)
+    e = rnd(n)
+    P = Ed.mul(rnd(n), Ed.gen(n))
+    P[:, :, (1 << 20)] = Ed.inf(1)[:, :, 0]
+    x, y, _ = Ed.mul_get(e, P)
+    wx, wy, _ = Ed.get(Ed.mul(e, P.clone()))
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+
+
 def test_fused_rejects_bad_arguments(fx):
     C, Ed, g, torch = fx
     from modarith_amd.edwards import Edwards
