@@ -1,6 +1,6 @@
 """The device arithmetic of the fused kernels, compiled for the HOST and run against the CPU oracle (no GPU needed):
 tools/fe_host_check.hip instantiates the very functions the kernels wrap -- x25519_fe26_one, x448_fe28_one (ladders),
-ed25519_mul_get_one, ed25519_mul2_get_one, ed448_mul_get_one (fused scalar / double multiplication + affine export) and the half-limb column products of
+Ed26Lad / Ed28Lad::mul_get_one and mulgen2_get_one (the ladder forms of the fused multiplications, with every exceptional class of input), ed25519 / ed448_mul2_get_straus_one (the Straus forms of the double multiplication), the fixed-base forms and the half-limb column products of
 Field<P_X25519,true>, Field<P_NIST256,true> and Field<P_X448,true> -- with MA_DEV = __host__ __device__, and compares every output with the oracle
 (rfc7748, ecn mul + ecn get, modmul / modsqr), including special points, corner scalars and the limb contract's edge
 classes.  This checks the limb arithmetic and the group-law logic; code generation for gfx950 is checked on the GPU box."""
