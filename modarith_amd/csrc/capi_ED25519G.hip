@@ -18,30 +18,46 @@ struct CombED25519 {
     static __device__ __forceinline__ int32_t get(int idx) { return comb_ed25519[idx]; }
 };
 
-// MULGEN_G scalars per lane (elements t, t + lanes, ... of a MULGEN_G * lanes stride) share one inversion
-#ifndef MULGEN_G
-#define MULGEN_G 4
-#endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
-void k_ed25519_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned char* yb, int* sign, size_t n) {
+// e*G through the fixed-base table, ONE scalar per lane.  SELF = false (the product path, round 5): the Edwards (X : Y : Z) go to the shared
+// inversion of csrc/edlad_k.h (one inversion per up to 32 records; rounds 2-4 shared one between the FOUR scalars of a lane).  SELF = true:
+// the inversion in the kernel, for callers without scratch (a stream under capture).
+template <bool SELF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
+void k_ed25519_mulgen(const unsigned char* e, unsigned char* xb, unsigned char* yb, int* sign, size_t first, size_t n, Ed26lWs ws) {
     using P = P_X25519;
-    const size_t lanes = (size_t)gridDim.x * blockDim.x;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += MULGEN_G * lanes) {
-        spint xw[MULGEN_G][4], yw[MULGEN_G][4];
-        ed25519_mulgen_get_many<C_ED25519, CombED25519, MULGEN_G>(
-            [&](int g, spint* ew) { const size_t tg = t + (size_t)g * lanes; load_be_record<P>(e, tg < n ? tg : t, ew); }, xw, yw);
-        static_for<0, MULGEN_G>([&](auto GI) {
-            const size_t tg = t + (size_t)GI * lanes;
-            if (tg < n) {
-                if (xb) store_be_record<P>(xb, tg, xw[GI]);
-                if (yb) store_be_record<P>(yb, tg, yw[GI]);
-                if (sign) sign[tg] = !yb ? (int)(yw[GI][0] & 1) : (!xb ? (int)(xw[GI][0] & 1) : 0);
-            }
-        });
+    using F = Fe26;
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= n) return;
+    Ed26<C_ED25519>::Ext R;
+    {
+        spint ew[4];
+        load_be_record<P>(e, first + t, ew);
+        ed25519_mulgen_acc<C_ED25519, CombED25519>(ew, R);
+    }
+    if constexpr (SELF) {
+        uint32_t zi[10], ax[10];
+        spint w[4];
+        F::invert(R.Z, zi);
+        F::mul(R.X, zi, ax);
+        F::to_words(ax, w);
+        const int sx = (int)(w[0] & 1);
+        if (xb) store_be_record<P>(xb, first + t, w);
+        F::mul(R.Y, zi, ax);
+        F::to_words(ax, w);
+        if (yb) store_be_record<P>(yb, first + t, w);
+        if (sign) sign[first + t] = !yb ? (int)(w[0] & 1) : (!xb ? sx : 0);
+    } else {
+        ws.store_xyz(t, R.X, R.Y, R.Z);
     }
 }
 
-// rfc7748() on the base point u = 9 (x25519_base_many): little-endian 32-byte records as rfc7748_X25519_batch takes them
+// rfc7748() on the base point u = 9 (ed26.h x25519_base_many): little-endian 32-byte records as rfc7748_X25519_batch takes them; MULGEN_G
+// keys per lane (elements t, t + lanes, ... of a MULGEN_G * lanes stride) share one inversion.  (The one-key-per-lane form with the
+// shared inversion of edlad_k.h, as k_ed25519_mulgen and k_x448_base run, was built for this kernel too in round 5 and left out: the
+// compiler brings its window loop out at 168 registers + 101 spilled where the identical loop of k_ed25519_mulgen takes 129.)
+#ifndef MULGEN_G
+#define MULGEN_G 4
+#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
 void k_x25519_base(const uint64_t* bk, uint64_t* bv, size_t n) {
     const size_t lanes = (size_t)gridDim.x * blockDim.x;
@@ -118,9 +134,20 @@ extern "C" int ecn_ed25519_mulgen_get_batch(const char* e, char* x, char* y, int
         set_error("ecn mulgen_get: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
     }
-    const size_t lanes = ((n + MULGEN_G - 1) / MULGEN_G + 63) / 64 * 64, cap = (size_t)4 * 1024 * 64;       // MULGEN_G scalars per lane; at most 4 waves on each of the 1024 SIMDs
-    k_ed25519_mulgen_get<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(
-        reinterpret_cast<const unsigned char*>(e), reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n);
+    hipStream_t s = (hipStream_t)st;
+    const unsigned char* eb = reinterpret_cast<const unsigned char*>(e);
+    unsigned char *xb = reinterpret_cast<unsigned char*>(x), *yb = reinterpret_cast<unsigned char*>(y);
+    EdLadScratch ws(nullptr, 0, ed26l_workspace_bytes(n), 8, s);          // this entry point has no workspace argument: the library's scratch pool
+    for (size_t first = 0; first < n; first += EDLAD_CHUNK) {
+        const size_t m = n - first < EDLAD_CHUNK ? n - first : EDLAD_CHUNK;
+        if (ws.p) {
+            Ed26lWs w(ws.p, m);
+            k_ed25519_mulgen<false><<<(unsigned)((m + 63) / 64), 64, 0, s>>>(eb, xb, yb, sign, first, m, w);
+            edlad_export<LadT25519, 4>(w, xb, yb, sign, first, s);
+        } else {
+            k_ed25519_mulgen<true><<<(unsigned)((m + 63) / 64), 64, 0, s>>>(eb, xb, yb, sign, first, m, Ed26lWs(nullptr, m));
+        }
+    }
     return check_launch("ecn mulgen_get");
 }
 

@@ -88,7 +88,7 @@ void k_x448_base(const uint64_t* bk, uint64_t* bv, size_t first, size_t n, Ed28l
         F::to_words(u, ow);
         static_for<0, 7>([&](auto K) { bv[(first + tt()) * 7 + K] = ow[K]; });
     } else {
-        ws.store_xyz(tt(), y2, y2, x2);                     // B = C = the numerator, A = the denominator
+        ws.store_nd(tt(), y2, x2);
     }
 }
 // the quotient as a little-endian record of the caller's output array
@@ -197,7 +197,7 @@ extern "C" int rfc7748_X448_base_batch(const char* bk, char* bv, size_t n, void*
             size_t L;
             int rounds;
             edlad_rounds(m, &L, &rounds);
-            k_fe_batch_div<Fe28, 16, 7, SinkLE448, 4><<<(unsigned)((L + 63) / 64), 64, 0, s>>>(w.A, w.B, w.Cn, w.wc, m, L, rounds, SinkLE448{vb, first});
+            k_fe_batch_div<Fe28, 16, 7, SinkLE448, 4><<<(unsigned)((L + 63) / 64), 64, 0, s>>>(w.A, w.B, w.B, w.wc, m, L, rounds, SinkLE448{vb, first});
         } else {
             k_x448_base<true><<<(unsigned)((m + 63) / 64), 64, 0, s>>>(kb, vb, first, m, Ed28lWs(nullptr, m));
         }

@@ -208,42 +208,6 @@ MA_DEV void ed25519_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* y
     F::to_words(ax, xw);
     F::to_words(ay, yw);
 }
-// G scalars per lane with ONE inversion (Montgomery's trick on the prefix products of the Z, which are never zero on this
-// curve): the inversion is a fifth of the single-scalar kernel.  load(g, ew) fetches the g-th scalar of this lane; the
-// window loop is rolled over g (one copy in the instruction stream).  xw, yw: G x 4 words.
-template <class C, class TAB, int G, class LOAD>
-MA_DEV void ed25519_mulgen_get_many(LOAD load, uint64_t (*xw)[4], uint64_t (*yw)[4]) {
-    using F = Fe26;
-    uint32_t X[G][10], Y[G][10], Z[G][10], pre[G][10];
-    typename Ed26<C>::Ext R;
-#pragma unroll 1
-    for (int g = 0; g < G; g++) {
-        uint64_t ew[4];
-        load(g, ew);
-        ed25519_mulgen_acc<C, TAB>(ew, R);
-        static_for<0, G>([&](auto GI) {                                  // (static register indices only)
-            if (g == GI) { F::copy(R.X, X[GI]); F::copy(R.Y, Y[GI]); F::copy(R.Z, Z[GI]); }
-        });
-    }
-    F::copy(Z[0], pre[0]);
-    static_for<1, G>([&](auto GI) { F::mul(pre[GI - 1], Z[GI], pre[GI]); });
-    uint32_t inv[10], t[10], u[10];
-    F::invert(pre[G - 1], inv);
-    static_for<0, G>([&](auto GI) {
-        constexpr int g = G - 1 - GI;
-        if constexpr (g > 0) {
-            F::mul(inv, pre[g - 1], t);         // 1 / Z_g
-            F::mul(inv, Z[g], inv);             // 1 / (Z_0 ... Z_{g-1})
-        } else {
-            F::copy(inv, t);
-        }
-        F::mul(X[g], t, u);
-        F::to_words(u, xw[g]);
-        F::mul(Y[g], t, u);
-        F::to_words(u, yw[g]);
-    });
-}
-
 // rfc7748() on the BASE POINT u = 9 (public-key generation: every Diffie-Hellman exchange opens with it, rfc7748.c:297-333
 // `rfc7748(alice, base, apk)`).  The generator of ED25519 is the image of (9, v) under the birational map u = (1 + y) / (1 - y),
 // so [k](9) = (Z + Y) / (Z - Y) of k*G on the Edwards curve, with k*G from the fixed-base table (ed25519_mulgen_acc: no

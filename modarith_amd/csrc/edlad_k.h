@@ -44,6 +44,17 @@ struct EdLadWs {
         T::F::from_words(ww, w);
         return flags[t];
     }
+    // one numerator / denominator pair (B / A): the base-point ladders; the shared inversion is then given B for both of its numerators
+    MA_DEV void store_nd(size_t t, const uint32_t* num, const uint32_t* den) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(t));
+#endif
+        uint64_t w[T::NW];
+        T::F::to_words(den, w);
+        static_for<0, T::NW>([&](auto K) { A[(size_t)K * m + t] = w[K]; });
+        T::F::to_words(num, w);
+        static_for<0, T::NW>([&](auto K) { B[(size_t)K * m + t] = w[K]; });
+    }
     MA_DEV void store_xyz(size_t t, const uint32_t* X, const uint32_t* Y, const uint32_t* Z) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+v"(t));     // the row addresses are formed HERE: hoisted above the caller's loops they cost 3 NW register pairs (spilled in k_ed448_lad_gen2)

@@ -46,7 +46,7 @@ AUDITED = [
     # the fused kernels that take a SECRET scalar (key generation, signing, key agreement): mul + get, gen + mul + get, base-point ladders.
     # (mul2_get / mulgen2_get are the verification patterns: public inputs, and the reference's own mul2 is variable time.)
     ("capi_NIST256F.o", "_mul_get"), ("capi_SECP256K1F.o", "_mul_get"),
-    ("capi_ED25519G.o", "mulgen_get"), ("capi_ED448G.o", "k_ed448_mulgen<"), ("capi_NIST256G.o", "mulgen_get"), ("capi_SECP256K1G.o", "mulgen_get"),
+    ("capi_ED25519G.o", "k_ed25519_mulgen<"), ("capi_ED448G.o", "k_ed448_mulgen<"), ("capi_NIST256G.o", "mulgen_get"), ("capi_SECP256K1G.o", "mulgen_get"),
     ("capi_ED25519G.o", "k_x25519_base"), ("capi_ED448G.o", "k_x448_base"),
     # round 5: the ladder form of the fused ED25519 multiplications (csrc/ed26l.h): prep, the two shared inversions, the ladder
     ("capi_ED25519F.o", "k_ed25519_lad("), ("capi_ED25519F.o", "k_edlad_prep<"), ("capi_ED25519F.o", "k_fe_batch_div<"),

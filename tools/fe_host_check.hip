@@ -991,14 +991,6 @@ int main(int argc, char** argv) {
     bad += run<7>("x448_base_one (u = 5)", n / 4 + 8, [](const uint64_t* k, const uint64_t*, uint64_t* o) { ma::x448_base_one<HostComb448>(k, o); }, rfc7748_X448, 5);
     bad += run_edgen<32, pt25519>("ed25519_mulgen_get_one", n / 4 + 80, [](const uint64_t* e, uint64_t* x, uint64_t* y) { ma::ed25519_mulgen_get_one<ma::C_ED25519, HostComb25519>(e, x, y); },
                                   ecn_ed25519_gen, ecn_ed25519_mul, ecn_ed25519_get);
-    bad += run_edgen<32, pt25519>("ed25519_mulgen_get_many<4>", n / 4 + 80, [](const uint64_t* e, uint64_t* x, uint64_t* y) {
-                                      // this scalar as element 2 of a group of four (neighbours: 0, all ones, 1), one shared inversion
-                                      uint64_t xw[4][4], yw[4][4];
-                                      ma::ed25519_mulgen_get_many<ma::C_ED25519, HostComb25519, 4>([&](int g, uint64_t* ew) {
-                                          for (int k = 0; k < 4; k++) ew[k] = g == 2 ? e[k] : (g == 0 ? 0 : (g == 1 ? ~0ull : (k == 0)));
-                                      }, xw, yw);
-                                      for (int k = 0; k < 4; k++) { x[k] = xw[2][k]; y[k] = yw[2][k]; }
-                                  }, ecn_ed25519_gen, ecn_ed25519_mul, ecn_ed25519_get);
     bad += run_ed25519_mulgen2_lad(n / 8 + 24);
     bad += run_edgen<56, pt448>("ed448_mulgen_get_one", n / 8 + 130, [](const uint64_t* e, uint64_t* x, uint64_t* y) { ma::ed448_mulgen_get_one<HostComb448>(e, x, y); },
                                 ecn_ed448_gen, ecn_ed448_mul, ecn_ed448_get);

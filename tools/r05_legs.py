@@ -30,8 +30,9 @@ def legs():
             out[C + "_ecn_mul2_get_fused"] = [("k_%s_mul2_straus" % low, base + "F2.o", 1, 1), ("SinkExportBE<ma::%s>, 3>" % ("P_X25519" if C == "ED25519" else "P_X448"), base + "F2.o", 1, "rounds")]
         else:
             out[C + "_ecn_mul2_get_fused"] = [("k_%s_mul2_get" % low, base + "F2.o", 1, 1)]
-        if C == "ED448":
-            out[C + "_ecn_mulgen_get_fused"] = [("k_ed448_mulgen<false>", base + "G.o", 1, 1), ("SinkExportBE<ma::P_X448>, 3>", base + "G.o", 1, "rounds")]
+        if C in ("ED25519", "ED448"):
+            out[C + "_ecn_mulgen_get_fused"] = [("k_%s_mulgen<false>" % low, base + "G.o", 1, 1),
+                                                ("SinkExportBE<ma::%s>, %d>" % (("P_X25519", 4) if C == "ED25519" else ("P_X448", 3)), base + "G.o", 1, "rounds")]
         else:
             out[C + "_ecn_mulgen_get_fused"] = [("k_%s_mulgen_get" % low, base + "G.o", g, 1)]
     return out
