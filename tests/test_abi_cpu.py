@@ -181,3 +181,22 @@ assert L.modarith_amd_status() == 0
     out = p.stdout.strip().splitlines()[-1]
     assert out.startswith("status ") and int(out.split()[1]) != 0, out
     assert "c [0, 0, 0, 0, 0]" in out and "pred 0" in out and "bv True" in out and "staging" in out, out
+
+
+def test_fused_workspace_sizes_are_bounded(lib):
+    """round 5: the ladder / Straus forms of the fused Edwards kernels work in chunks of 2^20 records, so what a caller must allocate stops
+    growing there (include/modarith_amd.h): 140 / 236 bytes per record for ed25519 / ed448, plus the table slabs of the resident grid
+    (2048 waves) for the double multiplications"""
+    sz = ctypes.c_size_t
+    for name in ("ecn_ed25519_mul_get_workspace_bytes", "ecn_ed25519_mulgen2_get_workspace_bytes", "ecn_ed25519_mul2_get_workspace_bytes",
+                 "ecn_ed448_mul_get_workspace_bytes", "ecn_ed448_mulgen2_get_workspace_bytes", "ecn_ed448_mul2_get_workspace_bytes"):
+        f = getattr(lib, name)
+        f.argtypes, f.restype = [sz], sz
+    chunk = 1 << 20
+    for n in (1, 4096, chunk - 1, chunk, chunk + 1, 1 << 26):
+        m = min(n, chunk)
+        assert lib.ecn_ed25519_mul_get_workspace_bytes(n) == 140 * m == lib.ecn_ed25519_mulgen2_get_workspace_bytes(n)
+        assert lib.ecn_ed448_mul_get_workspace_bytes(n) == 236 * m == lib.ecn_ed448_mulgen2_get_workspace_bytes(n)
+        waves = min((m + 63) // 64, 2048)
+        assert lib.ecn_ed25519_mul2_get_workspace_bytes(n) == waves * 64 * 18 * 128 + 140 * m
+        assert lib.ecn_ed448_mul2_get_workspace_bytes(n) == waves * 64 * 18 * 256 + 236 * m
