@@ -226,6 +226,42 @@ def test_fused_ladder_and_straus_forms_cross_their_chunk_boundary():
     assert torch.equal(x, wx) and torch.equal(y, wy)
 
 
+def test_fused_ladder_form_under_stream_capture():
+    """the ladder form is four kernels and a workspace: with the caller's workspace it only enqueues kernels, so it can be captured into a
+    hipGraph and replayed on new data; WITHOUT one it would have to take scratch from the library's pool, which a stream under capture
+    does not allow -- the call then fails with hipErrorInvalidValue and a message, it does not break the capture or fall back"""
+    import torch
+    from modarith_amd.edwards import Curve
+    from modarith_amd import _lib
+    Ed = Curve("ED25519")
+    n = 4096 + 5
+    gen = torch.Generator(device="cuda").manual_seed(96)
+    rnd = lambda: torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=gen)
+    e, e2 = rnd(), rnd()
+    P = Ed.mul(rnd(), Ed.gen(n))
+    want = Ed.mul_get(e, P)                                      # eager (also sizes the object's workspace before the capture)
+    want2 = Ed.mul_get(e2, P)
+    L = _lib.load()
+    ws = torch.empty(int(L.ecn_ed25519_mul_get_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    x, y = torch.empty_like(want[0]), torch.empty_like(want[1])
+    eb = e.clone()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            rc_none = L.ecn_ed25519_mul_get_batch(eb.data_ptr(), P.data_ptr(), x.data_ptr(), y.data_ptr(), None, n, n, None, 0, side.cuda_stream)
+            msg = L.modarith_amd_last_error().decode()
+            rc = L.ecn_ed25519_mul_get_batch(eb.data_ptr(), P.data_ptr(), x.data_ptr(), y.data_ptr(), None, n, n, ws.data_ptr(), ws.numel(), side.cuda_stream)
+    assert rc == 0 and rc_none != 0 and "workspace" in msg, (rc, rc_none, msg)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(x, want[0]) and torch.equal(y, want[1])
+    eb.copy_(e2)                                                 # new scalars in the captured buffer
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(x, want2[0]) and torch.equal(y, want2[1])
+
+
 def test_fused_rejects_bad_arguments(fx):
     C, Ed, g, torch = fx
     from modarith_amd.edwards import Edwards
