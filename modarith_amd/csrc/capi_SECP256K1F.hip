@@ -5,29 +5,32 @@
 #include "generated/curve_SECP256K1.h"
 #include "kernels.h"
 #include "wn26.h"
+#include "glv26.h"
 
 namespace ma {
 
 constexpr size_t SECP256K1_ROW_SKEW = 32 + 4;   // words added to the row pitch of the table workspace (as in capi_ED448F.hip)
 
-// one scalar multiplication per lane, one wave per workgroup: window tables in the wave's slab of the workspace ([word][64 lanes]: every
+// one scalar multiplication per lane, one wave per workgroup, the scalar split by the curve's endomorphism (csrc/glv26.h: 128 doublings
+// instead of 256 on the same table): window tables in the wave's slab of the workspace ([word][64 lanes]: every
 // access one contiguous 512-byte row, row addresses formed at the access -- wn26.h WnTabSlab), recoded scalar in LDS (one byte per
 // window, written before the point is loaded), element index = wave-uniform base + lane, formed where it is used
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_secp256k1_mul_get(const unsigned char* e, const spint* Pb, unsigned char* xb, unsigned char* yb, int* sign, size_t n, size_t ld,
                        uint64_t* ws) {
     using P = P_SECP256K1;
-    using DIG = WnLds<4, 260>;
+    using DIG = GlvLds;
     __shared__ unsigned char digs[DIG::COUNT * 64];
     const WnTabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)WN26_TABLE_WORDS), threadIdx.x};
     unsigned char* col = digs + threadIdx.x;
     for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
         auto t = [&]() { return base + (size_t)(T.origin() - T.base); };
         if (t() >= n) continue;
+        DIG dig;
         {
             spint ew[4];
             load_be_record<P>(e, t(), ew);
-            DIG::fill(ew, col);
+            dig.fill(ew, col);
         }
         spint X[5], Y[5], Z[5], xw[4], yw[4];
         static_for<0, 5>([&](auto I) {
@@ -35,8 +38,7 @@ void k_secp256k1_mul_get(const unsigned char* e, const spint* Pb, unsigned char*
             Y[I] = Pb[(size_t)(5 + I) * ld + t()];
             Z[I] = Pb[(size_t)(10 + I) * ld + t()];
         });
-        DIG dig{col};
-        wn26_mul_get_dig<CvSecp256k1>(dig, X, Y, Z, T, xw, yw);
+        secp256k1_glv_mul_get_dig(dig, X, Y, Z, T, xw, yw);
         if (xb) store_be_record<P>(xb, t(), xw);
         if (yb) store_be_record<P>(yb, t(), yw);
         if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);

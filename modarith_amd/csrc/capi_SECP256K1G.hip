@@ -7,6 +7,7 @@
 #include "generated/comb_SECP256K1.h"
 #include "kernels.h"
 #include "wn26.h"
+#include "glv26.h"
 
 namespace ma {
 
@@ -46,17 +47,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_secp256k1_mulgen2_get(const unsigned char* e, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb, int* sign,
                            size_t n, size_t ld, uint64_t* ws) {
     using P = P_SECP256K1;
-    using DIG = WnLds<4, 260>;
-    __shared__ unsigned char digs[DIG::COUNT * 64];          // f's windows in LDS; Q's table in the wave's slab; index at use: see the mul_get unit
+    using DIG = GlvLds;                                      // f split by the endomorphism (csrc/glv26.h)
+    __shared__ unsigned char digs[DIG::COUNT * 64];          // the windows of f's halves in LDS; Q's table in the wave's slab; index at use: see the mul_get unit
     const WnTabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)WN26_TABLE_WORDS), threadIdx.x};
     unsigned char* col = digs + threadIdx.x;
     for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
         auto t = [&]() { return base + (size_t)(T.origin() - T.base); };
         if (t() >= n) continue;
+        DIG dig;
         {
             spint fw[4];
             load_be_record<P>(f, t(), fw);
-            DIG::fill(fw, col);
+            dig.fill(fw, col);
         }
         spint ew[4], X[5], Y[5], Z[5], xw[4], yw[4];
         static_for<0, 5>([&](auto I) {
@@ -65,8 +67,7 @@ void k_secp256k1_mulgen2_get(const unsigned char* e, const unsigned char* f, con
             Z[I] = Qb[(size_t)(10 + I) * ld + t()];
         });
         load_be_record<P>(e, t(), ew);
-        DIG dig{col};
-        wn26_mulgen2_get_dig<CvSecp256k1, CombSECP256K1>(ew, dig, X, Y, Z, T, xw, yw);
+        secp256k1_glv_mulgen2_get_dig<CombSECP256K1>(ew, dig, X, Y, Z, T, xw, yw);
         if (xb) store_be_record<P>(xb, t(), xw);
         if (yb) store_be_record<P>(yb, t(), yw);
         if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);

@@ -102,6 +102,83 @@ def test_secp256k1_fused_on_host_against_oracle(oracle, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")
+def test_secp256k1_endomorphism_split_and_fused_forms_on_host(oracle, tmp_path):
+    """csrc/glv26.h on the host: (1) the split k = k1 + k2 lambda (mod n) against Python integers -- identity and |k1|, |k2| < 2^128
+    on corner scalars (0, 1, n, n +- 1, lambda, n - lambda, 2^128 +- 1, all ones) and 10^5 random ones; (2) the fused forms built on
+    it (k P and e G + f Q as 128 doublings on one table) against the oracle's ecn mul / ecn mul2 followed by ecn get: random projective
+    points, the point at infinity, the generator, Q = +-G, scalars that cancel"""
+    import ctypes
+    import random
+    so = str(tmp_path / "libwn26_host.so")
+    cc = HIPCC if os.path.exists(HIPCC) else "hipcc"
+    subprocess.run([cc, "-O2", "-std=c++17", "-w", "-shared", "-fPIC", "--offload-host-only", os.path.join(ROOT, "tools", "wn26_host.hip"), "-o", so],
+                   check=True, timeout=900)
+    lib = ctypes.CDLL(so)
+    U64 = ctypes.c_uint64
+    n = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    lam = 0x5363ad4cc05c30e0a5261c028812645a122e22ea20816678df02967c1b23bd72
+    assert pow(lam, 3, n) == 1 and lam != 1
+    rng = random.Random(17)
+    words = lambda v: (U64 * 4)(*[(v >> (64 * k)) & (2**64 - 1) for k in range(4)])
+    val = lambda w: sum(int(x) << (64 * i) for i, x in enumerate(w))
+    corner = [0, 1, 2, 7, 8, 9, n - 1, n, n + 1, 2**256 - 1, 2**255, lam, n - lam, lam + 1, lam - 1, 2**128, 2**128 - 1, 2**128 + 1, 2**129,
+              (n + 1) // 2, n // 2, 2**256 - n, int("8" * 64, 16), int("7" * 64, 16)]
+    for it in range(100000):
+        e = corner[it] if it < len(corner) else rng.getrandbits(256)
+        k1, k2 = (U64 * 3)(), (U64 * 3)()
+        sg = lib.secp256k1_glv_split_host(words(e), k1, k2)
+        a, b = val(k1), val(k2)
+        assert a < 2**128 and b < 2**128, hex(e)
+        assert ((-a if sg & 1 else a) + (-b if sg & 2 else b) * lam - e) % n == 0, hex(e)
+
+    C = "secp256k1"
+    Pt, nb = oracle.ed[C]
+    be = lambda v: v.to_bytes(32, "big")
+
+    def point(kind):
+        p = Pt()
+        if kind == "inf":
+            oracle.ecn(C, "inf")(ctypes.byref(p))
+            return p
+        oracle.ecn(C, "gen")(ctypes.byref(p))
+        if kind == "rand":
+            oracle.ecn(C, "mul")(be(rng.getrandbits(256)), ctypes.byref(p))
+        if kind == "neg":
+            oracle.ecn(C, "neg")(ctypes.byref(p))
+        return p
+
+    def affine(p):
+        x, y = ctypes.create_string_buffer(nb), ctypes.create_string_buffer(nb)
+        oracle.ecn(C, "get")(ctypes.byref(p), x, y)
+        return x.raw, y.raw
+
+    out_bytes = lambda xw, yw: (b"".join(int(xw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0)), b"".join(int(yw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0)))
+    for it in range(160):
+        kind = "inf" if it % 16 == 1 else ("gen" if it % 16 == 4 else "rand")
+        e = corner[it] if it < len(corner) else rng.getrandbits(256)
+        p = point(kind)
+        xw, yw = (U64 * 4)(), (U64 * 4)()
+        lib.secp256k1_glv_mul_get_host(words(e), p.x, p.y, p.z, xw, yw)
+        oracle.ecn(C, "mul")(be(e), ctypes.byref(p))
+        assert out_bytes(xw, yw) == affine(p), ("glv mul_get", it, hex(e))
+    for it in range(80):
+        e, f = rng.getrandbits(256), rng.getrandbits(256)
+        kind = ("rand", "inf", "gen", "neg")[it % 4] if it < 40 else "rand"
+        if it % 8 == 2:
+            f = e                                   # e G + e G
+        if it % 8 == 3:
+            f = e                                   # with Q = -G: infinity
+        if it % 8 == 5:
+            e, f = corner[it % len(corner)], corner[(it * 7) % len(corner)]
+        qq = point(kind)
+        xw, yw = (U64 * 4)(), (U64 * 4)()
+        lib.secp256k1_glv_mulgen2_get_host(words(e), words(f), qq.x, qq.y, qq.z, xw, yw)
+        g, r = point("gen"), Pt()
+        oracle.ecn(C, "mul2")(be(e), ctypes.byref(g), be(f), ctypes.byref(qq), ctypes.byref(r))
+        assert out_bytes(xw, yw) == affine(r), ("glv mulgen2_get", it, kind)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")
 def test_lazy_limb_bounds_of_the_fused_weierstrass_fields(tmp_path):
     """fm26.h / fk26.h at the limb magnitudes wn26.h lets them reach (|limb| <= K 2^26 with the K of the comments there):
     products, squarings and two-product reductions of worst-case operands (all limbs at +-(K 2^26 - 1), alternating signs,

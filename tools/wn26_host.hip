@@ -61,3 +61,24 @@ extern "C" void wn26_mulgen2_get_host(int which, const uint64_t* ew, const uint6
     if (which == 0) ma::wn26_mulgen2_get_one<ma::CvNist256, HostCombNist256>(ew, fw, QX, QY, QZ, tab, 1, xw, yw);
     else ma::wn26_mulgen2_get_one<ma::CvSecp256k1, HostCombSecp256k1>(ew, fw, QX, QY, QZ, tab, 1, xw, yw);
 }
+
+// round 5: the secp256k1 endomorphism (csrc/glv26.h).  split: |k1|, |k2| (three words each) and the signs (bit 0: k1 < 0, bit 1: k2 < 0)
+#include "../modarith_amd/csrc/glv26.h"
+extern "C" int secp256k1_glv_split_host(const uint64_t* ew, uint64_t* k1, uint64_t* k2) {
+    bool n1, n2;
+    ma::GlvSecp256k1::split(ew, k1, n1, k2, n2);
+    return (n1 ? 1 : 0) | (n2 ? 2 : 0);
+}
+extern "C" void secp256k1_glv_mul_get_host(const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, uint64_t* xw, uint64_t* yw) {
+    uint64_t tab[ma::WN26_TABLE_WORDS];
+    ma::GlvRegs dig;
+    dig.init(ew);
+    ma::secp256k1_glv_mul_get_dig(dig, X, Y, Z, ma::WnTabStrided{tab, 1}, xw, yw);
+}
+extern "C" void secp256k1_glv_mulgen2_get_host(const uint64_t* ew, const uint64_t* fw, const uint64_t* QX, const uint64_t* QY, const uint64_t* QZ,
+                                               uint64_t* xw, uint64_t* yw) {
+    uint64_t tab[ma::WN26_TABLE_WORDS];
+    ma::GlvRegs dig;
+    dig.init(fw);
+    ma::secp256k1_glv_mulgen2_get_dig<HostCombSecp256k1>(ew, dig, QX, QY, QZ, ma::WnTabStrided{tab, 1}, xw, yw);
+}
