@@ -7,30 +7,33 @@
 #include "generated/curve_SECP256K1.h"
 #include "kernels.h"
 #include "wn26.h"
+#include "glv26.h"
 
 namespace ma {
 
 constexpr size_t SECP256K1_ROW_SKEW2 = 32 + 4;
 
-// tables in the wave's slab, the two recoded scalars in LDS, element index formed at use: see the mul_get unit
+// both scalars split by the endomorphism (csrc/glv26.h), the two tables of eight in the wave's slab (a double slot), the four recoded
+// half scalars in LDS, element index formed at use: see the mul_get unit
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_secp256k1_mul2_get(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb,
                         int* sign, size_t n, size_t ld, uint64_t* ws) {
     using P = P_SECP256K1;
-    using DIG = WnLds<3, 258>;
+    using DIG = GlvLds;
     __shared__ unsigned char digs[2 * DIG::COUNT * 64];
-    const WnTabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)WN26_TABLE_WORDS), threadIdx.x};
+    const WnTabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)GLV2_TABLE_WORDS), threadIdx.x};
     unsigned char* ce = digs + threadIdx.x;
     unsigned char* cf = ce + DIG::COUNT * 64;
     for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
         auto t = [&]() { return base + (size_t)(T.origin() - T.base); };
         if (t() >= n) continue;
+        DIG de, df;
         {
             spint ew[4];
             load_be_record<P>(e, t(), ew);
-            DIG::fill(ew, ce);
+            de.fill(ew, ce);
             load_be_record<P>(f, t(), ew);
-            DIG::fill(ew, cf);
+            df.fill(ew, cf);
         }
         spint PX[5], PY[5], PZ[5], QX[5], QY[5], QZ[5], xw[4], yw[4];
         static_for<0, 5>([&](auto I) {
@@ -41,8 +44,7 @@ void k_secp256k1_mul2_get(const unsigned char* e, const spint* Pb, const unsigne
             QY[I] = Qb[(size_t)(5 + I) * ld + t()];
             QZ[I] = Qb[(size_t)(10 + I) * ld + t()];
         });
-        DIG de{ce}, df{cf};
-        wn26_mul2_get_dig<CvSecp256k1>(de, PX, PY, PZ, df, QX, QY, QZ, T, xw, yw);
+        secp256k1_glv_mul2_get_dig(de, PX, PY, PZ, df, QX, QY, QZ, T, xw, yw);
         if (xb) store_be_record<P>(xb, t(), xw);
         if (yb) store_be_record<P>(yb, t(), yw);
         if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
@@ -60,7 +62,7 @@ size_t fused_lanes(size_t n) {
 }
 }  // namespace
 
-extern "C" size_t ecn_secp256k1_mul2_get_workspace_bytes(size_t n) { return (fused_lanes(n) + SECP256K1_ROW_SKEW2) * WN26_TABLE_WORDS * sizeof(uint64_t); }
+extern "C" size_t ecn_secp256k1_mul2_get_workspace_bytes(size_t n) { return (fused_lanes(n) + SECP256K1_ROW_SKEW2) * GLV2_TABLE_WORDS * sizeof(uint64_t); }
 
 extern "C" int ecn_secp256k1_mul2_get_batch(const char* e, const ma_spint* P, const char* f, const ma_spint* Q, char* x, char* y, int* sign,
                                           size_t n, size_t ld, void* workspace, size_t workspace_bytes, void* st) {
@@ -70,7 +72,7 @@ extern "C" int ecn_secp256k1_mul2_get_batch(const char* e, const ma_spint* P, co
         return (int)hipErrorInvalidValue;
     }
     const size_t lanes = fused_lanes(n);
-    if (workspace == nullptr || workspace_bytes < (lanes + SECP256K1_ROW_SKEW2) * WN26_TABLE_WORDS * sizeof(uint64_t)) {
+    if (workspace == nullptr || workspace_bytes < (lanes + SECP256K1_ROW_SKEW2) * GLV2_TABLE_WORDS * sizeof(uint64_t)) {
         set_error("ecn mul2_get: workspace too small (see ecn_secp256k1_mul2_get_workspace_bytes)");
         return (int)hipErrorInvalidValue;
     }

@@ -176,6 +176,29 @@ def test_secp256k1_endomorphism_split_and_fused_forms_on_host(oracle, tmp_path):
         g, r = point("gen"), Pt()
         oracle.ecn(C, "mul2")(be(e), ctypes.byref(g), be(f), ctypes.byref(qq), ctypes.byref(r))
         assert out_bytes(xw, yw) == affine(r), ("glv mulgen2_get", it, kind)
+    for it in range(80):                             # e P + f Q, both split: P, Q random / infinite / equal / opposite
+        e, f = rng.getrandbits(256), rng.getrandbits(256)
+        p, qq = point("rand"), point("rand")
+        if it % 8 == 1:
+            p = point("inf")
+        if it % 8 == 2:
+            qq = point("inf")
+        if it % 8 in (3, 4, 5):
+            oracle.ecn(C, "cpy")(ctypes.byref(p), ctypes.byref(qq))
+            if it % 8 != 4:
+                oracle.ecn(C, "neg")(ctypes.byref(qq))
+            if it % 8 == 3:
+                f = e                                # e P + e (-P) = infinity -> (0, 1)
+        if it % 8 == 6:
+            e, f = corner[it % len(corner)], corner[(it * 5) % len(corner)]
+        xw, yw = (U64 * 4)(), (U64 * 4)()
+        lib.secp256k1_glv_mul2_get_host(words(e), p.x, p.y, p.z, words(f), qq.x, qq.y, qq.z, xw, yw)
+        r = Pt()
+        oracle.ecn(C, "mul2")(be(e), ctypes.byref(p), be(f), ctypes.byref(qq), ctypes.byref(r))
+        want = affine(r)
+        assert out_bytes(xw, yw) == want, ("glv mul2_get", it)
+        if it % 8 == 3:
+            assert want == (be(0), be(1))
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")

@@ -82,3 +82,11 @@ extern "C" void secp256k1_glv_mulgen2_get_host(const uint64_t* ew, const uint64_
     dig.init(fw);
     ma::secp256k1_glv_mulgen2_get_dig<HostCombSecp256k1>(ew, dig, QX, QY, QZ, ma::WnTabStrided{tab, 1}, xw, yw);
 }
+extern "C" void secp256k1_glv_mul2_get_host(const uint64_t* ew, const uint64_t* PX, const uint64_t* PY, const uint64_t* PZ,
+                                            const uint64_t* fw, const uint64_t* QX, const uint64_t* QY, const uint64_t* QZ, uint64_t* xw, uint64_t* yw) {
+    uint64_t tab[ma::GLV2_TABLE_WORDS];
+    ma::GlvRegs de, df;
+    de.init(ew);
+    df.init(fw);
+    ma::secp256k1_glv_mul2_get_dig(de, PX, PY, PZ, df, QX, QY, QZ, ma::WnTabStrided{tab, 1}, xw, yw);
+}
