@@ -5,12 +5,14 @@
 #include "generated/curve_NIST256.h"
 #include "kernels.h"
 #include "wn26.h"
+#include "wj26.h"
 
 namespace ma {
 
 constexpr size_t NIST256_ROW_SKEW = 32 + 4;   // words added to the row pitch of the table workspace (as in capi_ED448F.hip)
 
-// one scalar multiplication per lane, one wave per workgroup: window tables in the wave's slab of the workspace ([word][64 lanes]: every
+// one scalar multiplication per lane, one wave per workgroup, in Jacobian coordinates with the last addition complete (csrc/wj26.h; the
+// scalar reduced mod n first): window tables in the wave's slab of the workspace ([word][64 lanes]: every
 // access one contiguous 512-byte row, row addresses formed at the access -- wn26.h WnTabSlab), recoded scalar in LDS (one byte per
 // window, written before the point is loaded), element index = wave-uniform base + lane, formed where it is used
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -25,9 +27,10 @@ void k_nist256_mul_get(const unsigned char* e, const spint* Pb, unsigned char* x
         auto t = [&]() { return base + (size_t)(T.origin() - T.base); };
         if (t() >= n) continue;
         {
-            spint ew[4];
+            spint ew[4], kw[4];
             load_be_record<P>(e, t(), ew);
-            DIG::fill(ew, col);
+            Wj26::reduce_scalar(ew, kw);
+            DIG::fill(kw, col);
         }
         spint X[5], Y[5], Z[5], xw[4], yw[4];
         static_for<0, 5>([&](auto I) {
@@ -36,7 +39,7 @@ void k_nist256_mul_get(const unsigned char* e, const spint* Pb, unsigned char* x
             Z[I] = Pb[(size_t)(10 + I) * ld + t()];
         });
         DIG dig{col};
-        wn26_mul_get_dig<CvNist256>(dig, X, Y, Z, T, xw, yw);
+        Wj26::mul_get_dig(dig, X, Y, Z, T, xw, yw);
         if (xb) store_be_record<P>(xb, t(), xw);
         if (yb) store_be_record<P>(yb, t(), yw);
         if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);

@@ -7,6 +7,7 @@
 #include "generated/comb_NIST256.h"
 #include "kernels.h"
 #include "wn26.h"
+#include "wj26.h"
 
 namespace ma {
 
@@ -54,9 +55,10 @@ void k_nist256_mulgen2_get(const unsigned char* e, const unsigned char* f, const
         auto t = [&]() { return base + (size_t)(T.origin() - T.base); };
         if (t() >= n) continue;
         {
-            spint fw[4];
+            spint fw[4], kw[4];
             load_be_record<P>(f, t(), fw);
-            DIG::fill(fw, col);
+            Wj26::reduce_scalar(fw, kw);                       // f Q in Jacobian coordinates (csrc/wj26.h)
+            DIG::fill(kw, col);
         }
         spint ew[4], X[5], Y[5], Z[5], xw[4], yw[4];
         static_for<0, 5>([&](auto I) {
@@ -66,7 +68,7 @@ void k_nist256_mulgen2_get(const unsigned char* e, const unsigned char* f, const
         });
         load_be_record<P>(e, t(), ew);
         DIG dig{col};
-        wn26_mulgen2_get_dig<CvNist256, CombNIST256>(ew, dig, X, Y, Z, T, xw, yw);
+        Wj26::mulgen2_get_dig<CombNIST256>(ew, dig, X, Y, Z, T, xw, yw);
         if (xb) store_be_record<P>(xb, t(), xw);
         if (yb) store_be_record<P>(yb, t(), yw);
         if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);

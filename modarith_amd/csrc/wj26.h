@@ -1,0 +1,218 @@
+// modarith_amd/csrc/wj26.h -- the fused P-256 scalar multiplication k P in JACOBIAN coordinates (round 5).
+//
+// wn26.h runs the complete projective formulas of Renes-Costello-Batina the reference uses (weierstrass.c:68-281): for a = -3 a
+// doubling is 8M + 3S + 2 multiplications by b, 1 649 multiply-adds on fm26.h.  The fused entry points only let canonical affine
+// bytes out (ecnXXXmul followed by ecnXXXget, nist256.c:155-161, 219-222, 251-256), so the coordinate system inside is as free as
+// the window width and the limb form: in Jacobian coordinates (x = X / Z^2, y = Y / Z^3) the a = -3 doubling is 3M + 5S = 927
+// multiply-adds (Bernstein-Lange dbl-2001-b), the general addition 11M + 5S with one shared reduction = 2 035 (add-2007-bl) against
+// 1 928.  256 doublings + 65 additions: 372 k multiply-adds instead of 547 k.
+//
+// The Jacobian addition is NOT complete: it fails for R = +-Q and for either operand at infinity.  Where those can happen is decided
+// by the SCALAR alone, because the group has prime order n and cofactor 1 (every point of the curve other than infinity has order n):
+//   * the scalar is reduced mod n first (e < 2^256 < 2n: one masked subtraction; e P = (e mod n) P for every point of the curve);
+//   * with the signed digits of wn26.h (e' = e + sum 8 * 16^i, d_j = window_j(e') - 8), the accumulator before digit j is added is
+//     16 m P with m = floor(e' / 16^(j+1)) - 0x88..8 >= 0, and 16 m + d_j = floor(e' / 16^j) - 0x88..8 <= e / 16^j + 1.  For j >= 1 both
+//     16 m and 16 m + d_j are below n / 16 + 17 < n - 8: 16 m = +-d_j (mod n) forces m = 0 = d_j.  So for every digit but the LAST the
+//     only exceptional cases are an accumulator at infinity (m = 0: a lane flag, the sum is then the table entry), a zero digit or
+//     an input point at infinity (the sum is the accumulator), and doubling never fails (a point of odd order has Y != 0);
+//   * for the last digit the accumulator CAN meet +-Q (e = n - 2: 16 m = n - 1, d_0 = -1), so the last addition is the complete one of
+//     wn26.h (RCB algorithm 4) on the two points converted to homogeneous coordinates (X Z : Y : Z^3) -- 2M + 1S each -- and the
+//     result leaves in those, ready for wn26.h's export and for the complete mixed additions of the generator part (e G + f Q, where
+//     Q = k G for an unknown k and the accumulator can meet any table entry).
+//   * the table {1..8}P: 2P, 4P, 6P, 8P by doubling, 3P, 5P, 7P as (k-1)P + P -- no two multiples below n coincide.
+// Input points off the curve mean nothing on either side (wn26.h).  Flags are lane masks: the same instruction and address sequence
+// for every scalar and point.  The double multiplication e P + f Q of two caller points stays on the complete formulas
+// (wn26_mul2_get_dig): there the accumulator depends on both points and can meet a table entry anywhere in the loop.
+//
+// K (fm26.h: |limb| <= K 2^26; a product needs K_f K_g <= 190, every limb below 2^31) is given in the comments.
+#pragma once
+#include "wn26.h"
+
+namespace ma {
+
+struct Wj26 {
+    using F = Fm26;
+    using E = Wn26<CvNist256>;
+    using Pt = E::Pt;                       // (X, Y, Z), Jacobian here
+
+    // the group order, little-endian words
+    static constexpr uint64_t n_(int i) { constexpr uint64_t v[4] = {0xF3B9CAC2FC632551ull, 0xBCE6FAADA7179E84ull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFF00000000ull}; return v[i]; }
+    static MA_DEV void reduce_scalar(const uint64_t* ew, uint64_t* k) {
+        uint64_t d[4], bw = 0;
+        static_for<0, 4>([&](auto I) {
+            constexpr uint64_t nI = n_(I);
+            const uint64_t x = ew[I] - nI, b1 = ew[I] < nI;
+            d[I] = x - bw;
+            bw = b1 | ((x < bw) ? 1u : 0u);
+        });
+        const uint64_t keep = (uint64_t)0 - bw;                 // borrow: e < n
+        static_for<0, 4>([&](auto I) { k[I] = (ew[I] & keep) | (d[I] & ~keep); });
+    }
+
+    // P = 2P (dbl-2001-b).  In: X, Y K <= 9, Z K <= 3.  Out: X, Y K = 9, Z K = 3.  Z = 0 stays Z = 0.
+    static MA_DEV void dbl(Pt& p) {
+        int32_t d[10], g[10], b[10], a[10], t0[10], t1[10];
+        F::sqr(p.Z, d);             // delta
+        F::sqr(p.Y, g);             // gamma
+        F::mul(p.X, g, b);          // beta
+        F::sub(p.X, d, t0);         // 10
+        F::add(p.X, d, t1);         // 10
+        F::mul(t0, t1, a);
+        F::add(a, a, t0);
+        F::add(a, t0, a);           // 3   alpha = 3 (X - delta)(X + delta)
+        F::add(p.Y, p.Z, t0);       // 12
+        F::sqr(t0, t0);
+        F::sub(t0, g, t0);
+        F::sub(t0, d, p.Z);         // 3   Z3 = (Y + Z)^2 - gamma - delta
+        F::add(b, b, b);
+        F::add(b, b, b);            // 4   4 beta
+        F::sqr(a, t0);
+        F::sub(t0, b, t0);
+        F::sub(t0, b, p.X);         // 9   X3 = alpha^2 - 8 beta
+        F::sub(b, p.X, t1);         // 13
+        F::sqr(g, g);
+        F::add(g, g, g);
+        F::add(g, g, g);
+        F::add(g, g, g);            // 8   8 gamma^2
+        F::mul(a, t1, t0);
+        F::sub(t0, g, p.Y);         // 9   Y3 = alpha (4 beta - X3) - 8 gamma^2
+    }
+    // P += Q (add-2007-bl), neither at infinity, P != +-Q.  In: K <= 9 (X, Y), <= 3 (Z) on both.  Out: X K = 4, Y, Z K = 1.
+    static MA_DEV void add(const Pt& q, Pt& p) {
+        int32_t z1z1[10], z2z2[10], u1[10], u2[10], s1[10], s2[10], h[10], i_[10], j[10], r[10], v[10], t[10];
+        F::sqr(p.Z, z1z1);
+        F::sqr(q.Z, z2z2);
+        F::mul(p.X, z2z2, u1);
+        F::mul(q.X, z1z1, u2);
+        F::mul(q.Z, z2z2, t);
+        F::mul(p.Y, t, s1);
+        F::mul(p.Z, z1z1, t);
+        F::mul(q.Y, t, s2);
+        F::sub(u2, u1, h);          // 2
+        F::add(h, h, t);            // 4
+        F::sqr(t, i_);              //     I = (2H)^2
+        F::mul(h, i_, j);           //     J = H I
+        F::sub(s2, s1, r);
+        F::add(r, r, r);            // 4   r = 2 (S2 - S1)
+        F::mul(u1, i_, v);          //     V = U1 I
+        F::add(p.Z, q.Z, t);        // 6
+        F::sqr(t, t);
+        F::sub(t, z1z1, t);
+        F::sub(t, z2z2, t);         // 3
+        F::mul(t, h, p.Z);          //     Z3 = ((Z1 + Z2)^2 - Z1Z1 - Z2Z2) H
+        F::sqr(r, t);
+        F::sub(t, j, t);
+        F::sub(t, v, t);
+        F::sub(t, v, p.X);          // 4   X3 = r^2 - J - 2V
+        F::sub(v, p.X, t);          // 5
+        F::add(s1, s1, s1);         // 2
+        F::neg(s1, s1);
+        F::mul2(r, t, s1, j, p.Y);  //     Y3 = r (V - X3) - 2 S1 J:  4 x 5 + 2 x 1
+    }
+    // homogeneous (X : Y : Z) of the reference's form -> Jacobian (X Z, Y Z^2, Z); Z = 0 gives (0, 0, 0)
+    static MA_DEV void from_projective(Pt& p) {
+        int32_t zz[10];
+        F::sqr(p.Z, zz);
+        F::mul(p.X, p.Z, p.X);
+        F::mul(p.Y, zz, p.Y);
+    }
+    // Jacobian -> homogeneous (X Z : Y : Z^3), K = 1 throughout; inf: the point is at infinity whatever the coordinates say -> (0 : 1 : 0)
+    static MA_DEV void to_projective(bool inf, Pt& p) {
+        int32_t zz[10], o[10], z[10];
+        F::set_one(o);
+        F::zero(z);
+        F::sqr(p.Z, zz);
+        F::mul(p.X, p.Z, p.X);
+        F::mul(p.Y, o, p.Y);        // Y as it is, limbs carried (the complete addition takes K <= 4)
+        F::mul(p.Z, zz, p.Z);
+        F::select(inf, p.X, z, p.X);
+        F::select(inf, p.Y, o, p.Y);
+        F::select(inf, p.Z, z, p.Z);
+    }
+    static MA_DEV bool is_zero(const int32_t* f) {
+        uint64_t w[4];
+        F::to_words(f, w);          // canonical
+        return (w[0] | w[1] | w[2] | w[3]) == 0;
+    }
+
+    // entries base .. base + 7 = P, 2P, ..., 8P (Jacobian), one copy of dbl and add in the instruction stream (wn26.h build_table)
+    static MA_DEV void build_table(const Pt& p, uint64_t* tab, size_t tstride) {
+        E::put(tab, tstride, 0, p);
+#pragma unroll 1
+        for (int k = 2; k <= 8; k++) {
+            Pt t;
+            E::get(tab, tstride, (k & 1) ? k - 2 : (k >> 1) - 1, t);
+            if (k & 1) add(p, t);
+            else dbl(t);
+            E::put(tab, tstride, k - 1, t);
+        }
+    }
+
+    // R = (the scalar whose digits dig delivers) * (X : Y : Z), homogeneous on return.  The digits must be those of a scalar below n
+    // (reduce_scalar before the recoding).
+    template <class TAB, class DIG>
+    static MA_DEV void mul_acc(DIG& dig, const spint* X, const spint* Y, const spint* Z, const TAB& T, Pt& R) {
+        Pt Q;
+        E::load_point(X, Y, Z, Q);
+        const bool pinf = is_zero(Q.Z);
+        from_projective(Q);
+        build_table(Q, T.origin(), T.stride());
+        F::set_one(R.X);
+        F::set_one(R.Y);
+        F::zero(R.Z);
+        bool rinf = true;
+#pragma unroll 1
+        for (int i = 0; i < 64; i++) {
+            const int dgt = (int)dig.window(i) - 8;                 // [-8, 7]
+            const bool neg = dgt < 0;
+            const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0..8
+            if (i != 0) {
+#pragma unroll 1
+                for (int j = 0; j < 4; j++) dbl(R);
+            }
+            E::template lookup<8>(T.origin(), T.stride(), 0, m, neg, Q);
+            const bool qinf = (m == 0) || pinf;
+            Pt S = R;
+            add(Q, S);
+            // R at infinity: the sum is Q; Q at infinity: the sum is R; both: R stays at infinity
+            static_for<0, 3>([&](auto CI) {
+                int32_t* rc = CI == 0 ? R.X : CI == 1 ? R.Y : R.Z;
+                const int32_t* sc = CI == 0 ? S.X : CI == 1 ? S.Y : S.Z;
+                const int32_t* qc = CI == 0 ? Q.X : CI == 1 ? Q.Y : Q.Z;
+                int32_t u[10];
+                F::select(rinf, sc, qc, u);
+                F::select(qinf, u, rc, rc);
+            });
+            rinf = rinf && qinf;
+        }
+        // the last digit: complete addition on homogeneous coordinates
+        {
+            const int dgt = (int)dig.window(64) - 8;
+            const bool neg = dgt < 0;
+            const uint32_t m = (uint32_t)(neg ? -dgt : dgt);
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) dbl(R);
+            E::template lookup<8>(T.origin(), T.stride(), 0, m, neg, Q);
+            to_projective((m == 0) || pinf, Q);
+            to_projective(rinf, R);
+            E::add(Q, R);
+        }
+    }
+    template <class TAB, class DIG>
+    static MA_DEV void mul_get_dig(DIG& dig, const spint* X, const spint* Y, const spint* Z, const TAB& T, uint64_t* xw, uint64_t* yw) {
+        Pt R;
+        mul_acc(dig, X, Y, Z, T, R);
+        E::affine_words(R, xw, yw);
+    }
+    // e G + f Q: f Q as above (digf: the digits of f mod n), e G through the fixed-base table with the complete mixed additions
+    template <class COMB, class TAB, class DIG>
+    static MA_DEV void mulgen2_get_dig(const uint64_t* ew, DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T,
+                                       uint64_t* xw, uint64_t* yw) {
+        Pt R;
+        mul_acc(digf, QX, QY, QZ, T, R);
+        wn26_mulgen_acc<CvNist256, COMB, false>(ew, R);
+        E::affine_words(R, xw, yw);
+    }
+};
+
+}  // namespace ma

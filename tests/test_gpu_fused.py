@@ -155,6 +155,41 @@ def test_fused_weierstrass_special_points_and_scalars(fx):
     assert torch.equal(x2, w2x) and torch.equal(y2, w2y)
 
 
+def test_fused_weierstrass_scalars_of_the_exceptional_cases(fx):
+    """round 5: P-256 runs k P in Jacobian coordinates with the exceptional cases decided by the scalar (csrc/wj26.h), secp256k1 splits
+    the scalar by the endomorphism (csrc/glv26.h).  The scalars where those forms have something to get wrong -- q - 2m and q + 2m (the
+    Jacobian accumulator meets +-Q at the last digit), leading zero windows, single digits, multiples of 16, lambda, q - lambda, 2^128
+    +- 1, values between q and 2^256 -- on G, -G, a random point, its negative and the point at infinity: mul_get against ecn mul +
+    ecn get (the reference's complete formulas, bit-exact to the oracle in tests/test_gpu_weierstrass.py), mulgen2_get against
+    ecn mul2 + ecn get with the generator as first point, every scalar of the list as f and as e"""
+    C, Ed, g, torch = fx
+    if C not in WEIER:
+        pytest.skip("Weierstrass curves")
+    q = int(g["order"], 16)
+    lam = 0x5363ad4cc05c30e0a5261c028812645a122e22ea20816678df02967c1b23bd72
+    be = lambda v: v.to_bytes(Ed.nbytes, "big").hex()
+    gen = torch.Generator(device="cuda").manual_seed(55)
+    G = Ed.gen(1)
+    Rn = Ed.mul(torch.randint(0, 256, (1, Ed.nbytes), dtype=torch.uint8, device="cuda", generator=gen), Ed.gen(1))
+    pts = [G, Ed.neg(G.clone()), Rn, Ed.neg(Rn.clone()), Ed.inf(1)]
+    scalars = [q - 2 * m for m in range(1, 9)] + [q + 2 * m for m in range(1, 9)] + [q - m for m in (1, 3, 15, 16, 17)] + list(range(0, 18))
+    scalars += [d << (4 * i) for i in (1, 2, 31, 32, 33, 62, 63) for d in (1, 7, 8, 9, 15)]
+    scalars += [lam, q - lam, lam + 1, lam - 1, (lam * 2) % q, 2**128, 2**128 - 1, 2**128 + 1, 2**129, 2**256 - 1, 2**256 - 2, 2**256 - q, 2 * q - 2**256 + 5, q // 2, (q + 1) // 2]
+    P = torch.cat([p for p in pts for _ in scalars], dim=2).contiguous()
+    e = dev_bytes(torch, [be(s) for _ in pts for s in scalars])
+    x, y, _ = Ed.mul_get(e, P)
+    wx, wy, _ = Ed.get(Ed.mul(e, P.clone()))
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+    n = e.shape[0]
+    other = dev_bytes(torch, [be(scalars[(7 * i + 3) % len(scalars)]) for i in range(n)])
+    for ee, ff in ((other, e), (e, other), (e, e)):
+        x2, y2, _ = Ed.mulgen2_get(ee, ff, P)
+        w2x, w2y, _ = Ed.get(Ed.mul2(ee, Ed.gen(n), ff, P.clone()))
+        assert torch.equal(x2, w2x) and torch.equal(y2, w2y)
+        x3, y3, _ = Ed.mul2_get(ee, Ed.gen(n), ff, P)
+        assert torch.equal(x3, w2x) and torch.equal(y3, w2y)
+
+
 def test_fused_more_points_than_resident_lanes(fx):
     """the kernels hold one table slot per RESIDENT lane (131 072) and walk larger batches grid-stride, rebuilding the
     table in the same slot: 2 full passes + a ragged third one, against the two-call form"""

@@ -202,6 +202,74 @@ def test_secp256k1_endomorphism_split_and_fused_forms_on_host(oracle, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")
+def test_nist256_jacobian_fused_forms_on_host_against_oracle(oracle, tmp_path):
+    """csrc/wj26.h on the host (P-256 in Jacobian coordinates, exceptional cases decided by the scalar, the last addition complete)
+    against the oracle's ecn mul / ecn mul2 followed by ecn get.  The scalars are chosen for the exceptional cases: n - 2m and n + 2m
+    (the accumulator meets +-Q at the last digit: m = 1..8), 0, 1..17, multiples of 16 (zero last digit), n, n +- 1, 2n - 2^256 .. 2^256 - 1
+    (reduced mod n first), leading zero windows (accumulator at infinity for many digits), single non-zero digits anywhere, all
+    nibbles 8 / 7 / 9; the points: random projective, the generator (Z = 1), the point at infinity"""
+    import ctypes
+    import random
+    so = str(tmp_path / "libwn26_host.so")
+    cc = HIPCC if os.path.exists(HIPCC) else "hipcc"
+    subprocess.run([cc, "-O2", "-std=c++17", "-w", "-shared", "-fPIC", "--offload-host-only", os.path.join(ROOT, "tools", "wn26_host.hip"), "-o", so],
+                   check=True, timeout=900)
+    lib = ctypes.CDLL(so)
+    U64 = ctypes.c_uint64
+    n = 0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551
+    C = "nist256"
+    Pt, nb = oracle.ed[C]
+    rng = random.Random(23)
+    be = lambda v: v.to_bytes(32, "big")
+    words = lambda v: (U64 * 4)(*[(v >> (64 * k)) & (2**64 - 1) for k in range(4)])
+
+    def point(kind):
+        p = Pt()
+        if kind == "inf":
+            oracle.ecn(C, "inf")(ctypes.byref(p))
+            return p
+        oracle.ecn(C, "gen")(ctypes.byref(p))
+        if kind == "rand":
+            oracle.ecn(C, "mul")(be(rng.getrandbits(256)), ctypes.byref(p))
+        if kind == "neg":
+            oracle.ecn(C, "neg")(ctypes.byref(p))
+        return p
+
+    def affine(p):
+        x, y = ctypes.create_string_buffer(nb), ctypes.create_string_buffer(nb)
+        oracle.ecn(C, "get")(ctypes.byref(p), x, y)
+        return x.raw, y.raw
+
+    out_bytes = lambda xw, yw: (b"".join(int(xw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0)), b"".join(int(yw[k]).to_bytes(8, "big") for k in (3, 2, 1, 0)))
+    scalars = list(range(0, 18)) + [n - 2 * m for m in range(1, 9)] + [n + 2 * m for m in range(1, 9)] + [n - m for m in (1, 3, 5, 15, 16, 17, 32)]
+    scalars += [n, n + 1, 2**256 - 1, 2**256 - 2, 2**255, 2**256 - n, 2 * n - 2**256 + 5, 16, 32, 0x100, 0x880, 0x1000000]
+    scalars += [d << (4 * i) for i in (1, 2, 31, 62, 63) for d in (1, 7, 8, 9, 15)] + [int("8" * 64, 16), int("7" * 64, 16), int("9" * 64, 16) % 2**256]
+    scalars += [rng.getrandbits(b) for b in (8, 16, 64, 128, 200, 252) for _ in range(3)] + [rng.getrandbits(256) for _ in range(40)]
+    for it, e in enumerate(scalars):
+        kind = "inf" if it % 16 == 9 else ("gen" if it % 4 == 1 else "rand")
+        p = point(kind)
+        xw, yw = (U64 * 4)(), (U64 * 4)()
+        lib.nist256_jac_mul_get_host(words(e), p.x, p.y, p.z, xw, yw)
+        oracle.ecn(C, "mul")(be(e), ctypes.byref(p))
+        assert out_bytes(xw, yw) == affine(p), ("jacobian mul_get", it, hex(e), kind)
+    for it in range(120):                            # e G + f Q: Q random / infinite / +-G, scalars cancelling, f from the exceptional list
+        e, f = rng.getrandbits(256), rng.getrandbits(256)
+        kind = ("rand", "inf", "gen", "neg")[it % 4] if it < 48 else "rand"
+        if it % 8 in (2, 3):
+            f = e                                    # Q = G: 2e G;  Q = -G: infinity
+        if it % 8 == 5:
+            f = scalars[(it * 3) % 60]
+        if it % 8 == 6:
+            e, f = scalars[it % 60], scalars[(it * 7) % 60]
+        qq = point(kind)
+        xw, yw = (U64 * 4)(), (U64 * 4)()
+        lib.nist256_jac_mulgen2_get_host(words(e), words(f), qq.x, qq.y, qq.z, xw, yw)
+        g, r = point("gen"), Pt()
+        oracle.ecn(C, "mul2")(be(e), ctypes.byref(g), be(f), ctypes.byref(qq), ctypes.byref(r))
+        assert out_bytes(xw, yw) == affine(r), ("jacobian mulgen2_get", it, kind, hex(e), hex(f))
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")
 def test_lazy_limb_bounds_of_the_fused_weierstrass_fields(tmp_path):
     """fm26.h / fk26.h at the limb magnitudes wn26.h lets them reach (|limb| <= K 2^26 with the K of the comments there):
     products, squarings and two-product reductions of worst-case operands (all limbs at +-(K 2^26 - 1), alternating signs,

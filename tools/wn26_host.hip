@@ -90,3 +90,21 @@ extern "C" void secp256k1_glv_mul2_get_host(const uint64_t* ew, const uint64_t* 
     df.init(fw);
     ma::secp256k1_glv_mul2_get_dig(de, PX, PY, PZ, df, QX, QY, QZ, ma::WnTabStrided{tab, 1}, xw, yw);
 }
+
+// round 5: P-256 in Jacobian coordinates (csrc/wj26.h)
+#include "../modarith_amd/csrc/wj26.h"
+extern "C" void nist256_jac_mul_get_host(const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, uint64_t* xw, uint64_t* yw) {
+    uint64_t tab[ma::WN26_TABLE_WORDS], k[4];
+    ma::Wj26::reduce_scalar(ew, k);
+    ma::WnRegs<4, 260> dig;
+    dig.init(k);
+    ma::Wj26::mul_get_dig(dig, X, Y, Z, ma::WnTabStrided{tab, 1}, xw, yw);
+}
+extern "C" void nist256_jac_mulgen2_get_host(const uint64_t* ew, const uint64_t* fw, const uint64_t* QX, const uint64_t* QY, const uint64_t* QZ,
+                                             uint64_t* xw, uint64_t* yw) {
+    uint64_t tab[ma::WN26_TABLE_WORDS], k[4];
+    ma::Wj26::reduce_scalar(fw, k);
+    ma::WnRegs<4, 260> dig;
+    dig.init(k);
+    ma::Wj26::mulgen2_get_dig<HostCombNist256>(ew, dig, QX, QY, QZ, ma::WnTabStrided{tab, 1}, xw, yw);
+}
