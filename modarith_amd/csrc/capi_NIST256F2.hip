@@ -7,6 +7,7 @@
 #include "generated/curve_NIST256.h"
 #include "kernels.h"
 #include "wn26.h"
+#include "wj26.h"
 
 namespace ma {
 
@@ -17,9 +18,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_nist256_mul2_get(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb,
                         int* sign, size_t n, size_t ld, uint64_t* ws) {
     using P = P_NIST256;
-    using DIG = WnLds<3, 258>;
+    using DIG = WnLds<4, 260>;                              // four-bit windows, doublings in Jacobian coordinates (csrc/wj26.h mul2_get_dig)
     __shared__ unsigned char digs[2 * DIG::COUNT * 64];
-    const WnTabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)WN26_TABLE_WORDS), threadIdx.x};
+    const WnTabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)Wj26::TABLE2_WORDS), threadIdx.x};
     unsigned char* ce = digs + threadIdx.x;
     unsigned char* cf = ce + DIG::COUNT * 64;
     for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
@@ -42,7 +43,7 @@ void k_nist256_mul2_get(const unsigned char* e, const spint* Pb, const unsigned 
             QZ[I] = Qb[(size_t)(10 + I) * ld + t()];
         });
         DIG de{ce}, df{cf};
-        wn26_mul2_get_dig<CvNist256>(de, PX, PY, PZ, df, QX, QY, QZ, T, xw, yw);
+        Wj26::mul2_get_dig(de, PX, PY, PZ, df, QX, QY, QZ, T, xw, yw);
         if (xb) store_be_record<P>(xb, t(), xw);
         if (yb) store_be_record<P>(yb, t(), yw);
         if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
@@ -60,7 +61,7 @@ size_t fused_lanes(size_t n) {
 }
 }  // namespace
 
-extern "C" size_t ecn_nist256_mul2_get_workspace_bytes(size_t n) { return (fused_lanes(n) + NIST256_ROW_SKEW2) * NIST256_TABLE_WORDS * sizeof(uint64_t); }
+extern "C" size_t ecn_nist256_mul2_get_workspace_bytes(size_t n) { return (fused_lanes(n) + NIST256_ROW_SKEW2) * Wj26::TABLE2_WORDS * sizeof(uint64_t); }
 
 extern "C" int ecn_nist256_mul2_get_batch(const char* e, const ma_spint* P, const char* f, const ma_spint* Q, char* x, char* y, int* sign,
                                           size_t n, size_t ld, void* workspace, size_t workspace_bytes, void* st) {
@@ -70,7 +71,7 @@ extern "C" int ecn_nist256_mul2_get_batch(const char* e, const ma_spint* P, cons
         return (int)hipErrorInvalidValue;
     }
     const size_t lanes = fused_lanes(n);
-    if (workspace == nullptr || workspace_bytes < (lanes + NIST256_ROW_SKEW2) * NIST256_TABLE_WORDS * sizeof(uint64_t)) {
+    if (workspace == nullptr || workspace_bytes < (lanes + NIST256_ROW_SKEW2) * Wj26::TABLE2_WORDS * sizeof(uint64_t)) {
         set_error("ecn mul2_get: workspace too small (see ecn_nist256_mul2_get_workspace_bytes)");
         return (int)hipErrorInvalidValue;
     }

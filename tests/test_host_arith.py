@@ -267,6 +267,33 @@ def test_nist256_jacobian_fused_forms_on_host_against_oracle(oracle, tmp_path):
         g, r = point("gen"), Pt()
         oracle.ecn(C, "mul2")(be(e), ctypes.byref(g), be(f), ctypes.byref(qq), ctypes.byref(r))
         assert out_bytes(xw, yw) == affine(r), ("jacobian mulgen2_get", it, kind, hex(e), hex(f))
+    for it in range(100):                            # e P + f Q, complete additions, doublings in Jacobian coordinates between conversions
+        e, f = rng.getrandbits(256), rng.getrandbits(256)
+        p, qq = point("rand"), point("rand")
+        if it % 8 == 1:
+            p = point("inf")
+        if it % 8 == 2:
+            qq = point("inf")
+        if it % 8 in (3, 4, 5):
+            oracle.ecn(C, "cpy")(ctypes.byref(p), ctypes.byref(qq))
+            if it % 8 != 4:
+                oracle.ecn(C, "neg")(ctypes.byref(qq))
+            if it % 8 == 3:
+                f = e                                # e P + e (-P): the accumulator is at infinity after EVERY window
+        if it % 8 == 6:
+            e, f = scalars[it % 60], scalars[(it * 7) % 60]
+        if it == 7:
+            p, qq = point("inf"), point("inf")
+        if it == 15:
+            e = f = 0
+        xw, yw = (U64 * 4)(), (U64 * 4)()
+        lib.nist256_jac_mul2_get_host(words(e), p.x, p.y, p.z, words(f), qq.x, qq.y, qq.z, xw, yw)
+        r = Pt()
+        oracle.ecn(C, "mul2")(be(e), ctypes.byref(p), be(f), ctypes.byref(qq), ctypes.byref(r))
+        want = affine(r)
+        assert out_bytes(xw, yw) == want, ("jacobian-doubling mul2_get", it)
+        if it % 8 == 3:
+            assert want == (be(0), be(1))
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")

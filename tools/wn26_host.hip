@@ -108,3 +108,11 @@ extern "C" void nist256_jac_mulgen2_get_host(const uint64_t* ew, const uint64_t*
     dig.init(k);
     ma::Wj26::mulgen2_get_dig<HostCombNist256>(ew, dig, QX, QY, QZ, ma::WnTabStrided{tab, 1}, xw, yw);
 }
+extern "C" void nist256_jac_mul2_get_host(const uint64_t* ew, const uint64_t* PX, const uint64_t* PY, const uint64_t* PZ,
+                                          const uint64_t* fw, const uint64_t* QX, const uint64_t* QY, const uint64_t* QZ, uint64_t* xw, uint64_t* yw) {
+    uint64_t tab[ma::Wj26::TABLE2_WORDS];
+    ma::WnRegs<4, 260> de, df;
+    de.init(ew);
+    df.init(fw);
+    ma::Wj26::mul2_get_dig(de, PX, PY, PZ, df, QX, QY, QZ, ma::WnTabStrided{tab, 1}, xw, yw);
+}
