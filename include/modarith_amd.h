@@ -421,10 +421,15 @@ int ecn_ed448_mul2_get_batch(const char *e, const ma_spint *P, const char *f, co
 size_t ecn_ed448_mul_get_workspace_bytes(size_t n);
 int ecn_ed448_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
                             void *workspace, size_t workspace_bytes, void *stream);
-/* NIST P-256 (csrc/wn26.h): the ECDSA patterns nist256.c:155-161, 219-222 (ecnXXXmul + ecnXXXget) and nist256.c:251-256
- * (ecnXXXmul2 + ecnXXXget).  Ten signed 26-bit limbs, Montgomery form with R' = 2^286, the same complete a = -3 formulas
- * as weierstrass.c:68-281; 960 bytes of window table per resident lane (at most 126 MB).  A result at infinity leaves
- * as x = 0, y = 1, the bytes ecnXXXget produces for it (weierstrass.c:299-310). */
+/* NIST P-256 (csrc/wn26.h, wj26.h): the ECDSA patterns nist256.c:155-161, 219-222 (ecnXXXmul + ecnXXXget) and nist256.c:251-256
+ * (ecnXXXmul2 + ecnXXXget).  Ten signed 26-bit limbs, Montgomery form with R' = 2^286.  Round 5: the scalar is reduced mod the
+ * group order and k P runs in Jacobian coordinates (doubling 3M + 5S against the 8M + 3S + 2 m_b of the complete formulas); where
+ * the Jacobian addition could fail is decided by the scalar alone on a curve of prime order -- lane flags for the accumulator or the
+ * digit at infinity, the LAST addition the complete one of weierstrass.c:68-175 -- so the affine bytes are the reference's for
+ * every scalar and every point of the curve, the point at infinity included.  mul2_get keeps the complete additions (its
+ * accumulator depends on both points) and runs only the doublings in Jacobian coordinates.  Window tables: 960 bytes per resident
+ * lane for mul_get / mulgen2_get (at most 126 MB), 1 920 for mul2_get.  A result at infinity leaves as x = 0, y = 1, the bytes
+ * ecnXXXget produces for it (weierstrass.c:299-310).  Points off the curve mean nothing on either side and may differ. */
 size_t ecn_nist256_mul_get_workspace_bytes(size_t n);
 int ecn_nist256_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
                               void *workspace, size_t workspace_bytes, void *stream);
@@ -432,7 +437,10 @@ size_t ecn_nist256_mul2_get_workspace_bytes(size_t n);
 int ecn_nist256_mul2_get_batch(const char *e, const ma_spint *P, const char *f, const ma_spint *Q, char *x, char *y, int *sign,
                                size_t n, size_t ld, void *workspace, size_t workspace_bytes, void *stream);
 /* secp256k1 (curve.py:190-198; csrc/wn26.h on csrc/fk26.h): the same patterns on the a = 0 complete formulas
- * (weierstrass.c:120-157, 189-226), ten signed 26-bit limbs with the pseudo-Mersenne fold 2^260 = 2^36 + 0x3d10 */
+ * (weierstrass.c:120-157, 189-226), ten signed 26-bit limbs with the pseudo-Mersenne fold 2^260 = 2^36 + 0x3d10.  Round 5
+ * (csrc/glv26.h): every scalar is reduced mod the group order and split by the curve's endomorphism, k = k1 + k2 lambda with
+ * |k1|, |k2| < 2^128, so that k P = k1 P + k2 (beta x, y) takes 128 doublings on the one table of P; all additions stay the
+ * complete ones.  Same bytes as the two-call form for every scalar and every point of the curve.  Window tables as for P-256. */
 size_t ecn_secp256k1_mul_get_workspace_bytes(size_t n);
 int ecn_secp256k1_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
                                 void *workspace, size_t workspace_bytes, void *stream);
