@@ -6,6 +6,7 @@
 #include "kernels.h"
 #include "wn26.h"
 #include "wj26.h"
+#include "wn_export.h"
 
 namespace ma {
 
@@ -16,8 +17,8 @@ constexpr size_t NIST256_ROW_SKEW = 32 + 4;   // words added to the row pitch of
 // access one contiguous 512-byte row, row addresses formed at the access -- wn26.h WnTabSlab), recoded scalar in LDS (one byte per
 // window, written before the point is loaded), element index = wave-uniform base + lane, formed where it is used
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_nist256_mul_get(const unsigned char* e, const spint* Pb, unsigned char* xb, unsigned char* yb, int* sign, size_t n, size_t ld,
-                       uint64_t* ws) {
+void k_nist256_mul_get(const unsigned char* e, const spint* Pb, size_t ld, uint64_t* ws, WnExpWs ex) {
+    const size_t n = ex.m;                                  // the records of this chunk; (X : Y : Z) of the result to the shared inversion (wn_export.h)
     using P = P_NIST256;
     using DIG = WnLds<4, 260>;
     __shared__ unsigned char digs[DIG::COUNT * 64];
@@ -32,17 +33,16 @@ void k_nist256_mul_get(const unsigned char* e, const spint* Pb, unsigned char* x
             Wj26::reduce_scalar(ew, kw);
             DIG::fill(kw, col);
         }
-        spint X[5], Y[5], Z[5], xw[4], yw[4];
+        spint X[5], Y[5], Z[5];
         static_for<0, 5>([&](auto I) {
             X[I] = Pb[(size_t)I * ld + t()];
             Y[I] = Pb[(size_t)(5 + I) * ld + t()];
             Z[I] = Pb[(size_t)(10 + I) * ld + t()];
         });
         DIG dig{col};
-        Wj26::mul_get_dig(dig, X, Y, Z, T, xw, yw);
-        if (xb) store_be_record<P>(xb, t(), xw);
-        if (yb) store_be_record<P>(yb, t(), yw);
-        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+        Wj26::Pt R;
+        Wj26::mul_acc(dig, X, Y, Z, T, R);
+        ex.store<Fm26>(t(), R.X, R.Y, R.Z);
     }
 }
 
@@ -58,7 +58,8 @@ size_t fused_lanes(size_t n) {
 }
 }  // namespace
 
-extern "C" size_t ecn_nist256_mul_get_workspace_bytes(size_t n) { return (fused_lanes(n) + NIST256_ROW_SKEW) * NIST256_TABLE_WORDS * sizeof(uint64_t); }
+static size_t slab_bytes(size_t n) { return (fused_lanes(n) + NIST256_ROW_SKEW) * NIST256_TABLE_WORDS * sizeof(uint64_t); }
+extern "C" size_t ecn_nist256_mul_get_workspace_bytes(size_t n) { return slab_bytes(n) + WnExpWs::bytes(n); }
 
 extern "C" int ecn_nist256_mul_get_batch(const char* e, const ma_spint* P, char* x, char* y, int* sign, size_t n, size_t ld,
                                          void* workspace, size_t workspace_bytes, void* st) {
@@ -67,13 +68,17 @@ extern "C" int ecn_nist256_mul_get_batch(const char* e, const ma_spint* P, char*
         set_error("ecn mul_get: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
     }
-    const size_t lanes = fused_lanes(n);
-    if (workspace == nullptr || workspace_bytes < (lanes + NIST256_ROW_SKEW) * NIST256_TABLE_WORDS * sizeof(uint64_t)) {
+    if (workspace == nullptr || workspace_bytes < ecn_nist256_mul_get_workspace_bytes(n)) {
         set_error("ecn mul_get: workspace too small (see ecn_nist256_mul_get_workspace_bytes)");
         return (int)hipErrorInvalidValue;
     }
-    k_nist256_mul_get<<<(unsigned)(lanes / 64), 64, 0, (hipStream_t)st>>>(
-        reinterpret_cast<const unsigned char*>(e), P, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, n, ld,
-        reinterpret_cast<uint64_t*>(workspace));
+    hipStream_t s = (hipStream_t)st;
+    const unsigned char* eb = reinterpret_cast<const unsigned char*>(e);
+    for (size_t first = 0; first < n; first += WNEXP_CHUNK) {
+        const size_t m = n - first < WNEXP_CHUNK ? n - first : WNEXP_CHUNK;
+        const WnExpWs ex(reinterpret_cast<char*>(workspace) + slab_bytes(n), m);
+        k_nist256_mul_get<<<(unsigned)(fused_lanes(m) / 64), 64, 0, s>>>(eb + first * P_NIST256::NBYTES, P + first, ld, reinterpret_cast<uint64_t*>(workspace), ex);
+        wn_export<Fm26, P_NIST256, 1>(ex, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, first, s);
+    }
     return check_launch("ecn mul_get");
 }

@@ -8,6 +8,7 @@
 #include "kernels.h"
 #include "wn26.h"
 #include "wj26.h"
+#include "wn_export.h"
 
 namespace ma {
 
@@ -15,8 +16,8 @@ constexpr size_t NIST256_ROW_SKEW2 = 32 + 4;
 
 // tables in the wave's slab, the two recoded scalars in LDS, element index formed at use: see the mul_get unit
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_nist256_mul2_get(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb,
-                        int* sign, size_t n, size_t ld, uint64_t* ws) {
+void k_nist256_mul2_get(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, size_t ld, uint64_t* ws, WnExpWs ex) {
+    const size_t n = ex.m;                                  // the records of this chunk; (X : Y : Z) of the result to the shared inversion (wn_export.h)
     using P = P_NIST256;
     using DIG = WnLds<4, 260>;                              // four-bit windows, doublings in Jacobian coordinates (csrc/wj26.h mul2_get_dig)
     __shared__ unsigned char digs[2 * DIG::COUNT * 64];
@@ -33,7 +34,7 @@ void k_nist256_mul2_get(const unsigned char* e, const spint* Pb, const unsigned 
             load_be_record<P>(f, t(), ew);
             DIG::fill(ew, cf);
         }
-        spint PX[5], PY[5], PZ[5], QX[5], QY[5], QZ[5], xw[4], yw[4];
+        spint PX[5], PY[5], PZ[5], QX[5], QY[5], QZ[5];
         static_for<0, 5>([&](auto I) {
             PX[I] = Pb[(size_t)I * ld + t()];
             PY[I] = Pb[(size_t)(5 + I) * ld + t()];
@@ -43,10 +44,9 @@ void k_nist256_mul2_get(const unsigned char* e, const spint* Pb, const unsigned 
             QZ[I] = Qb[(size_t)(10 + I) * ld + t()];
         });
         DIG de{ce}, df{cf};
-        Wj26::mul2_get_dig(de, PX, PY, PZ, df, QX, QY, QZ, T, xw, yw);
-        if (xb) store_be_record<P>(xb, t(), xw);
-        if (yb) store_be_record<P>(yb, t(), yw);
-        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+        Wj26::Pt R;
+        Wj26::mul2_acc(de, PX, PY, PZ, df, QX, QY, QZ, T, R);
+        ex.store<Fm26>(t(), R.X, R.Y, R.Z);
     }
 }
 
@@ -61,7 +61,8 @@ size_t fused_lanes(size_t n) {
 }
 }  // namespace
 
-extern "C" size_t ecn_nist256_mul2_get_workspace_bytes(size_t n) { return (fused_lanes(n) + NIST256_ROW_SKEW2) * Wj26::TABLE2_WORDS * sizeof(uint64_t); }
+static size_t slab_bytes(size_t n) { return (fused_lanes(n) + NIST256_ROW_SKEW2) * Wj26::TABLE2_WORDS * sizeof(uint64_t); }
+extern "C" size_t ecn_nist256_mul2_get_workspace_bytes(size_t n) { return slab_bytes(n) + WnExpWs::bytes(n); }
 
 extern "C" int ecn_nist256_mul2_get_batch(const char* e, const ma_spint* P, const char* f, const ma_spint* Q, char* x, char* y, int* sign,
                                           size_t n, size_t ld, void* workspace, size_t workspace_bytes, void* st) {
@@ -70,13 +71,16 @@ extern "C" int ecn_nist256_mul2_get_batch(const char* e, const ma_spint* P, cons
         set_error("ecn mul2_get: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
     }
-    const size_t lanes = fused_lanes(n);
-    if (workspace == nullptr || workspace_bytes < (lanes + NIST256_ROW_SKEW2) * Wj26::TABLE2_WORDS * sizeof(uint64_t)) {
+    if (workspace == nullptr || workspace_bytes < ecn_nist256_mul2_get_workspace_bytes(n)) {
         set_error("ecn mul2_get: workspace too small (see ecn_nist256_mul2_get_workspace_bytes)");
         return (int)hipErrorInvalidValue;
     }
-    k_nist256_mul2_get<<<(unsigned)(lanes / 64), 64, 0, (hipStream_t)st>>>(
-        reinterpret_cast<const unsigned char*>(e), P, reinterpret_cast<const unsigned char*>(f), Q, reinterpret_cast<unsigned char*>(x),
-        reinterpret_cast<unsigned char*>(y), sign, n, ld, reinterpret_cast<uint64_t*>(workspace));
+    hipStream_t s = (hipStream_t)st;
+    for (size_t first = 0; first < n; first += WNEXP_CHUNK) {
+        const size_t m = n - first < WNEXP_CHUNK ? n - first : WNEXP_CHUNK;
+        const WnExpWs ex(reinterpret_cast<char*>(workspace) + slab_bytes(n), m);
+        k_nist256_mul2_get<<<(unsigned)(fused_lanes(m) / 64), 64, 0, s>>>(reinterpret_cast<const unsigned char*>(e) + first * P_NIST256::NBYTES, P + first, reinterpret_cast<const unsigned char*>(f) + first * P_NIST256::NBYTES, Q + first, ld, reinterpret_cast<uint64_t*>(workspace), ex);
+        wn_export<Fm26, P_NIST256, 2>(ex, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, first, s);
+    }
     return check_launch("ecn mul2_get");
 }

@@ -8,6 +8,7 @@
 #include "kernels.h"
 #include "wn26.h"
 #include "glv26.h"
+#include "wn_export.h"
 
 namespace ma {
 
@@ -44,8 +45,8 @@ void k_secp256k1_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned 
 // e*G + f*Q and its affine export (verification, nist256.c:251-256): the per-lane table of Q in the workspace as for mul_get,
 // the generator part through the constant table above
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_secp256k1_mulgen2_get(const unsigned char* e, const unsigned char* f, const spint* Qb, unsigned char* xb, unsigned char* yb, int* sign,
-                           size_t n, size_t ld, uint64_t* ws) {
+void k_secp256k1_mulgen2_get(const unsigned char* e, const unsigned char* f, const spint* Qb, size_t ld, uint64_t* ws, WnExpWs ex) {
+    const size_t n = ex.m;                                  // the records of this chunk; (X : Y : Z) of the result to the shared inversion (wn_export.h)
     using P = P_SECP256K1;
     using DIG = GlvLds;                                      // f split by the endomorphism (csrc/glv26.h)
     __shared__ unsigned char digs[DIG::COUNT * 64];          // the windows of f's halves in LDS; Q's table in the wave's slab; index at use: see the mul_get unit
@@ -60,17 +61,16 @@ void k_secp256k1_mulgen2_get(const unsigned char* e, const unsigned char* f, con
             load_be_record<P>(f, t(), fw);
             dig.fill(fw, col);
         }
-        spint ew[4], X[5], Y[5], Z[5], xw[4], yw[4];
+        spint ew[4], X[5], Y[5], Z[5];
         static_for<0, 5>([&](auto I) {
             X[I] = Qb[(size_t)I * ld + t()];
             Y[I] = Qb[(size_t)(5 + I) * ld + t()];
             Z[I] = Qb[(size_t)(10 + I) * ld + t()];
         });
         load_be_record<P>(e, t(), ew);
-        secp256k1_glv_mulgen2_get_dig<CombSECP256K1>(ew, dig, X, Y, Z, T, xw, yw);
-        if (xb) store_be_record<P>(xb, t(), xw);
-        if (yb) store_be_record<P>(yb, t(), yw);
-        if (sign) sign[t()] = !yb ? (int)(yw[0] & 1) : (!xb ? (int)(xw[0] & 1) : 0);
+        Wn26<CvSecp256k1>::Pt R;
+        secp256k1_glv_mulgen2_acc<CombSECP256K1>(ew, dig, X, Y, Z, T, R);
+        ex.store<Fk26>(t(), R.X, R.Y, R.Z);
     }
 }
 
@@ -85,7 +85,8 @@ size_t fused2_lanes(size_t n) {
 }
 }  // namespace
 
-extern "C" size_t ecn_secp256k1_mulgen2_get_workspace_bytes(size_t n) { return (fused2_lanes(n) + 36) * WN26_TABLE_WORDS * sizeof(uint64_t); }
+static size_t slab_bytes(size_t n) { return (fused2_lanes(n) + 36) * WN26_TABLE_WORDS * sizeof(uint64_t); }
+extern "C" size_t ecn_secp256k1_mulgen2_get_workspace_bytes(size_t n) { return slab_bytes(n) + WnExpWs::bytes(n); }
 
 extern "C" int ecn_secp256k1_mulgen2_get_batch(const char* e, const char* f, const ma_spint* Q, char* x, char* y, int* sign, size_t n, size_t ld,
                                            void* workspace, size_t workspace_bytes, void* st) {
@@ -94,14 +95,17 @@ extern "C" int ecn_secp256k1_mulgen2_get_batch(const char* e, const char* f, con
         set_error("ecn mulgen2_get: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
     }
-    const size_t lanes = fused2_lanes(n);
-    if (workspace == nullptr || workspace_bytes < (lanes + 36) * WN26_TABLE_WORDS * sizeof(uint64_t)) {
+    if (workspace == nullptr || workspace_bytes < ecn_secp256k1_mulgen2_get_workspace_bytes(n)) {
         set_error("ecn mulgen2_get: workspace too small (see ecn_secp256k1_mulgen2_get_workspace_bytes)");
         return (int)hipErrorInvalidValue;
     }
-    k_secp256k1_mulgen2_get<<<(unsigned)(lanes / 64), 64, 0, (hipStream_t)st>>>(
-        reinterpret_cast<const unsigned char*>(e), reinterpret_cast<const unsigned char*>(f), Q, reinterpret_cast<unsigned char*>(x),
-        reinterpret_cast<unsigned char*>(y), sign, n, ld, reinterpret_cast<uint64_t*>(workspace));
+    hipStream_t s = (hipStream_t)st;
+    for (size_t first = 0; first < n; first += WNEXP_CHUNK) {
+        const size_t m = n - first < WNEXP_CHUNK ? n - first : WNEXP_CHUNK;
+        const WnExpWs ex(reinterpret_cast<char*>(workspace) + slab_bytes(n), m);
+        k_secp256k1_mulgen2_get<<<(unsigned)(fused2_lanes(m) / 64), 64, 0, s>>>(reinterpret_cast<const unsigned char*>(e) + first * P_SECP256K1::NBYTES, reinterpret_cast<const unsigned char*>(f) + first * P_SECP256K1::NBYTES, Q + first, ld, reinterpret_cast<uint64_t*>(workspace), ex);
+        wn_export<Fk26, P_SECP256K1, 3>(ex, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, first, s);
+    }
     return check_launch("ecn mulgen2_get");
 }
 

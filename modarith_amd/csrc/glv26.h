@@ -219,17 +219,23 @@ MA_DEV void secp256k1_glv_mulgen2_get_dig(const uint64_t* ew, DIG& digf, const s
     wn26_mulgen_acc<CvSecp256k1, COMB, false>(ew, R);
     Wn26<CvSecp256k1>::affine_words(R, xw, yw);
 }
+template <class COMB, class TAB, class DIG>
+MA_DEV void secp256k1_glv_mulgen2_acc(const uint64_t* ew, DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T,
+                                      Wn26<CvSecp256k1>::Pt& R) {
+    secp256k1_glv_mul_acc(digf, QX, QY, QZ, T, R);
+    wn26_mulgen_acc<CvSecp256k1, COMB, false>(ew, R);
+}
 
 // e P + f Q: both scalars split, the tables {1..8}P and {1..8}Q in a double slot (entries 0..7 and 8..15), per window four doublings
 // and four additions: 128 doublings + 132 additions against the 255 + 172 of wn26_mul2_get_dig (three-bit windows on two tables of
 // four).  Every lookup scans its eight entries.  An infinite result leaves as (0, 1).
 constexpr int GLV2_TABLE_WORDS = 2 * WN26_TABLE_WORDS;
 template <class TAB, class DIG>
-MA_DEV void secp256k1_glv_mul2_get_dig(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
-                                       DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T, uint64_t* xw, uint64_t* yw) {
+MA_DEV void secp256k1_glv_mul2_acc(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
+                                   DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T, Wn26<CvSecp256k1>::Pt& R) {
     using E = Wn26<CvSecp256k1>;
     using F = Fk26;
-    E::Pt R, Q;
+    E::Pt Q;
     E::load_point(PX, PY, PZ, Q);
     E::template build_table<8>(Q, T.origin(), T.stride(), 0);
     E::load_point(QX, QY, QZ, Q);
@@ -256,7 +262,13 @@ MA_DEV void secp256k1_glv_mul2_get_dig(DIG& dige, const spint* PX, const spint* 
             E::add(Q, R);
         }
     }
-    E::affine_words(R, xw, yw);
+}
+template <class TAB, class DIG>
+MA_DEV void secp256k1_glv_mul2_get_dig(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
+                                       DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T, uint64_t* xw, uint64_t* yw) {
+    Wn26<CvSecp256k1>::Pt R;
+    secp256k1_glv_mul2_acc(dige, PX, PY, PZ, digf, QX, QY, QZ, T, R);
+    Wn26<CvSecp256k1>::affine_words(R, xw, yw);
 }
 
 }  // namespace ma

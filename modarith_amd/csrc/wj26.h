@@ -209,9 +209,13 @@ struct Wj26 {
     static MA_DEV void mulgen2_get_dig(const uint64_t* ew, DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T,
                                        uint64_t* xw, uint64_t* yw) {
         Pt R;
+        mulgen2_acc<COMB>(ew, digf, QX, QY, QZ, T, R);
+        E::affine_words(R, xw, yw);
+    }
+    template <class COMB, class TAB, class DIG>
+    static MA_DEV void mulgen2_acc(const uint64_t* ew, DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T, Pt& R) {
         mul_acc(digf, QX, QY, QZ, T, R);
         wn26_mulgen_acc<CvNist256, COMB, false>(ew, R);
-        E::affine_words(R, xw, yw);
     }
 
     // ---- e P + f Q of two caller points.  The accumulator depends on both points, so the additions stay the complete ones of wn26.h;
@@ -224,7 +228,14 @@ struct Wj26 {
     template <class TAB, class DIG>
     static MA_DEV void mul2_get_dig(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
                                     DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T, uint64_t* xw, uint64_t* yw) {
-        Pt R, Q;
+        Pt R;
+        mul2_acc(dige, PX, PY, PZ, digf, QX, QY, QZ, T, R);
+        E::affine_words(R, xw, yw);
+    }
+    template <class TAB, class DIG>
+    static MA_DEV void mul2_acc(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
+                                DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T, Pt& R) {
+        Pt Q;
         E::load_point(PX, PY, PZ, Q);
         E::template build_table<8>(Q, T.origin(), T.stride(), 0);
         E::load_point(QX, QY, QZ, Q);
@@ -248,7 +259,6 @@ struct Wj26 {
                 E::add(Q, R);
             }
         }
-        E::affine_words(R, xw, yw);
     }
 };
 

@@ -261,6 +261,46 @@ def test_fused_ladder_and_straus_forms_cross_their_chunk_boundary():
     assert torch.equal(x, wx) and torch.equal(y, wy)
 
 
+@pytest.mark.parametrize("name", ["NIST256", "SECP256K1"])
+def test_fused_weierstrass_export_crosses_its_chunk_boundary(name):
+    """round 5: the fused Weierstrass kernels hand (X : Y : Z) to an inversion shared by up to 32 records (csrc/wn_export.h) and work
+    through a batch in chunks of 2^20 records: one full chunk and a ragged second one, points at infinity and scalars 0 / n (infinite
+    results leave as (0, 1) and count as Z = 1 in the shared product) on both sides of the boundary and next to ordinary records of the
+    same column, all three fused forms against the call-by-call forms; sign-only and x-only outputs"""
+    import torch
+    from modarith_amd.edwards import Curve
+    W = Curve(name)
+    nb = W.nbytes
+    n = (1 << 20) + 2053
+    gen = torch.Generator(device="cuda").manual_seed(97)
+    rnd = lambda m: torch.randint(0, 256, (m, nb), dtype=torch.uint8, device="cuda", generator=gen)
+    e, f = rnd(n), rnd(n)
+    P = W.mul(rnd(n), W.gen(n))
+    q = {"NIST256": "ffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551",
+         "SECP256K1": "fffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364141"}[name]
+    qb = torch.tensor(list(bytes.fromhex(q)), dtype=torch.uint8)
+    for j in (0, 7, 65536, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, n - 3):
+        P[:, :, j] = W.inf(1)[:, :, 0]
+        e[j + 1] = 0
+        e[j + 2] = qb
+    x, y, sg = W.mul_get(e, P)
+    wx, wy, wsg = W.get(W.mul(e, P.clone()))
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+    z = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    one = z.clone(); one[-1] = 1
+    for j in (0, 1, 2, 1 << 20, (1 << 20) + 1, (1 << 20) + 2):
+        assert torch.equal(x[j], z) and torch.equal(y[j], one), j
+    x, y, _ = W.mulgen2_get(e, f, P)
+    wx, wy, _ = W.get(W.mul2(e, W.gen(n), f, P))
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+    m = (1 << 20) + 130
+    Q = W.mul(f[:m].contiguous(), W.gen(m))
+    Pm, em, fm = P[:, :, :m].contiguous(), e[:m].contiguous(), f[:m].contiguous()
+    x, y, _ = W.mul2_get(em, Pm, fm, Q)
+    wx, wy, _ = W.get(W.mul2(em, Pm, fm, Q))
+    assert torch.equal(x, wx) and torch.equal(y, wy)
+
+
 def test_fused_ladder_form_under_stream_capture():
     """the ladder form is four kernels and a workspace: with the caller's workspace it only enqueues kernels, so it can be captured into a
     hipGraph and replayed on new data; WITHOUT one it would have to take scratch from the library's pool, which a stream under capture
