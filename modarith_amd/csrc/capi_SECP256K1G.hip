@@ -19,6 +19,20 @@ struct CombSECP256K1 {
     static __device__ __forceinline__ int32_t get(int idx) { return comb_secp256k1[idx]; }
 };
 
+// e*G, ONE scalar per lane, (X : Y : Z) to the inversion shared by up to 32 records (csrc/wn_export.h; round 5).  Rounds 2-4 shared one
+// inversion between the four scalars of a lane, whose four results cost 120 registers (the kernel below: 252-254 registers, two waves
+// per SIMD); it stays for callers without scratch (a stream under capture: this entry point has no workspace argument).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
+void k_secp256k1_mulgen(const unsigned char* e, WnExpWs ex) {
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= ex.m) return;
+    spint ew[4];
+    load_be_record<P_SECP256K1>(e, t, ew);
+    Wn26<CvSecp256k1>::Pt R;
+    wn26_mulgen_acc<CvSecp256k1, CombSECP256K1>(ew, R);
+    ex.store<Fk26>(t, R.X, R.Y, R.Z);
+}
+
 // MULGEN_G scalars per lane (elements t, t + lanes, ... of a MULGEN_G * lanes stride) share one inversion
 #ifndef MULGEN_G
 #define MULGEN_G 4
@@ -114,6 +128,17 @@ extern "C" int ecn_secp256k1_mulgen_get_batch(const char* e, char* x, char* y, i
     if ((reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 7u) {
         set_error("ecn mulgen_get: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
+    }
+    hipStream_t s = (hipStream_t)st;
+    EdLadScratch ws(nullptr, 0, WnExpWs::bytes(n), 8, s);              // no workspace argument: the library's scratch pool
+    if (ws.p) {
+        for (size_t first = 0; first < n; first += WNEXP_CHUNK) {
+            const size_t m = n - first < WNEXP_CHUNK ? n - first : WNEXP_CHUNK;
+            const WnExpWs ex(ws.p, m);
+            k_secp256k1_mulgen<<<(unsigned)((m + 63) / 64), 64, 0, s>>>(reinterpret_cast<const unsigned char*>(e) + first * P_SECP256K1::NBYTES, ex);
+            wn_export<Fk26, P_SECP256K1, 4>(ex, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, first, s);
+        }
+        return check_launch("ecn mulgen_get");
     }
     const size_t lanes = ((n + MULGEN_G - 1) / MULGEN_G + 63) / 64 * 64, cap = (size_t)4 * 1024 * 64;       // MULGEN_G scalars per lane; at most 4 waves on each of the 1024 SIMDs
     k_secp256k1_mulgen_get<<<(unsigned)((lanes < cap ? lanes : cap) / 64), 64, 0, (hipStream_t)st>>>(

@@ -70,4 +70,17 @@ struct StageBase {
 void* scratch_alloc(size_t bytes, hipStream_t s);   // stream-ordered scratch from the library's own pool; nullptr if unavailable
 void scratch_free(void* p, hipStream_t s);
 
+// the caller's workspace when it is large enough, else stream-ordered scratch of the library's own pool (released in stream order when
+// this object goes); p = nullptr when neither is to be had (a stream under capture and no caller workspace)
+struct EdLadScratch {
+    void* p = nullptr;
+    void* own = nullptr;
+    hipStream_t s;
+    EdLadScratch(void* workspace, size_t workspace_bytes, size_t need, size_t align, hipStream_t s_) : s(s_) {
+        if (workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & (align - 1)) == 0) { p = workspace; return; }
+        p = own = scratch_alloc(need, s);
+    }
+    ~EdLadScratch() { if (own) scratch_free(own, s); }
+};
+
 }  // namespace ma

@@ -69,19 +69,6 @@ struct EdLadWs {
     }
 };
 
-// the caller's workspace when it is large enough, else stream-ordered scratch of the library's own pool (released in stream order when
-// this object goes); p = nullptr when neither is to be had (a stream under capture and no caller workspace)
-struct EdLadScratch {
-    void* p = nullptr;
-    void* own = nullptr;
-    hipStream_t s;
-    EdLadScratch(void* workspace, size_t workspace_bytes, size_t need, size_t align, hipStream_t s_) : s(s_) {
-        if (workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & (align - 1)) == 0) { p = workspace; return; }
-        p = own = scratch_alloc(need, s);
-    }
-    ~EdLadScratch() { if (own) scratch_free(own, s); }
-};
-
 // P = (X : Y : Z), rows of the caller's batch (limb stride ld), records first .. first + m
 template <class T, int TAG>
 __global__ __launch_bounds__(256) void k_edlad_prep(const spint* Pb, size_t first, size_t ld, EdLadWs<T> ws) {

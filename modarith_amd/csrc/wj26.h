@@ -218,6 +218,64 @@ struct Wj26 {
         wn26_mulgen_acc<CvNist256, COMB, false>(ew, R);
     }
 
+    // ---- e G through the fixed-base table (wn26.h wn26_mulgen_acc) with the Jacobian MIXED addition (madd-2007-bl, 7M + 4S: 1 360
+    // multiply-adds against the 1 740 of the complete mixed addition).  The window digits d_i = window_i(e + sum 16 * 32^i) - 16 are taken
+    // from the bottom; before window i the accumulator is s G with |s| < 0.52 * 32^i (the low windows' value) and the table point is
+    // d_i 32^i G with |d_i 32^i| >= 32^i: never +-s as integers, and |s| + |d_i| 32^i < n for i <= 50.  At i = 51 (32^51 = 2^255, d in
+    // {0, 1, 2} for e < n) s = e - d 2^255, and s = +-d 2^255 (mod n) would need e = d 2^256 (mod n) -- a value far below 2^255, whose top
+    // digit is 0 -- or e = 0.  So with e < n (reduced first) the only exceptional cases are the accumulator at infinity (s = 0: every
+    // lower digit zero, a lane flag; the sum is then the table point with Z = 1) and a zero digit (the sum is the accumulator).  Returns
+    // the homogeneous (X Z : Y : Z^3).  kw: the scalar reduced mod n.
+    static MA_DEV void madd(const int32_t* x2, const int32_t* y2, Pt& p) {       // in: X K <= 4, Y K <= 1, Z K <= 3; out the same
+        int32_t z1z1[10], u2[10], s2[10], h[10], hh[10], i_[10], j[10], r[10], v[10], t[10];
+        F::sqr(p.Z, z1z1);
+        F::mul(x2, z1z1, u2);
+        F::mul(p.Z, z1z1, t);
+        F::mul(y2, t, s2);
+        F::sub(u2, p.X, h);         // 5
+        F::sqr(h, hh);
+        F::add(hh, hh, i_);
+        F::add(i_, i_, i_);         // 4   I = 4 HH
+        F::mul(h, i_, j);
+        F::sub(s2, p.Y, r);
+        F::add(r, r, r);            // 4   r = 2 (S2 - Y1)
+        F::mul(p.X, i_, v);
+        F::add(p.Z, h, t);          // 8
+        F::sqr(t, t);
+        F::sub(t, z1z1, t);
+        F::sub(t, hh, p.Z);         // 3   Z3 = (Z1 + H)^2 - Z1Z1 - HH
+        F::sqr(r, t);
+        F::sub(t, j, t);
+        F::sub(t, v, t);
+        F::sub(t, v, p.X);          // 4   X3 = r^2 - J - 2V
+        F::sub(v, p.X, t);          // 5
+        F::add(p.Y, p.Y, u2);       // 2
+        F::neg(u2, u2);
+        F::mul2(r, t, u2, j, p.Y);  //     Y3 = r (V - X3) - 2 Y1 J:  4 x 5 + 2 x 1
+    }
+    template <class COMB>
+    static MA_DEV void mulgen_acc(const uint64_t* kw, Pt& R) {
+        F::set_one(R.X);
+        F::set_one(R.Y);
+        F::zero(R.Z);
+        bool rinf = true;
+        wn26_mulgen_walk<CvNist256, COMB>(kw, [&](const int32_t* sx, const int32_t* sy, bool zero) {
+            Pt S = R;
+            madd(sx, sy, S);
+            int32_t one[10], u[10];
+            F::set_one(one);
+            // accumulator at infinity: the sum is (sx, sy, 1); zero digit: the accumulator stays
+            F::select(rinf, S.X, sx, u);
+            F::select(zero, u, R.X, R.X);
+            F::select(rinf, S.Y, sy, u);
+            F::select(zero, u, R.Y, R.Y);
+            F::select(rinf, S.Z, one, u);
+            F::select(zero, u, R.Z, R.Z);
+            rinf = rinf && zero;
+        });
+        to_projective(rinf, R);
+    }
+
     // ---- e P + f Q of two caller points.  The accumulator depends on both points, so the additions stay the complete ones of wn26.h;
     // the DOUBLINGS have no exceptional case on a curve of odd order (Y = 0 only for a point of order two; the point at infinity stays
     // Z = 0), so the four doublings of a window run in Jacobian coordinates between two conversions: (X : Y : Z) -> (X Z, Y Z^2, Z)

@@ -577,9 +577,9 @@ MA_DEV void wn26_mul2_get_one(const uint64_t* ew, const spint* PX, const spint* 
 // table in the constant address space, scalar loads) and selected by lane predication, the sign negates y, and one
 // complete MIXED addition follows; a zero digit adds (0, 0) and keeps the old sum.  52 mixed additions + a share of one
 // inversion per scalar against 256 doublings + 65 additions: the same bytes as ecn gen + ecn mul + ecn get for every scalar.
-template <class CV, class TAB, bool INIT = true>       // INIT = false: R += e*G (R holds a sum already)
-MA_DEV void wn26_mulgen_acc(const uint64_t* ew, typename Wn26<CV>::Pt& R) {
-    using E = Wn26<CV>;
+// the walk over the windows of e: step(sx, sy, zero) is handed +-(the window's selected multiple of G), affine, or zero = true for a zero digit
+template <class CV, class TAB, class STEP>
+MA_DEV void wn26_mulgen_walk(const uint64_t* ew, STEP step) {
     using F = typename CV::F;
     constexpr int W = TAB::W, NW = TAB::NW, E2 = 1 << (W - 1);       // window width, windows, entries per window
     static_assert(W * NW >= 257 && W * NW <= 316, "e + bias must fit the windows and five words");
@@ -594,7 +594,6 @@ MA_DEV void wn26_mulgen_acc(const uint64_t* ew, typename Wn26<CV>::Pt& R) {
             if constexpr (k < 4) w[k] |= t[k + 1] << (64 - SH);
         });
     }
-    if constexpr (INIT) E::inf(R);
 #pragma unroll 1
     for (int i = 0; i < NW; i++) {
         const int dgt = (int)((uint32_t)w[0] & (uint32_t)(2 * E2 - 1)) - E2;        // [-2^(W-1), 2^(W-1) - 1]
@@ -623,13 +622,21 @@ MA_DEV void wn26_mulgen_acc(const uint64_t* ew, typename Wn26<CV>::Pt& R) {
         });
         F::neg(sy, ny);
         F::select(neg, sy, ny, sy);
+        step(sx, sy, m == 0);
+    }
+}
+template <class CV, class TAB, bool INIT = true>       // INIT = false: R += e*G (R holds a sum already)
+MA_DEV void wn26_mulgen_acc(const uint64_t* ew, typename Wn26<CV>::Pt& R) {
+    using E = Wn26<CV>;
+    using F = typename CV::F;
+    if constexpr (INIT) E::inf(R);
+    wn26_mulgen_walk<CV, TAB>(ew, [&](const int32_t* sx, const int32_t* sy, bool keep) {
         typename E::Pt S = R;
         E::madd(sx, sy, S);
-        const bool keep = (m == 0);
         F::select(keep, S.X, R.X, R.X);
         F::select(keep, S.Y, R.Y, R.Y);
         F::select(keep, S.Z, R.Z, R.Z);
-    }
+    });
 }
 template <class CV, class TAB>
 MA_DEV void wn26_mulgen_get_one(const uint64_t* ew, uint64_t* xw, uint64_t* yw) {

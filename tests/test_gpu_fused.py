@@ -180,6 +180,13 @@ def test_fused_weierstrass_scalars_of_the_exceptional_cases(fx):
     x, y, _ = Ed.mul_get(e, P)
     wx, wy, _ = Ed.get(Ed.mul(e, P.clone()))
     assert torch.equal(x, wx) and torch.equal(y, wy)
+    # e G on the fixed-base table (P-256: Jacobian mixed additions): the list above, top comb digit 0 / 1 / 2, e = d 2^256 mod q, single comb digits
+    gs = scalars + [2**256 - q, 2 * (2**256 - q), (2**256 - q) + 2**255, q - 2**255, q - 2**255 + 1, 3 * 2**254 - 1, 3 * 2**254, 3 * 2**254 + 1]
+    gs += [d << (5 * i) for i in range(0, 52) for d in (1, 15, 16, 17, 31) if (d << (5 * i)) < 2**256]
+    eg = dev_bytes(torch, [be(v) for v in gs])
+    gx, gy, _ = Ed.mulgen_get(eg)
+    wgx, wgy, _ = Ed.get(Ed.mul(eg, Ed.gen(len(gs))))
+    assert torch.equal(gx, wgx) and torch.equal(gy, wgy)
     n = e.shape[0]
     other = dev_bytes(torch, [be(scalars[(7 * i + 3) % len(scalars)]) for i in range(n)])
     for ee, ff in ((other, e), (e, other), (e, e)):

@@ -252,6 +252,16 @@ def test_nist256_jacobian_fused_forms_on_host_against_oracle(oracle, tmp_path):
         lib.nist256_jac_mul_get_host(words(e), p.x, p.y, p.z, xw, yw)
         oracle.ecn(C, "mul")(be(e), ctypes.byref(p))
         assert out_bytes(xw, yw) == affine(p), ("jacobian mul_get", it, hex(e), kind)
+    # e G on the fixed-base table with the Jacobian mixed addition: top digit 0 / 1 / 2, e = d 2^256 mod n, single digits in every window
+    gscalars = scalars + [2**256 - n, 2 * (2**256 - n), (2**256 - n) + 2**255, n - 2**255, n - 2**255 + 1, 2**255 + 2**254, 3 * 2**254 - 1, 3 * 2**254, 3 * 2**254 + 1,
+                          int("10" * 128, 2), int("01" * 128, 2)]
+    gscalars += [d << (5 * i) for i in range(0, 52, 3) for d in (1, 15, 16, 17, 31) if (d << (5 * i)) < 2**256]
+    for e in gscalars:
+        xw, yw = (U64 * 4)(), (U64 * 4)()
+        lib.nist256_jac_mulgen_get_host(words(e), xw, yw)
+        p = point("gen")
+        oracle.ecn(C, "mul")(be(e), ctypes.byref(p))
+        assert out_bytes(xw, yw) == affine(p), ("jacobian mulgen_get", hex(e))
     for it in range(120):                            # e G + f Q: Q random / infinite / +-G, scalars cancelling, f from the exceptional list
         e, f = rng.getrandbits(256), rng.getrandbits(256)
         kind = ("rand", "inf", "gen", "neg")[it % 4] if it < 48 else "rand"

@@ -24,17 +24,19 @@ def legs():
                 out[C + leg] = [("k_edlad_prep<ma::%s, %d>" % (T, tag), base + unit, 1, 1), ("SinkWords<%d>, %d>" % (NW, tag), base + unit, 1, "rounds"),
                                 ("SinkExportBE<ma::%s>, %d>" % (PF, tag), base + unit, 1, "rounds"), (lad, base + unit, 1, 1)]
         else:
-            out[C + "_ecn_mul_get_fused"] = [("k_%s_mul_get" % low, base + "F.o", 1, 1)]
-            out[C + "_ecn_mulgen2_get_fused"] = [("k_%s_mulgen2_get" % low, base + "G.o", 1, 1)]
+            # the window kernels of csrc/wj26.h / glv26.h and the shared inversion + export behind them (csrc/wn_export.h)
+            FX = "ma::Fm26, ma::P_NIST256" if C == "NIST256" else "ma::Fk26, ma::P_SECP256K1"
+            out[C + "_ecn_mul_get_fused"] = [("k_%s_mul_get" % low, base + "F.o", 1, 1), ("k_wn_export<%s, 1>" % FX, base + "F.o", 1, "rounds")]
+            out[C + "_ecn_mulgen2_get_fused"] = [("k_%s_mulgen2_get" % low, base + "G.o", 1, 1), ("k_wn_export<%s, 3>" % FX, base + "G.o", 1, "rounds")]
         if C in ("ED25519", "ED448"):
             out[C + "_ecn_mul2_get_fused"] = [("k_%s_mul2_straus" % low, base + "F2.o", 1, 1), ("SinkExportBE<ma::%s>, 3>" % ("P_X25519" if C == "ED25519" else "P_X448"), base + "F2.o", 1, "rounds")]
         else:
-            out[C + "_ecn_mul2_get_fused"] = [("k_%s_mul2_get" % low, base + "F2.o", 1, 1)]
+            out[C + "_ecn_mul2_get_fused"] = [("k_%s_mul2_get" % low, base + "F2.o", 1, 1), ("k_wn_export<%s, 2>" % FX, base + "F2.o", 1, "rounds")]
         if C in ("ED25519", "ED448"):
             out[C + "_ecn_mulgen_get_fused"] = [("k_%s_mulgen<false>" % low, base + "G.o", 1, 1),
                                                 ("SinkExportBE<ma::%s>, %d>" % (("P_X25519", 4) if C == "ED25519" else ("P_X448", 3)), base + "G.o", 1, "rounds")]
         else:
-            out[C + "_ecn_mulgen_get_fused"] = [("k_%s_mulgen_get" % low, base + "G.o", g, 1)]
+            out[C + "_ecn_mulgen_get_fused"] = [("k_%s_mulgen(" % low, base + "G.o", 1, 1), ("k_wn_export<%s, 4>" % FX, base + "G.o", 1, "rounds")]
     return out
 
 

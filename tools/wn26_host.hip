@@ -116,3 +116,10 @@ extern "C" void nist256_jac_mul2_get_host(const uint64_t* ew, const uint64_t* PX
     df.init(fw);
     ma::Wj26::mul2_get_dig(de, PX, PY, PZ, df, QX, QY, QZ, ma::WnTabStrided{tab, 1}, xw, yw);
 }
+extern "C" void nist256_jac_mulgen_get_host(const uint64_t* ew, uint64_t* xw, uint64_t* yw) {
+    uint64_t k[4];
+    ma::Wj26::reduce_scalar(ew, k);
+    ma::Wj26::Pt R;
+    ma::Wj26::mulgen_acc<HostCombNist256>(k, R);
+    ma::Wn26<ma::CvNist256>::affine_words(R, xw, yw);
+}
