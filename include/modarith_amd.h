@@ -452,8 +452,11 @@ int ecn_secp256k1_mul2_get_batch(const char *e, const ma_spint *P, const char *f
 /* Generator multiplication + affine export: ecnXXXgen, ecnXXXmul, ecnXXXget in one kernel -- the opening of
  * NIST256_KEY_PAIR and NIST256_SIGN (nist256.c:150-161, 214-222).  x, y, sign as for mul_get; there is no point
  * argument and no workspace: the multiples m * 32^i * G, m = 1..16, live in a 66 560-byte constant table
- * (generated/comb_<C>.h), every window reads all of its entries (constant-time) and adds one with the complete mixed addition;
- * four scalars per lane share one inversion.  Same
+ * (generated/comb_<C>.h), every window reads all of its entries (constant-time) and adds one -- secp256k1 with the complete mixed
+ * addition, P-256 (round 5) with the Jacobian one after reducing the scalar mod the group order (csrc/wj26.h: on the fixed-base
+ * table the accumulator can meet the table point for no scalar below the order); one scalar per lane, the inversion shared by up
+ * to 32 records through stream-ordered scratch of the library's pool (160 bytes per record for at most 2^20 records; on a stream
+ * under capture, where that pool is not available: four scalars per lane sharing one inversion, as in rounds 2-4).  Same
  * bytes as ecn_<c>_gen_batch + ecn_<c>_mul_batch + ecn_<c>_get_batch for every 32-byte scalar. */
 int ecn_nist256_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_t n, void *stream);
 int ecn_secp256k1_mulgen_get_batch(const char *e, char *x, char *y, int *sign, size_t n, void *stream);
