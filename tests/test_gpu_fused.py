@@ -344,6 +344,46 @@ def test_fused_ladder_form_under_stream_capture():
     assert torch.equal(x, want2[0]) and torch.equal(y, want2[1])
 
 
+@pytest.mark.parametrize("name", ["NIST256", "SECP256K1"])
+def test_fused_weierstrass_forms_under_stream_capture(name):
+    """round 5: mul_get of the Weierstrass curves is two kernels per chunk on the caller's workspace (window kernel, shared inversion +
+    export) and captures as it is; mulgen_get has no workspace argument and takes the shared inversion's scratch from the library's pool
+    -- not available under capture, where it falls back to the four-scalars-per-lane kernel of rounds 2-4.  Both replayed on new data,
+    against the eager calls"""
+    import torch
+    from modarith_amd.edwards import Curve
+    from modarith_amd import _lib
+    W = Curve(name)
+    c = name.lower()
+    n = 4096 + 5
+    gen = torch.Generator(device="cuda").manual_seed(98)
+    rnd = lambda: torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=gen)
+    e, e2 = rnd(), rnd()
+    e[3] = 0
+    P = W.mul(rnd(), W.gen(n))
+    P[:, :, 7] = W.inf(1)[:, :, 0]
+    want, want2 = W.mul_get(e, P), W.mul_get(e2, P)
+    gwant, gwant2 = W.mulgen_get(e), W.mulgen_get(e2)             # eager: one scalar per lane through the scratch pool
+    L = _lib.load()
+    ws = torch.empty(int(getattr(L, "ecn_%s_mul_get_workspace_bytes" % c)(n)), dtype=torch.uint8, device="cuda")
+    x, y, gx, gy = (torch.empty_like(want[0]) for _ in range(4))
+    eb = e.clone()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            rc = getattr(L, "ecn_%s_mul_get_batch" % c)(eb.data_ptr(), P.data_ptr(), x.data_ptr(), y.data_ptr(), None, n, n, ws.data_ptr(), ws.numel(), side.cuda_stream)
+            rcg = getattr(L, "ecn_%s_mulgen_get_batch" % c)(eb.data_ptr(), gx.data_ptr(), gy.data_ptr(), None, n, side.cuda_stream)
+    assert rc == 0 and rcg == 0, (rc, rcg, L.modarith_amd_last_error().decode())
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(x, want[0]) and torch.equal(y, want[1]) and torch.equal(gx, gwant[0]) and torch.equal(gy, gwant[1])
+    eb.copy_(e2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(x, want2[0]) and torch.equal(y, want2[1]) and torch.equal(gx, gwant2[0]) and torch.equal(gy, gwant2[1])
+
+
 def test_fused_rejects_bad_arguments(fx):
     C, Ed, g, torch = fx
     from modarith_amd.edwards import Edwards
