@@ -51,6 +51,9 @@ AUDITED = [
     # round 5: the ladder form of the fused ED25519 multiplications (csrc/ed26l.h): prep, the two shared inversions, the ladder
     ("capi_ED25519F.o", "k_ed25519_lad("), ("capi_ED25519F.o", "k_edlad_prep<"), ("capi_ED25519F.o", "k_fe_batch_div<"),
     ("capi_ED448F.o", "k_ed448_lad("), ("capi_ED448F.o", "k_edlad_prep<"), ("capi_ED448F.o", "k_fe_batch_div<"), ("capi_ED448G.o", "k_fe_batch_div<"),
+    # round 5: one scalar per lane on the fixed-base tables of P-256 / secp256k1, and the shared inversion + export behind the Weierstrass kernels
+    ("capi_NIST256G.o", "k_nist256_mulgen("), ("capi_SECP256K1G.o", "k_secp256k1_mulgen("),
+    ("capi_NIST256F.o", "k_wn_export<"), ("capi_SECP256K1F.o", "k_wn_export<"), ("capi_NIST256G.o", "k_wn_export<"), ("capi_SECP256K1G.o", "k_wn_export<"),
 ]
 
 
@@ -306,6 +309,7 @@ def run(verbose=False):
     allow = json.load(open(ALLOW))["kernels"] if os.path.exists(ALLOW) else []
     rows, problems = [], []
     cache = {}
+    todo = []
     for og, pat in AUDITED:
         for o in fnmatch.filter(objs, og):
             if o not in cache:
@@ -317,25 +321,30 @@ def run(verbose=False):
                 name = re.sub(r"^void ", "", names.get(sym, sym))
                 if pat not in name or not ins:
                     continue
-                a = audit_function(ins)
-                short = re.sub(r"\(.*", "", name)
-                entry = next((e for e in allow if e["match"] in short), None)
-                row = {"object": o, "kernel": short, **{k: a[k] for k in a if k != "detail"}}
-                rows.append(row)
-                if verbose:
-                    print(short)
-                    for d in a["detail"]:
-                        print("    " + d)
-                if entry is None:
-                    problems.append("%s: no allow-list entry" % short)
-                    continue
-                lane = a["scc_lane_data"] + a["vcc_lane_data"] + a["exec_lane_data"]
-                if lane > entry.get("lane_data_branches", 0):
-                    problems.append("%s: %d data-dependent branch(es), %d allowed" % (short, lane, entry.get("lane_data_branches", 0)))
-                if a["exec"] + a["lane_index"] > entry.get("exec_branches", 0):
-                    problems.append("%s: %d exec-mask / lane-index branch(es), %d allowed" % (short, a["exec"] + a["lane_index"], entry.get("exec_branches", 0)))
-                if a["unknown"] > entry.get("unknown", 0):
-                    problems.append("%s: %d unclassified branch(es)" % (short, a["unknown"]))
+                todo.append((o, name, ins))
+    # the register tracing is pure Python and takes a second or two per kernel: one worker per core
+    import multiprocessing
+    with multiprocessing.Pool(min(8, os.cpu_count() or 1)) as pool:
+        audits = pool.map(audit_function, [t[2] for t in todo], chunksize=1)
+    for (o, name, ins), a in zip(todo, audits):
+        short = re.sub(r"\(.*", "", name)
+        entry = next((e for e in allow if e["match"] in short), None)
+        row = {"object": o, "kernel": short, **{k: a[k] for k in a if k != "detail"}}
+        rows.append(row)
+        if verbose:
+            print(short)
+            for d in a["detail"]:
+                print("    " + d)
+        if entry is None:
+            problems.append("%s: no allow-list entry" % short)
+            continue
+        lane = a["scc_lane_data"] + a["vcc_lane_data"] + a["exec_lane_data"]
+        if lane > entry.get("lane_data_branches", 0):
+            problems.append("%s: %d data-dependent branch(es), %d allowed" % (short, lane, entry.get("lane_data_branches", 0)))
+        if a["exec"] + a["lane_index"] > entry.get("exec_branches", 0):
+            problems.append("%s: %d exec-mask / lane-index branch(es), %d allowed" % (short, a["exec"] + a["lane_index"], entry.get("exec_branches", 0)))
+        if a["unknown"] > entry.get("unknown", 0):
+            problems.append("%s: %d unclassified branch(es)" % (short, a["unknown"]))
     return rows, problems
 
 
