@@ -1,4 +1,4 @@
-// tools/wn26_host.hip -- the per-lane functions of the fused secp256k1 kernels (csrc/wn26.h on csrc/fk26.h) compiled for
+// tools/wn26_host.hip -- the per-lane functions of the fused P-256 / secp256k1 kernels (csrc/wn26.h, wj26.h, glv26.h on csrc/fm26.h, fk26.h) compiled for
 // the HOST into a small shared library, so that tests/test_host_arith.py can run them against the CPU oracle through
 // ctypes (the secp256k1 oracle is bound to its parameter block at run time by tests/oracle_binding.py, which a C main
 // cannot do).  Test tooling, not product code.
