@@ -428,7 +428,7 @@ int ecn_ed448_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, 
  * digit at infinity, the LAST addition the complete one of weierstrass.c:68-175 -- so the affine bytes are the reference's for
  * every scalar and every point of the curve, the point at infinity included.  mul2_get keeps the complete additions (its
  * accumulator depends on both points) and runs only the doublings in Jacobian coordinates.  Workspace (ecn_<c>_*_get_workspace_bytes(n)): the window tables,
- * 960 bytes per resident lane for mul_get / mulgen2_get (at most 126 MB), 1 920 for mul2_get, followed by 160 bytes per record for at
+ * 960 bytes per resident lane for mul_get / mulgen2_get (three waves on each of the 1 024 SIMDs: at most 189 MB), 1 920 for mul2_get (377 MB), followed by 160 bytes per record for at
  * most 2^20 records -- (X : Y : Z) of the results, whose inversion is shared by up to 32 records (csrc/wn_export.h).  A result at infinity leaves as x = 0, y = 1, the bytes
  * ecnXXXget produces for it (weierstrass.c:299-310).  Points off the curve mean nothing on either side and may differ. */
 size_t ecn_nist256_mul_get_workspace_bytes(size_t n);

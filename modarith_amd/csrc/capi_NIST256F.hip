@@ -16,12 +16,12 @@ constexpr size_t NIST256_ROW_SKEW = 32 + 4;   // words added to the row pitch of
 // scalar reduced mod n first): window tables in the wave's slab of the workspace ([word][64 lanes]: every
 // access one contiguous 512-byte row, row addresses formed at the access -- wn26.h WnTabSlab), recoded scalar in LDS (one byte per
 // window, written before the point is loaded), element index = wave-uniform base + lane, formed where it is used
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_nist256_mul_get(const unsigned char* e, const spint* Pb, size_t ld, uint64_t* ws, WnExpWs ex) {
     const size_t n = ex.m;                                  // the records of this chunk; (X : Y : Z) of the result to the shared inversion (wn_export.h)
     using P = P_NIST256;
     using DIG = WnLds<4, 260>;
-    __shared__ unsigned char digs[DIG::COUNT * 64];
+    __shared__ unsigned char digs[DIG::ROWS * 64];
     const WnTabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)NIST256_TABLE_WORDS), threadIdx.x};
     unsigned char* col = digs + threadIdx.x;
     for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
@@ -33,15 +33,16 @@ void k_nist256_mul_get(const unsigned char* e, const spint* Pb, size_t ld, uint6
             Wj26::reduce_scalar(ew, kw);
             DIG::fill(kw, col);
         }
-        spint X[5], Y[5], Z[5];
-        static_for<0, 5>([&](auto I) {
-            X[I] = Pb[(size_t)I * ld + t()];
-            Y[I] = Pb[(size_t)(5 + I) * ld + t()];
-            Z[I] = Pb[(size_t)(10 + I) * ld + t()];
-        });
+        auto point = [&](spint* X, spint* Y, spint* Z) {      // the 3 x 5 limbs of record t(), fetched where the table is built
+            static_for<0, 5>([&](auto I) {
+                X[I] = Pb[(size_t)I * ld + t()];
+                Y[I] = Pb[(size_t)(5 + I) * ld + t()];
+                Z[I] = Pb[(size_t)(10 + I) * ld + t()];
+            });
+        };
         DIG dig{col};
         Wj26::Pt R;
-        Wj26::mul_acc(dig, X, Y, Z, T, R);
+        Wj26::mul_acc_ld(dig, point, T, R);
         ex.store<Fm26>(t(), R.X, R.Y, R.Z);
     }
 }
@@ -53,7 +54,7 @@ using namespace ma;
 namespace {
 // resident grid: 2 waves on each of the 1024 SIMDs, grid-stride over the batch
 size_t fused_lanes(size_t n) {
-    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
+    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)3 * 1024 * 64;
     return lanes < cap ? lanes : cap;
 }
 }  // namespace

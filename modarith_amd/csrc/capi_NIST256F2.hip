@@ -15,7 +15,7 @@ namespace ma {
 constexpr size_t NIST256_ROW_SKEW2 = 32 + 4;
 
 // tables in the wave's slab, the two recoded scalars in LDS, element index formed at use: see the mul_get unit
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_nist256_mul2_get(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, size_t ld, uint64_t* ws, WnExpWs ex) {
     const size_t n = ex.m;                                  // the records of this chunk; (X : Y : Z) of the result to the shared inversion (wn_export.h)
     using P = P_NIST256;
@@ -34,18 +34,18 @@ void k_nist256_mul2_get(const unsigned char* e, const spint* Pb, const unsigned 
             load_be_record<P>(f, t(), ew);
             DIG::fill(ew, cf);
         }
-        spint PX[5], PY[5], PZ[5], QX[5], QY[5], QZ[5];
-        static_for<0, 5>([&](auto I) {
-            PX[I] = Pb[(size_t)I * ld + t()];
-            PY[I] = Pb[(size_t)(5 + I) * ld + t()];
-            PZ[I] = Pb[(size_t)(10 + I) * ld + t()];
-            QX[I] = Qb[(size_t)I * ld + t()];
-            QY[I] = Qb[(size_t)(5 + I) * ld + t()];
-            QZ[I] = Qb[(size_t)(10 + I) * ld + t()];
-        });
+        auto point = [&](const spint* B) {                   // the 3 x 5 limbs of record t() of a point batch, fetched when its table is built
+            return [&, B](spint* X, spint* Y, spint* Z) {
+                static_for<0, 5>([&](auto I) {
+                    X[I] = B[(size_t)I * ld + t()];
+                    Y[I] = B[(size_t)(5 + I) * ld + t()];
+                    Z[I] = B[(size_t)(10 + I) * ld + t()];
+                });
+            };
+        };
         DIG de{ce}, df{cf};
         Wj26::Pt R;
-        Wj26::mul2_acc(de, PX, PY, PZ, df, QX, QY, QZ, T, R);
+        Wj26::mul2_acc_ld(de, point(Pb), df, point(Qb), T, R);
         ex.store<Fm26>(t(), R.X, R.Y, R.Z);
     }
 }
@@ -56,7 +56,7 @@ using namespace ma;
 
 namespace {
 size_t fused_lanes(size_t n) {
-    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
+    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)3 * 1024 * 64;
     return lanes < cap ? lanes : cap;
 }
 }  // namespace

@@ -59,12 +59,12 @@ void k_nist256_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned ch
 
 // e*G + f*Q and its affine export (verification, nist256.c:251-256): the per-lane table of Q in the workspace as for mul_get,
 // the generator part through the constant table above
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_nist256_mulgen2_get(const unsigned char* e, const unsigned char* f, const spint* Qb, size_t ld, uint64_t* ws, WnExpWs ex) {
     const size_t n = ex.m;                                  // the records of this chunk; (X : Y : Z) of the result to the shared inversion (wn_export.h)
     using P = P_NIST256;
     using DIG = WnLds<4, 260>;
-    __shared__ unsigned char digs[DIG::COUNT * 64];          // f's windows in LDS; Q's table in the wave's slab; index at use: see the mul_get unit
+    __shared__ unsigned char digs[DIG::ROWS * 64];          // f's windows in LDS; Q's table in the wave's slab; index at use: see the mul_get unit
     const WnTabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)WN26_TABLE_WORDS), threadIdx.x};
     unsigned char* col = digs + threadIdx.x;
     for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
@@ -76,16 +76,19 @@ void k_nist256_mulgen2_get(const unsigned char* e, const unsigned char* f, const
             Wj26::reduce_scalar(fw, kw);                       // f Q in Jacobian coordinates (csrc/wj26.h)
             DIG::fill(kw, col);
         }
-        spint ew[4], X[5], Y[5], Z[5];
-        static_for<0, 5>([&](auto I) {
-            X[I] = Qb[(size_t)I * ld + t()];
-            Y[I] = Qb[(size_t)(5 + I) * ld + t()];
-            Z[I] = Qb[(size_t)(10 + I) * ld + t()];
-        });
-        load_be_record<P>(e, t(), ew);
+        auto point = [&](spint* X, spint* Y, spint* Z) {      // the 3 x 5 limbs of record t(), fetched where the table is built
+            static_for<0, 5>([&](auto I) {
+                X[I] = Qb[(size_t)I * ld + t()];
+                Y[I] = Qb[(size_t)(5 + I) * ld + t()];
+                Z[I] = Qb[(size_t)(10 + I) * ld + t()];
+            });
+        };
         DIG dig{col};
         Wj26::Pt R;
-        Wj26::mulgen2_acc<CombNIST256>(ew, dig, X, Y, Z, T, R);
+        Wj26::mul_acc_ld(dig, point, T, R);
+        spint ew[4];
+        load_be_record<P>(e, t(), ew);                          // (fetched here: eight registers less across f Q)
+        wn26_mulgen_acc<CvNist256, CombNIST256, false>(ew, R);
         ex.store<Fm26>(t(), R.X, R.Y, R.Z);
     }
 }
@@ -96,7 +99,7 @@ using namespace ma;
 
 namespace {
 size_t fused2_lanes(size_t n) {
-    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
+    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)3 * 1024 * 64;
     return lanes < cap ? lanes : cap;
 }
 }  // namespace

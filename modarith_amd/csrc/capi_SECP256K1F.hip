@@ -16,7 +16,7 @@ constexpr size_t SECP256K1_ROW_SKEW = 32 + 4;   // words added to the row pitch 
 // instead of 256 on the same table): window tables in the wave's slab of the workspace ([word][64 lanes]: every
 // access one contiguous 512-byte row, row addresses formed at the access -- wn26.h WnTabSlab), recoded scalar in LDS (one byte per
 // window, written before the point is loaded), element index = wave-uniform base + lane, formed where it is used
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_secp256k1_mul_get(const unsigned char* e, const spint* Pb, size_t ld, uint64_t* ws, WnExpWs ex) {
     const size_t n = ex.m;                                  // the records of this chunk; (X : Y : Z) of the result to the shared inversion (wn_export.h)
     using P = P_SECP256K1;
@@ -52,7 +52,7 @@ using namespace ma;
 namespace {
 // resident grid: 2 waves on each of the 1024 SIMDs, grid-stride over the batch
 size_t fused_lanes(size_t n) {
-    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
+    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)3 * 1024 * 64;
     return lanes < cap ? lanes : cap;
 }
 }  // namespace

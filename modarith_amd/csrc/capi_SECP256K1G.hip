@@ -58,7 +58,7 @@ void k_secp256k1_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned 
 
 // e*G + f*Q and its affine export (verification, nist256.c:251-256): the per-lane table of Q in the workspace as for mul_get,
 // the generator part through the constant table above
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_secp256k1_mulgen2_get(const unsigned char* e, const unsigned char* f, const spint* Qb, size_t ld, uint64_t* ws, WnExpWs ex) {
     const size_t n = ex.m;                                  // the records of this chunk; (X : Y : Z) of the result to the shared inversion (wn_export.h)
     using P = P_SECP256K1;
@@ -75,15 +75,17 @@ void k_secp256k1_mulgen2_get(const unsigned char* e, const unsigned char* f, con
             load_be_record<P>(f, t(), fw);
             dig.fill(fw, col);
         }
-        spint ew[4], X[5], Y[5], Z[5];
+        spint X[5], Y[5], Z[5];
         static_for<0, 5>([&](auto I) {
             X[I] = Qb[(size_t)I * ld + t()];
             Y[I] = Qb[(size_t)(5 + I) * ld + t()];
             Z[I] = Qb[(size_t)(10 + I) * ld + t()];
         });
-        load_be_record<P>(e, t(), ew);
         Wn26<CvSecp256k1>::Pt R;
-        secp256k1_glv_mulgen2_acc<CombSECP256K1>(ew, dig, X, Y, Z, T, R);
+        secp256k1_glv_mul_acc(dig, X, Y, Z, T, R);
+        spint ew[4];
+        load_be_record<P>(e, t(), ew);                          // (fetched here: eight registers less across f Q)
+        wn26_mulgen_acc<CvSecp256k1, CombSECP256K1, false>(ew, R);
         ex.store<Fk26>(t(), R.X, R.Y, R.Z);
     }
 }
@@ -94,7 +96,7 @@ using namespace ma;
 
 namespace {
 size_t fused2_lanes(size_t n) {
-    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)2 * 1024 * 64;
+    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)3 * 1024 * 64;
     return lanes < cap ? lanes : cap;
 }
 }  // namespace

@@ -230,16 +230,22 @@ MA_DEV void secp256k1_glv_mulgen2_acc(const uint64_t* ew, DIG& digf, const spint
 // and four additions: 128 doublings + 132 additions against the 255 + 172 of wn26_mul2_get_dig (three-bit windows on two tables of
 // four).  Every lookup scans its eight entries.  An infinite result leaves as (0, 1).
 constexpr int GLV2_TABLE_WORDS = 2 * WN26_TABLE_WORDS;
-template <class TAB, class DIG>
-MA_DEV void secp256k1_glv_mul2_acc(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
-                                   DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T, Wn26<CvSecp256k1>::Pt& R) {
+// loadP(X, Y, Z) / loadQ fetch the 3 x 5 limbs of a point when its table is about to be built (the kernel: from the caller's arrays -- Q's
+// thirty registers are then not live while P's table is built)
+template <class TAB, class DIG, class LP, class LQ>
+MA_DEV void secp256k1_glv_mul2_acc_ld(DIG& dige, LP loadP, DIG& digf, LQ loadQ, const TAB& T, Wn26<CvSecp256k1>::Pt& R) {
     using E = Wn26<CvSecp256k1>;
     using F = Fk26;
     E::Pt Q;
-    E::load_point(PX, PY, PZ, Q);
-    E::template build_table<8>(Q, T.origin(), T.stride(), 0);
-    E::load_point(QX, QY, QZ, Q);
-    E::template build_table<8>(Q, T.origin(), T.stride(), 8);
+    {
+        spint X[5], Y[5], Z[5];
+        loadP(X, Y, Z);
+        E::load_point(X, Y, Z, Q);
+        E::template build_table<8>(Q, T.origin(), T.stride(), 0);
+        loadQ(X, Y, Z);
+        E::load_point(X, Y, Z, Q);
+        E::template build_table<8>(Q, T.origin(), T.stride(), 8);
+    }
     E::inf(R);
 #pragma unroll 1
     for (int i = 0; i < GLV_WINDOWS; i++) {
@@ -262,6 +268,14 @@ MA_DEV void secp256k1_glv_mul2_acc(DIG& dige, const spint* PX, const spint* PY, 
             E::add(Q, R);
         }
     }
+}
+template <class TAB, class DIG>
+MA_DEV void secp256k1_glv_mul2_acc(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
+                                   DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T, Wn26<CvSecp256k1>::Pt& R) {
+    auto cp = [](const spint* a, const spint* b, const spint* c) {
+        return [=](spint* x, spint* y, spint* z) { static_for<0, 5>([&](auto I) { x[I] = a[I]; y[I] = b[I]; z[I] = c[I]; }); };
+    };
+    secp256k1_glv_mul2_acc_ld(dige, cp(PX, PY, PZ), digf, cp(QX, QY, QZ), T, R);
 }
 template <class TAB, class DIG>
 MA_DEV void secp256k1_glv_mul2_get_dig(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,

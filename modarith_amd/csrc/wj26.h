@@ -142,8 +142,13 @@ struct Wj26 {
         for (int k = 2; k <= 8; k++) {
             Pt t;
             E::get(tab, tstride, (k & 1) ? k - 2 : (k >> 1) - 1, t);
-            if (k & 1) add(p, t);
-            else dbl(t);
+            if (k & 1) {
+                Pt q;
+                E::get(tab, tstride, 0, q);             // (P from entry 0, not held across the loop: wn26.h build_table)
+                add(q, t);
+            } else {
+                dbl(t);
+            }
             E::put(tab, tstride, k - 1, t);
         }
     }
@@ -152,9 +157,20 @@ struct Wj26 {
     // (reduce_scalar before the recoding).
     template <class TAB, class DIG>
     static MA_DEV void mul_acc(DIG& dig, const spint* X, const spint* Y, const spint* Z, const TAB& T, Pt& R) {
+        mul_acc_ld(dig, [=](spint* x, spint* y, spint* z) { static_for<0, 5>([&](auto I) { x[I] = X[I]; y[I] = Y[I]; z[I] = Z[I]; }); }, T, R);
+    }
+    // load(X, Y, Z) fetches the 3 x 5 limbs of the point (the kernels: from the caller's arrays, here and not above the digit recoding)
+    template <class TAB, class DIG, class LD>
+    static MA_DEV void mul_acc_ld(DIG& dig, LD load, const TAB& T, Pt& R) {
         Pt Q;
-        E::load_point(X, Y, Z, Q);
-        const bool pinf = is_zero(Q.Z);
+        {
+            spint X[5], Y[5], Z[5];
+            load(X, Y, Z);
+            E::load_point(X, Y, Z, Q);
+        }
+        // "P is the point at infinity" waits beside the digits (in LDS in the kernels: no register across the loops; and decided HERE: sunk
+        // to its first use, the comparison kept ten limbs alive across the table loop)
+        dig.park(is_zero(Q.Z) ? 1u : 0u);
         from_projective(Q);
         build_table(Q, T.origin(), T.stride());
         F::set_one(R.X);
@@ -171,7 +187,8 @@ struct Wj26 {
                 for (int j = 0; j < 4; j++) dbl(R);
             }
             E::template lookup<8>(T.origin(), T.stride(), 0, m, neg, Q);
-            const bool qinf = (m == 0) || pinf;
+            const uint32_t pk = dig.parked();                       // read on every lane: "m == 0 ||" would be a branch on the digit
+            const bool qinf = ((m == 0) | (pk != 0)) != 0;
             Pt S = R;
             add(Q, S);
             // R at infinity: the sum is Q; Q at infinity: the sum is R; both: R stays at infinity
@@ -193,7 +210,8 @@ struct Wj26 {
 #pragma unroll 1
             for (int j = 0; j < 4; j++) dbl(R);
             E::template lookup<8>(T.origin(), T.stride(), 0, m, neg, Q);
-            to_projective((m == 0) || pinf, Q);
+            const uint32_t pk = dig.parked();
+            to_projective(((m == 0) | (pk != 0)) != 0, Q);
             to_projective(rinf, R);
             E::add(Q, R);
         }
@@ -293,11 +311,25 @@ struct Wj26 {
     template <class TAB, class DIG>
     static MA_DEV void mul2_acc(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
                                 DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T, Pt& R) {
+        auto cp = [](const spint* a, const spint* b, const spint* c) {
+            return [=](spint* x, spint* y, spint* z) { static_for<0, 5>([&](auto I) { x[I] = a[I]; y[I] = b[I]; z[I] = c[I]; }); };
+        };
+        mul2_acc_ld(dige, cp(PX, PY, PZ), digf, cp(QX, QY, QZ), T, R);
+    }
+    // loadP(X, Y, Z) / loadQ fetch the 3 x 5 limbs of a point when its table is about to be built (the kernel: from the caller's arrays --
+    // Q's thirty registers are then not live while P's table is built)
+    template <class TAB, class DIG, class LP, class LQ>
+    static MA_DEV void mul2_acc_ld(DIG& dige, LP loadP, DIG& digf, LQ loadQ, const TAB& T, Pt& R) {
         Pt Q;
-        E::load_point(PX, PY, PZ, Q);
-        E::template build_table<8>(Q, T.origin(), T.stride(), 0);
-        E::load_point(QX, QY, QZ, Q);
-        E::template build_table<8>(Q, T.origin(), T.stride(), 8);
+        {
+            spint X[5], Y[5], Z[5];
+            loadP(X, Y, Z);
+            E::load_point(X, Y, Z, Q);
+            E::template build_table<8>(Q, T.origin(), T.stride(), 0);
+            loadQ(X, Y, Z);
+            E::load_point(X, Y, Z, Q);
+            E::template build_table<8>(Q, T.origin(), T.stride(), 8);
+        }
         E::inf(R);
 #pragma unroll 1
         for (int i = 0; i < 65; i++) {

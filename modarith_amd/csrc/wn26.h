@@ -294,6 +294,8 @@ struct Wn26 {
     }
     // entries base .. base + COUNT - 1 = P, 2P, ..., COUNT P: even multiples by doubling, odd ones as (k-1)P + P, rolled
     // into one loop so that the instruction stream holds a single copy of dbl and add for the table
+    // (P itself comes back from entry 0 for every odd multiple: held in registers across the loop it cost 14-28 spilled registers at three
+    // waves per SIMD)
     template <int COUNT>
     static MA_DEV void build_table(const Pt& p, uint64_t* tab, size_t tstride, int base) {
         put(tab, tstride, base, p);
@@ -301,8 +303,13 @@ struct Wn26 {
         for (int k = 2; k <= COUNT; k++) {
             Pt t;
             get(tab, tstride, base + ((k & 1) ? k - 2 : (k >> 1) - 1), t);
-            if (k & 1) add(p, t);
-            else dbl(t);
+            if (k & 1) {
+                Pt q;
+                get(tab, tstride, base, q);
+                add(q, t);
+            } else {
+                dbl(t);
+            }
             put(tab, tstride, base + k - 1, t);
         }
     }
@@ -444,13 +451,17 @@ MA_DEV uint32_t wn26_take(uint64_t* w) {
 template <int W, int BITS>
 struct WnRegs {
     uint64_t w[5];
+    uint32_t flag = 0;
     MA_DEV void init(const uint64_t* ew) { wn26_recode<W, BITS>(ew, w); }
     MA_DEV uint32_t window(int) { return wn26_take<W>(w); }
+    MA_DEV void park(uint32_t v) { flag = v; }                  // one per-lane flag kept beside the digits (WnLds: in LDS, not in a register)
+    MA_DEV uint32_t parked() const { return flag; }
 };
 template <int W, int BITS>
 struct WnLds {
     static constexpr int COUNT = (BITS + W - 1) / W;            // 65 windows of 4 bits (260), 86 of 3 bits (258)
-    const unsigned char* col;
+    static constexpr int ROWS = COUNT + 1;                      // + one row for a per-lane flag (park / parked)
+    unsigned char* col;
     static MA_DEV void fill(const uint64_t* ew, unsigned char* col) {
         WnRegs<W, BITS> r;
         r.init(ew);
@@ -458,6 +469,8 @@ struct WnLds {
         for (int i = 0; i < COUNT; i++) col[(size_t)i * 64] = (unsigned char)r.window(i);
     }
     MA_DEV uint32_t window(int i) const { return col[(size_t)i * 64]; }
+    MA_DEV void park(uint32_t v) { col[(size_t)COUNT * 64] = (unsigned char)v; }
+    MA_DEV uint32_t parked() const { return col[(size_t)COUNT * 64]; }
 };
 struct WnTabStrided {
     uint64_t* tab;
