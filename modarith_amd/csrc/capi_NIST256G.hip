@@ -57,55 +57,48 @@ void k_nist256_mulgen_get(const unsigned char* e, unsigned char* xb, unsigned ch
     }
 }
 
-// e*G + f*Q and its affine export (verification, nist256.c:251-256): the per-lane table of Q in the workspace as for mul_get,
-// the generator part through the constant table above
+// e*G + f*Q and its affine export (verification, nist256.c:251-256): f Q as in the mul_get unit (the table of Q brought to Z = 1,
+// csrc/wn_affine.h; Jacobian mixed additions, csrc/wj26.h), the generator part through the constant table above
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_nist256_table2(const spint* Qb, size_t ld, WnAffWs ws) {
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= ws.m) return;
+    Wj26::table_of([&](spint* X, spint* Y, spint* Z) {
+        static_for<0, 5>([&](auto I) {
+            X[I] = Qb[(size_t)I * ld + t];
+            Y[I] = Qb[(size_t)(5 + I) * ld + t];
+            Z[I] = Qb[(size_t)(10 + I) * ld + t];
+        });
+    }, ws, t);
+}
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_nist256_mulgen2_get(const unsigned char* e, const unsigned char* f, const spint* Qb, size_t ld, uint64_t* ws, WnExpWs ex) {
-    const size_t n = ex.m;                                  // the records of this chunk; (X : Y : Z) of the result to the shared inversion (wn_export.h)
+void k_nist256_mulgen2_get(const unsigned char* e, const unsigned char* f, WnAffWs ws, WnExpWs ex) {
     using P = P_NIST256;
     using DIG = WnLds<4, 260>;
-    __shared__ unsigned char digs[DIG::ROWS * 64];          // f's windows in LDS; Q's table in the wave's slab; index at use: see the mul_get unit
-    const WnTabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)WN26_TABLE_WORDS), threadIdx.x};
+    __shared__ unsigned char digs[DIG::ROWS * 64];          // f's windows in LDS
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= ws.m) return;
     unsigned char* col = digs + threadIdx.x;
-    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
-        auto t = [&]() { return base + (size_t)(T.origin() - T.base); };
-        if (t() >= n) continue;
-        {
-            spint fw[4], kw[4];
-            load_be_record<P>(f, t(), fw);
-            Wj26::reduce_scalar(fw, kw);                       // f Q in Jacobian coordinates (csrc/wj26.h)
-            DIG::fill(kw, col);
-        }
-        auto point = [&](spint* X, spint* Y, spint* Z) {      // the 3 x 5 limbs of record t(), fetched where the table is built
-            static_for<0, 5>([&](auto I) {
-                X[I] = Qb[(size_t)I * ld + t()];
-                Y[I] = Qb[(size_t)(5 + I) * ld + t()];
-                Z[I] = Qb[(size_t)(10 + I) * ld + t()];
-            });
-        };
-        DIG dig{col};
-        Wj26::Pt R;
-        Wj26::mul_acc_ld(dig, point, T, R);
-        spint ew[4];
-        load_be_record<P>(e, t(), ew);                          // (fetched here: eight registers less across f Q)
-        wn26_mulgen_acc<CvNist256, CombNIST256, false>(ew, R);
-        ex.store<Fm26>(t(), R.X, R.Y, R.Z);
+    {
+        spint fw[4], kw[4];
+        load_be_record<P>(f, t, fw);
+        Wj26::reduce_scalar(fw, kw);
+        DIG::fill(kw, col);
     }
+    DIG dig{col};
+    Wj26::Pt R;
+    Wj26::mul_acc_aff(dig, ws, t, R);
+    spint ew[4];
+    load_be_record<P>(e, t, ew);                                // (fetched here: eight registers less across f Q)
+    wn26_mulgen_acc<CvNist256, CombNIST256, false>(ew, R);
+    ex.store<Fm26>(t, R.X, R.Y, R.Z);
 }
 
 }  // namespace ma
 
 using namespace ma;
 
-namespace {
-size_t fused2_lanes(size_t n) {
-    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)3 * 1024 * 64;
-    return lanes < cap ? lanes : cap;
-}
-}  // namespace
-
-static size_t slab_bytes(size_t n) { return (fused2_lanes(n) + 36) * WN26_TABLE_WORDS * sizeof(uint64_t); }
-extern "C" size_t ecn_nist256_mulgen2_get_workspace_bytes(size_t n) { return slab_bytes(n) + WnExpWs::bytes(n); }
+extern "C" size_t ecn_nist256_mulgen2_get_workspace_bytes(size_t n) { return WnAffWs::bytes(n) + WnExpWs::bytes(n); }
 
 extern "C" int ecn_nist256_mulgen2_get_batch(const char* e, const char* f, const ma_spint* Q, char* x, char* y, int* sign, size_t n, size_t ld,
                                            void* workspace, size_t workspace_bytes, void* st) {
@@ -119,10 +112,16 @@ extern "C" int ecn_nist256_mulgen2_get_batch(const char* e, const char* f, const
         return (int)hipErrorInvalidValue;
     }
     hipStream_t s = (hipStream_t)st;
-    for (size_t first = 0; first < n; first += WNEXP_CHUNK) {
-        const size_t m = n - first < WNEXP_CHUNK ? n - first : WNEXP_CHUNK;
-        const WnExpWs ex(reinterpret_cast<char*>(workspace) + slab_bytes(n), m);
-        k_nist256_mulgen2_get<<<(unsigned)(fused2_lanes(m) / 64), 64, 0, s>>>(reinterpret_cast<const unsigned char*>(e) + first * P_NIST256::NBYTES, reinterpret_cast<const unsigned char*>(f) + first * P_NIST256::NBYTES, Q + first, ld, reinterpret_cast<uint64_t*>(workspace), ex);
+    char* wsb = reinterpret_cast<char*>(workspace);
+    for (size_t first = 0; first < n; first += WNAFF_CHUNK) {
+        const size_t m = n - first < WNAFF_CHUNK ? n - first : WNAFF_CHUNK;
+        const WnAffWs aw(wsb, m);
+        const WnExpWs ex(wsb + WnAffWs::bytes(n), m);
+        const unsigned g = (unsigned)((m + 63) / 64);
+        k_nist256_table2<<<g, 64, 0, s>>>(Q + first, ld, aw);
+        wn_table_affine<Fm26, true, 3>(aw, s);
+        k_nist256_mulgen2_get<<<g, 64, 0, s>>>(reinterpret_cast<const unsigned char*>(e) + first * P_NIST256::NBYTES,
+                                               reinterpret_cast<const unsigned char*>(f) + first * P_NIST256::NBYTES, aw, ex);
         wn_export<Fm26, P_NIST256, 3>(ex, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, first, s);
     }
     return check_launch("ecn mulgen2_get");

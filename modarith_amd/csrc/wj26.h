@@ -27,6 +27,7 @@
 // K (fm26.h: |limb| <= K 2^26; a product needs K_f K_g <= 190, every limb below 2^31) is given in the comments.
 #pragma once
 #include "wn26.h"
+#include "wn_affine.h"
 
 namespace ma {
 
@@ -49,7 +50,7 @@ struct Wj26 {
         static_for<0, 4>([&](auto I) { k[I] = (ew[I] & keep) | (d[I] & ~keep); });
     }
 
-    // P = 2P (dbl-2001-b).  In: X, Y K <= 9, Z K <= 3.  Out: X, Y K = 9, Z K = 3.  Z = 0 stays Z = 0.
+    // P = 2P (dbl-2001-b).  In: X, Y K <= 9, Z K <= 3.  Out: X K = 9, Y K = 1, Z K = 3.  Z = 0 stays Z = 0.
     static MA_DEV void dbl(Pt& p) {
         int32_t d[10], g[10], b[10], a[10], t0[10], t1[10];
         F::sqr(p.Z, d);             // delta
@@ -70,12 +71,11 @@ struct Wj26 {
         F::sub(t0, b, t0);
         F::sub(t0, b, p.X);         // 9   X3 = alpha^2 - 8 beta
         F::sub(b, p.X, t1);         // 13
-        F::sqr(g, g);
-        F::add(g, g, g);
-        F::add(g, g, g);
-        F::add(g, g, g);            // 8   8 gamma^2
-        F::mul(a, t1, t0);
-        F::sub(t0, g, p.Y);         // 9   Y3 = alpha (4 beta - X3) - 8 gamma^2
+        F::add(g, g, t0);
+        F::add(t0, t0, t0);
+        F::add(t0, t0, t0);
+        F::neg(t0, t0);             // 8   -8 gamma
+        F::mul2(a, t1, t0, g, p.Y); //     Y3 = alpha (4 beta - X3) - 8 gamma^2 under one reduction: 3 x 13 + 8 x 1 (the price of mul + sqr)
     }
     // P += Q (add-2007-bl), neither at infinity, P != +-Q.  In: K <= 9 (X, Y), <= 3 (Z) on both.  Out: X K = 4, Y, Z K = 1.
     static MA_DEV void add(const Pt& q, Pt& p) {
@@ -216,6 +216,70 @@ struct Wj26 {
             E::add(Q, R);
         }
     }
+    // ---- the same on an AFFINE table (wn_affine.h): the multiples of P were computed by table_of() in a kernel of their own and brought to
+    // Z = 1 by k_wn_table_affine; the window loop adds them with madd() below.  The exceptional cases are those of mul_acc_ld -- flags
+    // for an accumulator / digit at infinity, the last addition the complete MIXED one of wn26.h.
+    template <class LD>
+    static MA_DEV void table_of(LD load, const WnAffWs& ws, size_t t) {
+        Pt Q;
+        {
+            spint X[5], Y[5], Z[5];
+            load(X, Y, Z);
+            E::load_point(X, Y, Z, Q);
+        }
+        from_projective(Q);                                         // Z = 0 stays Z = 0 in every multiple: k_wn_table_affine flags the record
+        build_table(Q, ws.T + t, ws.m);
+    }
+    template <class DIG>
+    static MA_DEV void mul_acc_aff(DIG& dig, const WnAffWs& ws, size_t t, Pt& R) {
+        dig.park(ws.flag[t]);
+        F::set_one(R.X);
+        F::set_one(R.Y);
+        F::zero(R.Z);
+        bool rinf = true;
+        int32_t sx[10], sy[10];
+#pragma unroll 1
+        for (int i = 0; i < 64; i++) {
+            const int dgt = (int)dig.window(i) - 8;                 // [-8, 7]
+            const bool neg = dgt < 0;
+            const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0..8
+            if (i != 0) {
+#pragma unroll 1
+                for (int j = 0; j < 4; j++) dbl(R);
+            }
+            wn_affine_lookup<F>(ws, t, m, neg, sx, sy);
+            const uint32_t pk = dig.parked();
+            const bool qinf = ((m == 0) | (pk != 0)) != 0;
+            Pt S = R;
+            madd(sx, sy, S);
+            int32_t one[10], u[10];
+            F::set_one(one);
+            F::select(rinf, S.X, sx, u);
+            F::select(qinf, u, R.X, R.X);
+            F::select(rinf, S.Y, sy, u);
+            F::select(qinf, u, R.Y, R.Y);
+            F::select(rinf, S.Z, one, u);
+            F::select(qinf, u, R.Z, R.Z);
+            rinf = rinf && qinf;
+        }
+        {
+            const int dgt = (int)dig.window(64) - 8;
+            const bool neg = dgt < 0;
+            const uint32_t m = (uint32_t)(neg ? -dgt : dgt);
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) dbl(R);
+            wn_affine_lookup<F>(ws, t, m, neg, sx, sy);
+            const uint32_t pk = dig.parked();
+            const bool qinf = ((m == 0) | (pk != 0)) != 0;
+            to_projective(rinf, R);
+            Pt S = R;
+            E::madd(sx, sy, S);                                     // complete: R may be anything, the affine point is finite when it is used
+            F::select(qinf, S.X, R.X, R.X);
+            F::select(qinf, S.Y, R.Y, R.Y);
+            F::select(qinf, S.Z, R.Z, R.Z);
+        }
+    }
+
     template <class TAB, class DIG>
     static MA_DEV void mul_get_dig(DIG& dig, const spint* X, const spint* Y, const spint* Z, const TAB& T, uint64_t* xw, uint64_t* yw) {
         Pt R;
@@ -244,13 +308,13 @@ struct Wj26 {
     // digit is 0 -- or e = 0.  So with e < n (reduced first) the only exceptional cases are the accumulator at infinity (s = 0: every
     // lower digit zero, a lane flag; the sum is then the table point with Z = 1) and a zero digit (the sum is the accumulator).  Returns
     // the homogeneous (X Z : Y : Z^3).  kw: the scalar reduced mod n.
-    static MA_DEV void madd(const int32_t* x2, const int32_t* y2, Pt& p) {       // in: X K <= 4, Y K <= 1, Z K <= 3; out the same
+    static MA_DEV void madd(const int32_t* x2, const int32_t* y2, Pt& p) {       // in: X K <= 9, Y K <= 1, Z K <= 3; out: X K = 4, Y K = 1, Z K = 3
         int32_t z1z1[10], u2[10], s2[10], h[10], hh[10], i_[10], j[10], r[10], v[10], t[10];
         F::sqr(p.Z, z1z1);
         F::mul(x2, z1z1, u2);
         F::mul(p.Z, z1z1, t);
         F::mul(y2, t, s2);
-        F::sub(u2, p.X, h);         // 5
+        F::sub(u2, p.X, h);         // 10
         F::sqr(h, hh);
         F::add(hh, hh, i_);
         F::add(i_, i_, i_);         // 4   I = 4 HH
@@ -258,7 +322,7 @@ struct Wj26 {
         F::sub(s2, p.Y, r);
         F::add(r, r, r);            // 4   r = 2 (S2 - Y1)
         F::mul(p.X, i_, v);
-        F::add(p.Z, h, t);          // 8
+        F::add(p.Z, h, t);          // 13
         F::sqr(t, t);
         F::sub(t, z1z1, t);
         F::sub(t, hh, p.Z);         // 3   Z3 = (Z1 + H)^2 - Z1Z1 - HH

@@ -250,8 +250,11 @@ def test_nist256_jacobian_fused_forms_on_host_against_oracle(oracle, tmp_path):
         p = point(kind)
         xw, yw = (U64 * 4)(), (U64 * 4)()
         lib.nist256_jac_mul_get_host(words(e), p.x, p.y, p.z, xw, yw)
+        xa, ya = (U64 * 4)(), (U64 * 4)()
+        lib.nist256_aff_mul_get_host(words(e), p.x, p.y, p.z, xa, ya)      # the affine-table pipeline (csrc/wn_affine.h) for one record
         oracle.ecn(C, "mul")(be(e), ctypes.byref(p))
         assert out_bytes(xw, yw) == affine(p), ("jacobian mul_get", it, hex(e), kind)
+        assert out_bytes(xa, ya) == affine(p), ("jacobian mul_get on the affine table", it, hex(e), kind)
     # e G on the fixed-base table with the Jacobian mixed addition: top digit 0 / 1 / 2, e = d 2^256 mod n, single digits in every window
     gscalars = scalars + [2**256 - n, 2 * (2**256 - n), (2**256 - n) + 2**255, n - 2**255, n - 2**255 + 1, 2**255 + 2**254, 3 * 2**254 - 1, 3 * 2**254, 3 * 2**254 + 1,
                           int("10" * 128, 2), int("01" * 128, 2)]

@@ -123,3 +123,18 @@ extern "C" void nist256_jac_mulgen_get_host(const uint64_t* ew, uint64_t* xw, ui
     ma::Wj26::mulgen_acc<HostCombNist256>(k, R);
     ma::Wn26<ma::CvNist256>::affine_words(R, xw, yw);
 }
+
+// round 5: the affine-table pipeline of P-256 (csrc/wn_affine.h, wj26.h table_of / mul_acc_aff) for one record
+extern "C" void nist256_aff_mul_get_host(const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, uint64_t* xw, uint64_t* yw) {
+    static uint64_t buf[(8 * 15 + 8 * 5) + 1];
+    ma::WnAffWs ws(buf, 1);
+    ma::Wj26::table_of([&](uint64_t* x, uint64_t* y, uint64_t* z) { for (int i = 0; i < 5; i++) { x[i] = X[i]; y[i] = Y[i]; z[i] = Z[i]; } }, ws, 0);
+    ma::wn_table_affine_lane<ma::Fm26, true>(ws, 1, 1, 0);
+    uint64_t k[4];
+    ma::Wj26::reduce_scalar(ew, k);
+    ma::WnRegs<4, 260> dig;
+    dig.init(k);
+    ma::Wj26::Pt R;
+    ma::Wj26::mul_acc_aff(dig, ws, 0, R);
+    ma::Wn26<ma::CvNist256>::affine_words(R, xw, yw);
+}
