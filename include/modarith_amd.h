@@ -427,9 +427,12 @@ int ecn_ed448_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, 
  * the Jacobian addition could fail is decided by the scalar alone on a curve of prime order -- lane flags for the accumulator or the
  * digit at infinity, the LAST addition the complete one of weierstrass.c:68-175 -- so the affine bytes are the reference's for
  * every scalar and every point of the curve, the point at infinity included.  mul2_get keeps the complete additions (its
- * accumulator depends on both points) and runs only the doublings in Jacobian coordinates.  Workspace (ecn_<c>_*_get_workspace_bytes(n)): the window tables,
- * 960 bytes per resident lane for mul_get / mulgen2_get (three waves on each of the 1 024 SIMDs: at most 189 MB), 1 920 for mul2_get (377 MB), followed by 160 bytes per record for at
- * most 2^20 records -- (X : Y : Z) of the results, whose inversion is shared by up to 32 records (csrc/wn_export.h).  A result at infinity leaves as x = 0, y = 1, the bytes
+ * accumulator depends on both points) and runs only the doublings in Jacobian coordinates.  Workspace (ecn_<c>_*_get_workspace_bytes(n)): mul_get / mulgen2_get
+ * keep the eight multiples of every record's point, 1 284 bytes per record for at most 2^19 records (673 MB): a first kernel computes
+ * them, a second brings them to Z = 1 under an inversion shared by 32 entries, the window loop then runs mixed additions
+ * (csrc/wn_affine.h); mul2_get holds two projective tables of eight per resident lane (1 920 bytes, three waves on each of the 1 024
+ * SIMDs: 377 MB).  Behind either: 160 bytes per record for at most 2^20 records -- (X : Y : Z) of the results, whose inversion is
+ * shared by up to 32 records (csrc/wn_export.h).  A result at infinity leaves as x = 0, y = 1, the bytes
  * ecnXXXget produces for it (weierstrass.c:299-310).  Points off the curve mean nothing on either side and may differ. */
 size_t ecn_nist256_mul_get_workspace_bytes(size_t n);
 int ecn_nist256_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
@@ -441,7 +444,8 @@ int ecn_nist256_mul2_get_batch(const char *e, const ma_spint *P, const char *f, 
  * (weierstrass.c:120-157, 189-226), ten signed 26-bit limbs with the pseudo-Mersenne fold 2^260 = 2^36 + 0x3d10.  Round 5
  * (csrc/glv26.h): every scalar is reduced mod the group order and split by the curve's endomorphism, k = k1 + k2 lambda with
  * |k1|, |k2| < 2^128, so that k P = k1 P + k2 (beta x, y) takes 128 doublings on the one table of P; all additions stay the
- * complete ones.  Same bytes as the two-call form for every scalar and every point of the curve.  Window tables as for P-256. */
+ * complete ones.  Same bytes as the two-call form for every scalar and every point of the curve.  Projective window tables per resident lane: 960 bytes (mul_get,
+ * mulgen2_get: at most 189 MB), 1 920 (mul2_get: 377 MB), and the 160 bytes per record of the shared export as for P-256. */
 size_t ecn_secp256k1_mul_get_workspace_bytes(size_t n);
 int ecn_secp256k1_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, int *sign, size_t n, size_t ld,
                                 void *workspace, size_t workspace_bytes, void *stream);

@@ -1,13 +1,15 @@
-// modarith_amd/csrc/wn_affine.h -- AFFINE window tables for the fused Weierstrass kernels (round 5): the multiples 1P .. 8P of every
-// record are brought to Z = 1 with one inversion per up to 32 table entries, so that the window loop adds them with the MIXED addition
-// (P-256, Jacobian: 7M + 4S = 1 360 multiply-adds against the 2 035 of the general addition; secp256k1, complete: 1 324 against 1 816).
-// 64-66 additions per scalar at 500-700 multiply-adds less, for about 1 000 per table entry (8 000 per record) in the kernel below.
+// modarith_amd/csrc/wn_affine.h -- AFFINE window tables for the fused P-256 kernels (round 5): the multiples 1P .. 8P of every record
+// are brought to Z = 1 with one inversion per up to 32 table entries, so that the window loop adds them with the Jacobian MIXED addition
+// (7M + 4S = 1 360 multiply-adds against the 2 035 of the general one): 64 additions per scalar at 675 multiply-adds less, for about
+// 1 000 per table entry (8 000 per record) in the kernel below -- mul_get 5.2 -> 5.9-6.1e7/s.  (secp256k1 stays on projective tables:
+// its complete mixed addition, 11M = 1 310 multiply-adds, saves too little against the complete addition's 12M = 1 433 to pay for the
+// normalisation; built and measured, 8.3 -> 8.4e7/s for mul_get, 6.2 -> 5.9e7/s for mulgen2_get.)
 //
 // The table is per RECORD of a chunk, not per resident lane: T[entry][word][record] (wn26.h's put / get with the record count as the
 // stride), 15 words per entry while it is projective, the first 10 (x, y) after k_wn_table_affine; C holds the prefix products of the
 // shared inversion, flag[record] = "P is the point at infinity" (then every multiple is, and the window kernels never use the
-// entries).  1 284 bytes per record (2 564 with two tables) for at most WNAFF_CHUNK records.  Pipeline per chunk: the table kernel of the curve (wj26.h /
-// glv26.h) -> k_wn_table_affine -> the window kernel -> wn_export.h.
+// entries).  1 284 bytes per record (2 564 with two tables) for at most WNAFF_CHUNK records.  Pipeline per chunk: the table kernel of the curve (wj26.h) ->
+// k_wn_table_affine -> the window kernel -> wn_export.h.
 //
 // JAC = true: entries are Jacobian (x = X / Z^2, y = Y / Z^3); false: homogeneous (x = X / Z, y = Y / Z).
 #pragma once

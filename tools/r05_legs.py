@@ -28,6 +28,10 @@ def legs():
             FX = "ma::Fm26, ma::P_NIST256" if C == "NIST256" else "ma::Fk26, ma::P_SECP256K1"
             out[C + "_ecn_mul_get_fused"] = [("k_%s_mul_get" % low, base + "F.o", 1, 1), ("k_wn_export<%s, 1>" % FX, base + "F.o", 1, "rounds")]
             out[C + "_ecn_mulgen2_get_fused"] = [("k_%s_mulgen2_get" % low, base + "G.o", 1, 1), ("k_wn_export<%s, 3>" % FX, base + "G.o", 1, "rounds")]
+            if C == "NIST256":
+                # P-256: the window table of every record in a kernel of its own, brought to Z = 1 by a shared inversion (csrc/wn_affine.h)
+                out[C + "_ecn_mul_get_fused"] += [("k_nist256_table(", base + "F.o", 1, 1), ("k_wn_table_affine<ma::Fm26, true, 1>", base + "F.o", 1, "rounds")]
+                out[C + "_ecn_mulgen2_get_fused"] += [("k_nist256_table2(", base + "G.o", 1, 1), ("k_wn_table_affine<ma::Fm26, true, 3>", base + "G.o", 1, "rounds")]
         if C in ("ED25519", "ED448"):
             out[C + "_ecn_mul2_get_fused"] = [("k_%s_mul2_straus" % low, base + "F2.o", 1, 1), ("SinkExportBE<ma::%s>, 3>" % ("P_X25519" if C == "ED25519" else "P_X448"), base + "F2.o", 1, "rounds")]
         else:
