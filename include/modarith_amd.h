@@ -426,12 +426,13 @@ int ecn_ed448_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y, 
  * group order and k P runs in Jacobian coordinates (doubling 3M + 5S against the 8M + 3S + 2 m_b of the complete formulas); where
  * the Jacobian addition could fail is decided by the scalar alone on a curve of prime order -- lane flags for the accumulator or the
  * digit at infinity, the LAST addition the complete one of weierstrass.c:68-175 -- so the affine bytes are the reference's for
- * every scalar and every point of the curve, the point at infinity included.  mul2_get keeps the complete additions (its
- * accumulator depends on both points) and runs only the doublings in Jacobian coordinates.  Workspace (ecn_<c>_*_get_workspace_bytes(n)): mul_get / mulgen2_get
+ * every scalar and every point of the curve, the point at infinity included.  mul2_get (two caller points: its accumulator can meet
+ * a table point anywhere) runs Jacobian mixed additions too, tests every one of them for that case and redoes it with the complete
+ * formula: same bytes for every input, but a wave's instruction sequence then depends on the inputs -- public ones in a
+ * verification; the reference's own mul2 (a joint sparse form) branches on them as well.  Workspace (ecn_<c>_*_get_workspace_bytes(n)): mul_get / mulgen2_get
  * keep the eight multiples of every record's point, 1 284 bytes per record for at most 2^19 records (673 MB): a first kernel computes
  * them, a second brings them to Z = 1 under an inversion shared by 32 entries, the window loop then runs mixed additions
- * (csrc/wn_affine.h); mul2_get holds two projective tables of eight per resident lane (1 920 bytes, three waves on each of the 1 024
- * SIMDs: 377 MB).  Behind either: 160 bytes per record for at most 2^20 records -- (X : Y : Z) of the results, whose inversion is
+ * (csrc/wn_affine.h); mul2_get the same with two tables of eight (2 564 bytes per record, 1.34 GB for a chunk).  Behind either: 160 bytes per record for at most 2^20 records -- (X : Y : Z) of the results, whose inversion is
  * shared by up to 32 records (csrc/wn_export.h).  A result at infinity leaves as x = 0, y = 1, the bytes
  * ecnXXXget produces for it (weierstrass.c:299-310).  Points off the curve mean nothing on either side and may differ. */
 size_t ecn_nist256_mul_get_workspace_bytes(size_t n);

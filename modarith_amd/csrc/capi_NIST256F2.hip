@@ -1,7 +1,9 @@
 // modarith_amd/csrc/capi_NIST256F2.hip -- ecn_nist256_mul2_get_batch: double multiplication e*P + f*Q fused with the
-// affine export (csrc/wn26.h), the verification pattern ecnXXXmul2 + ecnXXXget of the reference's ECDSA code
-// (nist256.c:251-256).  A result at infinity leaves as x = 0, y = 1 (what ecnXXXget gives; the caller's ecnXXXisinf test
-// becomes x == 0 && y == 1, no point of the curve has x = 0 ... y = 1 since b is not 1).
+// affine export, the verification pattern ecnXXXmul2 + ecnXXXget of the reference's ECDSA code (nist256.c:251-256).  A result at
+// infinity leaves as x = 0, y = 1 (what ecnXXXget gives; the caller's ecnXXXisinf test becomes x == 0 && y == 1, no point of the curve
+// has x = 0 ... y = 1 since b is not 1).  Round 5 (csrc/wj26.h mul2_acc_aff): the two window tables of every record brought to Z = 1
+// (csrc/wn_affine.h), a Jacobian accumulator with mixed additions, the additions where it meets +- a table point detected and redone
+// with the complete formula (variable time: the inputs of a verification are public, the reference's own mul2 branches on them).
 #include "../../include/modarith_amd.h"
 #include "capi_common.h"
 #include "generated/curve_NIST256.h"
@@ -12,57 +14,50 @@
 
 namespace ma {
 
-constexpr size_t NIST256_ROW_SKEW2 = 32 + 4;
-
-// tables in the wave's slab, the two recoded scalars in LDS, element index formed at use: see the mul_get unit
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_nist256_mul2_get(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, size_t ld, uint64_t* ws, WnExpWs ex) {
-    const size_t n = ex.m;                                  // the records of this chunk; (X : Y : Z) of the result to the shared inversion (wn_export.h)
-    using P = P_NIST256;
-    using DIG = WnLds<4, 260>;                              // four-bit windows, doublings in Jacobian coordinates (csrc/wj26.h mul2_get_dig)
-    __shared__ unsigned char digs[2 * DIG::COUNT * 64];
-    const WnTabSlab T{ws + (size_t)blockIdx.x * (64 * (size_t)Wj26::TABLE2_WORDS), threadIdx.x};
-    unsigned char* ce = digs + threadIdx.x;
-    unsigned char* cf = ce + DIG::COUNT * 64;
-    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
-        auto t = [&]() { return base + (size_t)(T.origin() - T.base); };
-        if (t() >= n) continue;
-        {
-            spint ew[4];
-            load_be_record<P>(e, t(), ew);
-            DIG::fill(ew, ce);
-            load_be_record<P>(f, t(), ew);
-            DIG::fill(ew, cf);
-        }
-        auto point = [&](const spint* B) {                   // the 3 x 5 limbs of record t() of a point batch, fetched when its table is built
-            return [&, B](spint* X, spint* Y, spint* Z) {
-                static_for<0, 5>([&](auto I) {
-                    X[I] = B[(size_t)I * ld + t()];
-                    Y[I] = B[(size_t)(5 + I) * ld + t()];
-                    Z[I] = B[(size_t)(10 + I) * ld + t()];
-                });
-            };
+// the multiples 1..8 of P (entries 0..7) and of Q (8..15) of every record of the chunk (Jacobian), one record per lane
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_nist256_tables(const spint* Pb, const spint* Qb, size_t ld, WnAffWs ws) {
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= ws.m) return;
+    auto point = [&](const spint* B) {
+        return [&, B](spint* X, spint* Y, spint* Z) {
+            static_for<0, 5>([&](auto I) {
+                X[I] = B[(size_t)I * ld + t];
+                Y[I] = B[(size_t)(5 + I) * ld + t];
+                Z[I] = B[(size_t)(10 + I) * ld + t];
+            });
         };
-        DIG de{ce}, df{cf};
-        Wj26::Pt R;
-        Wj26::mul2_acc_ld(de, point(Pb), df, point(Qb), T, R);
-        ex.store<Fm26>(t(), R.X, R.Y, R.Z);
+    };
+    Wj26::table_of(point(Pb), ws, t, 0);
+    Wj26::table_of(point(Qb), ws, t, 8);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_nist256_mul2_get(const unsigned char* e, const unsigned char* f, WnAffWs ws, WnExpWs ex) {
+    using P = P_NIST256;
+    using DIG = WnLds<4, 260>;
+    __shared__ unsigned char digs[2 * DIG::ROWS * 64];
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= ws.m) return;
+    unsigned char* ce = digs + threadIdx.x;
+    unsigned char* cf = ce + DIG::ROWS * 64;
+    {
+        spint ew[4];
+        load_be_record<P>(e, t, ew);
+        DIG::fill(ew, ce);
+        load_be_record<P>(f, t, ew);
+        DIG::fill(ew, cf);
     }
+    DIG de{ce}, df{cf};
+    Wj26::Pt R;
+    Wj26::mul2_acc_aff(de, df, ws, t, R);
+    ex.store<Fm26>(t, R.X, R.Y, R.Z);
 }
 
 }  // namespace ma
 
 using namespace ma;
 
-namespace {
-size_t fused_lanes(size_t n) {
-    const size_t lanes = (n + 63) / 64 * 64, cap = (size_t)3 * 1024 * 64;
-    return lanes < cap ? lanes : cap;
-}
-}  // namespace
-
-static size_t slab_bytes(size_t n) { return (fused_lanes(n) + NIST256_ROW_SKEW2) * Wj26::TABLE2_WORDS * sizeof(uint64_t); }
-extern "C" size_t ecn_nist256_mul2_get_workspace_bytes(size_t n) { return slab_bytes(n) + WnExpWs::bytes(n); }
+extern "C" size_t ecn_nist256_mul2_get_workspace_bytes(size_t n) { return WnAffWs::bytes(n, 16) + WnExpWs::bytes(n); }
 
 extern "C" int ecn_nist256_mul2_get_batch(const char* e, const ma_spint* P, const char* f, const ma_spint* Q, char* x, char* y, int* sign,
                                           size_t n, size_t ld, void* workspace, size_t workspace_bytes, void* st) {
@@ -76,10 +71,16 @@ extern "C" int ecn_nist256_mul2_get_batch(const char* e, const ma_spint* P, cons
         return (int)hipErrorInvalidValue;
     }
     hipStream_t s = (hipStream_t)st;
-    for (size_t first = 0; first < n; first += WNEXP_CHUNK) {
-        const size_t m = n - first < WNEXP_CHUNK ? n - first : WNEXP_CHUNK;
-        const WnExpWs ex(reinterpret_cast<char*>(workspace) + slab_bytes(n), m);
-        k_nist256_mul2_get<<<(unsigned)(fused_lanes(m) / 64), 64, 0, s>>>(reinterpret_cast<const unsigned char*>(e) + first * P_NIST256::NBYTES, P + first, reinterpret_cast<const unsigned char*>(f) + first * P_NIST256::NBYTES, Q + first, ld, reinterpret_cast<uint64_t*>(workspace), ex);
+    char* wsb = reinterpret_cast<char*>(workspace);
+    for (size_t first = 0; first < n; first += WNAFF_CHUNK) {
+        const size_t m = n - first < WNAFF_CHUNK ? n - first : WNAFF_CHUNK;
+        const WnAffWs aw(wsb, m, 16);
+        const WnExpWs ex(wsb + WnAffWs::bytes(n, 16), m);
+        const unsigned g = (unsigned)((m + 63) / 64);
+        k_nist256_tables<<<g, 64, 0, s>>>(P + first, Q + first, ld, aw);
+        wn_table_affine<Fm26, true, 2>(aw, s);
+        k_nist256_mul2_get<<<g, 64, 0, s>>>(reinterpret_cast<const unsigned char*>(e) + first * P_NIST256::NBYTES,
+                                            reinterpret_cast<const unsigned char*>(f) + first * P_NIST256::NBYTES, aw, ex);
         wn_export<Fm26, P_NIST256, 2>(ex, reinterpret_cast<unsigned char*>(x), reinterpret_cast<unsigned char*>(y), sign, first, s);
     }
     return check_launch("ecn mul2_get");

@@ -4,8 +4,9 @@
 // doubling is 8M + 3S + 2 multiplications by b, 1 649 multiply-adds on fm26.h.  The fused entry points only let canonical affine
 // bytes out (ecnXXXmul followed by ecnXXXget, nist256.c:155-161, 219-222, 251-256), so the coordinate system inside is as free as
 // the window width and the limb form: in Jacobian coordinates (x = X / Z^2, y = Y / Z^3) the a = -3 doubling is 3M + 5S = 927
-// multiply-adds (Bernstein-Lange dbl-2001-b), the general addition 11M + 5S with one shared reduction = 2 035 (add-2007-bl) against
-// 1 928.  256 doublings + 65 additions: 372 k multiply-adds instead of 547 k.
+// multiply-adds (Bernstein-Lange dbl-2001-b); the general addition 11M + 5S with one shared reduction = 2 035 (add-2007-bl) builds the
+// window table, whose entries a shared inversion then brings to Z = 1 (wn_affine.h), so that the window loop adds with the MIXED
+// formula, 7M + 4S = 1 360 (madd-2007-bl).  256 doublings + 65 additions: 361 k multiply-adds instead of 547 k.
 //
 // The Jacobian addition is NOT complete: it fails for R = +-Q and for either operand at infinity.  Where those can happen is decided
 // by the SCALAR alone, because the group has prime order n and cofactor 1 (every point of the curve other than infinity has order n):
@@ -21,8 +22,9 @@
 //     Q = k G for an unknown k and the accumulator can meet any table entry).
 //   * the table {1..8}P: 2P, 4P, 6P, 8P by doubling, 3P, 5P, 7P as (k-1)P + P -- no two multiples below n coincide.
 // Input points off the curve mean nothing on either side (wn26.h).  Flags are lane masks: the same instruction and address sequence
-// for every scalar and point.  The double multiplication e P + f Q of two caller points stays on the complete formulas
-// (wn26_mul2_get_dig): there the accumulator depends on both points and can meet a table entry anywhere in the loop.
+// for every scalar and point.  The double multiplication e P + f Q of two caller points (mul2_acc_aff below) has no such argument --
+// its accumulator depends on both points and can meet a table entry anywhere in the loop: it tests every addition for that and redoes
+// it with the complete formula, wave by wave (variable time, public inputs).
 //
 // K (fm26.h: |limb| <= K 2^26; a product needs K_f K_g <= 190, every limb below 2^31) is given in the comments.
 #pragma once
@@ -136,91 +138,29 @@ struct Wj26 {
     }
 
     // entries base .. base + 7 = P, 2P, ..., 8P (Jacobian), one copy of dbl and add in the instruction stream (wn26.h build_table)
-    static MA_DEV void build_table(const Pt& p, uint64_t* tab, size_t tstride) {
-        E::put(tab, tstride, 0, p);
+    static MA_DEV void build_table(const Pt& p, uint64_t* tab, size_t tstride, int base = 0) {
+        E::put(tab, tstride, base, p);
 #pragma unroll 1
         for (int k = 2; k <= 8; k++) {
             Pt t;
-            E::get(tab, tstride, (k & 1) ? k - 2 : (k >> 1) - 1, t);
+            E::get(tab, tstride, base + ((k & 1) ? k - 2 : (k >> 1) - 1), t);
             if (k & 1) {
                 Pt q;
-                E::get(tab, tstride, 0, q);             // (P from entry 0, not held across the loop: wn26.h build_table)
+                E::get(tab, tstride, base, q);          // (P from entry 0, not held across the loop: wn26.h build_table)
                 add(q, t);
             } else {
                 dbl(t);
             }
-            E::put(tab, tstride, k - 1, t);
+            E::put(tab, tstride, base + k - 1, t);
         }
     }
 
-    // R = (the scalar whose digits dig delivers) * (X : Y : Z), homogeneous on return.  The digits must be those of a scalar below n
-    // (reduce_scalar before the recoding).
-    template <class TAB, class DIG>
-    static MA_DEV void mul_acc(DIG& dig, const spint* X, const spint* Y, const spint* Z, const TAB& T, Pt& R) {
-        mul_acc_ld(dig, [=](spint* x, spint* y, spint* z) { static_for<0, 5>([&](auto I) { x[I] = X[I]; y[I] = Y[I]; z[I] = Z[I]; }); }, T, R);
-    }
-    // load(X, Y, Z) fetches the 3 x 5 limbs of the point (the kernels: from the caller's arrays, here and not above the digit recoding)
-    template <class TAB, class DIG, class LD>
-    static MA_DEV void mul_acc_ld(DIG& dig, LD load, const TAB& T, Pt& R) {
-        Pt Q;
-        {
-            spint X[5], Y[5], Z[5];
-            load(X, Y, Z);
-            E::load_point(X, Y, Z, Q);
-        }
-        // "P is the point at infinity" waits beside the digits (in LDS in the kernels: no register across the loops; and decided HERE: sunk
-        // to its first use, the comparison kept ten limbs alive across the table loop)
-        dig.park(is_zero(Q.Z) ? 1u : 0u);
-        from_projective(Q);
-        build_table(Q, T.origin(), T.stride());
-        F::set_one(R.X);
-        F::set_one(R.Y);
-        F::zero(R.Z);
-        bool rinf = true;
-#pragma unroll 1
-        for (int i = 0; i < 64; i++) {
-            const int dgt = (int)dig.window(i) - 8;                 // [-8, 7]
-            const bool neg = dgt < 0;
-            const uint32_t m = (uint32_t)(neg ? -dgt : dgt);        // 0..8
-            if (i != 0) {
-#pragma unroll 1
-                for (int j = 0; j < 4; j++) dbl(R);
-            }
-            E::template lookup<8>(T.origin(), T.stride(), 0, m, neg, Q);
-            const uint32_t pk = dig.parked();                       // read on every lane: "m == 0 ||" would be a branch on the digit
-            const bool qinf = ((m == 0) | (pk != 0)) != 0;
-            Pt S = R;
-            add(Q, S);
-            // R at infinity: the sum is Q; Q at infinity: the sum is R; both: R stays at infinity
-            static_for<0, 3>([&](auto CI) {
-                int32_t* rc = CI == 0 ? R.X : CI == 1 ? R.Y : R.Z;
-                const int32_t* sc = CI == 0 ? S.X : CI == 1 ? S.Y : S.Z;
-                const int32_t* qc = CI == 0 ? Q.X : CI == 1 ? Q.Y : Q.Z;
-                int32_t u[10];
-                F::select(rinf, sc, qc, u);
-                F::select(qinf, u, rc, rc);
-            });
-            rinf = rinf && qinf;
-        }
-        // the last digit: complete addition on homogeneous coordinates
-        {
-            const int dgt = (int)dig.window(64) - 8;
-            const bool neg = dgt < 0;
-            const uint32_t m = (uint32_t)(neg ? -dgt : dgt);
-#pragma unroll 1
-            for (int j = 0; j < 4; j++) dbl(R);
-            E::template lookup<8>(T.origin(), T.stride(), 0, m, neg, Q);
-            const uint32_t pk = dig.parked();
-            to_projective(((m == 0) | (pk != 0)) != 0, Q);
-            to_projective(rinf, R);
-            E::add(Q, R);
-        }
-    }
-    // ---- the same on an AFFINE table (wn_affine.h): the multiples of P were computed by table_of() in a kernel of their own and brought to
-    // Z = 1 by k_wn_table_affine; the window loop adds them with madd() below.  The exceptional cases are those of mul_acc_ld -- flags
-    // for an accumulator / digit at infinity, the last addition the complete MIXED one of wn26.h.
+    // ---- k P on an AFFINE table (wn_affine.h): the multiples of P are computed by table_of() in a kernel of their own and brought to
+    // Z = 1 by k_wn_table_affine; the window loop adds them with madd() below.  R = (the scalar whose digits dig delivers) * P,
+    // homogeneous on return; the digits must be those of a scalar below n (reduce_scalar before the recoding).  Flags for an
+    // accumulator / digit at infinity, the last addition the complete MIXED one of wn26.h -- the header.
     template <class LD>
-    static MA_DEV void table_of(LD load, const WnAffWs& ws, size_t t) {
+    static MA_DEV void table_of(LD load, const WnAffWs& ws, size_t t, int base = 0) {
         Pt Q;
         {
             spint X[5], Y[5], Z[5];
@@ -228,7 +168,7 @@ struct Wj26 {
             E::load_point(X, Y, Z, Q);
         }
         from_projective(Q);                                         // Z = 0 stays Z = 0 in every multiple: k_wn_table_affine flags the record
-        build_table(Q, ws.T + t, ws.m);
+        build_table(Q, ws.T + t, ws.m, base);
     }
     template <class DIG>
     static MA_DEV void mul_acc_aff(DIG& dig, const WnAffWs& ws, size_t t, Pt& R) {
@@ -280,26 +220,6 @@ struct Wj26 {
         }
     }
 
-    template <class TAB, class DIG>
-    static MA_DEV void mul_get_dig(DIG& dig, const spint* X, const spint* Y, const spint* Z, const TAB& T, uint64_t* xw, uint64_t* yw) {
-        Pt R;
-        mul_acc(dig, X, Y, Z, T, R);
-        E::affine_words(R, xw, yw);
-    }
-    // e G + f Q: f Q as above (digf: the digits of f mod n), e G through the fixed-base table with the complete mixed additions
-    template <class COMB, class TAB, class DIG>
-    static MA_DEV void mulgen2_get_dig(const uint64_t* ew, DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T,
-                                       uint64_t* xw, uint64_t* yw) {
-        Pt R;
-        mulgen2_acc<COMB>(ew, digf, QX, QY, QZ, T, R);
-        E::affine_words(R, xw, yw);
-    }
-    template <class COMB, class TAB, class DIG>
-    static MA_DEV void mulgen2_acc(const uint64_t* ew, DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T, Pt& R) {
-        mul_acc(digf, QX, QY, QZ, T, R);
-        wn26_mulgen_acc<CvNist256, COMB, false>(ew, R);
-    }
-
     // ---- e G through the fixed-base table (wn26.h wn26_mulgen_acc) with the Jacobian MIXED addition (madd-2007-bl, 7M + 4S: 1 360
     // multiply-adds against the 1 740 of the complete mixed addition).  The window digits d_i = window_i(e + sum 16 * 32^i) - 16 are taken
     // from the bottom; before window i the accumulator is s G with |s| < 0.52 * 32^i (the low windows' value) and the table point is
@@ -309,12 +229,19 @@ struct Wj26 {
     // lower digit zero, a lane flag; the sum is then the table point with Z = 1) and a zero digit (the sum is the accumulator).  Returns
     // the homogeneous (X Z : Y : Z^3).  kw: the scalar reduced mod n.
     static MA_DEV void madd(const int32_t* x2, const int32_t* y2, Pt& p) {       // in: X K <= 9, Y K <= 1, Z K <= 3; out: X K = 4, Y K = 1, Z K = 3
+        bool hz;
+        madd_h<false>(x2, y2, p, hz);
+    }
+    // HZ: also report H = 0 -- the two points have the same x: P = +-(x2, y2), where this addition fails (or an operand at infinity)
+    template <bool HZ>
+    static MA_DEV void madd_h(const int32_t* x2, const int32_t* y2, Pt& p, bool& hz) {
         int32_t z1z1[10], u2[10], s2[10], h[10], hh[10], i_[10], j[10], r[10], v[10], t[10];
         F::sqr(p.Z, z1z1);
         F::mul(x2, z1z1, u2);
         F::mul(p.Z, z1z1, t);
         F::mul(y2, t, s2);
         F::sub(u2, p.X, h);         // 10
+        if constexpr (HZ) hz = is_zero(h);
         F::sqr(h, hh);
         F::add(hh, hh, i_);
         F::add(i_, i_, i_);         // 4   I = 4 HH
@@ -358,61 +285,67 @@ struct Wj26 {
         to_projective(rinf, R);
     }
 
-    // ---- e P + f Q of two caller points.  The accumulator depends on both points, so the additions stay the complete ones of wn26.h;
-    // the DOUBLINGS have no exceptional case on a curve of odd order (Y = 0 only for a point of order two; the point at infinity stays
-    // Z = 0), so the four doublings of a window run in Jacobian coordinates between two conversions: (X : Y : Z) -> (X Z, Y Z^2, Z)
-    // and back (X Z : Y : Z^3), the point at infinity (Z = 0, tested once per window) restored as (0 : 1 : 0).  Four-bit windows on two
-    // tables of eight in a double slot: per window 4 x 927 + 2 x 1 928 + about 1 000 for the conversions, 64 windows; wn26_mul2_get_dig
-    // (three-bit windows, two tables of four) takes 3 x 1 649 + 2 x 1 928 on 86.
-    static constexpr int TABLE2_WORDS = 2 * WN26_TABLE_WORDS;
-    template <class TAB, class DIG>
-    static MA_DEV void mul2_get_dig(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
-                                    DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T, uint64_t* xw, uint64_t* yw) {
-        Pt R;
-        mul2_acc(dige, PX, PY, PZ, digf, QX, QY, QZ, T, R);
-        E::affine_words(R, xw, yw);
-    }
-    template <class TAB, class DIG>
-    static MA_DEV void mul2_acc(DIG& dige, const spint* PX, const spint* PY, const spint* PZ,
-                                DIG& digf, const spint* QX, const spint* QY, const spint* QZ, const TAB& T, Pt& R) {
-        auto cp = [](const spint* a, const spint* b, const spint* c) {
-            return [=](spint* x, spint* y, spint* z) { static_for<0, 5>([&](auto I) { x[I] = a[I]; y[I] = b[I]; z[I] = c[I]; }); };
-        };
-        mul2_acc_ld(dige, cp(PX, PY, PZ), digf, cp(QX, QY, QZ), T, R);
-    }
-    // loadP(X, Y, Z) / loadQ fetch the 3 x 5 limbs of a point when its table is about to be built (the kernel: from the caller's arrays --
-    // Q's thirty registers are then not live while P's table is built)
-    template <class TAB, class DIG, class LP, class LQ>
-    static MA_DEV void mul2_acc_ld(DIG& dige, LP loadP, DIG& digf, LQ loadQ, const TAB& T, Pt& R) {
-        Pt Q;
-        {
-            spint X[5], Y[5], Z[5];
-            loadP(X, Y, Z);
-            E::load_point(X, Y, Z, Q);
-            E::template build_table<8>(Q, T.origin(), T.stride(), 0);
-            loadQ(X, Y, Z);
-            E::load_point(X, Y, Z, Q);
-            E::template build_table<8>(Q, T.origin(), T.stride(), 8);
-        }
-        E::inf(R);
+    // ---- e P + f Q on two AFFINE tables (wn_affine.h, entries 0..7 and 8..15), the accumulator Jacobian throughout: mixed additions (1 360
+    // multiply-adds against the 1 928 of the complete one) and no conversions around the doublings.  The accumulator of a double
+    // multiplication can meet +-(table point) anywhere (Q = +-P, f = e ...), which shows as H = 0 in the mixed addition: every addition
+    // tests it, and a WAVE in which some lane has it redoes that addition with the complete mixed formula on homogeneous coordinates
+    // and takes the result for the lanes concerned.  Its instruction sequence therefore depends on the inputs -- those of a
+    // verification, public, as for the reference's own mul2 (weierstrass.c: a joint sparse form with data-dependent branches) and the
+    // Straus forms of the Edwards curves (ed26s.h).
+    template <class DIG>
+    static MA_DEV void mul2_acc_aff(DIG& dige, DIG& digf, const WnAffWs& ws, size_t t, Pt& R) {
+        const uint32_t fl = ws.flag[t];
+        F::set_one(R.X);
+        F::set_one(R.Y);
+        F::zero(R.Z);
+        bool rinf = true;
 #pragma unroll 1
         for (int i = 0; i < 65; i++) {
             if (i != 0) {
-                const bool rinf = is_zero(R.Z);
-                from_projective(R);
 #pragma unroll 1
                 for (int j = 0; j < 4; j++) dbl(R);
-                to_projective(rinf, R);
             }
 #pragma unroll 1
             for (int which = 0; which < 2; which++) {
                 const int dgt = (int)(which ? digf.window(i) : dige.window(i)) - 8;     // [-8, 7]
                 const bool neg = dgt < 0;
                 const uint32_t m = (uint32_t)(neg ? -dgt : dgt);
-                E::template lookup<8>(T.origin(), T.stride(), 8 * which, m, neg, Q);
-                E::add(Q, R);
+                int32_t sx[10], sy[10], one[10], u[10];
+                wn_affine_lookup<F>(ws, t, m, neg, sx, sy, 8 * which);
+                const bool qinf = ((m == 0) | (((fl >> which) & 1u) != 0)) != 0;
+                Pt S = R;
+                bool hz;
+                madd_h<true>(sx, sy, S, hz);
+                bool sinf = false;
+                const bool exc = hz && !rinf && !qinf;
+#if defined(__HIP_DEVICE_COMPILE__)
+                const bool some = __any(exc);
+#else
+                const bool some = exc;
+#endif
+                if (some) {                                                             // wave-uniform
+                    Pt C = R;
+                    to_projective(false, C);
+                    E::madd(sx, sy, C);                                                 // complete: the double of the point, or the point at infinity
+                    const bool cinf = is_zero(C.Z);
+                    from_projective(C);
+                    F::select(exc, S.X, C.X, S.X);
+                    F::select(exc, S.Y, C.Y, S.Y);
+                    F::select(exc, S.Z, C.Z, S.Z);
+                    sinf = exc && cinf;
+                }
+                // R at infinity: the sum is (sx, sy, 1); a zero digit or the table's point at infinity: R stays
+                F::set_one(one);
+                F::select(rinf, S.X, sx, u);
+                F::select(qinf, u, R.X, R.X);
+                F::select(rinf, S.Y, sy, u);
+                F::select(qinf, u, R.Y, R.Y);
+                F::select(rinf, S.Z, one, u);
+                F::select(qinf, u, R.Z, R.Z);
+                rinf = qinf ? rinf : sinf;
             }
         }
+        to_projective(rinf, R);
     }
 };
 

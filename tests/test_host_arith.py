@@ -203,7 +203,8 @@ def test_secp256k1_endomorphism_split_and_fused_forms_on_host(oracle, tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")
 def test_nist256_jacobian_fused_forms_on_host_against_oracle(oracle, tmp_path):
-    """csrc/wj26.h on the host (P-256 in Jacobian coordinates, exceptional cases decided by the scalar, the last addition complete)
+    """csrc/wj26.h + wn_affine.h on the host -- the kernels' pipeline for one record: P-256 in Jacobian coordinates on affine window tables,
+    exceptional cases decided by the scalar and the last addition complete (k P, e G + f Q), detected per addition (e P + f Q) --
     against the oracle's ecn mul / ecn mul2 followed by ecn get.  The scalars are chosen for the exceptional cases: n - 2m and n + 2m
     (the accumulator meets +-Q at the last digit: m = 1..8), 0, 1..17, multiples of 16 (zero last digit), n, n +- 1, 2n - 2^256 .. 2^256 - 1
     (reduced mod n first), leading zero windows (accumulator at infinity for many digits), single non-zero digits anywhere, all
@@ -250,11 +251,8 @@ def test_nist256_jacobian_fused_forms_on_host_against_oracle(oracle, tmp_path):
         p = point(kind)
         xw, yw = (U64 * 4)(), (U64 * 4)()
         lib.nist256_jac_mul_get_host(words(e), p.x, p.y, p.z, xw, yw)
-        xa, ya = (U64 * 4)(), (U64 * 4)()
-        lib.nist256_aff_mul_get_host(words(e), p.x, p.y, p.z, xa, ya)      # the affine-table pipeline (csrc/wn_affine.h) for one record
         oracle.ecn(C, "mul")(be(e), ctypes.byref(p))
         assert out_bytes(xw, yw) == affine(p), ("jacobian mul_get", it, hex(e), kind)
-        assert out_bytes(xa, ya) == affine(p), ("jacobian mul_get on the affine table", it, hex(e), kind)
     # e G on the fixed-base table with the Jacobian mixed addition: top digit 0 / 1 / 2, e = d 2^256 mod n, single digits in every window
     gscalars = scalars + [2**256 - n, 2 * (2**256 - n), (2**256 - n) + 2**255, n - 2**255, n - 2**255 + 1, 2**255 + 2**254, 3 * 2**254 - 1, 3 * 2**254, 3 * 2**254 + 1,
                           int("10" * 128, 2), int("01" * 128, 2)]
@@ -280,7 +278,7 @@ def test_nist256_jacobian_fused_forms_on_host_against_oracle(oracle, tmp_path):
         g, r = point("gen"), Pt()
         oracle.ecn(C, "mul2")(be(e), ctypes.byref(g), be(f), ctypes.byref(qq), ctypes.byref(r))
         assert out_bytes(xw, yw) == affine(r), ("jacobian mulgen2_get", it, kind, hex(e), hex(f))
-    for it in range(100):                            # e P + f Q, complete additions, doublings in Jacobian coordinates between conversions
+    for it in range(100):                            # e P + f Q: Jacobian accumulator, two affine tables, R = +-(table point) detected and redone completely
         e, f = rng.getrandbits(256), rng.getrandbits(256)
         p, qq = point("rand"), point("rand")
         if it % 8 == 1:
@@ -299,12 +297,19 @@ def test_nist256_jacobian_fused_forms_on_host_against_oracle(oracle, tmp_path):
             p, qq = point("inf"), point("inf")
         if it == 15:
             e = f = 0
+        if it in (23, 31, 39):                       # Q = P and f = n - e: the sum is the point at infinity, met as R = -Q at the last addition of a window
+            oracle.ecn(C, "cpy")(ctypes.byref(p), ctypes.byref(qq))
+            e = rng.getrandbits(255) % n
+            f = n - e
+        if it in (47, 55):                           # Q = P, e = f small: the accumulator equals the table point at the first non-zero window
+            oracle.ecn(C, "cpy")(ctypes.byref(p), ctypes.byref(qq))
+            e = f = (3, 8)[it == 55]
         xw, yw = (U64 * 4)(), (U64 * 4)()
         lib.nist256_jac_mul2_get_host(words(e), p.x, p.y, p.z, words(f), qq.x, qq.y, qq.z, xw, yw)
         r = Pt()
         oracle.ecn(C, "mul2")(be(e), ctypes.byref(p), be(f), ctypes.byref(qq), ctypes.byref(r))
         want = affine(r)
-        assert out_bytes(xw, yw) == want, ("jacobian-doubling mul2_get", it)
+        assert out_bytes(xw, yw) == want, ("jacobian mul2_get on affine tables", it)
         if it % 8 == 3:
             assert want == (be(0), be(1))
 

@@ -91,50 +91,53 @@ extern "C" void secp256k1_glv_mul2_get_host(const uint64_t* ew, const uint64_t* 
     ma::secp256k1_glv_mul2_get_dig(de, PX, PY, PZ, df, QX, QY, QZ, ma::WnTabStrided{tab, 1}, xw, yw);
 }
 
-// round 5: P-256 in Jacobian coordinates (csrc/wj26.h)
+// round 5: P-256 in Jacobian coordinates on affine window tables (csrc/wj26.h, wn_affine.h): the kernels' pipeline for ONE record -- the table
+// of the point (two for e P + f Q), the normalisation, the window loop -- then wn26.h's export
 #include "../modarith_amd/csrc/wj26.h"
-extern "C" void nist256_jac_mul_get_host(const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, uint64_t* xw, uint64_t* yw) {
-    uint64_t tab[ma::WN26_TABLE_WORDS], k[4];
+static auto nist_cp(const uint64_t* a, const uint64_t* b, const uint64_t* c) {
+    return [=](uint64_t* x, uint64_t* y, uint64_t* z) { for (int i = 0; i < 5; i++) { x[i] = a[i]; y[i] = b[i]; z[i] = c[i]; } };
+}
+static void nist_kP(const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, ma::Wj26::Pt& R) {
+    static uint64_t buf[(8 * 15 + 8 * 5) + 1];
+    ma::WnAffWs ws(buf, 1);
+    ma::Wj26::table_of(nist_cp(X, Y, Z), ws, 0);
+    ma::wn_table_affine_lane<ma::Fm26, true>(ws, 1, 1, 0);
+    uint64_t k[4];
     ma::Wj26::reduce_scalar(ew, k);
     ma::WnRegs<4, 260> dig;
     dig.init(k);
-    ma::Wj26::mul_get_dig(dig, X, Y, Z, ma::WnTabStrided{tab, 1}, xw, yw);
+    ma::Wj26::mul_acc_aff(dig, ws, 0, R);
+}
+extern "C" void nist256_jac_mul_get_host(const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, uint64_t* xw, uint64_t* yw) {
+    ma::Wj26::Pt R;
+    nist_kP(ew, X, Y, Z, R);
+    ma::Wn26<ma::CvNist256>::affine_words(R, xw, yw);
 }
 extern "C" void nist256_jac_mulgen2_get_host(const uint64_t* ew, const uint64_t* fw, const uint64_t* QX, const uint64_t* QY, const uint64_t* QZ,
                                              uint64_t* xw, uint64_t* yw) {
-    uint64_t tab[ma::WN26_TABLE_WORDS], k[4];
-    ma::Wj26::reduce_scalar(fw, k);
-    ma::WnRegs<4, 260> dig;
-    dig.init(k);
-    ma::Wj26::mulgen2_get_dig<HostCombNist256>(ew, dig, QX, QY, QZ, ma::WnTabStrided{tab, 1}, xw, yw);
+    ma::Wj26::Pt R;
+    nist_kP(fw, QX, QY, QZ, R);
+    ma::wn26_mulgen_acc<ma::CvNist256, HostCombNist256, false>(ew, R);
+    ma::Wn26<ma::CvNist256>::affine_words(R, xw, yw);
 }
 extern "C" void nist256_jac_mul2_get_host(const uint64_t* ew, const uint64_t* PX, const uint64_t* PY, const uint64_t* PZ,
                                           const uint64_t* fw, const uint64_t* QX, const uint64_t* QY, const uint64_t* QZ, uint64_t* xw, uint64_t* yw) {
-    uint64_t tab[ma::Wj26::TABLE2_WORDS];
+    static uint64_t buf[(16 * 15 + 16 * 5) + 1];
+    ma::WnAffWs ws(buf, 1, 16);
+    ma::Wj26::table_of(nist_cp(PX, PY, PZ), ws, 0, 0);
+    ma::Wj26::table_of(nist_cp(QX, QY, QZ), ws, 0, 8);
+    ma::wn_table_affine_lane<ma::Fm26, true>(ws, 1, 1, 0);
     ma::WnRegs<4, 260> de, df;
     de.init(ew);
     df.init(fw);
-    ma::Wj26::mul2_get_dig(de, PX, PY, PZ, df, QX, QY, QZ, ma::WnTabStrided{tab, 1}, xw, yw);
+    ma::Wj26::Pt R;
+    ma::Wj26::mul2_acc_aff(de, df, ws, 0, R);
+    ma::Wn26<ma::CvNist256>::affine_words(R, xw, yw);
 }
 extern "C" void nist256_jac_mulgen_get_host(const uint64_t* ew, uint64_t* xw, uint64_t* yw) {
     uint64_t k[4];
     ma::Wj26::reduce_scalar(ew, k);
     ma::Wj26::Pt R;
     ma::Wj26::mulgen_acc<HostCombNist256>(k, R);
-    ma::Wn26<ma::CvNist256>::affine_words(R, xw, yw);
-}
-
-// round 5: the affine-table pipeline of P-256 (csrc/wn_affine.h, wj26.h table_of / mul_acc_aff) for one record
-extern "C" void nist256_aff_mul_get_host(const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, uint64_t* xw, uint64_t* yw) {
-    static uint64_t buf[(8 * 15 + 8 * 5) + 1];
-    ma::WnAffWs ws(buf, 1);
-    ma::Wj26::table_of([&](uint64_t* x, uint64_t* y, uint64_t* z) { for (int i = 0; i < 5; i++) { x[i] = X[i]; y[i] = Y[i]; z[i] = Z[i]; } }, ws, 0);
-    ma::wn_table_affine_lane<ma::Fm26, true>(ws, 1, 1, 0);
-    uint64_t k[4];
-    ma::Wj26::reduce_scalar(ew, k);
-    ma::WnRegs<4, 260> dig;
-    dig.init(k);
-    ma::Wj26::Pt R;
-    ma::Wj26::mul_acc_aff(dig, ws, 0, R);
     ma::Wn26<ma::CvNist256>::affine_words(R, xw, yw);
 }
