@@ -36,6 +36,8 @@ def legs():
             out[C + "_ecn_mul2_get_fused"] = [("k_%s_mul2_straus" % low, base + "F2.o", 1, 1), ("SinkExportBE<ma::%s>, 3>" % ("P_X25519" if C == "ED25519" else "P_X448"), base + "F2.o", 1, "rounds")]
         else:
             out[C + "_ecn_mul2_get_fused"] = [("k_%s_mul2_get" % low, base + "F2.o", 1, 1), ("k_wn_export<%s, 2>" % FX, base + "F2.o", 1, "rounds")]
+            if C == "NIST256":
+                out[C + "_ecn_mul2_get_fused"] += [("k_nist256_tables(", base + "F2.o", 1, 1), ("k_wn_table_affine<ma::Fm26, true, 2>", base + "F2.o", 1, "rounds")]
         if C in ("ED25519", "ED448"):
             out[C + "_ecn_mulgen_get_fused"] = [("k_%s_mulgen<false>" % low, base + "G.o", 1, 1),
                                                 ("SinkExportBE<ma::%s>, %d>" % (("P_X25519", 4) if C == "ED25519" else ("P_X448", 3)), base + "G.o", 1, "rounds")]
