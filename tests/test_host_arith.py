@@ -192,6 +192,13 @@ def test_secp256k1_endomorphism_split_and_fused_forms_on_host(oracle, tmp_path):
         if it % 8 == 6:
             e, f = corner[it % len(corner)], corner[(it * 5) % len(corner)]
         xw, yw = (U64 * 4)(), (U64 * 4)()
+        if it in (23, 31, 39):                       # Q = P and f = n - e: the point at infinity, met as R = -Q inside the loop
+            oracle.ecn(C, "cpy")(ctypes.byref(p), ctypes.byref(qq))
+            e = rng.getrandbits(255) % n
+            f = n - e
+        if it in (47, 55):                           # Q = P, e = f small: the accumulator equals the table point at the first non-zero window
+            oracle.ecn(C, "cpy")(ctypes.byref(p), ctypes.byref(qq))
+            e = f = (3, 8)[it == 55]
         lib.secp256k1_glv_mul2_get_host(words(e), p.x, p.y, p.z, words(f), qq.x, qq.y, qq.z, xw, yw)
         r = Pt()
         oracle.ecn(C, "mul2")(be(e), ctypes.byref(p), be(f), ctypes.byref(qq), ctypes.byref(r))
@@ -343,9 +350,11 @@ def test_lazy_limb_bounds_of_the_fused_weierstrass_fields(tmp_path):
         return [rng.randint(-top, top) for _ in range(10)]
 
     fields = ((0, 2**256 - 2**224 + 2**192 + 2**96 - 1, True,
-               [(0, 13, 13, 0, 0), (0, 8, 8, 0, 0), (0, 6, 15, 0, 0), (1, 4, 0, 0, 0), (3, 13, 3, 3, 15), (3, 13, 3, 3, 6), (3, 10, 10, 6, 15), (3, 10, 2, 15, 2)]),
+               [(0, 13, 13, 0, 0), (0, 8, 8, 0, 0), (0, 6, 15, 0, 0), (1, 4, 0, 0, 0), (3, 13, 3, 3, 15), (3, 13, 3, 3, 6), (3, 10, 10, 6, 15), (3, 10, 2, 15, 2),
+                (1, 13, 0, 0, 0), (1, 12, 0, 0, 0), (0, 10, 10, 0, 0), (0, 9, 4, 0, 0), (3, 3, 13, 8, 1), (3, 4, 5, 2, 1)]),                  # last row: the Jacobian forms of csrc/wj26.h
               (1, 2**256 - 2**32 - 977, False,
-               [(0, 4, 4, 0, 0), (0, 8, 1, 0, 0), (1, 2, 0, 0, 0), (1, 4, 0, 0, 0), (3, 3, 2, 1, 3), (3, 1, 3, 2, 2), (3, 2, 3, 3, 3), (3, 2, 4, 1, 8)]))
+               [(0, 4, 4, 0, 0), (0, 8, 1, 0, 0), (1, 2, 0, 0, 0), (1, 4, 0, 0, 0), (3, 3, 2, 1, 3), (3, 1, 3, 2, 2), (3, 2, 3, 3, 3), (3, 2, 4, 1, 8),
+                (1, 5, 0, 0, 0), (0, 5, 4, 0, 0), (0, 3, 7, 0, 0), (0, 2, 5, 0, 0), (3, 4, 5, 2, 1)]))        # last row: further pairs inside the bound (a Jacobian form that was tried)
     for which, p, mont, cases in fields:
         rinv2 = pow(pow(2, 286, p), -2, p) if mont else 1
         for mode, kf, kg, ku, kv in cases:
