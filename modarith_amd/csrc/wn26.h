@@ -21,6 +21,11 @@
 // secp256k1 (a = 0, b = 7; the second Weierstrass curve of curve.py:190-198 with a 256-bit pseudo-Mersenne field) runs the
 // same scalar-multiplication code on fk26.h with the a = 0 formulas (RCB algorithms 7 and 9, weierstrass.c:120-157,
 // 189-226): 3b = 21 is a small constant, the doubling costs 6M + 2S instead of 8M + 3S + 2m_b.
+//
+// Round 5: the P-256 KERNELS run csrc/wj26.h (Jacobian coordinates on affine window tables) on top of this file's point type, complete
+// additions (last window, generator part), lookups and export; the secp256k1 kernels run this file's complete formulas under the
+// scalar split of csrc/glv26.h.  wn26_mul_get_one / wn26_mul2_get_one below remain the complete-formula statement of both curves that
+// the host checks (tools/fe_host_check.hip, tools/wn26_host.hip) hold against the oracle.
 #pragma once
 #include "fm26.h"
 #include "fk26.h"
