@@ -60,8 +60,8 @@ extern "C" int ecn_nist256_mul_get_batch(const char* e, const ma_spint* P, char*
         set_error("ecn mul_get: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
     }
-    if (workspace == nullptr || workspace_bytes < ecn_nist256_mul_get_workspace_bytes(n)) {
-        set_error("ecn mul_get: workspace too small (see ecn_nist256_mul_get_workspace_bytes)");
+    if (workspace == nullptr || (reinterpret_cast<uintptr_t>(workspace) & 7u) || workspace_bytes < ecn_nist256_mul_get_workspace_bytes(n)) {
+        set_error("ecn mul_get: workspace missing, not 8-byte aligned or too small (see ecn_nist256_mul_get_workspace_bytes)");
         return (int)hipErrorInvalidValue;
     }
     hipStream_t s = (hipStream_t)st;

@@ -72,8 +72,8 @@ extern "C" int ecn_secp256k1_mul2_get_batch(const char* e, const ma_spint* P, co
         set_error("ecn mul2_get: byte records must be 8-byte aligned");
         return (int)hipErrorInvalidValue;
     }
-    if (workspace == nullptr || workspace_bytes < ecn_secp256k1_mul2_get_workspace_bytes(n)) {
-        set_error("ecn mul2_get: workspace too small (see ecn_secp256k1_mul2_get_workspace_bytes)");
+    if (workspace == nullptr || (reinterpret_cast<uintptr_t>(workspace) & 7u) || workspace_bytes < ecn_secp256k1_mul2_get_workspace_bytes(n)) {
+        set_error("ecn mul2_get: workspace missing, not 8-byte aligned or too small (see ecn_secp256k1_mul2_get_workspace_bytes)");
         return (int)hipErrorInvalidValue;
     }
     hipStream_t s = (hipStream_t)st;
