@@ -391,6 +391,22 @@ def test_fused_rejects_bad_arguments(fx):
         Edwards("NUMS256W").mul_get(torch.zeros((1, 32), dtype=torch.uint8, device="cuda"), Edwards("NUMS256W").gen(1))
     x, y, s = Ed.mul_get(torch.zeros((0, Ed.nbytes), dtype=torch.uint8, device="cuda"), Ed.empty(0))
     assert x.shape[0] == 0
+    if C in WEIER:
+        # the Weierstrass calls live on the caller's workspace: missing, misaligned or short -> hipErrorInvalidValue and a message, nothing launched
+        from modarith_amd import _lib
+        L = _lib.load()
+        n = 100
+        e = torch.zeros((n, Ed.nbytes), dtype=torch.uint8, device="cuda")
+        P = Ed.gen(n)
+        xo, yo = torch.empty_like(e), torch.empty_like(e)
+        need = int(getattr(L, "ecn_%s_mul_get_workspace_bytes" % C)(n))
+        ws = torch.empty(need + 64, dtype=torch.uint8, device="cuda")
+        call = getattr(L, "ecn_%s_mul_get_batch" % C)
+        for wp, wb in ((None, 0), (ws.data_ptr() + 1, need), (ws.data_ptr(), need - 8)):
+            assert call(e.data_ptr(), P.data_ptr(), xo.data_ptr(), yo.data_ptr(), None, n, n, wp, wb, None) != 0
+            assert "workspace" in L.modarith_amd_last_error().decode()
+        assert call(e.data_ptr(), P.data_ptr(), xo.data_ptr(), yo.data_ptr(), None, n, n, ws.data_ptr(), need, None) == 0
+        torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("C,name,lg", [("ed25519", "ED25519", 14), ("ed448", "ED448", 12), ("nist256", "NIST256", 14), ("secp256k1", "SECP256K1", 14)])
