@@ -108,6 +108,14 @@ def main():
         doc["legs"][leg] = L
     out = os.path.join(ROOT, "profiles", "r05_valu_pmc.json")
     json.dump(doc, open(out, "w"), indent=1)
+    # the --stats summary of the same pass (newest file only: gpurun merges every pass it has seen into gpurun_out/) and the leg rates
+    import glob
+    import shutil
+    st = sorted(glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+    if st:
+        shutil.copy(st[-1], os.path.join(ROOT, "profiles", "r05_legs_kernel_stats.csv"))
+    if os.path.exists(os.path.join(SRC, "leg_rates.log")):
+        shutil.copy(os.path.join(SRC, "leg_rates.log"), os.path.join(ROOT, "profiles", "r05_leg_rates.log"))
     print("%-32s %11s %11s %6s %7s %7s %9s" % ("leg", "VALU/rec", "mad/rec", "o/mad", "st/meas", "GHz(p)", "rate"))
     for leg, L in doc["legs"].items():
         print("%-32s %11.0f %11.0f %6.2f %7.3f %7.3f %9.3e" % (leg, L["instr_per_scalar"], L["mad_per_scalar"], L["non_mad_per_mad"] or 0, L["static_over_measured"] or 0,
