@@ -111,7 +111,8 @@ def main():
     # the --stats summary of the same pass (newest file only: gpurun merges every pass it has seen into gpurun_out/) and the leg rates
     import glob
     import shutil
-    st = sorted(glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+    # (tools/gpu_profile.sh r05 writes bench.py's --stats pass into the same directory: the leg pass is the one that holds a curve kernel)
+    st = [f for f in sorted(glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime) if "k_ed_mul<" in open(f).read()]
     if st:
         shutil.copy(st[-1], os.path.join(ROOT, "profiles", "r05_legs_kernel_stats.csv"))
     if os.path.exists(os.path.join(SRC, "leg_rates.log")):
