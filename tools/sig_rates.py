@@ -33,7 +33,18 @@ def main():
     out = {"n": n}
     for name in ("NIST256", "SECP256K1"):
         C = Curve(name)
-        G = Field(name + "Q", tile=None) if name == "NIST256" else None
+        if name == "NIST256":
+            G = Field("NIST256Q", tile=None)
+        else:
+            # the build has no group-order field of secp256k1: the generator mode makes one (a plug-in compiled in seconds -- what the reference's
+            # `python3 monty.py 64 <order>` is for a new modulus, curve.py:324-329); without hipcc at hand: the curve part only
+            try:
+                from modarith_amd import generate as _gen
+                _gen.generate("SECP256K1Q=0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141", family="monty")
+                G = Field("SECP256K1Q", tile=None)
+            except Exception as ex:                                             # noqa: BLE001
+                print("secp256k1 group-order field not generated (%s): curve part only" % ex)
+                G = None
         gen = torch.Generator(device="cuda").manual_seed(7)
         rnd = lambda: torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=gen)
         prv, thm, ran = rnd(), rnd(), rnd()
