@@ -200,45 +200,63 @@ def cpu_baseline(a_host, b_host, min_seconds=6.0):
 
 
 _VALU_DOC = {}
+MAD_ISSUE_CYCLES = 4.62        # v_mad_u64_u32, cycles per wave-instruction per SIMD at 8 waves/SIMD (profiles/r05_valubench.log:15)
+SIMDS = 1024                   # 256 CUs x 4 SIMDs
+
+
+def _valu_doc():
+    """the counter summary (instructions and multiply-adds per record of every VALU-bound leg, tools/collect_valu_legs_pmc.py), the
+    algorithmic floors (tools/mad_floor.py) and the unit hashes of the library in this tree (modarith_amd/unit_hashes.json)"""
+    if "doc" not in _VALU_DOC:
+        doc, floor, now = None, {}, {}
+        for name in ("r06_valu_pmc.json", "r05_valu_pmc.json"):
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                doc = json.load(open(path))
+                doc["_source"] = "profiles/" + name
+                break
+        fpath = os.path.join(ROOT, "profiles", "mad_floor.json")
+        if os.path.exists(fpath):
+            floor = json.load(open(fpath)).get("legs", {})
+        hpath = os.path.join(ROOT, "modarith_amd", "unit_hashes.json")
+        if os.path.exists(hpath):
+            now = json.load(open(hpath))
+        _VALU_DOC.update(doc=doc, floor=floor, now=now)
+    return _VALU_DOC["doc"], _VALU_DOC["floor"], _VALU_DOC["now"]
 
 
 def valu_roofline(leg, per_s_per_gpu, sclk_GHz=None):
-    """VALU-issue roofline of a VALU-bound leg (both ladders, ecn mul / mul2, the fused curve kernels).  Instruction counts per record
-    come from the committed counter summary of THIS tree's kernels (profiles/r05_valu_pmc.json, made by tools/gpu_r05_pmc.sh +
-    tools/collect_r05_pmc.py: SQ_INSTS_VALU of one pass of every kernel of the leg / records; the v_mad_u64_u32 share of each kernel
-    from its disassembly, tools/isa_mix.py); the rate is the one measured in THIS run, and so is the shader clock (modarith_amd/clock.py:
-    a one-wave probe beside the leg reads the shader-clock counter against the wall clock).
-      achieved = records/s x wave-instructions per record (= per-lane instructions / 64 lanes)          [wave-instr/s]
-      peak     = 1024 SIMDs x clock / cost,  cost = (5.0 x mad + 2.5 x (instr - mad)) / instr            [wave-instr/s]
-    5.0 / 2.5 cycles per wave-instruction per SIMD: measured issue costs of v_mad_u64_u32 and of simple 32-bit ALU instructions
-    (profiles/r01_valubench.log).  frac_at_2.4GHz prices the leg against the nominal peak clock (a lower bound when the part clocks
-    lower under this load), frac_at_measured_clock against the clock it actually held; `frac` is the former (rounds 2-4 reported it)."""
-    if "doc" not in _VALU_DOC:
-        path = os.path.join(ROOT, "profiles", "r05_valu_pmc.json")
-        _VALU_DOC["doc"] = json.load(open(path)) if os.path.exists(path) else None
-    doc = _VALU_DOC["doc"]
+    """Integer multiply-add roofline of a VALU-bound leg (both ladders, ecn mul / mul2, the fused curve kernels): SURVEY 8(d) "the
+    meaningful ceiling is integer-MAD issue" (rfc7748.c:186-221 is nothing but field products).
+      peak  = SIMDS x clock x 64 lanes / (MAD_ISSUE_CYCLES x mad_per_scalar)      [records/s]
+      frac  = achieved records/s / peak, at the shader clock measured beside the leg (modarith_amd/clock.py)
+    mad_per_scalar: v_mad_u64_u32 per record of THIS tree's kernels (disassembly weighted by trip counts, tools/isa_mix.py, in the
+    counter summary).  Every instruction that is not a multiply-add lowers `frac`; so does a multiply-add the algorithm does not need:
+    mad_floor_per_scalar is the schoolbook count of the leg's algorithm on its limb form (profiles/mad_floor.json, tools/mad_floor.py)
+    and frac_of_floor_ceiling prices the leg against THAT count.  frac_of_mix_ceiling is the figure rounds 2-5 led with: the ceiling of
+    the kernel's own instruction mix (5.0 / 2.5 cycles per multiply-add / other instruction at 2.4 GHz) -- a scheduler-efficiency
+    figure that cannot fall when instructions are wasted; kept for comparison only."""
+    doc, floors, now = _valu_doc()
     if not doc or leg not in doc.get("legs", {}):
         return None
     L = doc["legs"][leg]
+    # were the kernels of this leg rebuilt from other sources since the counters were taken?  (None: the summary does not say)
+    was = doc.get("unit_hashes")
+    stale = any(now.get(u) != was.get(u) for u in L["units"]) if (was and now and L.get("units")) else None
     instr, mad = L["instr_per_scalar"], L["mad_per_scalar"]
     if not instr or not mad:
         return None
-    cost = (5.0 * mad + 2.5 * (instr - mad)) / instr
-    achieved = per_s_per_gpu * instr / 64.0
-    peak = 1024 * 2.4e9 / cost
-    # the same mix priced at the ARCHITECTURAL issue rates -- 16 lanes per clock for the 64-bit multiply-add (4 cycles per wave, as fp64),
-    # 32 lanes per clock for 32-bit ALU instructions (2 cycles) -- at the measured clock: a ceiling no kernel can pass, whereas the
-    # micro-benchmarked 5.0 / 2.5 (isolated streams of one instruction, profiles/r01_valubench.log, r05_valubench.log: 4.6 / 2.5) are
-    # not additive in a mix and the ladder passes them by a few per cent when the clock sits low
-    cost_arch = (4.0 * mad + 2.0 * (instr - mad)) / instr
-    out = {"bound": "valu", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s", "frac": achieved / peak,
-           "frac_at_2.4GHz": achieved / peak, "frac_at_measured_clock": (achieved / (peak * sclk_GHz / 2.4)) if sclk_GHz else None,
-           "frac_of_architectural_issue_rate_at_measured_clock": (achieved / (1024 * sclk_GHz * 1e9 / cost_arch)) if sclk_GHz else None,
-           "sclk_GHz": sclk_GHz, "instr_per_scalar": instr, "mad_per_scalar": mad, "non_mad_per_mad": (instr - mad) / mad,
-           "issue_cost_of_mix_cycles": cost, "kernels": sorted(L["kernels"]), "cycles_per_instr_at_2.4GHz": 1024 * 2.4e9 / achieved,
-           "clock_GHz_nominal": 2.4, "source": "profiles/r05_valu_pmc.json", "static_over_measured_instr": L.get("static_over_measured"),
-           "mad_only_ceiling_per_s": 1024 * 2.4e9 * 64 / (5.0 * mad)}
-    return out
+    clk = sclk_GHz or 2.4
+    peak = SIMDS * clk * 1e9 * 64 / (MAD_ISSUE_CYCLES * mad)
+    floor = floors.get(leg, {}).get("mad_floor_per_scalar")
+    mix_cost = (5.0 * mad + 2.5 * (instr - mad)) / instr
+    mix_peak = SIMDS * 2.4e9 * 64 / (mix_cost * instr)
+    return {"bound": "valu-mad", "achieved": per_s_per_gpu, "peak": peak, "unit": "records/s", "frac": per_s_per_gpu / peak,
+            "frac_at_2.4GHz": per_s_per_gpu / (peak * 2.4 / clk), "sclk_GHz": sclk_GHz, "mad_issue_cycles": MAD_ISSUE_CYCLES,
+            "mad_per_scalar": mad, "mad_floor_per_scalar": floor, "mad_over_floor": (mad / floor) if floor else None,
+            "frac_of_floor_ceiling": (per_s_per_gpu / (peak * mad / floor)) if floor else None,
+            "frac_of_mix_ceiling": per_s_per_gpu / mix_peak, "instr_per_scalar": instr, "non_mad_per_mad": (instr - mad) / mad,
+            "kernels": sorted(L["kernels"]), "source": doc["_source"], "source_stale": stale}
 
 
 def measure_traffic(timeout_s=240):
@@ -286,6 +304,86 @@ def measure_traffic(timeout_s=240):
     return {"hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024, "hbm_read_bytes_per_launch": 2 * fk * 1024, "hbm_write_bytes_per_launch": wk * 1024,
             "launches_sampled": min(out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]),
             "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this script (FETCH_SIZE doubled per the gfx950 correction)"}
+
+
+DETAIL_NAME = "bench_detail.json"
+LINE_LIMIT = 4096              # bytes: the driver's parser refused the 35 KB line of round 5 (BENCH_r05.parsed = null); r04's 15 KB passed
+
+
+def _sig(x, digits=5):
+    """floats to `digits` significant figures (the detail file keeps full precision)"""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, list):
+        return [_sig(v, digits) for v in x]
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    return x
+
+
+def detail_lines(detail):
+    """the detail dict as stdout lines that do not start with "{": one per top-level key, one per leg of the two big blocks"""
+    out = []
+    for k, v in detail.items():
+        if k in ("other_configs", "data_sets") and isinstance(v, dict):
+            out += ["# detail %s.%s: %s" % (k, kk, json.dumps(vv)) for kk, vv in v.items()]
+        else:
+            out.append("# detail %s: %s" % (k, json.dumps(v)))
+    return out
+
+
+def contract_line(d, detail_note=DETAIL_NAME):
+    """The one JSON line the driver parses, built from the detail dict: the contract keys, the HBM roofline of the headline kernel with
+    its placement fractions, the CPU baseline summary, the X25519 ladder summary, the verdict of the oracle check and where the rest
+    is.  Pure function of `d` (tests/test_bench_line.py feeds it recorded detail files); never longer than LINE_LIMIT bytes."""
+    cfg, rl, cpu, lad, ver = d["config"], d["roofline"], d.get("cpu_baseline"), d.get("x25519"), d.get("verified_against_oracle")
+    out = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = {"workload": cfg["workload"], "elements_per_gpu": cfg["elements_per_gpu"], "placement_probe_GBps": cfg["placement_probe_GBps"],
+                     "placement_policy": cfg["placement_policy"][:120]}
+    out["roofline"] = {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch",
+                                               "frac_first_placement", "frac_median_placement")}
+    out["roofline"]["traffic_source"] = ("live rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE child passes" if "measured in this run" in (rl.get("traffic_source") or "")
+                                         else (rl.get("traffic_source") or "")[:160] or None)
+    if cpu:
+        tc = cpu.get("time_c_protocol") or {}
+        words = [leg for leg in (tc.get("modmul"), tc.get("modsqr"), tc.get("modinv")) if isinstance(leg, dict)]
+        for other in (cpu.get("time_c_protocol_other_fields") or {}).values():
+            words += [leg for leg in other.values() if isinstance(leg, dict)]
+        out["cpu_baseline"] = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "cpu_quota_cores": cpu.get("cpu_quota_cores"), "kind": cpu["kind"],
+                               "compiler": (cpu.get("compiler") or "")[:60], "flags": (cpu.get("flags") or "")[:90], "sample": (cpu.get("sample") or "")[:160],
+                               "ns_per_modmul_one_core": tc.get("ns_per_modmul"),
+                               "check_words_ok": bool(words) and all(w.get("check_word") == w.get("reference_check_word") for w in words), "check_words": len(words),
+                               "x25519_scalar_mults_per_s": cpu.get("x25519_scalar_mults_per_s")}
+    else:
+        out["cpu_baseline"] = None
+    if lad:
+        lr = lad.get("roofline") or {}
+        out["x25519"] = {"value": lad["value"], "unit": lad["unit"], "scalars_per_gpu": lad["scalars_per_gpu"], "scalars_total": lad.get("scalars_total"), "scaling": lad.get("scaling"),
+                         "sclk_GHz": lad.get("sclk_GHz"), "frac_of_mad_only_ceiling": lr.get("frac"), "frac_of_floor_ceiling": lr.get("frac_of_floor_ceiling"),
+                         "frac_of_mix_ceiling": lr.get("frac_of_mix_ceiling"), "mad_per_scalar": lr.get("mad_per_scalar"), "mad_floor_per_scalar": lr.get("mad_floor_per_scalar"),
+                         "value_wall_clock_3_passes": lad.get("value_wall_clock_3_passes"), "gather_ms": lad.get("gather_ms"), "gather_GBps": lad.get("gather_GBps"),
+                         "records_sha256": lad.get("records_sha256"),
+                         "host_resident_pipelined_per_s": (lad.get("host_resident") or {}).get("end_to_end_pipelined_per_s")}
+    else:
+        out["x25519"] = None
+    out["verified_against_oracle"] = ({"all_ranks_equal_oracle": ver.get("all_ranks_equal_oracle"), "ranks_checked": ver.get("ranks_checked"),
+                                       "modmul_elements_per_rank": ver.get("modmul_elements_per_rank"), "x25519_records_per_rank": ver.get("x25519_records_per_rank")}
+                                      if ver else None)
+    sp = (d.get("rank_spread") or {}).get("modmul_per_s")
+    if d["n_gpus"] > 1 and sp:
+        out["rank_spread_modmul_per_s"] = [sp["min"], sp["mean"], sp["max"]]
+    if d.get("dist"):
+        out["dist"] = d["dist"]
+    out["detail"] = detail_note
+    out = {k: (_sig(v) if isinstance(v, (dict, list)) else v) for k, v in out.items()}      # the contract's own scalars keep full precision
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:                               # cannot happen with the bounded strings above; the contract keys survive whatever does
+        for k in ("dist", "rank_spread_modmul_per_s", "x25519", "verified_against_oracle"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) <= LINE_LIMIT:
+                break
+    return line
 
 
 def launch_ranks(n_ranks, argv):
@@ -594,7 +692,7 @@ def main():
         last_clock = [None]
 
         def vleg(key, rate):                                     # the VALU roofline of a curve leg, at the clock just measured
-            return valu_roofline(key, rate, last_clock[0]) or {"bound": "valu", "note": "no counter summary for this leg in profiles/r05_valu_pmc.json"}
+            return valu_roofline(key, rate, last_clock[0]) or {"bound": "valu-mad", "note": "no counter summary for this leg under profiles/"}
         for cname, m in (("ED25519", 1 << 20), ("ED448", 1 << 19), ("SECP256K1", 1 << 19), ("NIST256", 1 << 19)):
             Cv = Curve(cname, dev)
             e = torch.randint(0, 256, (m, Cv.nbytes), dtype=torch.uint8, device=dev, generator=gen)
@@ -751,6 +849,12 @@ def main():
         lt_all = sorted(lts)
         ladder_clock, _ = clock_during(lambda: rfc7748("X25519", k, u, out=o), lt, dev)
         barrier()
+        # the method of rounds 2-4 beside the median, so that the rounds stay comparable: wall clock over three passes between barriers
+        tw0 = time.perf_counter()
+        for _ in range(3):
+            rfc7748("X25519", k, u, out=o)
+        barrier()
+        lt_wall = (time.perf_counter() - tw0) / 3
         my_lt = lt
         gather_ms = None
         m_all = m
@@ -774,7 +878,7 @@ def main():
                 import hashlib
                 records_sha = hashlib.sha256(allv.cpu().numpy().tobytes()).hexdigest()
             del allv
-            lt, gather_ms = max_over_ranks([lt, gather_ms])
+            lt, gather_ms, lt_wall = max_over_ranks([lt, gather_ms, lt_wall])
         ladder = {"value": m_all / lt, "unit": "X25519 scalar-mults/s", "scalars_per_gpu": m, "scalars_total": m_all, "ms_per_pass": lt * 1e3,
                   "scaling": args.scaling, "shard": [lo, hi] if args.scaling == "strong" else None,
                   "records_sha256": records_sha,      # strong scaling: all results in global index order (gathered to rank 0): the same for every N
@@ -782,7 +886,7 @@ def main():
                   "gather_GBps": (m_all * 32 / (gather_ms * 1e-3) / 1e9) if gather_ms else None,
                   "gather_payload_bytes": m_all * 32 if gather_ms else None,
                   "bound": "VALU 32-bit integer multiply-add issue (not HBM)",
-                  "timing": "median of %d event-timed passes after 2 full-size warm passes" % reps, "ms_per_pass_min": lt_all[0] * 1e3, "ms_per_pass_max": lt_all[-1] * 1e3,
+                  "value_wall_clock_3_passes": m_all / lt_wall, "timing": "value: median of %d event-timed passes after 2 full-size warm passes (max over ranks); value_wall_clock_3_passes: wall clock over 3 passes between barriers (the method of rounds 2-4)" % reps, "ms_per_pass_min": lt_all[0] * 1e3, "ms_per_pass_max": lt_all[-1] * 1e3,
                   "sclk_GHz": ladder_clock, "roofline": valu_roofline("x25519", m / my_lt, ladder_clock)}
         if single:
             # public-key generation: the same function on the base point u = 9 (rfc7748.c:297-333), fixed-base kernel
@@ -928,7 +1032,7 @@ def main():
         med = sorted(probe_rates)[len(probe_rates) // 2] if probe_rates else None      # upper median of the probe rates
         if probe_rates and len(probe_rates) % 2 == 0:
             med = 0.5 * (sorted(probe_rates)[len(probe_rates) // 2 - 1] + sorted(probe_rates)[len(probe_rates) // 2])
-        out = {
+        detail = {
             "metric": "256-bit modmul/s (2^255-19)", "value": value, "unit": "modmul/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
@@ -936,7 +1040,7 @@ def main():
             "config": {"workload": "batched modmul 2^255-19, 5x51-bit limbs, 2^%d elements per GPU, limb-interleaved SoA, %s" % (LOG2_ELEMS, ("tiles of %d elements [n/%d][5][%d]" % (TILE, TILE, TILE)) if TILE else "flat rows [5][n]"),
                        "layout": {"tile": TILE, "note": "limb i of element j at buf[((j / tile) * 5 + i) * tile + j % tile]; tile = 0: flat buf[i * n + j]; data_sets.other_layout_* times the other form"},
                        "elements_per_gpu": n, "placement_probe_GBps": [round(r, 1) for r in probe_rates], "inputs": "uniform mod p: splitmix64 stream (seed 42, array id, j) reduced mod p, generated on the device",
-                       "placement_policy": ("timed on the %s of %d probed operand placements (identical contents); placement_probe_GBps lists all of them, first-allocated first" % ("fastest" if keep_best else "FIRST-allocated", placements)) if placements > 1 else "single placement, no probe",
+                       "placement_policy": ("timed on the %s of %d probed operand placements (identical contents), first-allocated first" % ("fastest" if keep_best else "FIRST-allocated", placements)) if placements > 1 else "single placement, no probe",
                        "parallelism": "independent batches, %d rank(s), no data-path collective" % world},
             # the same quantity from the placement probe (10 launches each, rank 0): median and first-allocated placement
             "value_median_placement": (med * 1e9 / BYTES_PER_MODMUL * world) if med else None,
@@ -960,7 +1064,18 @@ def main():
                             "kernel_ms": {"min": min(kms), "mean": sum(kms) / len(kms), "max": max(kms)}},
             "dist": dist_info,
         }
-        line = json.dumps(out)
+        # Everything measured goes to the detail file beside this script (MA_BENCH_DETAIL names another path) and to stdout lines that
+        # start with "# "; the LAST stdout line is the compact contract line (<= LINE_LIMIT bytes), the only line that starts with "{".
+        detail_path = os.environ.get("MA_BENCH_DETAIL") or os.path.join(ROOT, DETAIL_NAME)
+        detail_note = os.path.basename(detail_path)
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(detail, f, indent=1)
+        except OSError as ex:                                # a read-only tree must not cost the line
+            detail_note = "not written (%s); see the '# detail' lines of stdout" % type(ex).__name__
+        for dl in detail_lines(detail):
+            print(dl)
+        line = contract_line(detail, detail_note)
     # The JSON line must be the LAST thing on stdout.  RCCL writes a version banner ("RCCL version : ...", five lines) to the C
     # stdout of rank 0 when the communicator is made; redirected to a file or a pipe that buffer is flushed at exit -- after a line
     # printed from Python.  So: every rank flushes its C and Python streams, the ranks meet, the process group is torn down, the

@@ -103,12 +103,36 @@ def _compile(unit) -> str:
     return obj
 
 
+UNIT_HASHES = os.path.join(HERE, "unit_hashes.json")
+
+
+def _write_unit_hashes() -> None:
+    """modarith_amd/unit_hashes.json: per unit, 16 hex digits of the hash of its command line and of every in-tree file it was compiled
+    from.  It travels with the library (the objects do not), so that a counter summary under profiles/ can say which build it was taken
+    on and bench.py can tell when the kernels of a leg have changed since (valu_roofline: source_stale)."""
+    import json
+    out = {}
+    for _, obj_name, _ in UNITS:
+        hfile = os.path.join(OBJ, obj_name + ".hash")
+        if os.path.exists(hfile):
+            out[obj_name] = open(hfile).read()[:16]
+    with open(UNIT_HASHES, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+
+def unit_hashes() -> dict:
+    import json
+    return json.load(open(UNIT_HASHES)) if os.path.exists(UNIT_HASHES) else {}
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     emit.emit_all()
     os.makedirs(OBJ, exist_ok=True)
     stamp_file = os.path.join(OBJ, "stamp")
     stamp = _stamp()
     if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        if not os.path.exists(UNIT_HASHES):
+            _write_unit_hashes()
         return LIB
     if force:
         for f in os.listdir(OBJ):
@@ -121,6 +145,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
     with open(stamp_file, "w") as f:
         f.write(stamp)
+    _write_unit_hashes()
     if verbose:
         slow = sorted(_TIMES.items(), key=lambda kv: -kv[1])[:6]
         print("[modarith_amd] compiled %d units; slowest: " % len(_TIMES) + ", ".join("%s %.0f s" % kv for kv in slow), flush=True)

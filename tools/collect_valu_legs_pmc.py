@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise tools/gpu_r05_pmc.sh (gpurun_out/prof_r05/) into profiles/r05_valu_pmc.json: per VALU-bound leg of bench.py
-(tools/r05_legs.py) and per kernel of the leg
+"""python tools/collect_valu_legs_pmc.py <tag>: summarise tools/gpu_valu_legs_pmc.sh (gpurun_out/prof_legs/) into profiles/<tag>_valu_pmc.json: per
+VALU-bound leg of bench.py (tools/valu_legs.py) and per kernel of the leg
 
   measured  SQ_INSTS_VALU (summed over the leg's dispatches of that kernel, whole GPU) x 64 / records = VALU instructions per record;
             GRBM_GUI_ACTIVE / 8 XCDs / duration = the shader clock under the profiler; duration
@@ -12,15 +12,18 @@ and per leg the sums: instr_per_scalar (measured), mad_per_scalar (measured: SQ_
 the latter's static share), static_over_measured (how well the static count reproduces SQ_INSTS_VALU: exact where every loop's trip
 count is inferred -- the ladders, k_ed25519_lad, k_ed_mul<ED25519 / ED448> --, off where the compiler's loop form defeats the inference:
 those kernels keep their measured totals and only borrow the static SHARE of the two 64-bit classes).
-bench.py's valu_roofline() reads the leg sums."""
+bench.py's valu_roofline() reads the leg sums.  The summary records the build it was taken on: `unit_hashes` (modarith_amd/unit_hashes.json as
+it was on the GPU box) and per leg the `units` its kernels come from; bench.py flags a leg whose units have been rebuilt since (source_stale)."""
 import collections, csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import isa_mix  # noqa: E402
-from r05_legs import legs, records  # noqa: E402
+from valu_legs import legs, records  # noqa: E402
 
-SRC = os.path.join(ROOT, "gpurun_out", "prof_r05")
+SRC = os.path.join(ROOT, "gpurun_out", "prof_legs")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def dispatches(tag):
@@ -39,18 +42,22 @@ def dispatches(tag):
 def main():
     pa, pb = dispatches("pmca"), dispatches("pmcb")
     rounds_of = lambda n: max(1, min(32, (n + 65535) // 65536))
-    doc = {"command": "tools/gpu_r05_pmc.sh: rocprofv3 --pmc <set A | set B> --kernel-trace --output-format csv -- <realpath of python> tools/run_r05_legs.py",
+    uh_box = json.load(open(os.path.join(SRC, "unit_hashes.json"))) if os.path.exists(os.path.join(SRC, "unit_hashes.json")) else {}
+    from modarith_amd.build import unit_hashes
+    uh_here = unit_hashes()
+    doc = {"command": "tools/gpu_valu_legs_pmc.sh: rocprofv3 --pmc <set A | set B> --kernel-trace --output-format csv -- <realpath of python> tools/run_valu_legs.py",
+           "unit_hashes": uh_box, "objects_here_are_the_profiled_build": all(uh_here.get(k) == v for k, v in uh_box.items()) if uh_box else None,
            "interpreter": open(os.path.join(SRC, "interpreter.txt")).read().strip() if os.path.exists(os.path.join(SRC, "interpreter.txt")) else None,
            "note": "per leg: instr_per_scalar = measured SQ_INSTS_VALU x 64 / records over all kernels of the leg; mad_per_scalar = measured instructions x the "
                    "static v_mad_u64_u32 share of each kernel (tools/isa_mix.py on the profiled objects); issue-cost model 5.0 cycles per multiply-add, 2.5 per other "
                    "VALU instruction per wave and SIMD (profiles/r01_valubench.log)", "legs": {}}
     rates = {}
-    rp = os.path.join(SRC, "r05_leg_rates.json")
+    rp = os.path.join(SRC, "valu_leg_rates.json")
     if os.path.exists(rp):
         rates = json.load(open(rp))
     for leg, ks in legs().items():
         n = records(leg)
-        L = {"records": n, "kernels": {}, "instr_per_scalar": 0.0, "mad_per_scalar": 0.0, "static_valu_per_scalar": 0.0, "duration_us": 0.0}
+        L = {"records": n, "units": sorted({o[:-2] for _, o, _, _ in ks}), "kernels": {}, "instr_per_scalar": 0.0, "mad_per_scalar": 0.0, "static_valu_per_scalar": 0.0, "duration_us": 0.0}
         cyc = 0.0
         for sub, obj, per_pass, unknown in ks:
             sel = [v for (name, _), v in pa.items() if sub in name]
@@ -106,7 +113,7 @@ def main():
         if leg in rates:
             L["unprofiled"] = rates[leg]
         doc["legs"][leg] = L
-    out = os.path.join(ROOT, "profiles", "r05_valu_pmc.json")
+    out = os.path.join(ROOT, "profiles", TAG + "_valu_pmc.json")
     json.dump(doc, open(out, "w"), indent=1)
     # the --stats summary of the same pass (newest file only: gpurun merges every pass it has seen into gpurun_out/) and the leg rates
     import glob
@@ -114,9 +121,9 @@ def main():
     # (tools/gpu_profile.sh r05 writes bench.py's --stats pass into the same directory: the leg pass is the one that holds a curve kernel)
     st = [f for f in sorted(glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime) if "k_ed_mul<" in open(f).read()]
     if st:
-        shutil.copy(st[-1], os.path.join(ROOT, "profiles", "r05_legs_kernel_stats.csv"))
+        shutil.copy(st[-1], os.path.join(ROOT, "profiles", TAG + "_legs_kernel_stats.csv"))
     if os.path.exists(os.path.join(SRC, "leg_rates.log")):
-        shutil.copy(os.path.join(SRC, "leg_rates.log"), os.path.join(ROOT, "profiles", "r05_leg_rates.log"))
+        shutil.copy(os.path.join(SRC, "leg_rates.log"), os.path.join(ROOT, "profiles", TAG + "_leg_rates.log"))
     print("%-32s %11s %11s %6s %7s %7s %9s" % ("leg", "VALU/rec", "mad/rec", "o/mad", "st/meas", "GHz(p)", "rate"))
     for leg, L in doc["legs"].items():
         print("%-32s %11.0f %11.0f %6.2f %7.3f %7.3f %9.3e" % (leg, L["instr_per_scalar"], L["mad_per_scalar"], L["non_mad_per_mad"] or 0, L["static_over_measured"] or 0,

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""round 5: ONE pass of every VALU-bound leg of bench.py at a fixed size (tools/r05_legs.py), each kernel family launched exactly once
-per curve -- the target of the counter passes of tools/gpu_r05_pmc.sh.  With `--time`: no profiler, every leg event-timed
+"""ONE pass of every VALU-bound leg of bench.py at a fixed size (tools/valu_legs.py), each kernel family launched exactly once
+per curve -- the target of the counter passes of tools/gpu_valu_legs_pmc.sh.  With `--time`: no profiler, every leg event-timed
 (median of 3 after 2 warm passes) with the shader-clock probe beside it."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
-from r05_legs import LOG2, records
+from valu_legs import LOG2, records
 from modarith_amd.field import rfc7748
 from modarith_amd.edwards import Curve
 
@@ -55,5 +55,5 @@ for name in ("ED25519", "ED448", "NIST256", "SECP256K1"):
     del e, f, G, Q, e2, f2, G2, Q2
 if TIME:
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(res, open("gpurun_out/r05_leg_rates.json", "w"), indent=1)
+    json.dump(res, open("gpurun_out/valu_leg_rates.json", "w"), indent=1)
 print("done")

@@ -1,5 +1,5 @@
-"""The VALU-bound legs of bench.py and the kernels each one launches (round 5): shared by tools/run_r05_legs.py (one pass of every leg, the
-target of the counter passes), tools/collect_r05_pmc.py (counters -> profiles/r05_valu_pmc.json) and, through that file only, bench.py.
+"""The VALU-bound legs of bench.py and the kernels each one launches : shared by tools/run_valu_legs.py (one pass of every leg, the
+target of the counter passes), tools/collect_valu_legs_pmc.py (counters -> profiles/<tag>_valu_pmc.json) and, through that file only, bench.py.
 A kernel entry: (substring of the demangled kernel name, object file glob under modarith_amd/build, records per pass of the kernel
 body: 1 unless a lane handles several records per outer iteration, loops without a compile-time trip count: "rounds" = the shared
 inversions' per-lane element count, else 1)."""
@@ -47,7 +47,7 @@ def legs():
 
 
 def records(leg):
-    """records one pass of tools/run_r05_legs.py hands to the leg"""
+    """records one pass of tools/run_valu_legs.py hands to the leg"""
     if leg in ("x25519", "x448"):
         return 1 << LOG2[leg]
     C = leg.split("_")[0]
