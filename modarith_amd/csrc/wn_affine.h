@@ -8,7 +8,8 @@
 // The table is per RECORD of a chunk, not per resident lane: T[entry][word][record] (wn26.h's put / get with the record count as the
 // stride), 15 words per entry while it is projective, the first 10 (x, y) after k_wn_table_affine; C holds the prefix products of the
 // shared inversion, flag[record] = "P is the point at infinity" (then every multiple is, and the window kernels never use the
-// entries).  1 284 bytes per record (2 564 with two tables) for at most WNAFF_CHUNK records.  Pipeline per chunk: the table kernel of the curve (wj26.h) ->
+// entries).  An entry with Z = 0 counts as 1 in the shared inversion in BOTH passes, whatever the flag says: a record whose point is
+// not on the curve cannot disturb the records it shares an inversion with.  1 284 bytes per record (2 564 with two tables) for at most WNAFF_CHUNK records.  Pipeline per chunk: the table kernel of the curve (wj26.h) ->
 // k_wn_table_affine -> the window kernel -> wn_export.h.
 //
 // JAC = true: entries are Jacobian (x = X / Z^2, y = Y / Z^3); false: homogeneous (x = X / Z, y = Y / Z).
@@ -81,7 +82,14 @@ MA_DEV void wn_table_affine_lane(const WnAffWs& ws, size_t L, int R, size_t j) {
         if (t >= ws.m) continue;                                    // (counted as 1 above: nothing to undo)
         int32_t zi[10], x[10];
         ws.load<F>(e, 2, t, z);
-        const bool z0 = ((ws.flag[t] >> (e >> 3)) & 1u) != 0;       // the point at infinity: every multiple is
+        // the SAME test as on the way up, entry by entry: what counted as 1 there must count as 1 here.  flag[t] only says that entry 0 /
+        // entry 8 is at infinity; an input off the curve -- (x, 0, Z != 0): its doubling has Z3 = 2 Y Z = 0 -- has Z = 0 in entries 2P, 4P,
+        // 6P, 8P alone, and taking their Z = 0 into `inv` here zeroed the tables of every record EARLIER in this lane's column (round-5
+        // advisor: one unvalidated public key in a verification batch spoiled up to three other records).  A record off the curve still
+        // means nothing itself; it no longer touches its neighbours.
+        uint64_t zw[4];
+        F::to_words(z, zw);
+        const bool z0 = (zw[0] | zw[1] | zw[2] | zw[3]) == 0;
         F::select(z0, z, one, z);
         if (g > 0) {
             const int ep = (g - 1) % ne;

@@ -268,6 +268,41 @@ def test_fused_ladder_and_straus_forms_cross_their_chunk_boundary():
     assert torch.equal(x, wx) and torch.equal(y, wy)
 
 
+def test_fused_p256_point_off_the_curve_leaves_its_neighbours_alone():
+    """round-5 advisor (csrc/wn_affine.h): the affine window tables of P-256 share one inversion between the entries of up to four
+    records of a lane's column.  A point off the curve with Y = 0 has Z = 0 in its entries 2P, 4P, 6P, 8P (Z3 = 2 Y Z) but not in entry
+    P: the way up counted those entries as 1, the way down multiplied them in as 0 and zeroed the tables of every EARLIER record of the
+    column -- in a verification batch one unvalidated public key spoiled other users' results.  Records off the curve placed second and
+    third in their columns: every other record must equal the call-by-call form, in all three fused forms that build such tables."""
+    import torch
+    from modarith_amd.edwards import Curve
+    W = Curve("NIST256")
+    nb = W.nbytes
+    n = (1 << 17) + 100                                     # one chunk; three records per column (ne = 8), two with two tables (ne = 16)
+    gen = torch.Generator(device="cuda").manual_seed(1906)
+    rnd = lambda m: torch.randint(0, 256, (m, nb), dtype=torch.uint8, device="cuda", generator=gen)
+    e, f = rnd(n), rnd(n)
+    P = W.mul(rnd(n), W.gen(n))
+    Q = W.mul(rnd(n), W.gen(n))
+    L3, L2 = (n + 2) // 3, (n + 1) // 2
+    bad = sorted({L3 + 5, 2 * L3 + 7, L2 + 5, L2 + 11, n - 1})
+    for j in bad:
+        P[1, :, j] = 0                                      # (x, 0, Z): not on the curve (the group has odd order: no point has y = 0)
+    keep = torch.ones(n, dtype=torch.bool, device="cuda")
+    keep[torch.tensor(bad, device="cuda")] = False
+    x, y, _ = W.mul_get(e, P)
+    wx, wy, _ = W.get(W.mul(e, P.clone()))
+    assert torch.equal(x[keep], wx[keep]) and torch.equal(y[keep], wy[keep])
+    assert int((x[keep] != 0).any(dim=1).sum()) > n - 10    # (and the neighbours are real points, not the zeros the bug left behind)
+    x, y, _ = W.mulgen2_get(e, f, P)
+    wx, wy, _ = W.get(W.mul2(e, W.gen(n), f, P))
+    assert torch.equal(x[keep], wx[keep]) and torch.equal(y[keep], wy[keep])
+    for A, B in ((P, Q), (Q, P)):                            # the bad points in the first table, then in the second
+        x, y, _ = W.mul2_get(e, A, f, B)
+        wx, wy, _ = W.get(W.mul2(e, A, f, B))
+        assert torch.equal(x[keep], wx[keep]) and torch.equal(y[keep], wy[keep])
+
+
 @pytest.mark.parametrize("name", ["NIST256", "SECP256K1"])
 def test_fused_weierstrass_export_crosses_its_chunk_boundary(name):
     """round 5: the fused Weierstrass kernels hand (X : Y : Z) to an inversion shared by up to 32 records (csrc/wn_export.h) and work

@@ -322,6 +322,47 @@ def test_nist256_jacobian_fused_forms_on_host_against_oracle(oracle, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc (host compile of the HIP headers)")
+def test_nist256_affine_table_ignores_a_neighbour_off_the_curve(oracle, tmp_path):
+    """csrc/wn_affine.h (round-5 advisor): two records in one lane's column share an inversion.  With (x, 0, Z != 0) -- off the curve,
+    entries 2P, 4P, 6P, 8P have Z = 0 while entry P has not -- as the SECOND record, the first record's affine table must be what it is
+    next to an ordinary neighbour (before the fix: 64 of its 64 x / y words came out different, all zero); flag(bad) stays 0."""
+    import ctypes
+    import random
+    so = str(tmp_path / "libwn26_host.so")
+    cc = HIPCC if os.path.exists(HIPCC) else "hipcc"
+    subprocess.run([cc, "-O2", "-std=c++17", "-w", "-shared", "-fPIC", "--offload-host-only", os.path.join(ROOT, "tools", "wn26_host.hip"), "-o", so],
+                   check=True, timeout=900)
+    lib = ctypes.CDLL(so)
+    C = "nist256"
+    Pt, nb = oracle.ed[C]
+    rng = random.Random(84)
+
+    def rand_point():
+        p = Pt()
+        oracle.ecn(C, "gen")(ctypes.byref(p))
+        oracle.ecn(C, "mul")(rng.getrandbits(256).to_bytes(32, "big"), ctypes.byref(p))
+        return p
+
+    def table(p, q):
+        t, fl = (ctypes.c_uint64 * 80)(), (ctypes.c_uint32 * 2)()
+        lib.nist256_affine_table_pair_host(p.x, p.y, p.z, q.x, q.y, q.z, t, fl)
+        return list(t), list(fl)
+
+    for _ in range(4):
+        good, other, bad = rand_point(), rand_point(), rand_point()
+        for k in range(5):
+            bad.y[k] = 0
+        want, fl = table(good, other)
+        assert fl == [0, 0] and any(want)
+        got, fl = table(good, bad)
+        assert fl == [0, 0]
+        assert got == want
+        inf = Pt()
+        oracle.ecn(C, "inf")(ctypes.byref(inf))
+        got, fl = table(good, inf)                            # (the documented case: a neighbour at infinity, flag bit 0)
+        assert fl == [0, 1] and got == want
+
+
 def test_lazy_limb_bounds_of_the_fused_weierstrass_fields(tmp_path):
     """fm26.h / fk26.h at the limb magnitudes wn26.h lets them reach (|limb| <= K 2^26 with the K of the comments there):
     products, squarings and two-product reductions of worst-case operands (all limbs at +-(K 2^26 - 1), alternating signs,

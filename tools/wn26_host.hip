@@ -108,6 +108,20 @@ static void nist_kP(const uint64_t* ew, const uint64_t* X, const uint64_t* Y, co
     dig.init(k);
     ma::Wj26::mul_acc_aff(dig, ws, 0, R);
 }
+// the affine table (8 entries x 10 words: x, y) of record 0 when it shares its inversion with record 1 (m = 2 records in one lane's
+// column: L = 1, R = 2) -- tests/test_host_arith.py puts a point off the curve next to a good one
+extern "C" void nist256_affine_table_pair_host(const uint64_t* X0, const uint64_t* Y0, const uint64_t* Z0, const uint64_t* X1, const uint64_t* Y1,
+                                               const uint64_t* Z1, uint64_t* table0, uint32_t* flags) {
+    static uint64_t buf[2 * (8 * 15 + 8 * 5) + 2];
+    ma::WnAffWs ws(buf, 2);
+    ma::Wj26::table_of(nist_cp(X0, Y0, Z0), ws, 0);
+    ma::Wj26::table_of(nist_cp(X1, Y1, Z1), ws, 1);
+    ma::wn_table_affine_lane<ma::Fm26, true>(ws, 1, 2, 0);
+    for (int e = 0; e < 8; e++)
+        for (int k = 0; k < 10; k++) table0[e * 10 + k] = ws.T[(size_t)(e * 15 + k) * 2 + 0];
+    flags[0] = ws.flag[0];
+    flags[1] = ws.flag[1];
+}
 extern "C" void nist256_jac_mul_get_host(const uint64_t* ew, const uint64_t* X, const uint64_t* Y, const uint64_t* Z, uint64_t* xw, uint64_t* yw) {
     ma::Wj26::Pt R;
     nist_kP(ew, X, Y, Z, R);
