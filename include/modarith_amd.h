@@ -109,6 +109,7 @@ int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbi
 #define MODARITH_AMD_ABI 1
 
 /* One block of declarations per prime.  Reference emitters cited once here:
+ *   prop     pseudo.py:223-251 / monty.py:352-380
  *   flatten  pseudo.py:255-269    modfsb pseudo.py:272-283     modadd pseudo.py:286-304
  *   modsub   pseudo.py:307-326    modneg pseudo.py:329-348     modmli pseudo.py:705-728 / monty.py:876-978
  *   modmul   pseudo.py:616-659 / monty.py:663-872              modsqr pseudo.py:663-702 / monty.py:982-1165
@@ -128,6 +129,7 @@ int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbi
  */
 #define MODARITH_AMD_DECLARE(P)                                                                                         \
     /* ---------------- scalar form: reference signatures, host pointers ---------------- */                            \
+    ma_spint prop_##P##_ct(ma_spint *n);        /* static in field.c; exported so that all 32 emitted names exist */    \
     ma_spint flatten_##P##_ct(ma_spint *n);                                                                             \
     ma_spint modfsb_##P##_ct(ma_spint *n);                                                                              \
     void modadd_##P##_ct(const ma_spint *a, const ma_spint *b, ma_spint *n);                                            \
@@ -182,6 +184,7 @@ int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbi
     /* in place; flag (device int[n], may be NULL) receives the return value per element */                            \
     int modfsb_##P##_batch(ma_spint *a, int *flag, size_t n, size_t ld, void *stream);                                  \
     int flatten_##P##_batch(ma_spint *a, int *flag, size_t n, size_t ld, void *stream);                                 \
+    int prop_##P##_batch(ma_spint *a, int *flag, size_t n, size_t ld, void *stream);     /* flag: -1 / 0 (the mask) */   \
     int modhaf_##P##_batch(ma_spint *a, size_t n, size_t ld, void *stream);                                             \
     int modshl_##P##_batch(unsigned int k, ma_spint *a, size_t n, size_t ld, void *stream);                             \
     int modshr_##P##_batch(unsigned int k, ma_spint *a, int *out, size_t n, size_t ld, void *stream);                   \

@@ -56,6 +56,7 @@ _SIG = {
     "modnsqr": [_P, c_int, c_size_t, c_size_t, _P],
     "modfsb": [_P, _P, c_size_t, c_size_t, _P],
     "flatten": [_P, _P, c_size_t, c_size_t, _P],
+    "prop": [_P, _P, c_size_t, c_size_t, _P],
     "modhaf": [_P, c_size_t, c_size_t, _P],
     "modshl": [c_uint, _P, c_size_t, c_size_t, _P],
     "modshr": [c_uint, _P, _P, c_size_t, c_size_t, _P],
@@ -77,7 +78,7 @@ _SIG = {
 }
 BATCH_FUNCS = tuple(_SIG)
 # scalar (_ct) names declared by the header, for the symbol-export test
-SCALAR_FUNCS = ("flatten", "modfsb", "modadd", "modsub", "modneg", "modmli", "modmul", "modsqr", "modcpy", "modnsqr",
+SCALAR_FUNCS = ("prop", "flatten", "modfsb", "modadd", "modsub", "modneg", "modmli", "modmul", "modsqr", "modcpy", "modnsqr",
                 "modpro", "modinv", "modqr", "modsqrt", "nres", "redc", "modis1", "modis0", "modzer", "modone", "modint", "modcmv",
                 "modcsw", "modshl", "modshr", "modhaf", "mod2r", "modexp", "modimp", "modsign", "modcmp")
 UTIL_FUNCS = ("modarith_amd_abi_version", "modarith_amd_last_error", "modarith_amd_device_count",

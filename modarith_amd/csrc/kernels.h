@@ -428,7 +428,7 @@ __global__ __launch_bounds__(BLOCK) void k_cond(const int* d, spint* g, spint* f
 }
 
 // in-place normalisers / predicates; KIND selects the function, optional int result per element
-enum { K_MODFSB = 0, K_FLATTEN, K_MODIS1, K_MODIS0, K_MODSIGN, K_MODHAF, K_MODQR, K_MODLIMBS };
+enum { K_MODFSB = 0, K_FLATTEN, K_MODIS1, K_MODIS0, K_MODSIGN, K_MODHAF, K_MODQR, K_MODLIMBS, K_PROP };
 template <class P, int KIND>
 __global__ __launch_bounds__(BLOCK) void k_inplace(spint* a, int* out, size_t n, Ld ld) {
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += (size_t)gridDim.x * BLOCK) {
@@ -438,6 +438,7 @@ __global__ __launch_bounds__(BLOCK) void k_inplace(spint* a, int* out, size_t n,
         bool wr = false;
         if constexpr (KIND == K_MODFSB) { r = (int)Field<P>::modfsb(x[0]); wr = true; }
         if constexpr (KIND == K_FLATTEN) { r = (int)Field<P>::flatten(x[0]); wr = true; }
+        if constexpr (KIND == K_PROP) { r = (int)Field<P>::prop(x[0]); wr = true; }        // the mask: -1 (all ones) or 0
         if constexpr (KIND == K_MODIS1) r = Field<P>::modis1(x[0]);
         if constexpr (KIND == K_MODIS0) r = Field<P>::modis0(x[0]);
         if constexpr (KIND == K_MODSIGN) r = Field<P>::modsign(x[0]);

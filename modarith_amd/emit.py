@@ -585,6 +585,65 @@ def comb_edwards_header_text(name: str) -> str:
     return "\n".join(L)
 
 
+# the 32 function names of a generated field.c in emitted order (pseudo.py:1413-1445 functions(), monty.py:1885-1917)
+FIELD_C_NAMES = ("prop", "flatten", "modfsb", "modadd", "modsub", "modneg", "modmli", "modmul", "modsqr", "modcpy", "modnsqr", "modpro", "modinv",
+                 "nres", "redc", "modis1", "modis0", "modzer", "modone", "modint", "modqr", "modcmv", "modcsw", "modsqrt", "modshl", "modshr",
+                 "modhaf", "mod2r", "modexp", "modimp", "modsign", "modcmp")
+INCLUDE_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+
+
+def field_shim_text(fp: FieldParams, tag: str = None) -> str:
+    """include/field_<PRIME>.h: what a consumer includes where the reference says "paste field.c here" (rfc7748.c:24-28,
+    edwards.c:19-23 @field@, weierstrass.c:16-20, edge.c:5-9): the macro block at the top of the generated field.c
+    (pseudo.py:1388-1411, monty.py:1859-1882) with this driver's values, and the 32 undecorated names of pseudo.py:1413-1445
+    mapped onto the library's <fn>_<PRIME>_ct entry points (the names decoration=True gives them, pseudo.py:1940-1944)."""
+    tag = tag or fp.name
+    L = ["/* include/field_%s.h -- EMITTED by modarith_amd/emit.py field_shim_text(); do not edit." % tag,
+         " *",
+         " * Put  #include \"field_%s.h\"  where the reference's templates say \"paste field.c here\" (rfc7748.c:24-28," % tag,
+         " * edwards.c:19-23 @field@, weierstrass.c:16-20, edge.c:5-9; automated there by curve.py:335-351) and link",
+         " * libmodarith_amd.so%s: the template's calls modmul(a, b, c) ... then run" % ("" if tag in BUILT_PRIMES else " and the field's plug-in"),
+         " * on the GPU one element at a time (host pointers, the reference's signatures and aliasing rules; a bring-up path --",
+         " * throughput comes from the <fn>_%s_batch entry points of modarith_amd.h)." % tag,
+         " * prime %s = %s, %s" % (fp.name, hex(fp.p), "monty.py form" if fp.montgomery else "pseudo.py form"),
+         " */",
+         "#ifndef MODARITH_AMD_FIELD_%s_H" % tag,
+         "#define MODARITH_AMD_FIELD_%s_H" % tag,
+         "#include <stdio.h>",
+         "#include <stdint.h>",
+         '#include "modarith_amd.h"',
+         "MODARITH_AMD_DECLARE(%s)" % tag if tag not in BUILT_PRIMES else "/* (modarith_amd.h declares the %s entry points) */" % tag,
+         "",
+         "#define sspint int64_t",
+         "#define spint uint64_t",
+         "#define dpint __uint128_t",
+         "#define sdpint __int128_t",
+         "#define Wordlength 64",
+         "#define Nlimbs %d" % fp.nlimbs,
+         "#define Radix %d" % fp.radix,
+         "#define Nbits %d" % fp.n,
+         "#define Nbytes %d" % fp.nbytes,
+         ""]
+    if fp.montgomery:
+        L.append("#define MONTGOMERY")
+        if fp.name[0].isalpha():
+            L.append("#define %s" % fp.name.upper())
+        if fp.trin > 0:
+            L.append("#define MULBYINT")
+    else:
+        L += ["#define MERSENNE", "#define MULBYINT"]
+        if fp.name[0].isalpha():
+            L.append("#define %s" % fp.name)
+    L.append("")
+    L += ["#define %s %s_%s_ct" % (fn, fn, tag) for fn in FIELD_C_NAMES]
+    L += ["", "#endif", ""]
+    return "\n".join(L)
+
+
+def emit_field_shims(primes=CORE_PRIMES, out_dir: str = INCLUDE_DIR) -> List[str]:
+    return [_write(os.path.join(out_dir, "field_%s.h" % name), field_shim_text(derive(name))) for name in primes]
+
+
 def emit_all(primes=BUILT_PRIMES, out_dir: str = GEN_DIR) -> List[str]:
     os.makedirs(out_dir, exist_ok=True)
     paths = [_write(os.path.join(out_dir, "field_table.inc"), field_table_text(primes))]
@@ -611,6 +670,8 @@ def emit_all(primes=BUILT_PRIMES, out_dir: str = GEN_DIR) -> List[str]:
             with open(path, "w") as f:
                 f.write(text)
         paths.append(path)
+    if out_dir == GEN_DIR:
+        paths += emit_field_shims()
     return paths
 
 

@@ -307,6 +307,13 @@ class Field:
         self._call("flatten", a.data_ptr(), flag.data_ptr(), n, self._ld(a), _stream(self.device))
         return flag
 
+    def prop(self, a):
+        """in place (pseudo.py:223-251); returns the per-element mask as int32: -1 where the top limb went negative, else 0."""
+        n = self._chk(a)
+        flag = self._ints(n)
+        self._call("prop", a.data_ptr(), flag.data_ptr(), n, self._ld(a), _stream(self.device))
+        return flag
+
     def modhaf(self, a):
         n = self._chk(a)
         self._call("modhaf", a.data_ptr(), n, self._ld(a), _stream(self.device))

@@ -145,6 +145,8 @@ def generate(prime: str, wl: int = 64, family: Optional[str] = None, name: Optio
     obj, lib, meta = os.path.join(d, "capi_%s.o" % tag), plugin_path(tag, d), os.path.join(d, "%s.json" % tag)
     key = _key(fp, tag)
     emit._write(hdr, emit.header_text(fp))
+    # the paste-marker shim of this field, next to its plug-in: what a consumer includes where the reference says "paste field.c here"
+    emit._write(os.path.join(d, "field_%s.h" % tag), emit.field_shim_text(fp, tag))
     emit._write(unit, emit.capi_unit_text(tag).replace('"../capi_prime.inc"', '"capi_prime.inc"'))
     from .build import ARCH, HIPCC
     cmd = [HIPCC] + _flags() + ["-c", unit]
