@@ -552,7 +552,7 @@ def main():
     def rate(fn, reps=20, warm=3, warm_ms=60.0):
         # >= 3 warm-up launches AND >= 60 ms of them: the side legs are separated by host work (allocations, input
         # generation, a plug-in load), during which the part drops its clocks; the first 20-40 streaming launches after such a gap
-        # run 2-5 % slower while they ramp back (tools/chain_dvfs.py, profiles/r04_chain_dvfs.log: every kernel, not one in
+        # run 2-5 % slower while they ramp back (profiles/history/r04_chain_dvfs.log: every kernel, not one in
         # particular), and three launches of 0.3 ms do not cover that.  Kernels of tens of ms per launch get their three.
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -666,7 +666,8 @@ def main():
     # parity for them is in tests/; these are side figures, not the headline
     if not args.no_others and single:
         for P, ops in (("NIST256", ("modmul",)), ("X448", ("modmul", "modsqr"))):
-            Fp = Field(P, dev, tile=TILE or None)
+            # the tile size the library recommends for the field's shape (round 6: 8192 for the 8-limb X448, profiles/r06_tile_shape_sweep.log)
+            Fp = Field(P, dev, tile=(Field(P, dev).recommended_tile(n) if "MA_BENCH_TILE" not in os.environ else (TILE or None)))
             # uniform in [0,p) by the same recipe, then nres (Montgomery form)
             xa = Fp.uniform(n, seed=SEED, array=AID + 2)
             xb = Fp.uniform(n, seed=SEED, array=AID + 3)
@@ -684,7 +685,7 @@ def main():
                                              "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms,
                                              "control": "modadd" if op == "modmul" else "modcpy", "control_GBps": nbytes / (cms * 1e-3) / 1e9,
                                              "frac_of_control": cms / ms,
-                                             "inputs": "uniform mod p (splitmix64 recipe), nres'd"}
+                                             "tile": Fp.tile, "inputs": "uniform mod p (splitmix64 recipe), nres'd"}
             del xa, xb, xc
         # the curve layer built on the path, one pass each: side figures (VALU-bound kernels)
         from modarith_amd.edwards import Curve
@@ -710,7 +711,7 @@ def main():
 
             def timed_leg(fn, reps=3, warm=2):
                 # median of `reps` calls, each between HIP events, after `warm` full-size calls: the first launches after a host-side
-                # pause run 3-13 % slower while the part brings its clocks back (tools/ecn_sustained.py: 2.67, 2.93, 3.08, 3.17 ...
+                # pause run 3-13 % slower while the part brings its clocks back (profiles/history/r04_ecn_sustained.log: 2.67, 2.93, 3.08, 3.17 ...
                 # e7/s for P-256), and a single wall-clock call -- what this block timed until the end of round 4 -- reads exactly that.
                 # One further call runs with the shader-clock probe beside it (modarith_amd/clock.py): last_clock[0] = GHz during the leg.
                 t, ghz, out = timed_with_clock(fn, reps=reps, warm=warm)

@@ -68,6 +68,12 @@ const char *modarith_amd_last_error(void);
  * A caller of the reference's void signatures polls this where field.c's caller would have had nothing to check. */
 int modarith_amd_status(void);
 void modarith_amd_clear_status(void);
+/* the same for the CALLING THREAD alone: the first error its own scalar calls have recorded since its last clear (a thread that shares
+ * the process with others checks this one).  A failed scalar call launches nothing; it zero-fills its pure outputs, leaves operands
+ * that are also inputs (modnsqr(a, n), modmul(z, e, z), ecn dbl) as they were, and its predicates (modis0 modis1 modsign modcmp modqr
+ * modimp, ecn cmp / isinf / get) answer -1 instead of the reference's 0 / 1. */
+int modarith_amd_thread_status(void);
+void modarith_amd_clear_thread_status(void);
 int modarith_amd_device_count(void);
 int modarith_amd_set_device(int dev);
 int modarith_amd_malloc(void **dptr, size_t bytes);
@@ -90,6 +96,9 @@ int modarith_amd_soa_to_aos(const ma_spint *soa, ma_spint *aos, size_t n, int nl
  * the batch holds two of them, else flat rows: the TILED note above), and the number of 64-bit words a batch of n elements of
  * nlimbs limbs occupies with stride ld (flat: nlimbs*ld; tiled: ceil(n/ld) whole tiles) */
 size_t modarith_amd_recommended_ld(size_t n);
+/* ... with the shape of the field (round 6, profiles/r06_tile_shape_sweep.log): 8192 for elements of eight or more limbs once the batch
+ * holds two such tiles, else as above */
+size_t modarith_amd_recommended_ld_for(size_t n, int nlimbs);
 size_t modarith_amd_batch_words(size_t n, int nlimbs, size_t ld);
 /* the library's stream-ordered scratch (the split form of rfc7748_<C>_batch, in-place modinv_<P>_batch) caches up to 1.25 GiB per
  * device between calls; scratch_trim gives what is cached beyond keep_bytes on the current device back to the driver */
@@ -106,7 +115,16 @@ const char *modarith_amd_last_launch(void);
 /* per-prime macro block of field.c (pseudo.py:1403-1407): returns 0 if `prime` is unknown */
 int modarith_amd_field_info(const char *prime, int *nlimbs, int *radix, int *nbits, int *nbytes, int *montgomery);
 
-#define MODARITH_AMD_ABI 1
+/* ABI history.  No entry point has changed its signature or meaning since ABI 1; the number moves when a caller built against an older
+ * header could see different behaviour from an unchanged call:
+ *   1  rounds 1-5.
+ *   2  round 6.  (a) *_workspace_bytes(n) values differ from earlier builds (round 5: the P-256 fused forms grew to 0.67-1.5 GB for
+ *      their per-record window tables; round 6: ecn_ed25519 / ed448_mul2_get add 127 bytes of alignment slack): ask the function of
+ *      THIS library before every allocation, never keep a size across library versions.  (b) A caller workspace may sit at any
+ *      address; the library rounds it up itself (round 5 fell back to its own pool without a word when ecn_*_mul2_get got an
+ *      unaligned one).  (c) prop_<PRIME>_ct / _batch added.  (d) A failed scalar call leaves in/out operands untouched (see
+ *      modarith_amd_status). */
+#define MODARITH_AMD_ABI 2
 
 /* One block of declarations per prime.  Reference emitters cited once here:
  *   prop     pseudo.py:223-251 / monty.py:352-380
@@ -413,7 +431,7 @@ int ecn_ed25519_mul_get_batch(const char *e, const ma_spint *P, char *x, char *y
 /* R = e*P + f*Q and its affine export in one kernel: ecnXXXmul2 followed by ecnXXXget, the verification pattern
  * (ed448.c:305, nist256.c:251-254); same conventions as mul_get, P and Q are not modified.  ed25519 / ed448 (round 5): a Straus
  * walk over signed 4-bit windows whose table entries are read BY INDEX (variable time like the reference's own mul2: public
- * inputs); the workspace -- 128-byte aligned -- holds the table slabs of the resident grid (302 / 604 MB) and 140 / 236 bytes per
+ * inputs); the workspace (any address: the size reported includes the slack for the 128-byte alignment of the table lines) holds the table slabs of the resident grid (302 / 604 MB) and 140 / 236 bytes per
  * record for at most 2^20 records; NULL takes the library's scratch pool. */
 size_t ecn_ed25519_mul2_get_workspace_bytes(size_t n);
 int ecn_ed25519_mul2_get_batch(const char *e, const ma_spint *P, const char *f, const ma_spint *Q, char *x, char *y, int *sign,

@@ -85,8 +85,8 @@ UTIL_FUNCS = ("modarith_amd_abi_version", "modarith_amd_last_error", "modarith_a
               "modarith_amd_set_device", "modarith_amd_malloc", "modarith_amd_free", "modarith_amd_memcpy_h2d",
               "modarith_amd_memcpy_d2h", "modarith_amd_sync", "modarith_amd_aos_to_soa", "modarith_amd_soa_to_aos",
               "modarith_amd_stream_create", "modarith_amd_stream_destroy", "modarith_amd_stream_wait", "modarith_amd_host_alloc", "modarith_amd_host_free",
-              "modarith_amd_field_info", "modarith_amd_recommended_ld", "modarith_amd_batch_words", "modarith_amd_scratch_trim",
-              "modarith_amd_last_launch", "modarith_amd_status", "modarith_amd_clear_status", "modarith_amd_sclk_probe", "modarith_amd_wall_clock_khz")
+              "modarith_amd_field_info", "modarith_amd_recommended_ld", "modarith_amd_recommended_ld_for", "modarith_amd_batch_words", "modarith_amd_scratch_trim",
+              "modarith_amd_last_launch", "modarith_amd_status", "modarith_amd_clear_status", "modarith_amd_thread_status", "modarith_amd_clear_thread_status", "modarith_amd_sclk_probe", "modarith_amd_wall_clock_khz")
 
 
 def _declare_curve(lib, C: str) -> None:
@@ -193,6 +193,8 @@ def load() -> ctypes.CDLL:
     lib.modarith_amd_host_free.argtypes = [_P]
     lib.modarith_amd_recommended_ld.argtypes = [c_size_t]
     lib.modarith_amd_recommended_ld.restype = c_size_t
+    lib.modarith_amd_recommended_ld_for.argtypes = [c_size_t, c_int]
+    lib.modarith_amd_recommended_ld_for.restype = c_size_t
     lib.modarith_amd_batch_words.argtypes = [c_size_t, c_int, c_size_t]
     lib.modarith_amd_batch_words.restype = c_size_t
     lib.modarith_amd_scratch_trim.argtypes = [c_size_t]

@@ -24,7 +24,7 @@ LIB = os.path.join(HERE, "libmodarith_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 # -amdgpu-codegenprepare-mul24=0: the IR-level 24-bit-multiply formation of this compiler miscompiles the fused split-product
-# chains of C2065 (4 x 52-bit limbs; wrong for every lane, right at -O0, right with this switch: tools/diag_fast_chain.py);
+# chains of C2065 (4 x 52-bit limbs; wrong for every lane, right at -O0, right with this switch; found in round 3 by comparing the two product policies lane by lane);
 # the DAG-level mul24 selection stays on.  Measured cost on the VALU-bound kernels: see DESIGN.md.
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-codegenprepare-mul24=0"]
 # (source unit, object name, extra flags).  Every curve unit is compiled three times (MA_CURVE_PART, capi_curve.inc):

@@ -50,7 +50,7 @@ extern "C" int ecn_ed25519_mul_get_batch(const char* e, const ma_spint* P, char*
     hipStream_t s = (hipStream_t)st;
     EdLadScratch ws(workspace, workspace_bytes, ed26l_workspace_bytes(n), 8, s);
     if (!ws.p) {
-        set_error("ecn mul_get: no workspace (pass ecn_ed25519_mul_get_workspace_bytes(n) bytes; the library's own scratch pool is not available while the stream is being captured)");
+        set_error(std::string("ecn mul_get: no usable workspace -- " + std::string(ws.why) + " (pass ecn_ed25519_mul_get_workspace_bytes(n) bytes; the library's own scratch pool is not available while the stream is being captured)"));
         return (int)hipErrorInvalidValue;
     }
     const unsigned char* eb = reinterpret_cast<const unsigned char*>(e);

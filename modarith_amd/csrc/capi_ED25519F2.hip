@@ -67,10 +67,12 @@ static size_t straus_waves(size_t n) {
     return w < cap ? w : cap;
 }
 
-extern "C" size_t ecn_ed25519_mul2_get_workspace_bytes(size_t n) {
+static size_t mul2_get_net_bytes(size_t n) {
     const size_t m = n < EDLAD_CHUNK ? n : EDLAD_CHUNK;
     return straus_waves(m) * STRAUS_SLAB_BYTES_PER_WAVE + ed26l_workspace_bytes(n);
 }
+// (+ 127: the table slab wants 128-byte alignment, EdLadScratch rounds the caller's pointer up)
+extern "C" size_t ecn_ed25519_mul2_get_workspace_bytes(size_t n) { return mul2_get_net_bytes(n) + 127; }
 
 extern "C" int ecn_ed25519_mul2_get_batch(const char* e, const ma_spint* P, const char* f, const ma_spint* Q, char* x, char* y, int* sign,
                                           size_t n, size_t ld, void* workspace, size_t workspace_bytes, void* st) {
@@ -80,9 +82,9 @@ extern "C" int ecn_ed25519_mul2_get_batch(const char* e, const ma_spint* P, cons
         return (int)hipErrorInvalidValue;
     }
     hipStream_t s = (hipStream_t)st;
-    EdLadScratch wsp(workspace, workspace_bytes, ecn_ed25519_mul2_get_workspace_bytes(n), 128, s);
+    EdLadScratch wsp(workspace, workspace_bytes, mul2_get_net_bytes(n), 128, s);
     if (!wsp.p) {
-        set_error("ecn mul2_get: no workspace (pass ecn_ed25519_mul2_get_workspace_bytes(n) bytes, 128-byte aligned; the library's own scratch pool is not available while the stream is being captured)");
+        set_error(std::string("ecn mul2_get: no usable workspace -- " + std::string(wsp.why) + " (pass ecn_ed25519_mul2_get_workspace_bytes(n) bytes; the library's own scratch pool is not available while the stream is being captured)"));
         return (int)hipErrorInvalidValue;
     }
     const unsigned char *eb = reinterpret_cast<const unsigned char*>(e), *fb = reinterpret_cast<const unsigned char*>(f);

@@ -146,7 +146,7 @@ extern "C" int ecn_ed448_mulgen2_get_batch(const char* e, const char* f, const m
     hipStream_t s = (hipStream_t)st;
     EdLadScratch ws(workspace, workspace_bytes, ed28l_workspace_bytes(n), 8, s);
     if (!ws.p) {
-        set_error("ecn mulgen2_get: no workspace (pass ecn_ed448_mulgen2_get_workspace_bytes(n) bytes; the library's own scratch pool is not available while the stream is being captured)");
+        set_error(std::string("ecn mulgen2_get: no usable workspace -- " + std::string(ws.why) + " (pass ecn_ed448_mulgen2_get_workspace_bytes(n) bytes; the library's own scratch pool is not available while the stream is being captured)"));
         return (int)hipErrorInvalidValue;
     }
     const unsigned char *eb = reinterpret_cast<const unsigned char*>(e), *fb = reinterpret_cast<const unsigned char*>(f);

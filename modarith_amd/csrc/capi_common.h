@@ -43,6 +43,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 void fail(const char* what, hipError_t e);
 int sticky_status();
 void clear_sticky_status();
+int thread_status();            // the same per calling thread: what THIS thread's scalar calls have recorded
+void clear_thread_status();
 
 // staging area for the scalar (_ct) entry points: one small device buffer PER DEVICE, each guarded by its own mutex (scalar calls on
 // different devices do not serialise each other)
@@ -61,6 +63,12 @@ struct StageBase {
     unsigned char* base = nullptr;
     size_t used = 0;
     bool bad = false;
+    // host ranges this call has uploaded FROM: when the call fails, a result that would land on one of them (an in-place operand,
+    // modmul(z2, E, z2)) is left as it is -- only pure outputs are zero-filled (round-5 advisor: a failed modnsqr / ecn dbl zeroed its input)
+    struct Src { const unsigned char* p; size_t b; } src[8];
+    int nsrc = 0;
+    // a predicate's answer: -1, not the reference's 0 / 1, when the call failed
+    int answer(int r) const { return bad ? -1 : r; }
     StageBase();
     void* take(size_t bytes);
     void h2d(void* d, const void* h, size_t b);
@@ -70,14 +78,22 @@ struct StageBase {
 void* scratch_alloc(size_t bytes, hipStream_t s);   // stream-ordered scratch from the library's own pool; nullptr if unavailable
 void scratch_free(void* p, hipStream_t s);
 
-// the caller's workspace when it is large enough, else stream-ordered scratch of the library's own pool (released in stream order when
-// this object goes); p = nullptr when neither is to be had (a stream under capture and no caller workspace)
+// the caller's workspace when it holds `need` bytes behind its next `align`-aligned address (the pointer is rounded up HERE: a workspace
+// function whose kernels want more than 8-byte alignment reports need + align - 1, and any pointer will do), else stream-ordered scratch of
+// the library's own pool (released in stream order when this object goes); p = nullptr when neither is to be had (a stream under capture
+// and no usable caller workspace): `why` then says what was wrong with the caller's
 struct EdLadScratch {
     void* p = nullptr;
     void* own = nullptr;
     hipStream_t s;
+    const char* why = "no caller workspace";
     EdLadScratch(void* workspace, size_t workspace_bytes, size_t need, size_t align, hipStream_t s_) : s(s_) {
-        if (workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & (align - 1)) == 0) { p = workspace; return; }
+        if (workspace) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(workspace), up = (a + align - 1) & ~(uintptr_t)(align - 1);
+            if (workspace_bytes >= need + (size_t)(up - a)) { p = reinterpret_cast<void*>(up); return; }
+            why = workspace_bytes >= need ? "the caller's workspace is too small once its address is rounded up to the required alignment"
+                                          : "the caller's workspace is too small";
+        }
         p = own = scratch_alloc(need, s);
     }
     ~EdLadScratch() { if (own) scratch_free(own, s); }

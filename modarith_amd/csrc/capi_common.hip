@@ -67,10 +67,15 @@ bool ladder_use_field() {
 }
 
 static std::atomic<int> g_sticky{0};
+static thread_local int t_sticky = 0;
+int thread_status() { return t_sticky; }
+void clear_thread_status() { t_sticky = 0; }
 void fail(const char* what, hipError_t e) {
     set_error(std::string(what) + " failed: " + hipGetErrorString(e));
     int zero = 0;
-    g_sticky.compare_exchange_strong(zero, e == hipSuccess ? (int)hipErrorUnknown : (int)e);
+    const int code = e == hipSuccess ? (int)hipErrorUnknown : (int)e;
+    g_sticky.compare_exchange_strong(zero, code);
+    if (t_sticky == 0) t_sticky = code;
     (void)hipGetLastError();
 }
 int sticky_status() { return g_sticky.load(); }
@@ -106,6 +111,7 @@ void* StageBase::take(size_t bytes) {
     return d;
 }
 void StageBase::h2d(void* d, const void* h, size_t b) {
+    if (nsrc < 8) src[nsrc++] = Src{static_cast<const unsigned char*>(h), b};
     if (bad) return;
     hipError_t e = hipMemcpy(d, h, b, hipMemcpyHostToDevice);
     if (e != hipSuccess) { fail("hipMemcpy(h2d)", e); bad = true; }
@@ -117,6 +123,9 @@ void StageBase::d2h(void* h, const void* d, size_t b) {
         fail("hipMemcpy(d2h)", e);
         bad = true;
     }
+    const unsigned char* hp = static_cast<const unsigned char*>(h);
+    for (int i = 0; i < nsrc; i++)
+        if (hp < src[i].p + src[i].b && src[i].p < hp + b) return;         // also an input of this call: untouched
     memset(h, 0, b);
 }
 void StageBase::check(int rc, const char* what) {
@@ -202,7 +211,7 @@ static __global__ __launch_bounds__(BLOCK) void k_soa2aos(const spint* soa, spin
 // The same conversions through LDS, for 16-byte-aligned buffers, even strides and up to 14 limbs: a workgroup of 256 lanes moves
 // a chunk of 512 elements.  Both sides of the transposition then run as whole 16-byte-per-lane coalesced accesses -- the SoA rows
 // two elements per lane, the chunk's AoS image (512 * nlimbs consecutive words) as one linear stretch -- instead of one side
-// striding nlimbs words from lane to lane (soa->aos 2.8 -> TB/s class; tools/time_convert.py).  LDS image: sh[e * S + i] with
+// striding nlimbs words from lane to lane (soa->aos 2.8 -> TB/s class; profiles/history/r03_elementwise_and_converters.log).  LDS image: sh[e * S + i] with
 // S = nlimbs | 1 words per element (an odd pitch keeps the strided side at two-way bank conflicts).
 constexpr int CONV_CHUNK = 512;
 template <bool TO_SOA>
@@ -325,6 +334,8 @@ const char* modarith_amd_last_error(void) { return g_err.c_str(); }
 const char* modarith_amd_last_launch(void) { return g_last_launch; }
 int modarith_amd_status(void) { return sticky_status(); }
 void modarith_amd_clear_status(void) { clear_sticky_status(); }
+int modarith_amd_thread_status(void) { return thread_status(); }
+void modarith_amd_clear_thread_status(void) { clear_thread_status(); }
 int modarith_amd_wall_clock_khz(void) {
     int d = 0, khz = 0;
     if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -340,6 +351,14 @@ int modarith_amd_scratch_trim(size_t keep_bytes) { return scratch_trim(keep_byte
 // the limb stride a caller without a layout of its own should use (include/modarith_amd.h, TILED): tiles of 4096 elements once
 // the batch holds two of them, flat rows below
 size_t modarith_amd_recommended_ld(size_t n) { return n >= 2 * (size_t)4096 ? (size_t)4096 : n; }
+// the same with the shape of the field: 8-limb (and longer) elements stream best on tiles of 8192 -- at 2^24 elements the median of 24
+// operand placements is 0.808 / 0.823 of the HBM peak (modsqr / modmul of X448) against 0.801 / 0.821 on 4096, and the slow placements are
+// one in 24 instead of three or four; 5-limb fields keep 4096 (0.801 / 0.809 against 0.792 / 0.804); 16384 is worse for both
+// (profiles/r06_tile_shape_sweep.log).  No tile size moves the slow placements themselves (0.74-0.78): they belong to the memory system.
+size_t modarith_amd_recommended_ld_for(size_t n, int nlimbs) {
+    const size_t t = nlimbs >= 8 ? (size_t)8192 : (size_t)4096;
+    return n >= 2 * t ? t : modarith_amd_recommended_ld(n);
+}
 size_t modarith_amd_batch_words(size_t n, int nlimbs, size_t ld) {
     if (nlimbs < 1 || ld == 0) return 0;
     if (ld >= n) return (size_t)nlimbs * ld;                       // flat

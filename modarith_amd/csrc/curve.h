@@ -22,6 +22,18 @@ MA_DEV int scalar(int i) {
 #endif
     return i;
 }
+// ---- the limb contract of the scalar-multiplication kernels (round 6).  The reference's ecnXXXmul over the pasted field.c returns
+// DEFINED limbs for every 64-bit limb pattern (edwards.c:435-482: its products wrap at 128 bits, nothing else happens).  The classes
+// the kernels are built from are narrower: the FAST products of Field<P, true> and the resident half-limb forms (fh51.h: a limb of
+// 2^58 loses its top bits at load; fh56.h) equal the reference for limbs inside the budget 2^(Radix+2) that every field function's
+// output keeps (kernels.h in_limb_budget) and not beyond.  The kernels therefore take the vote OpMulAuto takes (kernels.h:117-124) at
+// point load, per wave and pass: a wave with a limb beyond the budget leaves its points untouched; a second launch, built from the EXACT
+// class of the same curve (Field<P, false>: the reference's rows for all inputs), takes the same vote and computes exactly those passes.  No legitimate point -- nothing a field or curve function returns -- ever takes the second path.
+template <class F> struct field_is_exact : std::false_type {};                         // resident forms: never
+template <class P, bool PIN> struct field_is_exact<Field<P, false, PIN>> : std::true_type {};
+template <class P, bool PIN> struct field_is_exact<Field<P, true, PIN>> : std::integral_constant<bool, !Field<P, true, PIN>::FAST && !Field<P, true, PIN>::SPLIT4> {};
+template <class Crv> struct exact_class;                                               // the same curve on Field<P, false>: edwards.h, weierstrass.h
+
 template <class Crv, class P_, class F_ = Field<P_, true>>
 struct CurveOps {
     using P = P_;
@@ -219,7 +231,7 @@ struct CurveOps {
     // w[k] = (bit_k(3e) - bit_k(e)) + 3 (bit_k(3f) - bit_k(f)) in {-4..4}, table W = {O, P, Q-P, Q, Q+P}, R = O, and from the first
     // non-zero digit down to k = 1: R = 2R, then R += W[w] or R -= W[-w].  Same field calls in the same order, hence the reference's
     // projective limbs -- and, like the reference ("not constant time"), a walk that depends on the scalars: lanes of a wave start
-    // at different digits and skip different additions, so the wave pays for the union of their paths (measured: 4-18 % slower than mul2 above, tools/time_mul2.py).
+    // at different digits and skip different additions, so the wave pays for the union of their paths (measured in round 3: 4-18 % slower than mul2 above).
     // jsf_digits() produces the digits from the top by shifting e, 3e, f, 3f left one bit per step and packs them, biased by 4, two
     // per byte into the lane's LDS column (4*NB+4 bytes) BEFORE any point is loaded: the four multi-word shift registers (up to 72
     // VGPRs for the 521-bit field) are dead by the time the walk starts.
@@ -301,6 +313,16 @@ struct CurveOps {
         });
         F::from_limbs(x, p.x); F::from_limbs(y, p.y); F::from_limbs(z, p.z);
     }
+    // every limb of point j inside the budget the field functions of this class are exact for?  (3 N loads that the load proper hits in L2)
+    static MA_DEV bool limbs_ok(const spint* Pb, size_t ld, size_t j) {
+        bool ok = true;
+        static_for<0, 3>([&](auto C) {
+            spint v[N];
+            static_for<0, N>([&](auto I) { v[I] = Pb[((size_t)(C * N + I)) * ld + j]; });
+            ok = ok & in_limb_budget<P>(v);                 // (&, not &&: one vote per pass is the only branch this makes)
+        });
+        return ok;
+    }
     static MA_DEV void store(spint* Pb, size_t ld, size_t j, const Point& p) {
         spint x[N], y[N], z[N];
         F::to_limbs(p.x, x); F::to_limbs(p.y, y); F::to_limbs(p.z, z);
@@ -318,10 +340,21 @@ struct CurveOps {
 #ifndef MA_MUL_WPS
 #define MA_MUL_WPS 2
 #endif
+// GUARD (the limb contract, see the top of this file): 0 = the class is exact for every limb pattern, no vote; +1 = the fast class: a
+// pass in which some lane's point has a limb beyond the budget is skipped, its points left as they are; -1 = the exact class, launched
+// behind it on the same batch: it takes the same vote and computes exactly the passes that have such a point.  It sees the fast
+// kernel's OUTPUTS where ecn mul worked in place, and votes them inside the budget -- as every output of a field function is (the
+// invariant the whole library rests on; modlimbs / Curve.limbs_ok test it) -- so no pass is computed twice and none is left out.
+// The vote is on the POINT's limbs; no scalar bit ever reaches a branch (tools/ct_allowlist.json).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MA_WAVE_ALL(x) __all(x)
+#else
+#define MA_WAVE_ALL(x) (x)
+#endif
 // One wave per workgroup; the workgroup's LDS holds the recoded scalars of its 64 lanes (CurveOps::recode), the workspace slab
 // blockIdx.x its window tables.
-template <class Crv>
-__global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul(const unsigned char* e, spint* Pb, size_t n, size_t ld, spint* ws) {
+template <class Crv, int GUARD = 0>
+__global__ __launch_bounds__(64, (GUARD < 0 ? 2 : MA_MUL_WPS)) void k_ed_mul(const unsigned char* e, spint* Pb, size_t n, size_t ld, spint* ws) {
     using E = Crv;
     // the LDS of a CU (160 KB on gfx950) must hold the digit arrays of all its resident workgroups (4 SIMDs x MA_MUL_WPS waves), for the
     // double multiplications too (two / JSF arrays per workgroup): ADVICE of round 4
@@ -333,6 +366,9 @@ __global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul(const unsigned char* 
     // (W.here(): the lane number as a fresh value), so no 64-bit index or address stays in VGPRs across the multiplication
     for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
         if (base + W.here() >= n) continue;
+        if constexpr (GUARD != 0) {
+            if ((MA_WAVE_ALL(E::limbs_ok(Pb, ld, base + W.here())) != 0) != (GUARD > 0)) continue;
+        }
         {
             spint ew[E::NW];
             load_be_record<typename E::P>(e, base + W.here(), ew);         // big-endian byte record -> little-endian words
@@ -345,8 +381,8 @@ __global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul(const unsigned char* 
     }
 }
 
-template <class Crv>
-__global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul2(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, spint* Rb,
+template <class Crv, int GUARD = 0>
+__global__ __launch_bounds__(64, (GUARD < 0 ? 2 : MA_MUL_WPS)) void k_ed_mul2(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, spint* Rb,
                                                 size_t n, size_t ld, spint* ws) {
     using E = Crv;
     __shared__ signed char digs[2 * E::NDIG * 64];
@@ -355,6 +391,10 @@ __global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul2(const unsigned char*
     signed char* df = de + E::NDIG * 64;
     for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
         if (base + W.here() >= n) continue;
+        if constexpr (GUARD != 0) {
+            const bool ok = ((int)E::limbs_ok(Pb, ld, base + W.here()) & (int)E::limbs_ok(Qb, ld, base + W.here())) != 0;
+            if ((MA_WAVE_ALL(ok) != 0) != (GUARD > 0)) continue;
+        }
         {
             spint ew[E::NW];
             load_be_record<typename E::P>(e, base + W.here(), ew);
@@ -374,8 +414,8 @@ __global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul2(const unsigned char*
     }
 }
 
-template <class Crv>
-__global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul2x(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, spint* Rb,
+template <class Crv, int GUARD = 0>
+__global__ __launch_bounds__(64, (GUARD < 0 ? 2 : MA_MUL_WPS)) void k_ed_mul2x(const unsigned char* e, const spint* Pb, const unsigned char* f, const spint* Qb, spint* Rb,
                                                  size_t n, size_t ld, spint* ws) {
     using E = Crv;
     __shared__ unsigned char digs[E::JSF_BYTES * 64];
@@ -383,6 +423,10 @@ __global__ __launch_bounds__(64, MA_MUL_WPS) void k_ed_mul2x(const unsigned char
     unsigned char* dj = digs + threadIdx.x;
     for (size_t base = (size_t)blockIdx.x * 64; base < n; base += (size_t)gridDim.x * 64) {
         if (base + W.here() >= n) continue;
+        if constexpr (GUARD != 0) {
+            const bool ok = ((int)E::limbs_ok(Pb, ld, base + W.here()) & (int)E::limbs_ok(Qb, ld, base + W.here())) != 0;
+            if ((MA_WAVE_ALL(ok) != 0) != (GUARD > 0)) continue;
+        }
         {
             spint ew[E::NW], fw[E::NW];
             load_be_record<typename E::P>(e, base + W.here(), ew);

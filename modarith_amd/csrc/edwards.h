@@ -170,5 +170,6 @@ struct Edwards : CurveOps<Edwards<C, F_>, typename C::FieldParams, F_> {
     }
 
 };
+template <class C, class F_> struct exact_class<Edwards<C, F_>> { using type = Edwards<C, Field<typename C::FieldParams, false>>; };   // curve.h "the limb contract"
 
 }  // namespace ma

@@ -108,7 +108,7 @@ template <class P> MA_DEV bool in_limb_budget(const spint* a) {
     constexpr bool fold52 = !P::MONTGOMERY && P::EPM && !P::OVERFLOW && P::RADIX == 52 && P::N == 5 && P::MM < (1ull << 16) && P::SPLIT == 0;
     if constexpr (fold52) {
         bool ok = true;
-        static_for<0, P::N>([&](auto I) { ok = ok && a[I] <= ~(spint)0 / (spint)P::MM; });
+        static_for<0, P::N>([&](auto I) { ok = ok & (a[I] <= ~(spint)0 / (spint)P::MM); });      // (&: no short-circuit branch per limb)
         return ok;
     } else {
         return in_split_contract<P>(a);

@@ -267,5 +267,6 @@ struct Weierstrass : CurveOps<Weierstrass<C, F_>, typename C::FieldParams, F_> {
         }
     }
 };
+template <class C, class F_> struct exact_class<Weierstrass<C, F_>> { using type = Weierstrass<C, Field<typename C::FieldParams, false>>; };   // curve.h "the limb contract"
 
 }  // namespace ma

@@ -225,7 +225,7 @@ class Edwards:
     def mul2(self, e, P, f, Q, exact: bool = False):
         """R = e*P + f*Q (ecnXXXmul2, edwards.c:486-510); returns a new batch.  Default: two fixed-window multiplications sharing
         their doublings (constant time, no lane divergence) -- the reference's point in another projective representative.
-        exact=True: the reference's own walk over its joint sparse form -- the reference's limbs, variable time, 4-18 % slower (tools/time_mul2.py)."""
+        exact=True: the reference's own walk over its joint sparse form -- the reference's limbs, variable time, 4-18 % slower (docs/curve_layer.md 4.5)."""
         n = self._chk(P, Q)
         R = torch.empty_like(P)
         ws = self._workspace(n)

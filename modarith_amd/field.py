@@ -116,6 +116,12 @@ class Field:
         return cls(_gen.generate(prime, **kw).tag, device, tile)
 
     # ------------------------------------------------------------------ buffers
+    def recommended_tile(self, n: int) -> Optional[int]:
+        """the tile size modarith_amd_recommended_ld_for(n, Nlimbs) names for a batch of n elements of this field (None: flat rows) --
+        `Field(P, tile=Field(P).recommended_tile(n))`; the object's own default stays 4096 for every field"""
+        t = int(self.lib.modarith_amd_recommended_ld_for(n, self.N))
+        return t if t < n else None
+
     def creates_tiled(self, n: int) -> bool:
         """whether a batch of n elements made by this object is tiled: at least two whole tiles and nothing left over (a
         torch tensor of whole tiles cannot say how many elements of a partial last tile are meant; such sizes stay flat --

@@ -378,7 +378,7 @@ class Chain:
              "        " + " ".join("spint v%d[EPT][P::N];" % i for i in range(nv))]
         if getattr(self, "aos_multi", self.nin * 512 * (N | 1) * 8 <= 65536):
             # one LDS image per input array while they fit 64 KB: every array's loads are issued before the first barrier
-            # (measured against one shared image, tools/aos_exp.py: X25519 0.577 -> 0.517 ms, X448 1.089 -> 1.038 ms)
+            # (measured against one shared image in round 3: X25519 0.577 -> 0.517 ms, X448 1.089 -> 1.038 ms)
             L = [l.replace("__shared__ spint sh[CH * SP];", "__shared__ spint sh[%d * CH * SP];" % self.nin) for l in L]
             L += ["        __syncthreads();"]
             L += ["        aos_load(A.in[%d] + c0 * (size_t)P::N, cnt, sh + %d * CH * SP);" % (i, i) for i in range(self.nin)]

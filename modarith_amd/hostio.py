@@ -8,7 +8,7 @@ uploaded while chunk i is computed and chunk i-1 is downloaded.  Everything here
 reference for a plain-C caller.  Host arrays must be page-locked (`PinnedArray`) for
 the copies to be asynchronous.
 
-Measured (tools/pcie_rate.py, 2^24 elements of 2^255-19, Gen5 x16): 33.5 ms with 2^19-element chunks against 35.5 ms
+Measured (round 2, 2^24 elements of 2^255-19, Gen5 x16): 33.5 ms with 2^19-element chunks against 35.5 ms
 for upload-all / compute / download-all -- on this platform uploads and downloads do not run concurrently (the two
 directions together move ~60 GB/s, one direction's rate), so the gain of pipelining is the bounded device footprint
 (two slots of three chunk buffers instead of three full arrays), not time."""

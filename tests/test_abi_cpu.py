@@ -67,7 +67,7 @@ def test_field_info_matches_driver(lib):
         fp = derive(P)
         assert [v.value for v in vals] == [fp.nlimbs, fp.radix, fp.n, fp.nbytes, int(fp.montgomery)]
     assert lib.modarith_amd_field_info(b"NOPE", None, None, None, None, None) == 0
-    assert lib.modarith_amd_abi_version() == 1
+    assert lib.modarith_amd_abi_version() == 2
 
 
 def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
@@ -150,7 +150,8 @@ def test_last_launch_and_scratch_trim_are_callable_without_a_gpu(lib):
 def test_scalar_entry_points_record_device_errors_instead_of_aborting():
     """Up to round 4 a scalar _ct call whose staging buffer could not be made (no device, no memory) called abort() inside the shared
     library.  Now it records the failure -- modarith_amd_last_error() for the thread, the sticky modarith_amd_status() for the
-    process --, launches nothing and hands back zero-filled outputs.  Here: no GPU at all (a child process, so that a regression
+    process, modarith_amd_thread_status() for the calling thread --, launches nothing, hands back zero-filled PURE outputs, leaves
+    operands that are also inputs as they were (round 6: modnsqr(a, n), modmul(z, e, z)), and its predicates answer -1.  Here: no GPU at all (a child process, so that a regression
     that aborts fails this test instead of ending the test run)."""
     import subprocess
     import sys
@@ -171,16 +172,23 @@ L.modis0_X25519_ct.restype = ctypes.c_int
 r = L.modis0_X25519_ct(a)
 bk = (ctypes.c_char * 32)(); bv = (ctypes.c_char * 32)(*([b"x"] * 32))
 L.rfc7748_X25519(bk, bk, bv)
-print("status", st, "c", list(c), "pred", r, "bv", bytes(bv) == bytes(32), "msg", msg)
+z = U(7, 7, 7, 7, 7)
+L.modmul_X25519_ct(z, b, z)                      # output aliases an input: untouched
+L.modnsqr_X25519_ct(a, 3)                        # in place: untouched
+L.modarith_amd_thread_status.restype = ctypes.c_int
+ts = L.modarith_amd_thread_status()
+print("status", st, "c", list(c), "pred", r, "bv", bytes(bv) == bytes(32), "z", list(z), "a", list(a), "thread", ts == st, "msg", msg)
 L.modarith_amd_clear_status()
-assert L.modarith_amd_status() == 0
+L.modarith_amd_clear_thread_status()
+assert L.modarith_amd_status() == 0 and L.modarith_amd_thread_status() == 0
 ''' % ROOT
     env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, (p.returncode, p.stdout[-500:], p.stderr[-2000:])
     out = p.stdout.strip().splitlines()[-1]
     assert out.startswith("status ") and int(out.split()[1]) != 0, out
-    assert "c [0, 0, 0, 0, 0]" in out and "pred 0" in out and "bv True" in out and "staging" in out, out
+    assert "c [0, 0, 0, 0, 0]" in out and "pred -1" in out and "bv True" in out and "staging" in out, out
+    assert "z [7, 7, 7, 7, 7]" in out and "a [1, 2, 3, 4, 5]" in out and "thread True" in out, out
 
 
 def test_fused_workspace_sizes_are_bounded(lib):
@@ -198,5 +206,6 @@ def test_fused_workspace_sizes_are_bounded(lib):
         assert lib.ecn_ed25519_mul_get_workspace_bytes(n) == 140 * m == lib.ecn_ed25519_mulgen2_get_workspace_bytes(n)
         assert lib.ecn_ed448_mul_get_workspace_bytes(n) == 236 * m == lib.ecn_ed448_mulgen2_get_workspace_bytes(n)
         waves = min((m + 63) // 64, 2048)
-        assert lib.ecn_ed25519_mul2_get_workspace_bytes(n) == waves * 64 * 18 * 128 + 140 * m
-        assert lib.ecn_ed448_mul2_get_workspace_bytes(n) == waves * 64 * 18 * 256 + 236 * m
+        # (+ 127: the table slab is aligned to 128 bytes INSIDE the workspace, whatever address the caller passes -- round 6)
+        assert lib.ecn_ed25519_mul2_get_workspace_bytes(n) == waves * 64 * 18 * 128 + 140 * m + 127
+        assert lib.ecn_ed448_mul2_get_workspace_bytes(n) == waves * 64 * 18 * 256 + 236 * m + 127

@@ -195,6 +195,76 @@ def test_exact_mul2_against_the_oracle_on_mixed_waves(oracle, name):
     assert W.cmp(W.mul2(rec(es), P.clone(), rec(fs), Q.clone()), R).cpu().tolist() == [1] * n
 
 
+@pytest.mark.parametrize("name", ["ED25519", "ED448", "NIST256", "SECP256K1", "NUMS256E", "NIST521"])
+def test_points_beyond_the_limb_budget_return_the_references_limbs(oracle, name):
+    """round 6 (csrc/curve.h "the limb contract"): the reference's ecnXXXmul over the pasted field.c returns defined limbs for EVERY 64-bit
+    limb pattern (edwards.c:435-482); the kernels' fast classes (FieldH51 / FieldH56, the FAST products) are exact only inside the budget
+    2^(Radix+2).  A wave that holds a point beyond it is left to a second launch on the exact class.  Four kinds of waves side by side:
+    ordinary points; ordinary points with ONE lane whose limbs run up to 2^63; fat but valid representatives (the same field elements with
+    2^(Radix+3) moved from limb 1 into limb 0); random 64-bit limbs in every lane.  mul and mul2(exact) limb for limb against the oracle
+    (which is the reference's field.c for all inputs: tests/test_oracle_golden.py, 64-bit limb classes); the default mul2 by value
+    on the valid representatives."""
+    import ctypes
+    import random
+    import torch
+    from modarith_amd.edwards import Curve
+    W = Curve(name)
+    C = name.lower()
+    Pt, nb = oracle.ed[C]
+    from modarith_amd import curves
+    from modarith_amd.params import derive
+    N = W.N
+    radix = derive((curves.CURVES[name] if name in curves.CURVES else curves.W_CURVES[name]).field).radix
+    rng = random.Random(606)
+    n = 6 * 64
+    rec = lambda ks: torch.tensor([list(k.to_bytes(nb, "big")) for k in ks], dtype=torch.uint8, device="cuda")
+    es = [rng.randrange(1, 1 << (8 * nb - 8)) for _ in range(n)]
+    fs = [rng.randrange(1, 1 << (8 * nb - 8)) for _ in range(n)]
+    P = W.mul(rec([rng.randrange(1, 1 << 200) for _ in range(n)]), W.gen(n))
+    Q = W.dbl(W.mul(rec([rng.randrange(1, 1 << 200) for _ in range(n)]), W.gen(n)))
+    hp, hq = P.cpu().numpy().view(np.uint64).copy(), Q.cpu().numpy().view(np.uint64).copy()
+    M64 = (1 << 64) - 1
+    hp[1, 2, 64 + 17] = (1 << 63) + 12345                                  # wave 1: one lane, one limb
+    hq[0, 0, 128 + 5] = (1 << 62) + 99                                     # wave 2: one lane of Q
+    fat = slice(192, 256)                                                  # wave 3: fat but valid representatives
+    for h in (hp, hq):
+        for c in range(3):
+            t = np.uint64(1 << 3)
+            ok = h[c, 1, fat] >= t
+            h[c, 0, fat] += np.where(ok, np.uint64(1 << (radix + 3)), np.uint64(0))
+            h[c, 1, fat] -= np.where(ok, t, np.uint64(0))
+    for j in range(256, 320):                                              # wave 4: random 64-bit limbs everywhere
+        for c in range(3):
+            for i in range(N):
+                hp[c, i, j] = rng.getrandbits(64) & M64
+                hq[c, i, j] = rng.getrandbits(64 if j % 2 else radix + 2) & M64
+    Pd, Qd = torch.from_numpy(hp.view(np.int64)).cuda(), torch.from_numpy(hq.view(np.int64)).cuda()
+    assert not bool(W.limbs_ok(Pd)[64 + 17]) and bool(W.limbs_ok(Pd)[0]) and not bool(W.limbs_ok(Pd)[200])
+    Mg = W.mul(rec(es), Pd.clone()).cpu().numpy().view(np.uint64)
+    Xg = W.mul2(rec(es), Pd.clone(), rec(fs), Qd.clone(), exact=True).cpu().numpy().view(np.uint64)
+    Dg = W.mul2(rec(es), Pd.clone(), rec(fs), Qd.clone())
+
+    def pt(h, j):
+        p = Pt()
+        for c, nm in enumerate("xyz"):
+            for i in range(N):
+                getattr(p, nm)[i] = int(h[c, i, j])
+        return p
+
+    want2 = np.zeros_like(Xg)
+    for j in range(n):
+        p, q, r = pt(hp, j), pt(hq, j), Pt()
+        oracle.ecn(C, "mul2")(es[j].to_bytes(nb, "big"), ctypes.byref(p), fs[j].to_bytes(nb, "big"), ctypes.byref(q), ctypes.byref(r))
+        oracle.ecn(C, "mul")(es[j].to_bytes(nb, "big"), ctypes.byref(p))
+        for c, nm in enumerate("xyz"):
+            assert [int(v) for v in Mg[c, :, j]] == list(getattr(p, nm)), (name, "mul", j, nm)
+            assert [int(v) for v in Xg[c, :, j]] == list(getattr(r, nm)), (name, "mul2 exact", j, nm)
+            want2[c, :, j] = list(getattr(r, nm))
+    valid = list(range(0, 64)) + list(range(192, 256)) + list(range(320, n))            # lanes whose points ARE points of the curve
+    same = W.cmp(Dg, torch.from_numpy(want2.view(np.int64)).cuda()).cpu().tolist()
+    assert [same[j] for j in valid] == [1] * len(valid)
+
+
 @pytest.mark.parametrize("name", ["ED25519", "NIST256", "ED448"])
 def test_scalar_entry_points_return_the_references_limbs(name):
     """the scalar API (host pointers, curve.h's own signatures): mul, dbl, add and mul2 on the fixture's records, limb for limb --

@@ -379,6 +379,43 @@ def test_fused_ladder_form_under_stream_capture():
     assert torch.equal(x, want2[0]) and torch.equal(y, want2[1])
 
 
+@pytest.mark.parametrize("c,name", [("ed25519", "ED25519"), ("ed448", "ED448")])
+def test_straus_form_takes_a_workspace_at_any_address(c, name):
+    """round-5 advisor: ecn_<c>_mul2_get_batch wanted its workspace 128-byte aligned and, handed a large enough one at another address,
+    took the library's pool without a word -- or, under stream capture (no pool), failed with a message that named no reason.  The library
+    now aligns inside the buffer (the reported size includes the slack).  Under capture, where only the caller's workspace can serve:
+    addresses off by 8, 64 and 120 bytes work; a workspace short by one byte is refused and the message says it is too small."""
+    import torch
+    from modarith_amd.edwards import Curve
+    from modarith_amd import _lib
+    Ed = Curve(name)
+    nb = Ed.nbytes
+    n = 1000
+    gen = torch.Generator(device="cuda").manual_seed(128)
+    rnd = lambda: torch.randint(0, 256, (n, nb), dtype=torch.uint8, device="cuda", generator=gen)
+    e, f = rnd(), rnd()
+    P, Q = Ed.mul(rnd(), Ed.gen(n)), Ed.mul(rnd(), Ed.gen(n))
+    want = Ed.mul2_get(e, P, f, Q)
+    L = _lib.load()
+    fn, szf = getattr(L, "ecn_%s_mul2_get_batch" % c), getattr(L, "ecn_%s_mul2_get_workspace_bytes" % c)
+    need = int(szf(n))
+    buf = torch.empty(need + 256, dtype=torch.uint8, device="cuda")
+    base = (buf.data_ptr() + 127) // 128 * 128
+    for off in (8, 64, 120, 0):
+        x, y = torch.zeros_like(want[0]), torch.zeros_like(want[1])
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                rc = fn(e.data_ptr(), P.data_ptr(), f.data_ptr(), Q.data_ptr(), x.data_ptr(), y.data_ptr(), None, n, n, base + off, need, side.cuda_stream)
+                rc_short = fn(e.data_ptr(), P.data_ptr(), f.data_ptr(), Q.data_ptr(), x.data_ptr(), y.data_ptr(), None, n, n, base + off, need - 128, side.cuda_stream)
+                msg = L.modarith_amd_last_error().decode()
+        assert rc == 0 and rc_short != 0 and "too small" in msg, (off, rc, rc_short, msg)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(x, want[0]) and torch.equal(y, want[1]), off
+
+
 @pytest.mark.parametrize("name", ["NIST256", "SECP256K1"])
 def test_fused_weierstrass_forms_under_stream_capture(name):
     """round 5: mul_get of the Weierstrass curves is two kernels per chunk on the caller's workspace (window kernel, shared inversion +

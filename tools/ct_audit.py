@@ -328,7 +328,7 @@ def run(verbose=False):
         audits = pool.map(audit_function, [t[2] for t in todo], chunksize=1)
     for (o, name, ins), a in zip(todo, audits):
         short = re.sub(r"\(.*", "", name)
-        entry = next((e for e in allow if e["match"] in short), None)
+        entry = next((e for e in allow if e["match"] in short and short.endswith(e.get("ends", ""))), None)
         row = {"object": o, "kernel": short, **{k: a[k] for k in a if k != "detail"}}
         rows.append(row)
         if verbose:
