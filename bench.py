@@ -624,7 +624,7 @@ def main():
     others = {}
     # (Measured right after the streaming data sets.  With ~75-80 % VALU issue occupancy the four-call chain has little headroom over
     # HBM and is the first kernel to show the clock ramp after a host-side pause -- rate() warms for 60 ms for that reason:
-    # docs/fused_chains.md, profiles/r04_chain_dvfs.log.)
+    # docs/fused_chains.md, profiles/history/r04_chain_dvfs.log.)
     # Fused chains (modarith_amd/fuse.py): a sequence of field.c calls per element as ONE streaming kernel on
     # registers, against the same calls through the batched API, on the timed region's own operands.  z = ((a + b)(a - b))^2:
     # four calls, 440 B per element call by call, 120 B fused.  The chain's plug-in is built by __graft_entry__.build() and
@@ -640,7 +640,7 @@ def main():
                 F.modadd(a, b, out=t1); F.modsub(a, b, out=t2); F.modmul(t1, t2, out=t1); F.modsqr(t1, out=zc)
             # The fused kernel is timed on the headline's own operand triple (a, b -> c): the same three streams over the same
             # placement as the timed region, so the two rates compare like with like (a separately allocated output lands on another
-            # placement and reads 5-10 % lower, which says nothing about the kernel: profiles/r04_chain_pmc.json).  c is restored
+            # placement and reads 5-10 % lower, which says nothing about the kernel: profiles/history/r04_chain_pmc.json).  c is restored
             # in the `finally` whatever happens, because the verifier below checks c = a * b.
             try:
                 ms_f = rate(lambda: fz(a, b, out=[c]))

@@ -12,7 +12,7 @@ namespace ma {
 // round 5, the ladder form (csrc/ed26l.h): one scalar multiplication per lane on the Montgomery curve, no table, no LDS; (u, w) of the
 // point come from the shared inversion in front, the Edwards (X : Y : Z) of the result go to the shared inversion behind
 // 163 VGPRs, no scratch: three waves per SIMD (a 128-register build for four waves measured the same rate, 1.128e8 mul_get/s, and
-// spilled 39 registers in the recovery; two waves -- enforced from outside through an LDS claim -- lost 12 %: profiles/r05_lad_ab.log)
+// spilled 39 registers in the recovery; two waves -- enforced from outside through an LDS claim -- lost 12 %: profiles/history/r05_lad_ab.log)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_ed25519_lad(const unsigned char* e, size_t first, Ed26lWs ws) {
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;

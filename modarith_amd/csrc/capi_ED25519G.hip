@@ -78,7 +78,7 @@ void k_x25519_base(const uint64_t* bk, uint64_t* bv, size_t n) {
 // round 5, the ladder form (csrc/ed26l.h): f*Q by the Montgomery ladder with the recovered Edwards point in extended coordinates,
 // e*G added through the constant table; the inversions in front and behind are shared (ed26l_k.h)
 // 163 VGPRs, no scratch: three waves per SIMD (a 128-register build for four waves measured the same rate, 1.128e8 mul_get/s, and
-// spilled 39 registers in the recovery; two waves -- enforced from outside through an LDS claim -- lost 12 %: profiles/r05_lad_ab.log)
+// spilled 39 registers in the recovery; two waves -- enforced from outside through an LDS claim -- lost 12 %: profiles/history/r05_lad_ab.log)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_ed25519_lad_gen2(const unsigned char* e, const unsigned char* f, size_t first, Ed26lWs ws) {
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;

@@ -25,7 +25,7 @@ bool ladder_use_field();   // env MA_LADDER_IMPL=field: X25519 ladder on the 5x5
 
 // tiled batches (kernels.h Ld) take a much larger cap: on tiles the streaming rate keeps rising with the number of
 // workgroups up to one 512-element chunk per workgroup (X25519 modmul 5.96 / 6.16 / 6.39 / 6.58 TB/s at 4096 / 8192 / 16384 /
-// 32768 workgroups, profiles/r03_tiled_exp_4_grid.log), whereas flat batches are insensitive to it
+// 32768 workgroups, profiles/history/r03_tiled_exp_4_grid.log), whereas flat batches are insensitive to it
 inline unsigned grid_for(size_t nthreads, int block = 256, bool tiled = false) {
     size_t b = (nthreads + (size_t)block - 1) / (size_t)block;
     size_t cap = (size_t)(tiled ? max_blocks_tiled() : max_blocks());

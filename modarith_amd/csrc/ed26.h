@@ -119,11 +119,11 @@ struct Ed26 {
 
 // (The window form of the single multiplication -- 3-bit signed windows, the table {1,2,3,4}P in registers / LDS, 255 doublings + 86
 // mixed additions + two inversions per lane: rounds 2-4, 9.1e7/s, 170 spilled registers in its table builder -- was replaced in
-// round 5 by the ladder form of csrc/ed26l.h: 1.13e8/s, no spills; same-box A/B in profiles/r05_lad_ab.log.)
+// round 5 by the ladder form of csrc/ed26l.h: 1.13e8/s, no spills; same-box A/B in profiles/history/r05_lad_ab.log.)
 
 // (The window form of the double multiplication -- 129 signed 2-bit windows, {P, 2P} in registers and {Q, 2Q} in LDS: rounds 2-4,
 // 5.7e7/s, 178 spilled registers in its table builder -- was replaced in round 5 by the Straus form of csrc/ed26s.h: 7.9e7/s, no
-// spills; same-box A/B in profiles/r05_mul2_ab.log.)
+// spills; same-box A/B in profiles/history/r05_mul2_ab.log.)
 
 // Fused GENERATOR multiplication + affine export: the affine coordinates of e*G -- ecnXXXgen, ecnXXXmul, ecnXXXget, the
 // opening of EdDSA key generation and signing (ed448.c:167-184 ED448_KEY_PAIR, 196-199 ED448_SIGN; curve.py builds the same

@@ -17,7 +17,7 @@ constexpr int BLOCK = 256;
 
 // Batches are streamed once (640 MiB+ per array, far beyond L2 / Infinity Cache): loads and stores carry
 // the non-temporal hint so they do not displace each other in the caches (measured +3..5 % on the
-// 3-stream pattern, profiles/r01_membench.log).
+// 3-stream pattern, profiles/history/r01_membench.log).
 typedef spint spint2 __attribute__((ext_vector_type(2)));
 #ifndef MA_NONTEMPORAL
 #define MA_NONTEMPORAL 1
@@ -42,7 +42,7 @@ template <class T> __device__ __forceinline__ void st_stream(T* p, T v) {
 // stride ld, tiles N * ld words apart -- buf[((j >> s) * N + i) * ld + (j & (ld - 1))].  One formula serves both: the flat case
 // carries s = 63, so that j >> s = 0 and j & (2^s - 1) = j.  Why tiles: with rows of 2^12 elements (32 KiB) the N limb rows a
 // workgroup streams lie within one contiguous 160 KiB (5 limbs) / 256 KiB (8 limbs) stretch instead of N stretches 128 MiB
-// apart, and the streaming rate no longer depends on where the driver placed the arrays (profiles/r03_tiled_exp_*).
+// apart, and the streaming rate no longer depends on where the driver placed the arrays (profiles/history/r03_tiled_exp_*).
 struct Ld {
     size_t ld;
     unsigned s;

@@ -28,11 +28,11 @@ doc = {"tag": tag, "kernel": "ma::k_binary<ma::P_X25519, ma::OpMulAuto<ma::P_X25
        "hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024, "algorithmic_bytes_per_launch": 120 * (1 << 24)}
 doc["traffic_over_algorithmic"] = doc["hbm_bytes_per_launch"] / doc["algorithmic_bytes_per_launch"]
 json.dump(doc, open("profiles/traffic_modmul_X25519.json", "w"), indent=1)
+# round 6: the last stdout line of bench.py is the compact contract line; the full record is the detail file
 line = open(src + "/bench_plain.log").read().strip().splitlines()[-1]
-open("profiles/%s_bench.json" % tag, "w").write(line + "\n")
-line2 = open(src + "/bench_under_rocprof.log").read().strip().splitlines()
-jl = [l for l in line2 if l.startswith("{")]
-if jl:
-    open("profiles/%s_bench_under_rocprof.json" % tag, "w").write(jl[-1] + "\n")
+open("profiles/%s_bench_line.json" % tag, "w").write(line + "\n")
+json.dump(json.load(open(src + "/bench_plain_detail.json")), open("profiles/%s_bench.json" % tag, "w"), indent=1)
+if os.path.exists(src + "/bench_under_rocprof_detail.json"):
+    json.dump(json.load(open(src + "/bench_under_rocprof_detail.json")), open("profiles/%s_bench_under_rocprof.json" % tag, "w"), indent=1)
 print(json.dumps(doc, indent=1))
-print(line[:400])
+print(len(line), line[:400])

@@ -50,7 +50,7 @@ def main():
            "interpreter": open(os.path.join(SRC, "interpreter.txt")).read().strip() if os.path.exists(os.path.join(SRC, "interpreter.txt")) else None,
            "note": "per leg: instr_per_scalar = measured SQ_INSTS_VALU x 64 / records over all kernels of the leg; mad_per_scalar = measured instructions x the "
                    "static v_mad_u64_u32 share of each kernel (tools/isa_mix.py on the profiled objects); issue-cost model 5.0 cycles per multiply-add, 2.5 per other "
-                   "VALU instruction per wave and SIMD (profiles/r01_valubench.log)", "legs": {}}
+                   "VALU instruction per wave and SIMD (profiles/history/r01_valubench.log)", "legs": {}}
     rates = {}
     rp = os.path.join(SRC, "valu_leg_rates.json")
     if os.path.exists(rp):

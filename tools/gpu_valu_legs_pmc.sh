@@ -15,12 +15,12 @@ cp $R/modarith_amd/unit_hashes.json $OUT/unit_hashes.json
 cd /tmp && export TMPDIR=/tmp
 A="SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD"
 B="SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU"
-rocprofv3 --pmc $A --kernel-trace --output-format csv -d $OUT/pmca -- $PY $R/tools/run_valu_legs.py > $OUT/pmca.log 2>&1
-rocprofv3 --pmc $B --kernel-trace --output-format csv -d $OUT/pmcb -- $PY $R/tools/run_valu_legs.py > $OUT/pmcb.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $PY $R/tools/run_valu_legs.py > $OUT/stats.log 2>&1
+timeout 900 rocprofv3 --pmc $A --kernel-trace --output-format csv -d $OUT/pmca -- $PY $R/tools/run_valu_legs.py > $OUT/pmca.log 2>&1
+timeout 900 rocprofv3 --pmc $B --kernel-trace --output-format csv -d $OUT/pmcb -- $PY $R/tools/run_valu_legs.py > $OUT/pmcb.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $PY $R/tools/run_valu_legs.py > $OUT/stats.log 2>&1
 echo "$PY" > $OUT/interpreter.txt
 cd $R
-$PY tools/run_valu_legs.py --time > $OUT/leg_rates.log 2>&1
+timeout 600 $PY tools/run_valu_legs.py --time > $OUT/leg_rates.log 2>&1
 cp gpurun_out/valu_leg_rates.json $OUT/ 2>/dev/null
 tail -n 30 $OUT/leg_rates.log
 find $OUT -name "*.csv" | wc -l

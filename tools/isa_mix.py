@@ -17,11 +17,11 @@ So the number of times each instruction executes per pass of the kernel body is 
 
 Each instruction is put into a class (multiplier = v_mad_u64_u32 / v_mad_i64_i32; mul32 = v_mul_lo / v_mul_hi / 24-bit forms, true 64-bit adds, carry adds, 64-bit shifts,
 32-bit add, logic, select, move, compare, LDS, vector memory, scratch, scalar, wait / nop) and weighted by the product of the trip
-counts around it.  Issue cycles per class per wave and SIMD: 5.0 for the multiplier class, 2.5 for other VALU (profiles/r01_valubench.log:
+counts around it.  Issue cycles per class per wave and SIMD: 5.0 for the multiplier class, 2.5 for other VALU (profiles/history/r01_valubench.log:
 measured), listed per class so that a table like docs/kernels_field.md's "what is left in a ladder step" can be made for any kernel.
 
 The result is validated where counters exist: sum(VALU) here against SQ_INSTS_VALU x 64 / records of a rocprofv3 --pmc pass
-(profiles/r05_valu_pmc.json records both)."""
+(profiles/history/r05_valu_pmc.json records both)."""
 import fnmatch
 import glob
 import json

@@ -15,8 +15,10 @@ def legs():
     for C, obj, low, g, fam in (("ED25519", "capi_ED25519", "ed25519", 4, "Edwards"), ("ED448", "capi_ED448", "ed448", 2, "Edwards"),
                                 ("NIST256", "capi_NIST256W", "nist256", 4, "Weierstrass"), ("SECP256K1", "capi_SECP256K1W", "secp256k1", 4, "Weierstrass")):
         base = "capi_" + C
-        out[C + "_ecn_mul"] = [("k_ed_mul<ma::%s<ma::C_%s," % (fam, C), obj + "_part1.o", 1, 1)]
-        out[C + "_ecn_mul2"] = [("k_ed_mul2<ma::%s<ma::C_%s," % (fam, C), obj + "_part2.o", 1, 1)]
+        # (round 6: the fast class, GUARD = 1; the exact class behind it -- "... Field<P, false, true> >, -1>" -- only votes and leaves)
+        fld = {"ED25519": "ma::FieldH51<", "ED448": "ma::FieldH56<", "NIST256": "ma::Field<ma::P_NIST256, true", "SECP256K1": "ma::Field<ma::P_SECP256K1, true"}[C]
+        out[C + "_ecn_mul"] = [("k_ed_mul<ma::%s<ma::C_%s, %s" % (fam, C, fld), obj + "_part1.o", 1, 1)]
+        out[C + "_ecn_mul2"] = [("k_ed_mul2<ma::%s<ma::C_%s, %s" % (fam, C, fld), obj + "_part2.o", 1, 1)]
         if C in ("ED25519", "ED448"):
             # the ladder form (csrc/ed26l.h, ed28l.h): prep, the shared inversion in front, the ladder, the shared inversion + export
             T, NW, PF = ("LadT25519", 4, "P_X25519") if C == "ED25519" else ("LadT448", 7, "P_X448")
