@@ -71,3 +71,61 @@ def test_prop_entry_point_returns_the_references_mask():
         flag = F.prop(t)
         assert F.to_limbs(t) == want
         assert flag.tolist() == [-1 if w else 0 for w in wmask]
+
+
+ORACLE_PROTOS = """
+spint flatten_%(P)s(spint *); spint modfsb_%(P)s(spint *);
+void modadd_%(P)s(const spint *, const spint *, spint *); void modsub_%(P)s(const spint *, const spint *, spint *); void modneg_%(P)s(const spint *, spint *);
+void modmli_%(P)s(const spint *, int, spint *); void modmul_%(P)s(const spint *, const spint *, spint *); void modsqr_%(P)s(const spint *, spint *);
+void modcpy_%(P)s(const spint *, spint *); void modnsqr_%(P)s(spint *, int); void modpro_%(P)s(const spint *, spint *);
+void modinv_%(P)s(const spint *, const spint *, spint *); void nres_%(P)s(const spint *, spint *); void redc_%(P)s(const spint *, spint *);
+int modis1_%(P)s(const spint *); int modis0_%(P)s(const spint *); void modzer_%(P)s(spint *); void modone_%(P)s(spint *); void modint_%(P)s(int, spint *);
+int modqr_%(P)s(const spint *, const spint *); void modcmv_%(P)s(int, const spint *, volatile spint *); void modcsw_%(P)s(int, volatile spint *, volatile spint *);
+void modsqrt_%(P)s(const spint *, const spint *, spint *); void modshl_%(P)s(unsigned int, spint *); int modshr_%(P)s(unsigned int, spint *);
+void modhaf_%(P)s(spint *); void mod2r_%(P)s(unsigned int, spint *); void modexp_%(P)s(const spint *, char *); int modimp_%(P)s(const char *, spint *);
+int modsign_%(P)s(const spint *); int modcmp_%(P)s(const spint *, const spint *);
+/* prop is static in field.c and in the oracle alike: the emitted form (pseudo.py:223-251, arithmetic shift) */
+static spint prop(spint *n) {
+    spint mask = ((spint)1 << Radix) - (spint)1;
+    sspint carry = (sspint)n[0];
+    carry >>= Radix;
+    n[0] &= mask;
+    for (int i = 1; i < Nlimbs - 1; i++) { carry += (sspint)n[i]; n[i] = (spint)carry & mask; carry >>= Radix; }
+    n[Nlimbs - 1] += (spint)carry;
+    return -((n[Nlimbs - 1] >> 1) >> (Wordlength - 2));
+}
+"""
+
+
+@pytest.mark.parametrize("P", ["X25519", "NIST256", "X448"])
+def test_all_32_names_through_the_pasted_header_equal_the_oracle(P, tmp_path):
+    """examples/paste_marker_all32.c calls every function of field.c through the undecorated names.  Built against include/field_<P>.h
+    + libmodarith_amd.so it runs on the GPU; built against a header that maps the same names onto oracle/liboracle.so it runs the CPU
+    restatement of the reference's emitted code.  Same program, same inputs: the outputs must be equal line for line -- limbs of the
+    add / sub / product / shift / conversion functions exactly, modpro / modinv / modsqrt by value."""
+    from tests.oracle_binding import build_oracle
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        build_oracle()
+    shim = open(os.path.join(ROOT, "include", "field_%s.h" % P)).read()
+    macros = [l for l in shim.splitlines() if l.startswith("#define ") and "_ct" not in l and "_H" not in l]
+    names = [l.split()[1] for l in shim.splitlines() if l.startswith("#define ") and l.endswith("_%s_ct" % P)]
+    assert len(names) == 32
+    ohdr = tmp_path / "oracle_field.h"
+    ohdr.write_text("#include <stdio.h>\n#include <stdint.h>\n" + "\n".join(macros) + "\n" + ORACLE_PROTOS % {"P": P}
+                    + "\n".join("#define %s %s_%s" % (n, n, P) for n in names if n != "prop") + "\n")
+    src = os.path.join(ROOT, "examples", "paste_marker_all32.c")
+    outs = {}
+    for tag, hdr, incs, libs in (("gpu", '"field_%s.h"' % P, ["-I" + os.path.join(ROOT, "include")],
+                                  ["-L" + os.path.join(ROOT, "modarith_amd"), "-l:libmodarith_amd.so", "-Wl,-rpath," + os.path.join(ROOT, "modarith_amd")]),
+                                 ("oracle", '"oracle_field.h"', ["-I" + str(tmp_path)],
+                                  ["-L" + os.path.join(ROOT, "oracle"), "-l:liboracle.so", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])):
+        exe = str(tmp_path / ("all32_" + tag))
+        subprocess.run(["gcc", "-O2", "-DFIELD_HEADER=" + hdr, src] + incs + libs + ["-o", exe], check=True, timeout=300)
+        p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (tag, p.stdout[-500:], p.stderr[-500:])
+        outs[tag] = p.stdout.strip().splitlines()
+    assert len(outs["gpu"]) >= 40 and [l.split()[0] for l in outs["gpu"]] == [l.split()[0] for l in outs["oracle"]]
+    for g, o in zip(outs["gpu"], outs["oracle"]):
+        assert g == o, (P, g, o)
+    got = dict((l.split()[0], l.split()[1:]) for l in outs["gpu"])
+    assert got["inv*a==1"] == ["1"] and got["sqrt^2==x"] == ["1"] and got["modimp"] == ["3"] and got["modcmp"] == ["1"]
