@@ -200,7 +200,8 @@ def cpu_baseline(a_host, b_host, min_seconds=6.0):
 
 
 _VALU_DOC = {}
-MAD_ISSUE_CYCLES = 4.62        # v_mad_u64_u32, cycles per wave-instruction per SIMD at 8 waves/SIMD (profiles/r05_valubench.log:15)
+MAD_ISSUE_CYCLES = 4.62        # v_mad_u64_u32, cycles per wave-instruction per SIMD at 8 waves/SIMD: measured, isolated stream of independent chains
+#                                (profiles/r05_valubench.log:15; 4.63 in profiles/r06_valubench.log).  Architectural: 16 lanes per clock = 4.0.
 SIMDS = 1024                   # 256 CUs x 4 SIMDs
 
 
@@ -252,7 +253,8 @@ def valu_roofline(leg, per_s_per_gpu, sclk_GHz=None):
     mix_cost = (5.0 * mad + 2.5 * (instr - mad)) / instr
     mix_peak = SIMDS * 2.4e9 * 64 / (mix_cost * instr)
     return {"bound": "valu-mad", "achieved": per_s_per_gpu, "peak": peak, "unit": "records/s", "frac": per_s_per_gpu / peak,
-            "frac_at_2.4GHz": per_s_per_gpu / (peak * 2.4 / clk), "sclk_GHz": sclk_GHz, "mad_issue_cycles": MAD_ISSUE_CYCLES,
+            "frac_at_2.4GHz": per_s_per_gpu / (peak * 2.4 / clk), "frac_at_architectural_4_cycles": per_s_per_gpu / (peak * MAD_ISSUE_CYCLES / 4.0),
+            "sclk_GHz": sclk_GHz, "mad_issue_cycles": MAD_ISSUE_CYCLES,
             "mad_per_scalar": mad, "mad_floor_per_scalar": floor, "mad_over_floor": (mad / floor) if floor else None,
             "frac_of_floor_ceiling": (per_s_per_gpu / (peak * mad / floor)) if floor else None,
             "frac_of_mix_ceiling": per_s_per_gpu / mix_peak, "instr_per_scalar": instr, "non_mad_per_mad": (instr - mad) / mad,
