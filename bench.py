@@ -11,14 +11,14 @@ one modmul pass over the batch (c[j] = a[j]*b[j], 120 algorithmic bytes per elem
 every rank owns its own 2^24-element batch (independent units, no data-path collective): weak
 scaling; value = all ranks' modmuls / max-over-ranks time.
 
-Also reported in the same JSON line:
-  roofline      HBM roofline of the modmul kernel: algorithmic bytes per launch / mean launch time,
-                measured with HIP events on the launch stream over the timed region.
-  cpu_baseline  (rank 0, N=1 only) the CPU oracle -- a port of the reference's generated field.c --
-                on the host cores: all-core modmul throughput on a bounded sample, plus the
-                reference's time.c protocol (serial latency, check word) on one core.
-  x25519        BASELINE.json configs[4] shape: batched RFC 7748 X25519 ladder, 2^23 scalars per GPU,
-                with the RCCL gather of the 32-byte results timed separately.
+Output: the LAST stdout line is the contract line the driver parses (contract_line(): at most 4 KB); everything measured goes to
+bench_detail.json beside this file (MA_BENCH_DETAIL: another path) and to stdout lines starting with "# detail".  In the line:
+  roofline      HBM roofline of the modmul kernel: algorithmic bytes per launch / mean launch time, measured with HIP events
+                on the launch stream over the timed region; traffic from rocprofv3 --pmc child passes of this script (N = 1).
+  cpu_baseline  (rank 0, N=1 only) the CPU oracle -- a port of the reference's generated field.c -- on the host cores:
+                all-core modmul throughput on a bounded sample, plus the reference's time.c protocol on one core.
+  x25519        BASELINE.json configs[4] shape: batched RFC 7748 X25519 ladder, 2^23 scalars per GPU (--scaling strong: 2^26 in
+                total over the ranks), fraction of the integer multiply-add issue ceiling, the RCCL gather timed separately.
 """
 import argparse
 import ctypes
