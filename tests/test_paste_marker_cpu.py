@@ -60,3 +60,23 @@ def test_consumer_uses_undecorated_names_only_and_links(flag, tmp_path):
     und = subprocess.run(["nm", "-u", exe], capture_output=True, text=True).stdout
     used = set(re.findall(r"\b(\w+)_%s_ct\b" % P, und))
     assert {"modimp", "modcsw", "modmul", "modsqr", "modmli", "modpro", "modinv", "modexp"} <= used and not re.search(r"rfc7748", und)
+
+
+@pytest.mark.parametrize("P", PRIMES)
+def test_all32_consumer_compiles_against_every_shim(P, tmp_path):
+    """examples/paste_marker_all32.c (every one of the 32 names, undecorated) compiles and links against include/field_<P>.h for the three
+    BASELINE fields; its run against the oracle-mapped twin is tests/test_gpu_paste_marker.py."""
+    src = os.path.join(ROOT, "examples", "paste_marker_all32.c")
+    code = re.sub(r"/\*.*?\*/", "", open(src).read(), flags=re.S)
+    assert not re.search(r"modarith_amd_|_ct\b|_batch\b", code)
+    for fn in NAMES:
+        if fn == "modmli":
+            continue                                                     # (guarded by MULBYINT, as in the reference's templates)
+        assert re.search(r"\b%s\(" % fn, code), fn
+    exe = str(tmp_path / "all32")
+    r = subprocess.run(["gcc", "-O2", "-Wall", "-Werror", '-DFIELD_HEADER="field_%s.h"' % P, src, "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "modarith_amd"),
+                        "-l:libmodarith_amd.so", "-Wl,-rpath," + os.path.join(ROOT, "modarith_amd"), "-o", exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    und = subprocess.run(["nm", "-u", exe], capture_output=True, text=True).stdout
+    used = set(re.findall(r"\b(\w+)_%s_ct\b" % P, und))
+    assert len(used) >= 31, sorted(set(NAMES) - used)
