@@ -14,7 +14,8 @@ forced by the prime's shape, but a multiply-add spent on them is a multiply-add 
 many there are (P-256's Montgomery form: 144 multiply-adds per product against the 100 column products).  The field-operation counts
 follow the formulas the kernels implement (cited per leg; the bit-exact `ecn mul` / `mul2` legs are pinned to the reference's own
 formulas, edwards.c:73-145, weierstrass.c:68-281, and its 4-bit fixed window, edwards.c:435-482).  Shared inversions count with
-their share per record (one inversion per 32 records of a lane's column, Montgomery's trick: 3M per record + 2M for two numerators).
+their share per record (one inversion per 32 records of a lane's column -- the share of a full chunk; smaller batches pay more, which only
+moves the kernel's count further above the floor -- Montgomery's trick: 3M per record + 2M for two numerators).
 
 A floor is a LOWER bound on the kernel's count: tests/test_bench_line.py asserts mad_per_scalar >= 0.98 floor for every leg whose
 counter summary is in profiles/ (a floor above the measured count means a formula here is wrong, not that the kernel is magic).
@@ -74,6 +75,11 @@ ED_EXT_DBL, ED_EXT_DBL_T = ops(M=3, S=4), ops(M=4, S=4)     # dbl-2008-hwcd with
 ED_EXT_ADD_CACHED, ED_EXT_ADD_CACHED_NOT = ops(M=8), ops(M=7)   # add-2008-hwcd-3 on cached (Y+X, Y-X, 2dT, 2Z) with / without T out
 ED_EXT_MADD = ops(M=7)                              # madd-2008-hwcd-3 on an affine cached entry (y+x, y-x, 2dxy)
 ED_EXT_ADD = ops(M=9)                               # add-2008-hwcd-3, both points extended
+# a = 1 (ED448: x^2 + y^2 = 1 + d x^2 y^2): the (Y - X)(Y' - X') trick of a = -1 is not available, A = X1 X2 and B = Y1 Y2 are separate
+# products and M = (X1 + Y1)(X2 + Y2) a third (add-2008-hwcd with d T2 precomputed): one product more per addition
+A1_MADD = ops(M=8)                                  # mixed, T out (csrc/ed28.h add_cached + add_tail)
+A1_ADD_CACHED, A1_ADD_CACHED_NOT = ops(M=9), ops(M=8)
+A1_ADD = ops(M=10)
 
 
 def fixed_window(nbytes, dbl, addf, adds_per_window=1, tables=1):
@@ -105,15 +111,18 @@ def legs():
 
     # ---- fused Edwards forms (docs/curve_layer.md "Round 5")
     for C, form, steps, inv, nwin in (("ED25519", F10, 256, "25519", 65), ("ED448", F16, 448, "448", 113)):
+        a1 = C == "ED448"
+        MADD = A1_MADD if a1 else ED_EXT_MADD
+        CACHED, CACHED_NOT, FULL = (A1_ADD_CACHED, A1_ADD_CACHED_NOT, A1_ADD) if a1 else (ED_EXT_ADD_CACHED, ED_EXT_ADD_CACHED_NOT, ED_EXT_ADD)
         lad = add(ops(M=3), shared_inv(inv), times(steps, LADDER_STEP), ops(M=12, S=1), shared_inv(inv))
         put(C + "_ecn_mul_get_fused", form, lad, "ed26l.h / ed28l.h: prep 3M, (u, w) of P under a shared inversion, %d ladder steps, Okeya-Sakurai recovery and map back 12M + 1S, "
             "(x, y) under a shared inversion" % steps)
-        put(C + "_ecn_mulgen2_get_fused", form, add(lad, ops(M=1), times(nwin, ED_EXT_MADD)),
-            "f Q by the ladder form with T recovered (+1M), e G through the fixed-base table: %d mixed additions of 7M" % nwin)
-        put(C + "_ecn_mulgen_get_fused", form, add(times(nwin, ED_EXT_MADD), shared_inv(inv)),
-            "fixed-base table: %d signed 4-bit windows, one mixed addition (7M) each, no doublings; export under a shared inversion" % nwin)
-        table = add(times(4, ED_EXT_DBL_T), times(3, ED_EXT_ADD), ops(M=8))            # 2P..8P, then the cached form (2dT) of eight entries
-        straus = add(times(2, table), times(steps - nwin, ED_EXT_DBL), times(nwin, ED_EXT_DBL_T), times(nwin, add(ED_EXT_ADD_CACHED, ED_EXT_ADD_CACHED_NOT)), shared_inv(inv))
+        put(C + "_ecn_mulgen2_get_fused", form, add(lad, ops(M=1), times(nwin, MADD)),
+            "f Q by the ladder form with T recovered (+1M), e G through the fixed-base table: %d mixed additions of %dM" % (nwin, MADD["M"]))
+        put(C + "_ecn_mulgen_get_fused", form, add(times(nwin, MADD), shared_inv(inv)),
+            "fixed-base table: %d signed 4-bit windows, one mixed addition (%dM) each, no doublings; export under a shared inversion" % (nwin, MADD["M"]))
+        table = add(times(4, ED_EXT_DBL_T), times(3, FULL), ops(M=8))                  # 2P..8P, then the cached form (d T) of eight entries
+        straus = add(times(2, table), times(steps - nwin, ED_EXT_DBL), times(nwin, ED_EXT_DBL_T), times(nwin, add(CACHED, CACHED_NOT)), shared_inv(inv))
         put(C + "_ecn_mul2_get_fused", form, straus, "ed26s.h / ed28s.h Straus: two projective cached tables {1..8}P, {1..8}Q, %d shared doublings, %d windows of two additions "
             "(8M + 7M), export under a shared inversion" % (steps, nwin))
 
