@@ -78,3 +78,19 @@ def test_line_survives_oversized_blocks():
     out = json.loads(line)
     for k in CONTRACT:
         assert k in out
+
+
+def test_algorithmic_floors_lie_below_the_kernels_counts():
+    """profiles/mad_floor.json (tools/mad_floor.py: field operations of each leg's algorithm x schoolbook column products) is a LOWER bound:
+    every leg's floor must not exceed the multiply-adds its kernels execute (profiles/r06_valu_pmc.json) -- a floor above the count means a
+    formula in the tool is wrong -- and every VALU leg of the counter summary has a floor.  The file is what the tool writes now."""
+    import subprocess
+    floors = json.load(open(os.path.join(ROOT, "profiles", "mad_floor.json")))["legs"]
+    legs = json.load(open(os.path.join(ROOT, "profiles", "r06_valu_pmc.json")))["legs"]
+    assert set(legs) <= set(floors) and len(legs) == 26
+    for leg, L in legs.items():
+        f = floors[leg]["mad_floor_per_scalar"]
+        assert 0.98 * f <= L["mad_per_scalar"] < 2.0 * f, (leg, f, L["mad_per_scalar"])
+    before = open(os.path.join(ROOT, "profiles", "mad_floor.json")).read()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mad_floor.py")], check=True, capture_output=True, timeout=120)
+    assert open(os.path.join(ROOT, "profiles", "mad_floor.json")).read() == before, "profiles/mad_floor.json is stale: python tools/mad_floor.py"
