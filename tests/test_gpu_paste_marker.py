@@ -4,7 +4,8 @@ with gcc, linked with libmodarith_amd.so, and must print the RFC 7748 public key
 (rfc7748.c:297-305: LCG-keyed scalar, (k, u) -> v, (k, v) -> u) at the survey-captured checkpoints (tests/golden/ladder_*.json
 ref_main_chain).  Every field call is one element through the device (about 4 700 calls per scalar multiplication), so the default run
 checks the checkpoint after 100 steps (X25519, 200 scalar multiplications, ~50 s) / 10 steps (X448); MA_FULL_CHAIN=1 runs the 5 000 steps of
-the reference's main() (about 40 minutes; profiles/r06_paste_marker_chain.log holds a 1 000-step run)."""
+the reference's main() (34 minutes: profiles/r06_paste_marker_chain_5000.log, final value 2ac5ee20...b1d41c as the reference prints it;
+profiles/r06_paste_marker_chain.log is a 1 000-step run)."""
 import os
 import re
 import subprocess
