@@ -71,14 +71,17 @@ def _unit_hash(obj: str, cmd) -> str | None:
     dep = obj[:-2] + ".d"
     if not (os.path.exists(dep) and os.path.exists(obj)):
         return None
-    h = hashlib.sha256(" ".join(cmd).encode())
+    # paths enter the hash RELATIVE to the repository root: the same sources built in another directory (a clone, the driver's scratch
+    # copy) get the same unit hashes, which profiles/<tag>_valu_pmc.json records to say which build its counters belong to
+    rel = lambda f: os.path.relpath(os.path.abspath(f), _ROOT)
+    h = hashlib.sha256(" ".join(rel(c) if os.path.isabs(c) and os.path.abspath(c).startswith(_ROOT + os.sep) else c for c in cmd).encode())
     text = open(dep).read().replace("\\\n", " ")
-    for f in sorted(set(text.split()[1:])):
+    for f in sorted(set(text.split()[1:]), key=rel):
         if not os.path.abspath(f).startswith(_ROOT + os.sep):
             continue                      # toolchain headers: covered by the hipcc path in the command line
         if not os.path.exists(f):
             return None
-        h.update(f.encode())
+        h.update(rel(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()
 
