@@ -195,7 +195,7 @@ def test_exact_mul2_against_the_oracle_on_mixed_waves(oracle, name):
     assert W.cmp(W.mul2(rec(es), P.clone(), rec(fs), Q.clone()), R).cpu().tolist() == [1] * n
 
 
-@pytest.mark.parametrize("name", ["ED25519", "ED448", "NIST256", "SECP256K1", "NUMS256E", "NIST521"])
+@pytest.mark.parametrize("name", ["ED25519", "ED448", "NIST256", "SECP256K1", "NUMS256E", "NIST521", "ED248", "ED376", "ED500", "NIST384", "NUMS256W"])
 def test_points_beyond_the_limb_budget_return_the_references_limbs(oracle, name):
     """round 6 (csrc/curve.h "the limb contract"): the reference's ecnXXXmul over the pasted field.c returns defined limbs for EVERY 64-bit
     limb pattern (edwards.c:435-482); the kernels' fast classes (FieldH51 / FieldH56, the FAST products) are exact only inside the budget
